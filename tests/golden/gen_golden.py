@@ -1,0 +1,233 @@
+#!/usr/bin/env python3
+"""Generate golden vectors by running the REFERENCE's own Python operators (CPU, float64).
+
+Runs only in the build container, where /root/reference is mounted (the reference never travels
+to the GPU box).  Output: small ``.npz`` fixtures next to this file, committed to the repo.  Each
+fixture holds inputs and the reference's outputs (data only -- no reference source text).
+
+    python tests/golden/gen_golden.py            # regenerate everything
+
+Reference entry points exercised (the ``raht_fn`` table of python/encode_3dgs.py:23-27 plus the
+voxelizer):  RAHT_param_reorder_fast (RAHT_param.py:190), RAHT2_optimized (RAHT.py:252),
+inverse_RAHT_optimized (iRAHT.py:40), get_morton_code / voxelize_pc_batched (voxelize_pc.py:25,62),
+and the driver-inline quantize/reorder arithmetic (encode_3dgs.py:204-217, 261-268).
+"""
+import os
+import sys
+
+import numpy as np
+
+REF = os.environ.get("RAHT_REFERENCE", "/root/reference/python")
+sys.path.insert(0, REF)
+import torch  # noqa: E402
+
+from RAHT import RAHT2_optimized  # noqa: E402
+from RAHT_param import RAHT_param, RAHT_param_reorder_fast  # noqa: E402
+from iRAHT import inverse_RAHT_optimized  # noqa: E402
+from voxelize_pc import get_morton_code, voxelize_pc_batched  # noqa: E402
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+torch.set_num_threads(4)
+
+
+def morton_np(V, J):
+    return get_morton_code(torch.from_numpy(V.astype(np.int64)), J).numpy().astype(np.uint64)
+
+
+def sorted_unique_voxels(V, J):
+    """Integer coords -> unique, Morton-sorted (what the encode drivers expect as input)."""
+    V = np.unique(V.astype(np.int64), axis=0)
+    mc = morton_np(V, J)
+    o = np.argsort(mc, kind="stable")
+    return V[o]
+
+
+def blob_cloud(rng, n, J, nblobs=8, sigma=0.05):
+    ctr = rng.uniform(0.1, 0.9, size=(nblobs, 3))
+    p = ctr[rng.integers(0, nblobs, size=n)] + rng.normal(0, sigma, size=(n, 3))
+    p = np.clip(p, 0.0, 1.0 - 1e-9)
+    return np.floor(p * (1 << J)).astype(np.int64)
+
+
+def gaussian_attrs(rng, n, D):
+    """3DGS-like attribute matrix (quats, scales, opacity, SH...), float32-representable."""
+    cols = []
+    q = rng.normal(size=(n, 4)); q /= np.linalg.norm(q, axis=1, keepdims=True)
+    cols.append(q)
+    cols.append(np.exp(rng.normal(-4, 1, size=(n, 3))))
+    cols.append(1 / (1 + np.exp(-rng.normal(0, 2, size=(n, 1)))))
+    cols.append(rng.normal(0, 0.5, size=(n, 3)))
+    cols.append(rng.normal(0, 0.1, size=(n, 64)))
+    A = np.concatenate(cols, axis=1)[:, :D]
+    return A.astype(np.float32)
+
+
+def transform_case(name, V, J, C32, steps=(), also_slow_param=False):
+    """V: sorted unique int64 (N,3); C32: float32 (N,D)."""
+    N = V.shape[0]
+    Vt = torch.from_numpy(V.astype(np.float64))
+    origin = torch.zeros(3, dtype=torch.float64)
+    List, Flags, weights, order = RAHT_param_reorder_fast(Vt, origin, 2 ** J, J)
+    if also_slow_param and N > 1:
+        L2, F2, W2 = RAHT_param(Vt, origin, 2 ** J, J)
+        assert len(L2) == len(List)
+        for a, b in zip(L2, List):
+            assert torch.equal(a.long(), b.long())
+        for a, b in zip(F2, Flags):
+            assert torch.equal(a.bool(), b.bool())
+    Ct = torch.from_numpy(C32.astype(np.float64))
+    T, w = RAHT2_optimized(Ct, List, Flags, weights)
+    Crec = inverse_RAHT_optimized(T, List, Flags, weights)
+    out = dict(
+        V=V.astype(np.int32), J=np.int32(J), C=C32,
+        morton=morton_np(V, J),
+        level_len=np.array([len(l) for l in List], dtype=np.int64),
+        list_cat=torch.cat(List).numpy().astype(np.int32),
+        flags_cat=np.packbits(torch.cat(Flags).numpy().astype(np.uint8)),
+        weights_cat=torch.cat(weights).numpy().astype(np.int32),
+        order=(np.array([-1], dtype=np.int64) if order is None else order.numpy().astype(np.int64)),
+        order_is_none=np.bool_(order is None),
+        T=T.numpy(), w=w.numpy().reshape(-1),
+        roundtrip_maxerr=np.float64((Crec - Ct).abs().max().item()),
+    )
+    for s in steps:                                   # encode_3dgs.py:204-217, 261-275
+        enc = torch.floor(T / s + 0.5)
+        reord = enc.index_select(0, order)
+        q = reord.to(torch.int32)
+        dec = q.to(torch.float64) * s
+        dec = dec[torch.argsort(order), :]
+        rec = inverse_RAHT_optimized(dec, List, Flags, weights)
+        out[f"q_step{s}"] = q.numpy()
+        out[f"crec_step{s}"] = rec.numpy().astype(np.float64)
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print(f"{name}: N={N} J={J} D={C32.shape[1]} levels={len(Flags)} "
+          f"order={'None' if order is None else tuple(order.shape)} rt={out['roundtrip_maxerr']:.2e}")
+
+
+def voxelize_case(name, PC32, J, vmin=None, width=None):
+    PC = torch.from_numpy(PC32)
+    vm = None if vmin is None else torch.tensor(vmin, dtype=torch.float32)
+    PCvox, PCsorted, vox_idx, DeltaPC, info = voxelize_pc_batched(PC, vm, width, J, device="cpu")
+    V = PC[:, :3]
+    V0 = V - info["vmin"].unsqueeze(0)
+    Vint = torch.clamp(torch.floor(V0 / info["voxel_size"]).long(), 0, 2 ** J - 1)
+    M = get_morton_code(Vint, J)
+    Ms, _ = torch.sort(M, stable=True)
+    out = dict(
+        PC=PC32, J=np.int32(J),
+        vmin_in=(np.zeros(0, np.float32) if vmin is None else np.asarray(vmin, np.float32)),
+        width_in=np.float64(-1.0 if width is None else width),
+        Vint=Vint.numpy().astype(np.int32), morton=M.numpy().astype(np.uint64),
+        keys_sorted=Ms.numpy().astype(np.uint64),
+        sort_idx_ref=info["sort_idx"].numpy().astype(np.int64),
+        voxel_indices=vox_idx.numpy().astype(np.int64), PCvox=PCvox.numpy().astype(np.float32),
+        Nvox=np.int64(info["Nvox"]), vmin=info["vmin"].numpy().astype(np.float32),
+        width=np.float64(info["width"]), voxel_size=np.float64(info["voxel_size"]),
+    )
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print(f"{name}: N={PC32.shape[0]} J={J} Nvox={info['Nvox']}")
+
+
+def main():
+    rng = np.random.default_rng(20251205)
+
+    # ---- tiny / edge cases of the plan (N = 1, 2, 3, 5; early termination before j = 3) --------
+    tiny = [
+        ("t_n1", [[0, 0, 0]], 1), ("t_n2_j1", [[0, 0, 0], [0, 0, 1]], 1),
+        ("t_n2_j3", [[0, 0, 0], [0, 0, 1]], 3), ("t_n2_y", [[0, 0, 0], [0, 1, 0]], 2),
+        ("t_n3", [[0, 0, 0], [0, 0, 1], [0, 1, 0]], 2), ("t_n2_far", [[0, 0, 0], [1, 1, 1]], 1),
+        ("t_n5_j1", [[0, 0, 0], [0, 0, 1], [0, 1, 0], [0, 1, 1], [1, 0, 0]], 1),
+        ("t_n5_j2", [[0, 0, 0], [0, 0, 1], [0, 1, 0], [0, 1, 1], [1, 0, 0]], 2),
+        ("t_n2_hi", [[3, 3, 2], [3, 3, 3]], 2),
+    ]
+    for name, V, J in tiny:
+        V = sorted_unique_voxels(np.array(V), J)
+        C = rng.normal(size=(V.shape[0], 2)).astype(np.float32)
+        transform_case(name, V, J, C)
+
+    # ---- N = 8 full cube at J = 1 and sparse at J = 2 -----------------------------------------
+    V = sorted_unique_voxels(np.array([[x, y, z] for x in (0, 1) for y in (0, 1) for z in (0, 1)]), 1)
+    transform_case("n8_cube_j1", V, 1, rng.normal(size=(8, 3)).astype(np.float32), steps=(1,))
+    V = sorted_unique_voxels(rng.integers(0, 4, size=(8, 3)), 2)
+    transform_case("n8_j2", V, 2, rng.normal(size=(V.shape[0], 3)).astype(np.float32), also_slow_param=True)
+
+    # ---- dense-ish J = 3 (512 cells), D = 11 -------------------------------------------------
+    V = sorted_unique_voxels(rng.integers(0, 8, size=(400, 3)), 3)[:257]
+    V = sorted_unique_voxels(V, 3)
+    transform_case("n257_j3_d11", V, 3, gaussian_attrs(rng, V.shape[0], 11), steps=(1, 8), also_slow_param=True)
+
+    # ---- cfg2-like: J = 10, D = 14 ----------------------------------------------------------
+    V = sorted_unique_voxels(blob_cloud(rng, 1000, 10), 10)
+    transform_case("n1000_j10_d14", V, 10, gaussian_attrs(rng, V.shape[0], 14), steps=(1, 4))
+
+    # ---- cfg3-like: J = 12, D = 56 and D = 59, with the driver's quantization steps ----------
+    V = sorted_unique_voxels(blob_cloud(rng, 1500, 12), 12)
+    transform_case("n1500_j12_d56", V, 12, gaussian_attrs(rng, V.shape[0], 56) * 100, steps=(1, 8, 64))
+    V = sorted_unique_voxels(blob_cloud(rng, 2000, 10), 10)
+    transform_case("n2000_j10_d59", V, 10, gaussian_attrs(rng, V.shape[0], 59))
+
+    # ---- cfg1-like: RGB-ish 3 channels (0..255), J = 18 (encode_ply.py:17-29) -----------------
+    V = sorted_unique_voxels(blob_cloud(rng, 3000, 18, nblobs=3, sigma=0.01), 18)
+    C = rng.integers(0, 256, size=(V.shape[0], 3)).astype(np.float32)
+    transform_case("n3000_j18_d3", V, 18, C, steps=(1, 16))
+
+    # ---- 60-bit keys: J = 20, D = 1 ----------------------------------------------------------
+    V = sorted_unique_voxels(rng.integers(0, 1 << 20, size=(500, 3)), 20)
+    transform_case("n500_j20_d1", V, 20, rng.normal(size=(V.shape[0], 1)).astype(np.float32))
+
+    # ---- early root: every point shares the high bits (coords < 8 at J = 10) ------------------
+    V = sorted_unique_voxels(rng.integers(0, 8, size=(300, 3)), 10)
+    transform_case("early_root_j10", V, 10, rng.normal(size=(V.shape[0], 2)).astype(np.float32), steps=(1,))
+
+    # ---- max coordinate present (2^J - 1 on every axis) and origin present -------------------
+    J = 6
+    V = np.vstack([rng.integers(0, 1 << J, size=(200, 3)), [[63, 63, 63]], [[0, 0, 0]], [[63, 0, 63]]])
+    V = sorted_unique_voxels(V, J)
+    transform_case("maxcoord_j6", V, J, rng.normal(size=(V.shape[0], 4)).astype(np.float32))
+
+    # ---- single long chain of strictly increasing / decreasing levels ------------------------
+    J = 7
+    keys = [0] + [1 << k for k in range(0, 21)]              # d = inf,0,1,2,...  (increasing)
+    def key_to_xyz(k):
+        x = y = z = 0
+        for i in range(J):
+            dgt = (k >> (3 * i)) & 7
+            z |= (dgt & 1) << i; y |= ((dgt >> 1) & 1) << i; x |= ((dgt >> 2) & 1) << i
+        return [x, y, z]
+    V = sorted_unique_voxels(np.array([key_to_xyz(k) for k in keys]), J)
+    transform_case("chain_inc_j7", V, J, rng.normal(size=(V.shape[0], 3)).astype(np.float32))
+    top = (1 << 21) - 1
+    keys = [0] + [top - ((1 << k) - 1) for k in range(20, -1, -1)]   # decreasing levels
+    V = sorted_unique_voxels(np.array([key_to_xyz(k) for k in keys]), J)
+    transform_case("chain_dec_j7", V, J, rng.normal(size=(V.shape[0], 3)).astype(np.float32))
+
+    # ---- voxelizer ------------------------------------------------------------------------
+    docs = np.array([[0.1, 0.1, 0.1], [0.9, 0.9, 0.9], [0.15, 0.12, 0.08], [0.5, 0.5, 0.5],
+                     [0.52, 0.48, 0.51], [0.3, 0.7, 0.2], [0.85, 0.92, 0.88], [0.0, 0.0, 0.0]],
+                    dtype=np.float32)                           # docs/voxelization.md:19-95
+    voxelize_case("vox_docs8_given", docs, 2, vmin=[0, 0, 0], width=1.0)
+    voxelize_case("vox_docs8_auto", docs, 2)
+    PC = np.concatenate([rng.uniform(-3, 5, size=(5000, 3)), rng.normal(size=(5000, 3))], axis=1).astype(np.float32)
+    voxelize_case("vox_n5000_j6_d3", PC, 6)
+    PC = np.concatenate([rng.normal(0, 1, size=(20000, 3)), gaussian_attrs(rng, 20000, 11)], axis=1).astype(np.float32)
+    voxelize_case("vox_n20000_j10_d11", PC, 10)
+    # adversarial: coordinates sitting (to float32 rounding) on voxel boundaries
+    J = 9
+    width = 7.3
+    vs = width / (1 << J)
+    k = rng.integers(0, 1 << J, size=(4000, 3))
+    bump = rng.integers(-1, 2, size=(4000, 3))
+    base = (k * vs).astype(np.float32)
+    pts = np.nextafter(base, np.where(bump > 0, np.float32(np.inf), np.float32(-np.inf)), dtype=np.float32)
+    pts = np.where(bump == 0, base, pts).astype(np.float32)
+    pts = np.clip(pts, 0, None)
+    pts[0] = 0.0
+    PC = np.concatenate([pts, rng.normal(size=(4000, 2)).astype(np.float32)], axis=1)
+    voxelize_case("vox_boundary_j9", PC, J, vmin=[0, 0, 0], width=width)
+    voxelize_case("vox_boundary_auto_j9", PC, J)
+    # positions only
+    voxelize_case("vox_posonly_j5", rng.uniform(0, 1, size=(3000, 3)).astype(np.float32), 5)
+
+
+if __name__ == "__main__":
+    main()
