@@ -1,0 +1,176 @@
+/*
+ * raht.h -- C ABI of the MI355X-native RAHT attribute codec (libraht_hip.so, gfx950).
+ *
+ * Drop-in boundary: the three-entry operator table every reference driver dispatches through,
+ *     raht_fn = {"RAHT", "iRAHT", "RAHT_param"}      (reference python/encode_3dgs.py:23-27,
+ *                                                      encode_ply.py:20-24, encode_dataset.py:20-24)
+ * plus the voxelizer that produces its input (python/voxelize_pc.py:62-172) and the driver-inline
+ * quantize / reorder arithmetic (python/encode_3dgs.py:204-217, 261-268).
+ *
+ * Conventions
+ *   - every function returns an int status: 0 = RAHT_OK, negative = error; raht_last_error()
+ *     returns a thread-local, human-readable description of the last failure;
+ *   - no C++ exceptions, no torch types: plain pointers and sizes only;
+ *   - all data pointers are DEVICE pointers (HBM) unless a parameter says "host";
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream). Transform entry points
+ *     (raht_fwd*, raht_inv*, raht_quant*, raht_dequant*) only enqueue kernels on `stream`: no
+ *     allocation, no host synchronisation, safe to capture in a hipGraph. Plan construction and
+ *     raht_voxelize allocate and synchronise `stream` (they size outputs from device counts);
+ *   - the caller owns every data buffer; a plan is an opaque handle owning its own HBM;
+ *   - rows of C / T are the points in Morton order, row-major, `ld*` = row stride in ELEMENTS;
+ *   - N < 2^31 rows; element offsets are 64-bit.
+ */
+#ifndef RAHT_H
+#define RAHT_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RAHT_VERSION 100
+
+enum raht_status {
+    RAHT_OK = 0,
+    RAHT_ERR_INVALID = -1,      /* bad argument (NULL, N < 1, depth out of range, D < 1 ...)          */
+    RAHT_ERR_UNSORTED = -2,     /* Morton keys not strictly increasing (unsorted or duplicate voxels):
+                                   the reference silently mis-pairs these (SURVEY 8a iii/iv)          */
+    RAHT_ERR_BOUNDS = -3,       /* a coordinate is < 0 or >= 2^depth (reference RAHT_param.py:26-27
+                                   raises ValueError in the slow path, the fast path does not check) */
+    RAHT_ERR_HIP = -4,          /* a HIP runtime call failed                                          */
+    RAHT_ERR_NOMEM = -5,
+    RAHT_ERR_UNSUPPORTED = -6
+};
+
+enum raht_dtype { RAHT_F32 = 0, RAHT_F64 = 1, RAHT_I32 = 2, RAHT_I64 = 3 };
+
+/* Which kernel family executes a transform.
+ *   RAHT_ENGINE_TILE  : LDS-tile-fused stages (default): a block stages a run of Morton-contiguous
+ *                       rows in LDS and performs every butterfly whose subtree lies inside the run;
+ *                       the few surviving low-pass rows are merged by later, much smaller stages.
+ *   RAHT_ENGINE_LEVEL : one launch per binary level (= per octree level per axis), rows gathered
+ *                       from HBM pairwise. Kept as the simple formulation and as a cross-check. */
+enum raht_engine { RAHT_ENGINE_TILE = 0, RAHT_ENGINE_LEVEL = 1 };
+
+typedef struct raht_plan raht_plan;
+typedef void *raht_stream_t;
+
+const char *raht_last_error(void);
+int raht_version(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * Plan ("RAHT_param").  Replaces RAHT_param_reorder_fast(V, minV, width, depth)
+ * (reference python/RAHT_param.py:190-279).
+ *
+ * V: N x 3 (x, y, z) coordinates holding integers, already Morton-sorted and duplicate-free, in
+ * v_dtype. Vint = floor((V - minV) / (width / 2^depth)); key = sum_k (z_k + 2 y_k + 4 x_k) << 3k.
+ * Instead of the reference's per-level List / Flags / weights the plan stores three arrays of
+ * length N derived from the sorted keys:
+ *     lvl[i] = msb(key[i] ^ key[i-1])    the one binary level at which row i is a right sibling
+ *     wl[i]  = i - i0                    weight (leaf count) of its left sibling, i0 = partner row
+ *     wr[i]  = nxt(i) - i                weight of the subtree rooted at row i
+ * plus order_RAGFT (coarse-to-fine coefficient permutation, RAHT_param.py:251-274).
+ * Errors: RAHT_ERR_UNSORTED, RAHT_ERR_BOUNDS (both checked on device; the reference checks neither).
+ * N == 1 yields order = [0] (the reference returns None and its drivers crash).
+ */
+int raht_plan_create(const void *V, int v_dtype, int64_t N, const double minV[3], double width,
+                     int depth, raht_stream_t stream, raht_plan **out);
+
+/* Same, from strictly increasing Morton keys (device, uint64) of `nbits` significant bits (<= 63).
+ * leaf_weights (device int64[N], may be NULL = all ones) gives every row an occupancy weight: used
+ * when rows are themselves roots of already-transformed subtrees (multi-GPU top levels). */
+int raht_plan_create_from_keys(const uint64_t *keys_sorted, int64_t N, int nbits,
+                               const int64_t *leaf_weights, raht_stream_t stream, raht_plan **out);
+
+int raht_plan_destroy(raht_plan *plan);
+int64_t raht_plan_size(const raht_plan *plan);          /* N */
+int raht_plan_nbits(const raht_plan *plan);             /* 3 * depth */
+
+/* Engine / tile-size selection (tile_rows = 0 keeps the automatic choice). */
+int raht_plan_set_engine(raht_plan *plan, int engine, int tile_rows);
+
+/* Reference-shaped views, for parity tests and the drivers' DEBUG save_lists
+ * (reference python/encode_3dgs.py:165). HOST output buffers.
+ *   raht_plan_levels       = len(Flags) of the reference
+ *   raht_plan_export_level : List[l] (int64), Flags[l] (uint8 0/1), weights[l] (int64); any of the
+ *                            three may be NULL; *n receives the length of level l. */
+int raht_plan_levels(const raht_plan *plan);
+int raht_plan_export_level(const raht_plan *plan, int level, int64_t *list, uint8_t *flags,
+                           int64_t *weights, int64_t *n);
+/* order_RAGFT into a DEVICE int64[N] buffer (usable by index_select / argsort as the drivers do,
+ * reference python/encode_3dgs.py:210,267). */
+int raht_plan_order(const raht_plan *plan, int64_t *order_dev, raht_stream_t stream);
+/* Device pointers of the internal arrays (valid until destroy), for inspection / tests. */
+int raht_plan_arrays(const raht_plan *plan, const uint64_t **keys, const uint8_t **lvl,
+                     const int32_t **wl, const int32_t **wr);
+/* Copy one internal array into a caller-provided DEVICE buffer of N elements:
+ * which = 0 keys (uint64), 1 lvl (uint8), 2 wl (int32), 3 wr (int32). */
+int raht_plan_copy_array(const raht_plan *plan, int which, void *dst_dev, raht_stream_t stream);
+/* Tile-engine schedule statistics: number of stages and active rows per stage (host int64[]). */
+int raht_plan_stage_stats(raht_plan *plan, int elem_size, int D, int *n_stages, int64_t *rows_per_stage,
+                          int max_stages, int *tile_rows);
+
+/* ------------------------------------------------------------------------------------------------
+ * Forward transform ("RAHT").  Replaces RAHT2_optimized(C, List, Flags, weights) -> (T, w)
+ * (reference python/RAHT.py:252-336): T[i0] = a x0 + b x1, T[i1] = -b x0 + a x1 with
+ * a = sqrt(w0/(w0+w1)), b = sqrt(w1/(w0+w1)) (weights are integer leaf counts; a, b are evaluated
+ * in float64 and rounded once). C is never modified; T may not alias C. w (N, may be NULL) receives
+ * the node weights of RAHT.py:325-328.
+ * f32: fp32 arithmetic, tolerance vs the float64 reference is stated in DESIGN.md / tests;
+ * f64: float64 arithmetic (the reference's own precision), rtol = atol = 1e-12.
+ */
+int raht_fwd(const raht_plan *plan, const float *C, int64_t ldc, int D, float *T, int64_t ldt,
+             float *w, raht_stream_t stream);
+int raht_fwd_f64(const raht_plan *plan, const double *C, int64_t ldc, int D, double *T, int64_t ldt,
+                 double *w, raht_stream_t stream);
+
+/* Inverse transform ("iRAHT").  Replaces inverse_RAHT_optimized(T, List, Flags, weights) -> C
+ * (reference python/iRAHT.py:40-114): x0 = a T0 - b T1, x1 = b T0 + a T1, levels top-down. */
+int raht_inv(const raht_plan *plan, const float *T, int64_t ldt, int D, float *C, int64_t ldc,
+             raht_stream_t stream);
+int raht_inv_f64(const raht_plan *plan, const double *T, int64_t ldt, int D, double *C, int64_t ldc,
+                 raht_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Quantize + reorder / dequantize + un-reorder (driver-inline in the reference,
+ * python/encode_3dgs.py:204 floor(x/step+0.5), :210 index_select(0, order_RAGFT), :215 int32;
+ * :261 x*step, :267-268 gather by argsort(order_RAGFT)).
+ *   Q[k, c] = (int32) floor(T[order[k], c] / step_c + 0.5)        T[order[k], c] = Q[k, c] * step_c
+ * steps: HOST array of n_steps values, n_steps == 1 (one step for all channels) or == D. */
+int raht_quant_reorder(const raht_plan *plan, const float *T, int64_t ldt, int D, const float *steps,
+                       int n_steps, int32_t *Q, int64_t ldq, raht_stream_t stream);
+int raht_dequant_unreorder(const raht_plan *plan, const int32_t *Q, int64_t ldq, int D,
+                           const float *steps, int n_steps, float *T, int64_t ldt,
+                           raht_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Voxelizer.  Replaces voxelize_pc_batched(PC, vmin, width, J) (reference
+ * python/voxelize_pc.py:62-172) and get_morton_code (:25-59): shift by vmin, Vint =
+ * clamp(floor((V - vmin) / (width / 2^J)), 0, 2^J - 1) in float32 as torch does, 3J-bit Morton
+ * key, STABLE LSD radix sort on device, voxel starts where the key changes, per-voxel attribute
+ * mean (sequential in sorted order, so bit-reproducible).
+ *   PC      : N x (3 + d) float32, row stride ldpc elements
+ *   vmin_in : HOST float[3] or NULL (-> per-axis minimum);  width_in < 0 -> max over axes of V - vmin
+ * Outputs (DEVICE, caller-allocated for N rows; any may be NULL):
+ *   keys_sorted uint64[N], sort_idx int64[N], voxel_indices int64[<=N], PCvox float[<=N x (3+d)]
+ *   (integer voxel coordinates as floats, then mean attributes), Vvox int64[<=N x 3].
+ * HOST outputs: *n_vox, vmin_out[3], *width_out, *voxel_size_out. */
+int raht_voxelize(const float *PC, int64_t ldpc, int64_t N, int d, const float *vmin_in,
+                  double width_in, int J, uint64_t *keys_sorted, int64_t *sort_idx,
+                  int64_t *voxel_indices, float *PCvox, int64_t *Vvox, int64_t *n_vox,
+                  float vmin_out[3], double *width_out, double *voxel_size_out,
+                  raht_stream_t stream);
+
+/* Morton keys of integer coordinates (get_morton_code, voxelize_pc.py:25-59). V: N x 3 int64. */
+int raht_morton(const int64_t *V, int64_t N, int J, uint64_t *keys, raht_stream_t stream);
+
+/* Stable LSD radix sort of uint64 keys (nbits significant) with an int64 index payload
+ * (idx_out[k] = original position). DEVICE buffers. */
+int raht_sort_keys(const uint64_t *keys_in, int64_t N, int nbits, uint64_t *keys_out,
+                   int64_t *idx_out, raht_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RAHT_H */

@@ -1,0 +1,95 @@
+"""ctypes loader for libraht_hip.so (the C ABI declared in include/raht.h).
+
+The product path fails loudly when the HIP library is missing -- there is no CPU fallback.
+"""
+import ctypes as C
+import os
+import subprocess
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+_CSRC = os.path.join(_PKG, "csrc")
+SO_PATH = os.path.join(_PKG, "libraht_hip.so")
+
+RAHT_OK = 0
+ERRORS = {-1: "RAHT_ERR_INVALID", -2: "RAHT_ERR_UNSORTED", -3: "RAHT_ERR_BOUNDS", -4: "RAHT_ERR_HIP",
+          -5: "RAHT_ERR_NOMEM", -6: "RAHT_ERR_UNSUPPORTED"}
+RAHT_F32, RAHT_F64, RAHT_I32, RAHT_I64 = 0, 1, 2, 3
+ENGINE_TILE, ENGINE_LEVEL = 0, 1
+
+# every symbol include/raht.h declares (checked by tests/test_abi.py)
+EXPORTS = [
+    "raht_last_error", "raht_version", "raht_plan_create", "raht_plan_create_from_keys",
+    "raht_plan_destroy", "raht_plan_size", "raht_plan_nbits", "raht_plan_set_engine",
+    "raht_plan_levels", "raht_plan_export_level", "raht_plan_order", "raht_plan_arrays",
+    "raht_plan_copy_array", "raht_plan_stage_stats", "raht_fwd", "raht_fwd_f64", "raht_inv", "raht_inv_f64",
+    "raht_quant_reorder", "raht_dequant_unreorder", "raht_voxelize", "raht_morton", "raht_sort_keys",
+]
+
+
+class RahtError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"{ERRORS.get(code, code)}: {msg}")
+        self.code = code
+
+
+def build(verbose=False):
+    """Compile every HIP source for gfx950 (hipcc cross-compiles without a GPU)."""
+    r = subprocess.run(["make", "-C", _CSRC, "-j4"], capture_output=True, text=True)
+    if verbose or r.returncode != 0:
+        print(r.stdout)
+        print(r.stderr)
+    if r.returncode != 0:
+        raise RuntimeError("building libraht_hip.so failed")
+    return SO_PATH
+
+
+_lib = None
+
+
+def lib():
+    """Load libraht_hip.so; raises if it has not been built (no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(SO_PATH):
+        raise RuntimeError(
+            f"raht-3dgs-codec_amd: HIP library {SO_PATH} is missing. Build it with "
+            f"`python -c 'import __graft_entry__ as g; g.build()'` (or `make -C {_CSRC}`). "
+            "There is no CPU fallback for the RAHT hot path.")
+    try:
+        import torch  # noqa: F401  -- make torch's libamdhip64 the process-wide HIP runtime first
+    except Exception:
+        pass
+    L = C.CDLL(SO_PATH)
+    vp, i64, i32, dbl = C.c_void_p, C.c_int64, C.c_int, C.c_double
+    L.raht_last_error.restype = C.c_char_p
+    L.raht_plan_create.argtypes = [vp, i32, i64, C.POINTER(dbl), dbl, i32, vp, C.POINTER(vp)]
+    L.raht_plan_create_from_keys.argtypes = [vp, i64, i32, vp, vp, C.POINTER(vp)]
+    L.raht_plan_destroy.argtypes = [vp]
+    L.raht_plan_size.argtypes = [vp]
+    L.raht_plan_size.restype = i64
+    L.raht_plan_nbits.argtypes = [vp]
+    L.raht_plan_set_engine.argtypes = [vp, i32, i32]
+    L.raht_plan_levels.argtypes = [vp]
+    L.raht_plan_export_level.argtypes = [vp, i32, vp, vp, vp, C.POINTER(i64)]
+    L.raht_plan_order.argtypes = [vp, vp, vp]
+    L.raht_plan_arrays.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
+    L.raht_plan_copy_array.argtypes = [vp, i32, vp, vp]
+    L.raht_plan_stage_stats.argtypes = [vp, i32, i32, C.POINTER(i32), C.POINTER(i64), i32, C.POINTER(i32)]
+    for f in (L.raht_fwd, L.raht_fwd_f64):
+        f.argtypes = [vp, vp, i64, i32, vp, i64, vp, vp]
+    for f in (L.raht_inv, L.raht_inv_f64):
+        f.argtypes = [vp, vp, i64, i32, vp, i64, vp]
+    L.raht_quant_reorder.argtypes = [vp, vp, i64, i32, C.POINTER(C.c_float), i32, vp, i64, vp]
+    L.raht_dequant_unreorder.argtypes = [vp, vp, i64, i32, C.POINTER(C.c_float), i32, vp, i64, vp]
+    L.raht_voxelize.argtypes = [vp, i64, i64, i32, C.POINTER(C.c_float), dbl, i32, vp, vp, vp, vp, vp,
+                                C.POINTER(i64), C.POINTER(C.c_float), C.POINTER(dbl), C.POINTER(dbl), vp]
+    L.raht_morton.argtypes = [vp, i64, i32, vp, vp]
+    L.raht_sort_keys.argtypes = [vp, i64, i32, vp, vp, vp]
+    _lib = L
+    return L
+
+
+def check(rc):
+    if rc != RAHT_OK:
+        raise RahtError(rc, lib().raht_last_error().decode("utf-8", "replace"))

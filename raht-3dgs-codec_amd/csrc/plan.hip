@@ -1,0 +1,536 @@
+// plan.hip -- the RAHT "plan": list-free replacement of the reference's RAHT_param_reorder_fast
+// (reference python/RAHT_param.py:190-279), built entirely on device from the sorted Morton keys.
+//
+// Structural identity used (verified against the reference lists by
+// tests/test_plan_*): with d[i] = msb(key[i] ^ key[i-1]), row i >= 1 is a right sibling at exactly
+// one binary level l = d[i]; its left partner is the first row of the level-l node that contains
+// row i-1, and its own subtree ends at the first later row whose key differs above bit l. Both ends
+// are found by a galloping + binary search over the sorted keys (O(log subtree) per row).
+#include "raht_common.h"
+
+#include <algorithm>
+#include <cstring>
+
+namespace raht {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+// ---- device error word -------------------------------------------------------------------------
+struct PlanErr {
+    int code;                 // first error code seen (0 = none)
+    unsigned int row;         // smallest offending row
+};
+
+__device__ __forceinline__ void report(PlanErr *e, int code, int64_t row)
+{
+    atomicCAS(&e->code, 0, code);
+    atomicMin(&e->row, (unsigned int)row);
+}
+
+// ---- Morton keys -------------------------------------------------------------------------------
+// get_morton_code (voxelize_pc.py:25-59) / RAHT_param.py:208-212: digit_k = z_k + 2 y_k + 4 x_k at
+// bits [3k, 3k+2]. Implemented with the 21-bit "spread by 3" magic-number sequence.
+__device__ __forceinline__ uint64_t spread3(uint64_t v)
+{
+    v &= 0x1fffffull;
+    v = (v | (v << 32)) & 0x001f00000000ffffull;
+    v = (v | (v << 16)) & 0x001f0000ff0000ffull;
+    v = (v | (v << 8)) & 0x100f00f00f00f00full;
+    v = (v | (v << 4)) & 0x10c30c30c30c30c3ull;
+    v = (v | (v << 2)) & 0x1249249249249249ull;
+    return v;
+}
+
+__device__ __forceinline__ uint64_t morton3(uint64_t x, uint64_t y, uint64_t z)
+{
+    return spread3(z) | (spread3(y) << 1) | (spread3(x) << 2);
+}
+
+template <typename VT>
+__global__ void keys_from_coords_kernel(const VT *__restrict__ V, int64_t N, double m0, double m1,
+                                        double m2, double Q, int depth, uint64_t *__restrict__ keys,
+                                        PlanErr *err)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    // RAHT_param.py:205-206  Vint = floor((V - minV) / Q)
+    const int64_t x = (int64_t)floor(((double)V[3 * i + 0] - m0) / Q);
+    const int64_t y = (int64_t)floor(((double)V[3 * i + 1] - m1) / Q);
+    const int64_t z = (int64_t)floor(((double)V[3 * i + 2] - m2) / Q);
+    const int64_t hi = (int64_t)1 << depth;
+    if (x < 0 || y < 0 || z < 0 || x >= hi || y >= hi || z >= hi) report(err, RAHT_ERR_BOUNDS, i);
+    keys[i] = morton3((uint64_t)x, (uint64_t)y, (uint64_t)z);
+}
+
+__global__ void morton_i64_kernel(const int64_t *__restrict__ V, int64_t N, uint64_t *__restrict__ keys)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    keys[i] = morton3((uint64_t)V[3 * i + 0], (uint64_t)V[3 * i + 1], (uint64_t)V[3 * i + 2]);
+}
+
+// ---- lvl[] -------------------------------------------------------------------------------------
+__global__ void level_kernel(const uint64_t *__restrict__ keys, int64_t N, int nbits,
+                             uint8_t *__restrict__ lvl, PlanErr *err, int *max_level)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int l = -1;                                  // every lane reaches the wave reduction below
+    if (i < N) {
+        const uint64_t k = keys[i];
+        if (nbits < 64 && (k >> nbits) != 0) report(err, RAHT_ERR_BOUNDS, i);
+        if (i == 0) {
+            lvl[0] = 255;
+        } else {
+            const uint64_t p = keys[i - 1];
+            if (k <= p) {
+                report(err, RAHT_ERR_UNSORTED, i);
+                lvl[i] = 0;
+            } else {
+                l = 63 - __clzll((long long)(k ^ p));
+                lvl[i] = (uint8_t)l;
+            }
+        }
+    }
+    int m = l;                                   // one atomic per wave
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) m = max(m, __shfl_xor(m, d, 64));
+    if ((threadIdx.x & 63) == 0 && m >= 0) atomicMax(max_level, m);
+}
+
+// ---- wl[], wr[] --------------------------------------------------------------------------------
+__global__ void extent_kernel(const uint64_t *__restrict__ keys, int64_t N,
+                              const uint8_t *__restrict__ lvl, int32_t *__restrict__ wl,
+                              int32_t *__restrict__ wr)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    if (i == 0) { wl[0] = 0; wr[0] = 0; return; }
+    const int l = lvl[i];
+    // right end: first m > i with (key[m] >> l) != (key[i] >> l), N if none
+    {
+        const uint64_t pref = keys[i] >> l;
+        int64_t pos = i, step = 1;
+        while (pos + step < N && (keys[pos + step] >> l) == pref) { pos += step; step <<= 1; }
+        int64_t lo = pos + 1, hi = min(pos + step, N);    // answer in [lo, hi]
+        while (lo < hi) {
+            const int64_t mid = (lo + hi) >> 1;
+            if ((keys[mid] >> l) == pref) lo = mid + 1; else hi = mid;
+        }
+        wr[i] = (int32_t)(lo - i);
+    }
+    // left end: first row of the level-l node containing row i-1
+    {
+        const uint64_t pref = keys[i - 1] >> l;
+        int64_t pos = i - 1, step = 1;
+        while (pos - step >= 0 && (keys[pos - step] >> l) == pref) { pos -= step; step <<= 1; }
+        int64_t lo = max(pos - step + 1, (int64_t)0), hi = pos;   // node start in [lo, hi]
+        while (lo < hi) {
+            const int64_t mid = (lo + hi) >> 1;
+            if ((keys[mid] >> l) == pref) hi = mid; else lo = mid + 1;
+        }
+        wl[i] = (int32_t)(i - lo);
+    }
+}
+
+// ---- order_RAGFT -------------------------------------------------------------------------------
+// RAHT_param.py:251-274: [root] ++ groups of rows that stop being node starts within octree level
+// g = lvl / 3, coarse to fine, ascending row index inside a group  ==  stable bucket sort by
+// bucket(0) = 0, bucket(i) = 1 + (20 - lvl[i] / 3).
+__global__ void order_bucket_kernel(const uint8_t *__restrict__ lvl, int64_t N, uint8_t *__restrict__ bucket)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    bucket[i] = (i == 0) ? 0 : (uint8_t)(1 + (20 - (int)lvl[i] / 3));
+}
+
+__global__ void level_bucket_kernel(const uint8_t *__restrict__ lvl, int64_t N, uint8_t *__restrict__ bucket)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    bucket[i] = lvl[i] & 63;      // row 0 (255) -> 63, the only member of that bucket
+}
+
+// ---- tile schedule -----------------------------------------------------------------------------
+// Entry j of a stage (row r = rows ? rows[j] : j) is merged inside its tile iff the whole subtree
+// [r - wl, r + wr) lies inside the tile's row range; otherwise it survives to the next stage.
+__global__ void stage_survivor_kernel(const uint32_t *__restrict__ rows, int64_t n, int R, int64_t N,
+                                      const int32_t *__restrict__ wl, const int32_t *__restrict__ wr,
+                                      uint32_t *__restrict__ survivor)
+{
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    const int64_t r = rows ? rows[j] : j;
+    const int64_t t = j / R;
+    const int64_t j0 = t * R, j1 = j0 + R;
+    const int64_t start = rows ? rows[j0] : j0;
+    const int64_t end = (j1 < n) ? (rows ? (int64_t)rows[j1] : j1) : N;
+    const bool merged = (r > 0) && (r - wl[r] >= start) && (r + wr[r] <= end);
+    survivor[j] = merged ? 0u : 1u;
+}
+
+int pick_chunk_channels(int elem_size, int D)
+{
+    (void)elem_size;
+    const int nchunks = (D + 63) / 64;
+    return (D + nchunks - 1) / nchunks;
+}
+
+size_t tile_lds_bytes(int R, int elem_size, int Dc)
+{
+    // data tile + per-slot metadata (row id, wl, wr, a, b, partner, merge list, level) + histograms
+    size_t data = ((size_t)R * Dc * elem_size + 15) & ~(size_t)15;
+    size_t meta = (size_t)R * (4 + 4 + 4 + 2 * elem_size + 2 + 2 + 1);
+    return data + ((meta + 15) & ~(size_t)15) + 1024;
+}
+
+int pick_tile_rows(const raht_plan *plan, int elem_size, int Dc)
+{
+    if (plan->tile_rows_override > 0) return plan->tile_rows_override;
+    static const int cand[] = {512, 384, 256, 192, 128};
+    const size_t budget = 78 * 1024;      // two blocks per CU out of 160 KiB of LDS
+    for (int R : cand) {
+        if (R > 256 && Dc > 32) continue;
+        if (tile_lds_bytes(R, elem_size, Dc) <= budget) return R;
+    }
+    return 0;
+}
+
+static void free_schedule(Schedule &sc)
+{
+    for (auto &st : sc.stages)
+        if (st.rows) (void)hipFree(st.rows);
+    sc.stages.clear();
+}
+
+int get_schedule(raht_plan *plan, int R, hipStream_t s, const Schedule **out)
+{
+    for (auto &sc : plan->schedules)
+        if (sc.tile_rows == R) { *out = &sc; return RAHT_OK; }
+    Schedule sc;
+    sc.tile_rows = R;
+    sc.valid = true;
+    const int64_t N = plan->N;
+    uint32_t *flag = nullptr;
+    RAHT_HIP_CHECK(hipMalloc(&flag, sizeof(uint32_t) * (size_t)N));
+    uint32_t *rows = nullptr;      // rows of the current stage (nullptr = identity)
+    int64_t n = N;
+    int rc = RAHT_OK;
+    for (int k = 0; k < 24; ++k) {
+        Stage st;
+        st.n_entries = n;
+        st.n_tiles = ceil_div(n, R);
+        st.rows = rows;
+        sc.stages.push_back(st);
+        if (n <= R) break;                                   // a single tile finishes the tree
+        hipLaunchKernelGGL(stage_survivor_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, s,
+                           rows, n, R, N, plan->wl, plan->wr, flag);
+        uint32_t *next = nullptr;
+        if (hipMalloc(&next, sizeof(uint32_t) * (size_t)n) != hipSuccess) { rc = RAHT_ERR_NOMEM; break; }
+        int64_t cnt = 0;
+        rc = compact_u32(rows, flag, next, n, &cnt, s);
+        if (rc != RAHT_OK) { (void)hipFree(next); break; }
+        if (cnt >= n || k == 23) {                           // no progress: pathological key pattern
+            (void)hipFree(next);
+            sc.valid = false;
+            break;
+        }
+        // shrink the allocation for long-lived schedules
+        uint32_t *fit = nullptr;
+        if (hipMalloc(&fit, sizeof(uint32_t) * (size_t)cnt) == hipSuccess) {
+            (void)hipMemcpyAsync(fit, next, sizeof(uint32_t) * (size_t)cnt, hipMemcpyDeviceToDevice, s);
+            (void)hipStreamSynchronize(s);
+            (void)hipFree(next);
+            next = fit;
+        }
+        rows = next;
+        n = cnt;
+    }
+    (void)hipFree(flag);
+    if (rc != RAHT_OK) { free_schedule(sc); set_error("schedule build failed"); return rc; }
+    plan->schedules.push_back(sc);
+    *out = &plan->schedules.back();
+    return RAHT_OK;
+}
+
+// ---- plan construction ---------------------------------------------------------------------------
+static int finish_plan(raht_plan *p, const int64_t *leaf_weights, hipStream_t s)
+{
+    const int64_t N = p->N;
+    const unsigned gb = (unsigned)ceil_div(N, 256);
+    PlanErr *derr = nullptr;
+    int *dmax = nullptr;
+    RAHT_HIP_CHECK(hipMalloc(&derr, sizeof(PlanErr)));
+    RAHT_HIP_CHECK(hipMalloc(&dmax, sizeof(int)));
+    PlanErr h0 = {0, 0xffffffffu};
+    int hm = -1;
+    RAHT_HIP_CHECK(hipMemcpyAsync(derr, &h0, sizeof(h0), hipMemcpyHostToDevice, s));
+    RAHT_HIP_CHECK(hipMemcpyAsync(dmax, &hm, sizeof(hm), hipMemcpyHostToDevice, s));
+    RAHT_HIP_CHECK(hipMalloc(&p->lvl, (size_t)N));
+    RAHT_HIP_CHECK(hipMalloc(&p->wl, sizeof(int32_t) * (size_t)N));
+    RAHT_HIP_CHECK(hipMalloc(&p->wr, sizeof(int32_t) * (size_t)N));
+    hipLaunchKernelGGL(level_kernel, dim3(gb), dim3(256), 0, s, p->keys, N, p->nbits, p->lvl, derr, dmax);
+    PlanErr he;
+    RAHT_HIP_CHECK(hipMemcpyAsync(&he, derr, sizeof(he), hipMemcpyDeviceToHost, s));
+    RAHT_HIP_CHECK(hipMemcpyAsync(&hm, dmax, sizeof(hm), hipMemcpyDeviceToHost, s));
+    RAHT_HIP_CHECK(hipStreamSynchronize(s));
+    (void)hipFree(derr);
+    (void)hipFree(dmax);
+    if (he.code != 0) {
+        if (he.code == RAHT_ERR_UNSORTED)
+            set_error("Morton keys are not strictly increasing at row %u (input must be Morton-sorted "
+                      "and duplicate-free)", he.row);
+        else
+            set_error("coordinate / key out of bounds at row %u for depth %d", he.row, p->nbits / 3);
+        return he.code;
+    }
+    p->max_level = hm;
+    hipLaunchKernelGGL(extent_kernel, dim3(gb), dim3(256), 0, s, p->keys, N, p->lvl, p->wl, p->wr);
+
+    // order_RAGFT and the per-level row buckets: two stable bucket sorts
+    uint8_t *bucket = nullptr;
+    uint32_t *boff = nullptr;
+    RAHT_HIP_CHECK(hipMalloc(&bucket, (size_t)N));
+    RAHT_HIP_CHECK(hipMalloc(&boff, sizeof(uint32_t) * 65));
+    RAHT_HIP_CHECK(hipMalloc(&p->order, sizeof(uint32_t) * (size_t)N));
+    RAHT_HIP_CHECK(hipMalloc(&p->level_rows, sizeof(uint32_t) * (size_t)N));
+    hipLaunchKernelGGL(order_bucket_kernel, dim3(gb), dim3(256), 0, s, p->lvl, N, bucket);
+    RAHT_RET(bucket_sort_u8(bucket, p->order, N, 5, nullptr, s));
+    hipLaunchKernelGGL(level_bucket_kernel, dim3(gb), dim3(256), 0, s, p->lvl, N, bucket);
+    RAHT_RET(bucket_sort_u8(bucket, p->level_rows, N, 6, boff, s));
+    RAHT_HIP_CHECK(hipMemcpyAsync(p->level_off, boff, sizeof(uint32_t) * 65, hipMemcpyDeviceToHost, s));
+    RAHT_HIP_CHECK(hipStreamSynchronize(s));
+    (void)hipFree(bucket);
+    (void)hipFree(boff);
+
+    if (leaf_weights) {
+        // prefix sums of the leaf weights on the host: weighted plans are tiny (<= 512 rows when
+        // they stitch the top octree levels of a sharded scene)
+        std::vector<int64_t> w((size_t)N), ps((size_t)N + 1);
+        RAHT_HIP_CHECK(hipMemcpy(w.data(), leaf_weights, sizeof(int64_t) * (size_t)N, hipMemcpyDeviceToHost));
+        ps[0] = 0;
+        for (int64_t i = 0; i < N; ++i) {
+            if (w[(size_t)i] < 1) { set_error("leaf weight < 1 at row %lld", (long long)i); return RAHT_ERR_INVALID; }
+            ps[(size_t)i + 1] = ps[(size_t)i] + w[(size_t)i];
+        }
+        RAHT_HIP_CHECK(hipMalloc(&p->wsum, sizeof(int64_t) * ((size_t)N + 1)));
+        RAHT_HIP_CHECK(hipMemcpy(p->wsum, ps.data(), sizeof(int64_t) * ((size_t)N + 1), hipMemcpyHostToDevice));
+    }
+    RAHT_HIP_CHECK(hipGetLastError());
+    // Build the default schedule now so that float32 transforms with D <= 64 never allocate.
+    const Schedule *sc = nullptr;
+    RAHT_RET(get_schedule(p, 256, s, &sc));
+    return RAHT_OK;
+}
+
+}  // namespace raht
+
+using namespace raht;
+
+extern "C" {
+
+const char *raht_last_error(void) { return g_err; }
+int raht_version(void) { return RAHT_VERSION; }
+
+int raht_plan_create(const void *V, int v_dtype, int64_t N, const double minV[3], double width,
+                     int depth, raht_stream_t stream, raht_plan **out)
+{
+    if (!V || !out || !minV) { set_error("raht_plan_create: NULL argument"); return RAHT_ERR_INVALID; }
+    if (N < 1 || N >= ((int64_t)1 << 31)) { set_error("raht_plan_create: N=%lld out of range", (long long)N); return RAHT_ERR_INVALID; }
+    if (depth < 1 || depth > 21) { set_error("raht_plan_create: depth=%d (1..21)", depth); return RAHT_ERR_INVALID; }
+    if (!(width > 0)) { set_error("raht_plan_create: width must be > 0"); return RAHT_ERR_INVALID; }
+    hipStream_t s = (hipStream_t)stream;
+    raht_plan *p = new raht_plan();
+    p->N = N;
+    p->nbits = 3 * depth;
+    int rc = RAHT_OK;
+    do {
+        if (hipMalloc(&p->keys, sizeof(uint64_t) * (size_t)N) != hipSuccess) { rc = RAHT_ERR_NOMEM; set_error("hipMalloc keys"); break; }
+        PlanErr *derr = nullptr;
+        if (hipMalloc(&derr, sizeof(PlanErr)) != hipSuccess) { rc = RAHT_ERR_NOMEM; break; }
+        PlanErr h0 = {0, 0xffffffffu};
+        (void)hipMemcpyAsync(derr, &h0, sizeof(h0), hipMemcpyHostToDevice, s);
+        const double Q = width / (double)((uint64_t)1 << depth);
+        const unsigned gb = (unsigned)ceil_div(N, 256);
+        switch (v_dtype) {
+        case RAHT_F64: hipLaunchKernelGGL(keys_from_coords_kernel<double>, dim3(gb), dim3(256), 0, s, (const double *)V, N, minV[0], minV[1], minV[2], Q, depth, p->keys, derr); break;
+        case RAHT_F32: hipLaunchKernelGGL(keys_from_coords_kernel<float>, dim3(gb), dim3(256), 0, s, (const float *)V, N, minV[0], minV[1], minV[2], Q, depth, p->keys, derr); break;
+        case RAHT_I32: hipLaunchKernelGGL(keys_from_coords_kernel<int32_t>, dim3(gb), dim3(256), 0, s, (const int32_t *)V, N, minV[0], minV[1], minV[2], Q, depth, p->keys, derr); break;
+        case RAHT_I64: hipLaunchKernelGGL(keys_from_coords_kernel<int64_t>, dim3(gb), dim3(256), 0, s, (const int64_t *)V, N, minV[0], minV[1], minV[2], Q, depth, p->keys, derr); break;
+        default: rc = RAHT_ERR_INVALID; set_error("raht_plan_create: bad v_dtype %d", v_dtype); break;
+        }
+        if (rc != RAHT_OK) { (void)hipFree(derr); break; }
+        PlanErr he;
+        hipError_t e = hipMemcpyAsync(&he, derr, sizeof(he), hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+        (void)hipFree(derr);
+        if (e != hipSuccess) { rc = RAHT_ERR_HIP; set_error("plan keys: %s", hipGetErrorString(e)); break; }
+        if (he.code != 0) {
+            rc = he.code;
+            set_error("coordinate out of [0, 2^%d) at row %u (reference RAHT_param.py:26-27 raises ValueError)", depth, he.row);
+            break;
+        }
+        rc = finish_plan(p, nullptr, s);
+    } while (0);
+    if (rc != RAHT_OK) { raht_plan_destroy(p); return rc; }
+    *out = p;
+    return RAHT_OK;
+}
+
+int raht_plan_create_from_keys(const uint64_t *keys_sorted, int64_t N, int nbits,
+                               const int64_t *leaf_weights, raht_stream_t stream, raht_plan **out)
+{
+    if (!keys_sorted || !out) { set_error("raht_plan_create_from_keys: NULL argument"); return RAHT_ERR_INVALID; }
+    if (N < 1 || N >= ((int64_t)1 << 31)) { set_error("raht_plan_create_from_keys: N=%lld out of range", (long long)N); return RAHT_ERR_INVALID; }
+    if (nbits < 1 || nbits > 63) { set_error("raht_plan_create_from_keys: nbits=%d (1..63)", nbits); return RAHT_ERR_INVALID; }
+    hipStream_t s = (hipStream_t)stream;
+    raht_plan *p = new raht_plan();
+    p->N = N;
+    p->nbits = nbits;
+    int rc = RAHT_OK;
+    if (hipMalloc(&p->keys, sizeof(uint64_t) * (size_t)N) != hipSuccess) { rc = RAHT_ERR_NOMEM; set_error("hipMalloc keys"); }
+    if (rc == RAHT_OK && hipMemcpyAsync(p->keys, keys_sorted, sizeof(uint64_t) * (size_t)N, hipMemcpyDeviceToDevice, s) != hipSuccess) { rc = RAHT_ERR_HIP; set_error("copy keys"); }
+    if (rc == RAHT_OK) rc = finish_plan(p, leaf_weights, s);
+    if (rc != RAHT_OK) { raht_plan_destroy(p); return rc; }
+    *out = p;
+    return RAHT_OK;
+}
+
+int raht_plan_destroy(raht_plan *p)
+{
+    if (!p) return RAHT_OK;
+    for (auto &sc : p->schedules) free_schedule(sc);
+    if (p->keys) (void)hipFree(p->keys);
+    if (p->lvl) (void)hipFree(p->lvl);
+    if (p->wl) (void)hipFree(p->wl);
+    if (p->wr) (void)hipFree(p->wr);
+    if (p->wsum) (void)hipFree(p->wsum);
+    if (p->order) (void)hipFree(p->order);
+    if (p->level_rows) (void)hipFree(p->level_rows);
+    delete p;
+    return RAHT_OK;
+}
+
+int64_t raht_plan_size(const raht_plan *p) { return p ? p->N : -1; }
+int raht_plan_nbits(const raht_plan *p) { return p ? p->nbits : -1; }
+
+int raht_plan_set_engine(raht_plan *p, int engine, int tile_rows)
+{
+    if (!p || (engine != RAHT_ENGINE_TILE && engine != RAHT_ENGINE_LEVEL)) { set_error("raht_plan_set_engine: bad argument"); return RAHT_ERR_INVALID; }
+    if (tile_rows != 0 && (tile_rows < 64 || tile_rows > 1024 || (tile_rows & 3))) { set_error("tile_rows must be a multiple of 4 in [64, 1024]"); return RAHT_ERR_INVALID; }
+    p->engine = engine;
+    p->tile_rows_override = tile_rows;
+    return RAHT_OK;
+}
+
+// len(Flags) of the reference: the loop of RAHT_param.py:226 stops at the level where a single
+// node is left, i.e. after the highest level that has a pair.
+int raht_plan_levels(const raht_plan *p)
+{
+    if (!p) return -1;
+    return p->N == 1 ? 1 : p->max_level + 1;
+}
+
+int raht_plan_export_level(const raht_plan *cp, int level, int64_t *list, uint8_t *flags,
+                           int64_t *weights, int64_t *n_out)
+{
+    raht_plan *p = const_cast<raht_plan *>(cp);
+    if (!p || !n_out) { set_error("raht_plan_export_level: NULL argument"); return RAHT_ERR_INVALID; }
+    if (level < 0 || level >= raht_plan_levels(p)) { set_error("raht_plan_export_level: level %d out of range", level); return RAHT_ERR_INVALID; }
+    if (p->lvl_host.empty()) {
+        p->lvl_host.resize((size_t)p->N);
+        RAHT_HIP_CHECK(hipMemcpy(p->lvl_host.data(), p->lvl, (size_t)p->N, hipMemcpyDeviceToHost));
+    }
+    const uint8_t *lv = p->lvl_host.data();
+    std::vector<int64_t> ws;
+    if (p->wsum) {
+        ws.resize((size_t)p->N + 1);
+        RAHT_HIP_CHECK(hipMemcpy(ws.data(), p->wsum, sizeof(int64_t) * ((size_t)p->N + 1), hipMemcpyDeviceToHost));
+    }
+    // nodes alive at `level` start at row 0 and at every row whose own level is >= `level`
+    int64_t n = 0, prev = -1;
+    for (int64_t i = 0; i < p->N; ++i) {
+        if (i != 0 && lv[i] < level) continue;
+        if (prev >= 0) {
+            if (weights) weights[n - 1] = p->wsum ? ws[(size_t)i] - ws[(size_t)prev] : i - prev;
+            if (flags) flags[n - 1] = (lv[i] == level) ? 1 : 0;
+        }
+        if (list) list[n] = i;
+        prev = i;
+        ++n;
+    }
+    if (weights) weights[n - 1] = p->wsum ? ws[(size_t)p->N] - ws[(size_t)prev] : p->N - prev;
+    if (flags) flags[n - 1] = 0;
+    *n_out = n;
+    return RAHT_OK;
+}
+
+__global__ void order_to_i64_kernel(const uint32_t *__restrict__ o, int64_t N, int64_t *__restrict__ out)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < N) out[i] = (int64_t)o[i];
+}
+
+int raht_plan_order(const raht_plan *p, int64_t *order_dev, raht_stream_t stream)
+{
+    if (!p || !order_dev) { set_error("raht_plan_order: NULL argument"); return RAHT_ERR_INVALID; }
+    hipLaunchKernelGGL(order_to_i64_kernel, dim3((unsigned)ceil_div(p->N, 256)), dim3(256), 0,
+                       (hipStream_t)stream, p->order, p->N, order_dev);
+    RAHT_HIP_CHECK(hipGetLastError());
+    return RAHT_OK;
+}
+
+int raht_plan_arrays(const raht_plan *p, const uint64_t **keys, const uint8_t **lvl,
+                     const int32_t **wl, const int32_t **wr)
+{
+    if (!p) return RAHT_ERR_INVALID;
+    if (keys) *keys = p->keys;
+    if (lvl) *lvl = p->lvl;
+    if (wl) *wl = p->wl;
+    if (wr) *wr = p->wr;
+    return RAHT_OK;
+}
+
+int raht_plan_copy_array(const raht_plan *p, int which, void *dst, raht_stream_t stream)
+{
+    if (!p || !dst || which < 0 || which > 3) { set_error("raht_plan_copy_array: bad argument"); return RAHT_ERR_INVALID; }
+    const void *src[4] = {p->keys, p->lvl, p->wl, p->wr};
+    const size_t es[4] = {8, 1, 4, 4};
+    RAHT_HIP_CHECK(hipMemcpyAsync(dst, src[which], es[which] * (size_t)p->N, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return RAHT_OK;
+}
+
+int raht_plan_stage_stats(raht_plan *p, int elem_size, int D, int *n_stages, int64_t *rows_per_stage,
+                          int max_stages, int *tile_rows)
+{
+    if (!p || !n_stages) return RAHT_ERR_INVALID;
+    const int Dc = pick_chunk_channels(elem_size, D);
+    const int R = pick_tile_rows(p, elem_size, Dc);
+    if (R == 0) { set_error("no tile size fits"); return RAHT_ERR_UNSUPPORTED; }
+    const Schedule *sc = nullptr;
+    RAHT_RET(get_schedule(p, R, nullptr, &sc));
+    *n_stages = sc->valid ? (int)sc->stages.size() : -(int)sc->stages.size();
+    if (tile_rows) *tile_rows = R;
+    for (int k = 0; k < (int)sc->stages.size() && k < max_stages; ++k)
+        if (rows_per_stage) rows_per_stage[k] = sc->stages[(size_t)k].n_entries;
+    return RAHT_OK;
+}
+
+int raht_morton(const int64_t *V, int64_t N, int J, uint64_t *keys, raht_stream_t stream)
+{
+    if (!V || !keys || N < 0 || J < 1 || J > 21) { set_error("raht_morton: bad argument"); return RAHT_ERR_INVALID; }
+    if (N == 0) return RAHT_OK;
+    hipLaunchKernelGGL(morton_i64_kernel, dim3((unsigned)ceil_div(N, 256)), dim3(256), 0,
+                       (hipStream_t)stream, V, N, keys);
+    RAHT_HIP_CHECK(hipGetLastError());
+    return RAHT_OK;
+}
+
+}  // extern "C"

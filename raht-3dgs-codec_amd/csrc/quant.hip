@@ -1,0 +1,100 @@
+// quant.hip -- quantize + reorder / dequantize + un-reorder, the driver-inline arithmetic around
+// the transform (reference python/encode_3dgs.py:204 floor(x/step+0.5), :210 index_select(0,
+// order_RAGFT), :215 int32; :261 x*step, :267-268 gather by argsort(order_RAGFT)).
+//
+// One wave per coefficient row: lanes map to channels, so the permuted row read (gather through
+// order_RAGFT) and the row write are each a single coalesced segment. HBM-bound, 8 bytes/element.
+#include "raht_common.h"
+
+#include <algorithm>
+
+namespace raht {
+
+constexpr int MAX_STEP_CH = 256;
+
+struct StepTable {
+    int n;                         // 1 or D
+    float v[MAX_STEP_CH];
+};
+
+__global__ __launch_bounds__(256) void quant_reorder_kernel(const float *__restrict__ T, int64_t ldt, int D,
+                                                            const uint32_t *__restrict__ order, int64_t N,
+                                                            const StepTable steps, int32_t *__restrict__ Q,
+                                                            int64_t ldq)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (int64_t k = wave; k < N; k += nwaves) {
+        const float *src = T + (int64_t)order[k] * ldt;          // :210
+        int32_t *dst = Q + k * ldq;
+        for (int c = lane; c < D; c += 64) {
+            const float st = steps.v[steps.n == 1 ? 0 : c];
+            dst[c] = (int32_t)floorf(src[c] / st + 0.5f);         // :204, :215
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void dequant_unreorder_kernel(const int32_t *__restrict__ Q, int64_t ldq, int D,
+                                                                const uint32_t *__restrict__ order, int64_t N,
+                                                                const StepTable steps, float *__restrict__ T,
+                                                                int64_t ldt)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (int64_t k = wave; k < N; k += nwaves) {
+        const int32_t *src = Q + k * ldq;
+        float *dst = T + (int64_t)order[k] * ldt;                 // inverse of :210 == :267-268
+        for (int c = lane; c < D; c += 64) {
+            const float st = steps.v[steps.n == 1 ? 0 : c];
+            dst[c] = (float)src[c] * st;                          // :261
+        }
+    }
+}
+
+static int fill_steps(StepTable &t, const float *steps, int n_steps, int D)
+{
+    if (!steps || !(n_steps == 1 || n_steps == D)) { set_error("quant: n_steps must be 1 or D"); return RAHT_ERR_INVALID; }
+    if (n_steps > MAX_STEP_CH) { set_error("quant: per-channel steps support D <= %d", MAX_STEP_CH); return RAHT_ERR_UNSUPPORTED; }
+    t.n = n_steps;
+    for (int c = 0; c < n_steps; ++c) {
+        if (!(steps[c] > 0.0f)) { set_error("quant: step[%d] must be > 0", c); return RAHT_ERR_INVALID; }
+        t.v[c] = steps[c];
+    }
+    return RAHT_OK;
+}
+
+}  // namespace raht
+
+using namespace raht;
+
+extern "C" {
+
+int raht_quant_reorder(const raht_plan *p, const float *T, int64_t ldt, int D, const float *steps, int n_steps,
+                       int32_t *Q, int64_t ldq, raht_stream_t stream)
+{
+    if (!p || !T || !Q || D < 1 || ldt < D || ldq < D) { set_error("raht_quant_reorder: bad argument"); return RAHT_ERR_INVALID; }
+    StepTable st;
+    RAHT_RET(fill_steps(st, steps, n_steps, D));
+    const unsigned gb = (unsigned)std::min<int64_t>(ceil_div(p->N, 4), 4096);
+    hipLaunchKernelGGL(quant_reorder_kernel, dim3(gb), dim3(256), 0, (hipStream_t)stream, T, ldt, D, p->order,
+                       p->N, st, Q, ldq);
+    RAHT_HIP_CHECK(hipGetLastError());
+    return RAHT_OK;
+}
+
+int raht_dequant_unreorder(const raht_plan *p, const int32_t *Q, int64_t ldq, int D, const float *steps,
+                           int n_steps, float *T, int64_t ldt, raht_stream_t stream)
+{
+    if (!p || !T || !Q || D < 1 || ldt < D || ldq < D) { set_error("raht_dequant_unreorder: bad argument"); return RAHT_ERR_INVALID; }
+    StepTable st;
+    RAHT_RET(fill_steps(st, steps, n_steps, D));
+    const unsigned gb = (unsigned)std::min<int64_t>(ceil_div(p->N, 4), 4096);
+    hipLaunchKernelGGL(dequant_unreorder_kernel, dim3(gb), dim3(256), 0, (hipStream_t)stream, Q, ldq, D,
+                       p->order, p->N, st, T, ldt);
+    RAHT_HIP_CHECK(hipGetLastError());
+    return RAHT_OK;
+}
+
+}  // extern "C"

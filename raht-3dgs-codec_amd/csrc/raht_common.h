@@ -1,0 +1,99 @@
+// raht_common.h -- internal declarations shared by the HIP translation units of libraht_hip.so.
+// gfx950 (MI355X) only: wave = 64 lanes, 160 KiB LDS per CU, 256 CUs in 8 XCDs.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <vector>
+
+#include "raht.h"
+
+#define RAHT_WAVE 64
+#define RAHT_MAX_LEVELS 64
+
+namespace raht {
+
+void set_error(const char *fmt, ...);
+
+#define RAHT_HIP_CHECK(expr)                                                              \
+    do {                                                                                  \
+        hipError_t _e = (expr);                                                           \
+        if (_e != hipSuccess) {                                                           \
+            raht::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, \
+                            __LINE__);                                                    \
+            return RAHT_ERR_HIP;                                                          \
+        }                                                                                 \
+    } while (0)
+
+#define RAHT_RET(expr)                 \
+    do {                               \
+        int _r = (expr);               \
+        if (_r != RAHT_OK) return _r;  \
+    } while (0)
+
+static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// ---- device primitives (scan_sort.hip) ---------------------------------------------------------
+// Exclusive prefix sum of n uint32 values, in place allowed (out may equal in). `total` (device
+// uint32*, may be NULL) receives the sum. Allocates its own small workspace (plan/voxelize time
+// only -- never called from the transform entry points).
+int exclusive_scan_u32(const uint32_t *in, uint32_t *out, int64_t n, uint32_t *total, hipStream_t s);
+
+// One stable LSD radix pass on `bits`-wide digits (bits <= 8) taken at `shift`.
+// keys are uint64; payload is uint32. keys_out / vals_in / vals_out may be NULL
+// (vals_in == NULL means payload = original index).
+int radix_pass_u64(const uint64_t *keys_in, const uint32_t *vals_in, uint64_t *keys_out,
+                   uint32_t *vals_out, int64_t n, int shift, int bits, hipStream_t s);
+// Same for uint8 bucket ids (< 2^bits); produces the stable permutation and, optionally, the
+// start offset of every bucket (bucket_off: device uint32[(1<<bits)+1]).
+int bucket_sort_u8(const uint8_t *bucket, uint32_t *perm_out, int64_t n, int bits,
+                   uint32_t *bucket_off, hipStream_t s);
+
+// out[k] = in[j] (or j when in == NULL) for the k-th j with flag[j] != 0. *count_host gets the
+// number of kept items (synchronises the stream).
+int compact_u32(const uint32_t *in, const uint32_t *flag, uint32_t *out, int64_t n,
+                int64_t *count_host, hipStream_t s);
+
+// ---- plan (plan.hip) ---------------------------------------------------------------------------
+struct Stage {
+    int64_t n_entries = 0;   // active rows entering this stage
+    int64_t n_tiles = 0;
+    uint32_t *rows = nullptr;  // device; nullptr for stage 0 (identity)
+};
+
+struct Schedule {
+    int tile_rows = 0;
+    bool valid = false;        // false: tile stages cannot finish the tree -> use the level engine
+    std::vector<Stage> stages;
+};
+
+}  // namespace raht
+
+struct raht_plan {
+    int64_t N = 0;
+    int nbits = 0;
+    int max_level = -1;          // highest binary level with a pair (-1 when N == 1)
+    uint64_t *keys = nullptr;    // device, sorted Morton keys
+    uint8_t *lvl = nullptr;      // device, 255 for row 0
+    int32_t *wl = nullptr;       // device
+    int32_t *wr = nullptr;       // device
+    int64_t *wsum = nullptr;     // device int64[N+1] prefix of leaf weights, or nullptr (all ones)
+    uint32_t *order = nullptr;   // device, order_RAGFT
+    uint32_t *level_rows = nullptr;          // device, rows 1..N-1 stably sorted by lvl
+    uint32_t level_off[RAHT_MAX_LEVELS + 1]; // host, start of every level inside level_rows
+    int engine = RAHT_ENGINE_TILE;
+    int tile_rows_override = 0;
+    std::vector<raht::Schedule> schedules;   // cache keyed by tile_rows
+    std::vector<uint8_t> lvl_host;           // lazily downloaded for export_level
+};
+
+namespace raht {
+// Tile schedule for `tile_rows` rows per tile (built on first use, cached in the plan).
+int get_schedule(raht_plan *plan, int tile_rows, hipStream_t s, const Schedule **out);
+// Rows per LDS tile for an element size / channel count (0 = does not fit).
+int pick_tile_rows(const raht_plan *plan, int elem_size, int chunk_channels);
+int pick_chunk_channels(int elem_size, int D);
+}  // namespace raht

@@ -1,0 +1,327 @@
+// scan_sort.hip -- device primitives for the plan and the voxelizer: exclusive scan, stable LSD
+// radix pass (wave64 ballot ranking), bucket sort, stream compaction. Hand-written for gfx950:
+// 64-lane ballots, LDS histograms, no library calls.
+//
+// These are integer/HBM-bound kernels (no MFMA). They run at plan / voxelize time, not inside the
+// transform entry points.
+#include "raht_common.h"
+
+namespace raht {
+
+// ------------------------------------------------------------------------------------------------
+// Exclusive scan (3 kernels, recursive on the block sums).
+// ------------------------------------------------------------------------------------------------
+constexpr int SCAN_THREADS = 256;
+constexpr int SCAN_ITEMS = 8;
+constexpr int SCAN_BLOCK = SCAN_THREADS * SCAN_ITEMS;   // 2048 items per block
+
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v)
+{
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint32_t t = __shfl_up(v, d, 64);
+        if (lane >= d) v += t;
+    }
+    return v;
+}
+
+// Block-wide exclusive scan of one value per thread (256 threads). Returns the exclusive prefix;
+// *block_total receives the sum (valid in every thread).
+__device__ __forceinline__ uint32_t block_excl_scan_256(uint32_t v, uint32_t *block_total)
+{
+    __shared__ uint32_t wsum[4];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    uint32_t inc = wave_incl_scan(v);
+    if (lane == 63) wsum[wid] = inc;
+    __syncthreads();
+    uint32_t base = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        uint32_t s = wsum[w];
+        if (w < wid) base += s;
+        tot += s;
+    }
+    __syncthreads();
+    *block_total = tot;
+    return base + inc - v;
+}
+
+__global__ __launch_bounds__(SCAN_THREADS) void scan_block_kernel(const uint32_t *in,   // may alias out
+                                                                  uint32_t *out,
+                                                                  uint32_t *sums,
+                                                                  int64_t n)
+{
+    const int64_t base = (int64_t)blockIdx.x * SCAN_BLOCK + (int64_t)threadIdx.x * SCAN_ITEMS;
+    uint32_t v[SCAN_ITEMS];
+    uint32_t tsum = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k) {
+        v[k] = (base + k < n) ? in[base + k] : 0u;
+        tsum += v[k];
+    }
+    uint32_t tot;
+    uint32_t ex = block_excl_scan_256(tsum, &tot);
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k) {
+        if (base + k < n) out[base + k] = ex;
+        ex += v[k];
+    }
+    if (threadIdx.x == 0 && sums) sums[blockIdx.x] = tot;
+}
+
+__global__ __launch_bounds__(SCAN_THREADS) void scan_add_kernel(uint32_t *__restrict__ out,
+                                                                const uint32_t *__restrict__ sums,
+                                                                int64_t n)
+{
+    const uint32_t add = sums[blockIdx.x];
+    const int64_t base = (int64_t)blockIdx.x * SCAN_BLOCK + (int64_t)threadIdx.x * SCAN_ITEMS;
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k)
+        if (base + k < n) out[base + k] += add;
+}
+
+__global__ void scan_total_kernel(const uint32_t *in_last, const uint32_t *out_last, uint32_t *total)
+{
+    *total = *in_last + *out_last;
+}
+
+static int scan_rec(const uint32_t *in, uint32_t *out, int64_t n, uint32_t *ws, hipStream_t s)
+{
+    const int64_t nb = ceil_div(n, SCAN_BLOCK);
+    if (nb == 1) {
+        hipLaunchKernelGGL(scan_block_kernel, dim3(1), dim3(SCAN_THREADS), 0, s, in, out,
+                           (uint32_t *)nullptr, n);
+        return RAHT_OK;
+    }
+    uint32_t *sums = ws;
+    hipLaunchKernelGGL(scan_block_kernel, dim3((unsigned)nb), dim3(SCAN_THREADS), 0, s, in, out, sums, n);
+    RAHT_RET(scan_rec(sums, sums, nb, ws + nb, s));
+    hipLaunchKernelGGL(scan_add_kernel, dim3((unsigned)nb), dim3(SCAN_THREADS), 0, s, out, sums, n);
+    return RAHT_OK;
+}
+
+int exclusive_scan_u32(const uint32_t *in, uint32_t *out, int64_t n, uint32_t *total, hipStream_t s)
+{
+    if (n <= 0) {
+        if (total) RAHT_HIP_CHECK(hipMemsetAsync(total, 0, sizeof(uint32_t), s));
+        return RAHT_OK;
+    }
+    // workspace: nb + nb/2048 + ... entries
+    int64_t wsn = 0;
+    for (int64_t m = ceil_div(n, SCAN_BLOCK); m > 1; m = ceil_div(m, SCAN_BLOCK)) wsn += m;
+    uint32_t *ws = nullptr;
+    uint32_t *last_in = nullptr;
+    if (wsn > 0) RAHT_HIP_CHECK(hipMalloc(&ws, sizeof(uint32_t) * (size_t)wsn));
+    if (total) {
+        // keep in[n-1] (out may alias in)
+        RAHT_HIP_CHECK(hipMalloc(&last_in, sizeof(uint32_t)));
+        RAHT_HIP_CHECK(hipMemcpyAsync(last_in, in + (n - 1), sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
+    }
+    int rc = scan_rec(in, out, n, ws, s);
+    if (rc == RAHT_OK && total)
+        hipLaunchKernelGGL(scan_total_kernel, dim3(1), dim3(1), 0, s, last_in, out + (n - 1), total);
+    // The stream-ordered frees below are safe: hipFree synchronises with outstanding work.
+    if (ws) (void)hipFree(ws);
+    if (last_in) (void)hipFree(last_in);
+    RAHT_HIP_CHECK(hipGetLastError());
+    return rc;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Stable LSD radix pass. A block owns RP_BLOCK consecutive items; its 4 waves own consecutive
+// quarter-chunks and walk them in rounds of 64 (one item per lane), so "earlier" in memory order is
+// (block, wave, round, lane) -- ranks are assigned in exactly that order, which makes the pass stable.
+// ------------------------------------------------------------------------------------------------
+constexpr int RP_THREADS = 256;
+constexpr int RP_WAVES = 4;
+constexpr int RP_ROUNDS = 16;
+constexpr int RP_WAVE_ITEMS = 64 * RP_ROUNDS;          // 1024
+constexpr int RP_BLOCK = RP_WAVES * RP_WAVE_ITEMS;     // 4096 items per block
+
+template <typename KeyT>
+__device__ __forceinline__ uint32_t digit_of(KeyT k, int shift, uint32_t mask)
+{
+    return (uint32_t)(k >> shift) & mask;
+}
+
+template <typename KeyT>
+__global__ __launch_bounds__(RP_THREADS) void radix_hist_kernel(const KeyT *__restrict__ keys,
+                                                                int64_t n, int shift, uint32_t mask,
+                                                                uint32_t *__restrict__ ghist,
+                                                                uint32_t nblocks)
+{
+    __shared__ uint32_t h[256];
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    const int64_t base = (int64_t)blockIdx.x * RP_BLOCK;
+#pragma unroll 4
+    for (int k = 0; k < RP_BLOCK / RP_THREADS; ++k) {
+        const int64_t i = base + (int64_t)k * RP_THREADS + threadIdx.x;
+        if (i < n) atomicAdd(&h[digit_of(keys[i], shift, mask)], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x <= mask) ghist[(size_t)threadIdx.x * nblocks + blockIdx.x] = h[threadIdx.x];
+}
+
+// Lanes of the wave holding the same digit as this lane (among `valid` lanes).
+__device__ __forceinline__ uint64_t match_digit(uint32_t digit, int bits, uint64_t valid)
+{
+    uint64_t m = valid;
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+        if (b < bits) {
+            const uint64_t bal = __ballot((digit >> b) & 1u);
+            m &= ((digit >> b) & 1u) ? bal : ~bal;
+        }
+    }
+    return m;
+}
+
+template <typename KeyT, bool HAS_VALS_IN, bool WRITE_KEYS>
+__global__ __launch_bounds__(RP_THREADS) void radix_scatter_kernel(
+    const KeyT *__restrict__ keys_in, const uint32_t *__restrict__ vals_in,
+    KeyT *__restrict__ keys_out, uint32_t *__restrict__ vals_out, int64_t n, int shift, int bits,
+    const uint32_t *__restrict__ goffs, uint32_t nblocks)
+{
+    __shared__ uint32_t wcnt[RP_WAVES][256];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const uint32_t mask = (1u << bits) - 1u;
+    for (int k = threadIdx.x; k < RP_WAVES * 256; k += RP_THREADS) (&wcnt[0][0])[k] = 0;
+    __syncthreads();
+
+    const int64_t wbase = (int64_t)blockIdx.x * RP_BLOCK + (int64_t)wid * RP_WAVE_ITEMS;
+    KeyT key[RP_ROUNDS];
+    // phase 1: per-wave digit histogram (keys stay in registers)
+#pragma unroll
+    for (int r = 0; r < RP_ROUNDS; ++r) {
+        const int64_t i = wbase + r * 64 + lane;
+        key[r] = (i < n) ? keys_in[i] : (KeyT)0;
+        if (i < n) atomicAdd(&wcnt[wid][digit_of(key[r], shift, mask)], 1u);
+    }
+    __syncthreads();
+    // phase 2: turn counts into start offsets: global digit offset of this block + earlier waves
+    if (threadIdx.x <= mask) {
+        uint32_t run = goffs[(size_t)threadIdx.x * nblocks + blockIdx.x];
+#pragma unroll
+        for (int w = 0; w < RP_WAVES; ++w) {
+            const uint32_t c = wcnt[w][threadIdx.x];
+            wcnt[w][threadIdx.x] = run;
+            run += c;
+        }
+    }
+    __syncthreads();
+    // phase 3: rank inside the round by ballots, bump the wave's running offset, scatter
+    volatile uint32_t *myc = wcnt[wid];
+    const uint64_t lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+#pragma unroll
+    for (int r = 0; r < RP_ROUNDS; ++r) {
+        const int64_t i = wbase + r * 64 + lane;
+        const bool valid = i < n;
+        const uint64_t vmask = __ballot(valid);
+        if (vmask == 0) break;                       // wave-uniform
+        const uint32_t d = digit_of(key[r], shift, mask);
+        const uint64_t same = match_digit(d, bits, vmask);
+        const uint32_t rank = (uint32_t)__popcll(same & lt);
+        uint32_t pos = 0;
+        if (valid) pos = myc[d] + rank;
+        __builtin_amdgcn_wave_barrier();
+        if (valid && rank == 0) myc[d] = pos + (uint32_t)__popcll(same);
+        __builtin_amdgcn_wave_barrier();
+        if (valid) {
+            if (WRITE_KEYS) keys_out[pos] = key[r];
+            vals_out[pos] = HAS_VALS_IN ? vals_in[i] : (uint32_t)i;
+        }
+    }
+}
+
+template <typename KeyT>
+static int radix_pass_impl(const KeyT *keys_in, const uint32_t *vals_in, KeyT *keys_out,
+                           uint32_t *vals_out, int64_t n, int shift, int bits, uint32_t *bucket_off,
+                           hipStream_t s)
+{
+    if (n <= 0) return RAHT_OK;
+    if (bits < 1 || bits > 8) { set_error("radix pass: bits=%d", bits); return RAHT_ERR_INVALID; }
+    const uint32_t nb = (uint32_t)ceil_div(n, RP_BLOCK);
+    const uint32_t nd = 1u << bits;
+    uint32_t *ghist = nullptr;
+    RAHT_HIP_CHECK(hipMalloc(&ghist, sizeof(uint32_t) * (size_t)nd * nb));
+    hipLaunchKernelGGL(radix_hist_kernel<KeyT>, dim3(nb), dim3(RP_THREADS), 0, s, keys_in, n, shift,
+                       nd - 1u, ghist, nb);
+    int rc = exclusive_scan_u32(ghist, ghist, (int64_t)nd * nb, nullptr, s);
+    if (rc != RAHT_OK) { (void)hipFree(ghist); return rc; }
+    if (bucket_off) {
+        // start of bucket d = goffs[d * nb + 0]; end sentinel = n
+        RAHT_HIP_CHECK(hipMemcpy2DAsync(bucket_off, sizeof(uint32_t), ghist, sizeof(uint32_t) * nb,
+                                        sizeof(uint32_t), nd, hipMemcpyDeviceToDevice, s));
+        const uint32_t n32 = (uint32_t)n;
+        RAHT_HIP_CHECK(hipMemcpyAsync(bucket_off + nd, &n32, sizeof(uint32_t), hipMemcpyHostToDevice, s));
+        RAHT_HIP_CHECK(hipStreamSynchronize(s));   // n32 lives on this stack frame
+    }
+    if (vals_in) {
+        if (keys_out)
+            hipLaunchKernelGGL((radix_scatter_kernel<KeyT, true, true>), dim3(nb), dim3(RP_THREADS), 0,
+                               s, keys_in, vals_in, keys_out, vals_out, n, shift, bits, ghist, nb);
+        else
+            hipLaunchKernelGGL((radix_scatter_kernel<KeyT, true, false>), dim3(nb), dim3(RP_THREADS), 0,
+                               s, keys_in, vals_in, keys_out, vals_out, n, shift, bits, ghist, nb);
+    } else {
+        if (keys_out)
+            hipLaunchKernelGGL((radix_scatter_kernel<KeyT, false, true>), dim3(nb), dim3(RP_THREADS), 0,
+                               s, keys_in, vals_in, keys_out, vals_out, n, shift, bits, ghist, nb);
+        else
+            hipLaunchKernelGGL((radix_scatter_kernel<KeyT, false, false>), dim3(nb), dim3(RP_THREADS), 0,
+                               s, keys_in, vals_in, keys_out, vals_out, n, shift, bits, ghist, nb);
+    }
+    RAHT_HIP_CHECK(hipGetLastError());
+    (void)hipFree(ghist);
+    return RAHT_OK;
+}
+
+int radix_pass_u64(const uint64_t *keys_in, const uint32_t *vals_in, uint64_t *keys_out,
+                   uint32_t *vals_out, int64_t n, int shift, int bits, hipStream_t s)
+{
+    return radix_pass_impl<uint64_t>(keys_in, vals_in, keys_out, vals_out, n, shift, bits, nullptr, s);
+}
+
+int bucket_sort_u8(const uint8_t *bucket, uint32_t *perm_out, int64_t n, int bits,
+                   uint32_t *bucket_off, hipStream_t s)
+{
+    return radix_pass_impl<uint8_t>(bucket, nullptr, nullptr, perm_out, n, 0, bits, bucket_off, s);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Stream compaction.
+// ------------------------------------------------------------------------------------------------
+__global__ void compact_scatter_kernel(const uint32_t *__restrict__ in, const uint32_t *__restrict__ flag,
+                                       const uint32_t *__restrict__ pos, uint32_t *__restrict__ out,
+                                       int64_t n)
+{
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < n && flag[j]) out[pos[j]] = in ? in[j] : (uint32_t)j;
+}
+
+int compact_u32(const uint32_t *in, const uint32_t *flag, uint32_t *out, int64_t n,
+                int64_t *count_host, hipStream_t s)
+{
+    *count_host = 0;
+    if (n <= 0) return RAHT_OK;
+    uint32_t *pos = nullptr, *total = nullptr;
+    RAHT_HIP_CHECK(hipMalloc(&pos, sizeof(uint32_t) * (size_t)n));
+    RAHT_HIP_CHECK(hipMalloc(&total, sizeof(uint32_t)));
+    int rc = exclusive_scan_u32(flag, pos, n, total, s);
+    if (rc == RAHT_OK) {
+        hipLaunchKernelGGL(compact_scatter_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, s, in,
+                           flag, pos, out, n);
+        uint32_t t = 0;
+        hipError_t e = hipMemcpyAsync(&t, total, sizeof(uint32_t), hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+        if (e != hipSuccess) { set_error("compact: %s", hipGetErrorString(e)); rc = RAHT_ERR_HIP; }
+        *count_host = t;
+    }
+    (void)hipFree(pos);
+    (void)hipFree(total);
+    return rc;
+}
+
+}  // namespace raht

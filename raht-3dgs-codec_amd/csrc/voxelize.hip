@@ -1,0 +1,260 @@
+// voxelize.hip -- on-device voxelizer: shift / quantize / clamp, 3J-bit Morton key, stable LSD radix
+// sort (8-bit digits, wave64 ballot ranking -- scan_sort.hip), voxel boundaries, per-voxel mean.
+// Replaces voxelize_pc_batched (reference python/voxelize_pc.py:62-172). Float32 arithmetic, as
+// torch performs it on a float32 point cloud; integer outputs are bit-exact.
+#include "raht_common.h"
+
+#include <algorithm>
+#include <cmath>
+
+namespace raht {
+
+__device__ __forceinline__ uint64_t vx_spread3(uint64_t v)
+{
+    v &= 0x1fffffull;
+    v = (v | (v << 32)) & 0x001f00000000ffffull;
+    v = (v | (v << 16)) & 0x001f0000ff0000ffull;
+    v = (v | (v << 8)) & 0x100f00f00f00f00full;
+    v = (v | (v << 4)) & 0x10c30c30c30c30c3ull;
+    v = (v | (v << 2)) & 0x1249249249249249ull;
+    return v;
+}
+
+__device__ __forceinline__ uint32_t vx_compact3(uint64_t v)
+{
+    v &= 0x1249249249249249ull;
+    v = (v | (v >> 2)) & 0x10c30c30c30c30c3ull;
+    v = (v | (v >> 4)) & 0x100f00f00f00f00full;
+    v = (v | (v >> 8)) & 0x001f0000ff0000ffull;
+    v = (v | (v >> 16)) & 0x001f00000000ffffull;
+    v = (v | (v >> 32)) & 0x1fffffull;
+    return (uint32_t)v;
+}
+
+// ---- per-axis min / global max reductions (two-stage: block partials, then host) ---------------
+__global__ __launch_bounds__(256) void minmax_kernel(const float *__restrict__ PC, int64_t ld, int64_t N,
+                                                     float s0, float s1, float s2,
+                                                     float *__restrict__ part /* [grid][4]: min x,y,z, max */)
+{
+    float mn0 = INFINITY, mn1 = INFINITY, mn2 = INFINITY, mx = -INFINITY;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (int64_t)gridDim.x * blockDim.x) {
+        const float x = PC[i * ld + 0], y = PC[i * ld + 1], z = PC[i * ld + 2];
+        mn0 = fminf(mn0, x); mn1 = fminf(mn1, y); mn2 = fminf(mn2, z);
+        mx = fmaxf(mx, fmaxf(x - s0, fmaxf(y - s1, z - s2)));      // voxelize_pc.py:92,95
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        mn0 = fminf(mn0, __shfl_xor(mn0, d, 64)); mn1 = fminf(mn1, __shfl_xor(mn1, d, 64));
+        mn2 = fminf(mn2, __shfl_xor(mn2, d, 64)); mx = fmaxf(mx, __shfl_xor(mx, d, 64));
+    }
+    __shared__ float sm[4][4];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    if (lane == 0) { sm[wid][0] = mn0; sm[wid][1] = mn1; sm[wid][2] = mn2; sm[wid][3] = mx; }
+    __syncthreads();
+    if (threadIdx.x < 4) {
+        float v = sm[0][threadIdx.x];
+        for (int w = 1; w < 4; ++w) v = (threadIdx.x < 3) ? fminf(v, sm[w][threadIdx.x]) : fmaxf(v, sm[w][threadIdx.x]);
+        part[blockIdx.x * 4 + threadIdx.x] = v;
+    }
+}
+
+// ---- keys --------------------------------------------------------------------------------------
+__global__ void vox_keys_kernel(const float *__restrict__ PC, int64_t ld, int64_t N, float m0, float m1,
+                                float m2, float vs, int J, uint64_t *__restrict__ keys)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const int64_t hi = ((int64_t)1 << J) - 1;
+    int64_t q[3];
+    const float m[3] = {m0, m1, m2};
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const float v0 = PC[i * ld + a] - m[a];                    // voxelize_pc.py:92
+        int64_t t = (int64_t)floorf(__fdiv_rn(v0, vs));            // :98 (IEEE divide, not rcp*mul)
+        t = t < 0 ? 0 : (t > hi ? hi : t);
+        q[a] = t;
+    }
+    keys[i] = vx_spread3((uint64_t)q[2]) | (vx_spread3((uint64_t)q[1]) << 1) | (vx_spread3((uint64_t)q[0]) << 2);
+}
+
+__global__ void boundary_kernel(const uint64_t *__restrict__ keys, int64_t N, uint32_t *__restrict__ flag)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    flag[i] = (i == 0 || keys[i] != keys[i - 1]) ? 1u : 0u;       // voxelize_pc.py:114-118
+}
+
+__global__ void u32_to_i64_kernel(const uint32_t *__restrict__ in, int64_t n, int64_t *__restrict__ out)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (int64_t)in[i];
+}
+
+// One wave per voxel, lanes = output columns (3 coordinates + d attributes). Members are summed
+// sequentially in sorted order (same order as a CPU scatter_add_, voxelize_pc.py:140-144).
+__global__ __launch_bounds__(256) void voxel_mean_kernel(const float *__restrict__ PC, int64_t ld, int64_t N, int d,
+                                                         const uint64_t *__restrict__ keys_sorted,
+                                                         const uint32_t *__restrict__ sort_idx,
+                                                         const uint32_t *__restrict__ vstart, int64_t nvox,
+                                                         float *__restrict__ PCvox, int64_t *__restrict__ Vvox)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    const int ldo = 3 + d;
+    for (int64_t v = wave; v < nvox; v += nwaves) {
+        const int64_t s = vstart[v];
+        const int64_t e = (v + 1 < nvox) ? (int64_t)vstart[v + 1] : N;
+        const uint64_t key = keys_sorted[s];
+        const uint32_t x = vx_compact3(key >> 2), y = vx_compact3(key >> 1), z = vx_compact3(key);
+        if (lane < 3) {
+            const uint32_t cv = lane == 0 ? x : (lane == 1 ? y : z);
+            if (PCvox) PCvox[v * ldo + lane] = (float)cv;         // :152,:155
+            if (Vvox) Vvox[v * 3 + lane] = (int64_t)cv;
+        }
+        if (PCvox && d > 0) {
+            const float cnt = (float)(e - s);                     // :137
+            for (int c = lane; c < d; c += 64) {
+                float acc = 0.0f;
+                for (int64_t i = s; i < e; ++i) acc += PC[(int64_t)sort_idx[i] * ld + 3 + c];
+                PCvox[v * ldo + 3 + c] = __fdiv_rn(acc, cnt);     // :144
+            }
+        }
+    }
+}
+
+static int sort_keys_u32idx(const uint64_t *keys_in, int64_t N, int nbits, uint64_t *keys_out,
+                            uint32_t *idx_out, hipStream_t s)
+{
+    // LSD passes of 8 bits; ping-pong between two (key, index) buffers, last pass lands in *_out
+    const int npass = std::max(1, (nbits + 7) / 8);
+    uint64_t *ktmp = nullptr;
+    uint32_t *itmp = nullptr;
+    if (npass > 1) {
+        RAHT_HIP_CHECK(hipMalloc(&ktmp, sizeof(uint64_t) * (size_t)N));
+        RAHT_HIP_CHECK(hipMalloc(&itmp, sizeof(uint32_t) * (size_t)N));
+    }
+    const uint64_t *kin = keys_in;
+    const uint32_t *iin = nullptr;
+    int rc = RAHT_OK;
+    for (int ps = 0; ps < npass && rc == RAHT_OK; ++ps) {
+        const bool to_out = ((npass - 1 - ps) % 2 == 0);
+        uint64_t *ko = to_out ? keys_out : ktmp;
+        uint32_t *io = to_out ? idx_out : itmp;
+        const int bits = std::min(8, nbits - 8 * ps);
+        rc = radix_pass_u64(kin, iin, ko, io, N, 8 * ps, bits < 1 ? 1 : bits, s);
+        kin = ko;
+        iin = io;
+    }
+    if (ktmp) (void)hipFree(ktmp);
+    if (itmp) (void)hipFree(itmp);
+    return rc;
+}
+
+}  // namespace raht
+
+using namespace raht;
+
+extern "C" {
+
+int raht_sort_keys(const uint64_t *keys_in, int64_t N, int nbits, uint64_t *keys_out, int64_t *idx_out,
+                   raht_stream_t stream)
+{
+    if (!keys_in || !keys_out || N < 0 || nbits < 1 || nbits > 64) { set_error("raht_sort_keys: bad argument"); return RAHT_ERR_INVALID; }
+    if (N == 0) return RAHT_OK;
+    if (N >= ((int64_t)1 << 31)) { set_error("raht_sort_keys: N too large"); return RAHT_ERR_INVALID; }
+    hipStream_t s = (hipStream_t)stream;
+    uint32_t *idx32 = nullptr;
+    RAHT_HIP_CHECK(hipMalloc(&idx32, sizeof(uint32_t) * (size_t)N));
+    int rc = sort_keys_u32idx(keys_in, N, nbits, keys_out, idx32, s);
+    if (rc == RAHT_OK && idx_out)
+        hipLaunchKernelGGL(u32_to_i64_kernel, dim3((unsigned)ceil_div(N, 256)), dim3(256), 0, s, idx32, N, idx_out);
+    hipError_t e = hipStreamSynchronize(s);
+    (void)hipFree(idx32);
+    if (e != hipSuccess) { set_error("raht_sort_keys: %s", hipGetErrorString(e)); return RAHT_ERR_HIP; }
+    return rc;
+}
+
+int raht_voxelize(const float *PC, int64_t ldpc, int64_t N, int d, const float *vmin_in, double width_in,
+                  int J, uint64_t *keys_sorted, int64_t *sort_idx, int64_t *voxel_indices, float *PCvox,
+                  int64_t *Vvox, int64_t *n_vox, float vmin_out[3], double *width_out,
+                  double *voxel_size_out, raht_stream_t stream)
+{
+    if (!PC || N < 1 || d < 0 || ldpc < 3 + d || J < 1 || J > 21 || !n_vox) { set_error("raht_voxelize: bad argument"); return RAHT_ERR_INVALID; }
+    if (N >= ((int64_t)1 << 31)) { set_error("raht_voxelize: N too large"); return RAHT_ERR_INVALID; }
+    hipStream_t s = (hipStream_t)stream;
+    float vmin[3];
+    double width = width_in;
+    // ---- vmin / width (voxelize_pc.py:87-95) ----
+    const int nb = (int)std::min<int64_t>(ceil_div(N, 256), 1024);
+    float *part = nullptr;
+    RAHT_HIP_CHECK(hipMalloc(&part, sizeof(float) * 4 * (size_t)nb));
+    std::vector<float> hp((size_t)nb * 4);
+    if (vmin_in) { vmin[0] = vmin_in[0]; vmin[1] = vmin_in[1]; vmin[2] = vmin_in[2]; }
+    else {
+        hipLaunchKernelGGL(minmax_kernel, dim3(nb), dim3(256), 0, s, PC, ldpc, N, 0.f, 0.f, 0.f, part);
+        RAHT_HIP_CHECK(hipMemcpyAsync(hp.data(), part, sizeof(float) * hp.size(), hipMemcpyDeviceToHost, s));
+        RAHT_HIP_CHECK(hipStreamSynchronize(s));
+        for (int a = 0; a < 3; ++a) {
+            float m = hp[(size_t)a];
+            for (int b = 1; b < nb; ++b) m = std::fmin(m, hp[(size_t)b * 4 + a]);
+            vmin[a] = m;
+        }
+    }
+    if (width_in < 0) {
+        hipLaunchKernelGGL(minmax_kernel, dim3(nb), dim3(256), 0, s, PC, ldpc, N, vmin[0], vmin[1], vmin[2], part);
+        RAHT_HIP_CHECK(hipMemcpyAsync(hp.data(), part, sizeof(float) * hp.size(), hipMemcpyDeviceToHost, s));
+        RAHT_HIP_CHECK(hipStreamSynchronize(s));
+        float m = hp[3];
+        for (int b = 1; b < nb; ++b) m = std::fmax(m, hp[(size_t)b * 4 + 3]);
+        width = (double)m;
+    }
+    (void)hipFree(part);
+    if (!(width > 0)) { set_error("raht_voxelize: width must be > 0 (got %g)", width); return RAHT_ERR_INVALID; }
+    const double voxel_size = width / (double)((uint64_t)1 << J);   // :97
+    const float vs = (float)voxel_size;
+
+    // ---- keys, sort ----
+    uint64_t *keys = nullptr, *ks = keys_sorted;
+    uint32_t *idx = nullptr, *flag = nullptr, *vstart = nullptr;
+    bool own_ks = false;
+    int rc = RAHT_OK;
+    int64_t nv = 0;
+    do {
+        if (hipMalloc(&keys, sizeof(uint64_t) * (size_t)N) != hipSuccess) { rc = RAHT_ERR_NOMEM; break; }
+        if (!ks) { if (hipMalloc(&ks, sizeof(uint64_t) * (size_t)N) != hipSuccess) { rc = RAHT_ERR_NOMEM; break; } own_ks = true; }
+        if (hipMalloc(&idx, sizeof(uint32_t) * (size_t)N) != hipSuccess) { rc = RAHT_ERR_NOMEM; break; }
+        if (hipMalloc(&flag, sizeof(uint32_t) * (size_t)N) != hipSuccess) { rc = RAHT_ERR_NOMEM; break; }
+        if (hipMalloc(&vstart, sizeof(uint32_t) * (size_t)N) != hipSuccess) { rc = RAHT_ERR_NOMEM; break; }
+        const unsigned gb = (unsigned)ceil_div(N, 256);
+        hipLaunchKernelGGL(vox_keys_kernel, dim3(gb), dim3(256), 0, s, PC, ldpc, N, vmin[0], vmin[1], vmin[2], vs, J, keys);
+        rc = sort_keys_u32idx(keys, N, 3 * J, ks, idx, s);
+        if (rc != RAHT_OK) break;
+        hipLaunchKernelGGL(boundary_kernel, dim3(gb), dim3(256), 0, s, ks, N, flag);
+        rc = compact_u32(nullptr, flag, vstart, N, &nv, s);
+        if (rc != RAHT_OK) break;
+        if (PCvox || Vvox) {
+            const unsigned gv = (unsigned)std::min<int64_t>(ceil_div(nv, 4), 4096);
+            hipLaunchKernelGGL(voxel_mean_kernel, dim3(gv), dim3(256), 0, s, PC, ldpc, N, d, ks, idx, vstart, nv, PCvox, Vvox);
+        }
+        if (sort_idx) hipLaunchKernelGGL(u32_to_i64_kernel, dim3(gb), dim3(256), 0, s, idx, N, sort_idx);
+        if (voxel_indices) hipLaunchKernelGGL(u32_to_i64_kernel, dim3((unsigned)ceil_div(nv, 256)), dim3(256), 0, s, vstart, nv, voxel_indices);
+        hipError_t e = hipStreamSynchronize(s);
+        if (e == hipSuccess) e = hipGetLastError();
+        if (e != hipSuccess) { set_error("raht_voxelize: %s", hipGetErrorString(e)); rc = RAHT_ERR_HIP; }
+    } while (0);
+    if (rc == RAHT_ERR_NOMEM) set_error("raht_voxelize: out of device memory");
+    if (keys) (void)hipFree(keys);
+    if (own_ks && ks) (void)hipFree(ks);
+    if (idx) (void)hipFree(idx);
+    if (flag) (void)hipFree(flag);
+    if (vstart) (void)hipFree(vstart);
+    if (rc != RAHT_OK) return rc;
+    *n_vox = nv;
+    if (vmin_out) { vmin_out[0] = vmin[0]; vmin_out[1] = vmin[1]; vmin_out[2] = vmin[2]; }
+    if (width_out) *width_out = width;
+    if (voxel_size_out) *voxel_size_out = voxel_size;
+    return RAHT_OK;
+}
+
+}  // extern "C"

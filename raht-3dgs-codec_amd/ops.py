@@ -1,0 +1,369 @@
+"""Host-side mirror of the reference's operator interface for the RAHT hot path.
+
+Same names, argument meaning and return shapes as the reference's L3 operators, so that the
+three-entry dispatch table of its drivers (reference python/encode_3dgs.py:23-27) can be replaced by
+
+    from raht_3dgs_codec_amd import raht_fn      # {"RAHT", "iRAHT", "RAHT_param"}
+
+Everything below runs on the MI355X through the C ABI of include/raht.h (libraht_hip.so); torch
+is only plumbing (device memory, current stream). There is no CPU path: CPU tensors raise.
+
+Differences from the reference, all deliberate:
+  * ``RAHT_param_reorder_fast`` returns one opaque plan token per list instead of 3J tensors per
+    list; the tokens are real device tensors, so the drivers' ``[t.to(device) for t in ListC]``
+    keeps working, and they are handed back opaquely to RAHT / iRAHT exactly as before.
+    ``plan_of(ListC).export_lists()`` materialises the reference-shaped List/Flags/weights.
+  * unsorted / duplicate / out-of-range voxels raise ``RahtError`` (the reference silently
+    mis-pairs them); N == 1 returns order_RAGFT = [0] (the reference returns None).
+  * compute dtype follows the input: float32 in -> float32 kernels (the fast path), float64 in ->
+    float64 kernels (the reference's own precision). The reference always returns float64.
+"""
+import collections
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import RahtError, check  # noqa: F401
+
+_MAGIC = 0x52414854_504C414E  # "RAHTPLAN"
+_plans = collections.OrderedDict()   # id -> RahtPlan (strong refs to the most recent plans)
+_PLAN_CACHE = 16
+_next_id = [1]
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _need_cuda(t, name):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise RuntimeError(f"raht-3dgs-codec_amd: {name} must be a CUDA (HIP) tensor; this package has "
+                           "no CPU path for the RAHT hot path")
+
+
+_VDT = {torch.float32: _lib.RAHT_F32, torch.float64: _lib.RAHT_F64, torch.int32: _lib.RAHT_I32,
+        torch.int64: _lib.RAHT_I64}
+
+
+class RahtPlan:
+    """Owns a ``raht_plan*`` (device-resident lvl / wl / wr / order_RAGFT and tile schedules)."""
+
+    def __init__(self, handle, device):
+        self._h = handle
+        self.device = device
+        L = _lib.lib()
+        self.N = int(L.raht_plan_size(handle))
+        self.nbits = int(L.raht_plan_nbits(handle))
+        self.id = _next_id[0]
+        _next_id[0] += 1
+        self._order = None
+
+    # -- construction ---------------------------------------------------------------------------
+    @staticmethod
+    def from_coords(V, minV, width, depth):
+        _need_cuda(V, "V")
+        if V.dim() != 2 or V.shape[1] != 3:
+            raise ValueError("V must be (N, 3)")
+        if V.dtype not in _VDT:
+            V = V.to(torch.float64)
+        V = V.contiguous()
+        if isinstance(minV, torch.Tensor):
+            mv = [float(x) for x in minV.detach().cpu().reshape(-1).tolist()]
+        else:
+            mv = [float(x) for x in minV]
+        if len(mv) != 3:
+            raise ValueError("minV must have 3 entries")
+        arr = (C.c_double * 3)(*mv)
+        h = C.c_void_p()
+        with torch.cuda.device(V.device):
+            check(_lib.lib().raht_plan_create(C.c_void_p(V.data_ptr()), _VDT[V.dtype], V.shape[0], arr,
+                                              float(width), int(depth), _stream(), C.byref(h)))
+        return RahtPlan(h, V.device)
+
+    @staticmethod
+    def from_keys(keys_sorted, nbits, leaf_weights=None):
+        _need_cuda(keys_sorted, "keys_sorted")
+        k = keys_sorted.contiguous()
+        if k.dtype not in (torch.int64, torch.uint64):
+            raise ValueError("keys must be int64/uint64")
+        lw = None
+        if leaf_weights is not None:
+            _need_cuda(leaf_weights, "leaf_weights")
+            lw = leaf_weights.to(torch.int64).contiguous()
+        h = C.c_void_p()
+        with torch.cuda.device(k.device):
+            check(_lib.lib().raht_plan_create_from_keys(C.c_void_p(k.data_ptr()), k.shape[0], int(nbits),
+                                                        C.c_void_p(lw.data_ptr()) if lw is not None else None,
+                                                        _stream(), C.byref(h)))
+        return RahtPlan(h, k.device)
+
+    def __del__(self):
+        try:
+            if self._h:
+                _lib.lib().raht_plan_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    # -- views ----------------------------------------------------------------------------------
+    @property
+    def order_RAGFT(self):
+        if self._order is None:
+            o = torch.empty(self.N, dtype=torch.int64, device=self.device)
+            with torch.cuda.device(self.device):
+                check(_lib.lib().raht_plan_order(self._h, C.c_void_p(o.data_ptr()), _stream()))
+            self._order = o
+        return self._order
+
+    @property
+    def levels(self):
+        return int(_lib.lib().raht_plan_levels(self._h))
+
+    def set_engine(self, engine="tile", tile_rows=0):
+        e = {"tile": _lib.ENGINE_TILE, "level": _lib.ENGINE_LEVEL}[engine]
+        check(_lib.lib().raht_plan_set_engine(self._h, e, int(tile_rows)))
+
+    def export_lists(self):
+        """Reference-shaped (List, Flags, weights) as CPU tensors (RAHT_param.py:190-279 outputs)."""
+        import numpy as np
+        L = _lib.lib()
+        List, Flags, weights = [], [], []
+        for l in range(self.levels):
+            n = C.c_int64()
+            check(L.raht_plan_export_level(self._h, l, None, None, None, C.byref(n)))
+            a = np.empty(n.value, np.int64)
+            f = np.empty(n.value, np.uint8)
+            w = np.empty(n.value, np.int64)
+            check(L.raht_plan_export_level(self._h, l, a.ctypes.data_as(C.c_void_p), f.ctypes.data_as(C.c_void_p),
+                                           w.ctypes.data_as(C.c_void_p), C.byref(n)))
+            List.append(torch.from_numpy(a))
+            Flags.append(torch.from_numpy(f.astype(bool)))
+            weights.append(torch.from_numpy(w))
+        return List, Flags, weights
+
+    def arrays(self):
+        """(keys, lvl, wl, wr) copied to CPU numpy arrays (inspection / tests)."""
+        import numpy as np
+        out = []
+        with torch.cuda.device(self.device):
+            for which, dt in enumerate((torch.int64, torch.uint8, torch.int32, torch.int32)):
+                t = torch.empty(self.N, dtype=dt, device=self.device)
+                check(_lib.lib().raht_plan_copy_array(self._h, which, C.c_void_p(t.data_ptr()), _stream()))
+                out.append(t.cpu().numpy())
+        out[0] = out[0].view(np.uint64)
+        return tuple(out)
+
+    def stage_stats(self, elem_size=4, D=59):
+        n = C.c_int()
+        rows = (C.c_int64 * 32)()
+        tr = C.c_int()
+        check(_lib.lib().raht_plan_stage_stats(self._h, elem_size, D, C.byref(n), rows, 32, C.byref(tr)))
+        k = abs(n.value)
+        return dict(valid=n.value > 0, tile_rows=tr.value, rows_per_stage=[int(rows[i]) for i in range(k)])
+
+    # -- transforms -----------------------------------------------------------------------------
+    def _xform(self, X, inverse, want_w=False):
+        _need_cuda(X, "C" if not inverse else "T")
+        if X.dim() != 2 or X.shape[0] != self.N:
+            raise ValueError(f"expected ({self.N}, D) tensor, got {tuple(X.shape)}")
+        if X.dtype not in (torch.float32, torch.float64):
+            X = X.to(torch.float32)
+        if X.stride(1) != 1 or X.stride(0) < X.shape[1]:
+            X = X.contiguous()
+        D = X.shape[1]
+        out = torch.empty((self.N, D), dtype=X.dtype, device=X.device)
+        w = torch.empty((self.N, 1), dtype=X.dtype, device=X.device) if want_w else None
+        L = _lib.lib()
+        f64 = X.dtype == torch.float64
+        with torch.cuda.device(X.device):
+            if not inverse:
+                fn = L.raht_fwd_f64 if f64 else L.raht_fwd
+                check(fn(self._h, C.c_void_p(X.data_ptr()), X.stride(0), D, C.c_void_p(out.data_ptr()), D,
+                         C.c_void_p(w.data_ptr()) if w is not None else None, _stream()))
+            else:
+                fn = L.raht_inv_f64 if f64 else L.raht_inv
+                check(fn(self._h, C.c_void_p(X.data_ptr()), X.stride(0), D, C.c_void_p(out.data_ptr()), D,
+                         _stream()))
+        return (out, w) if want_w else out
+
+    def forward(self, Cmat, want_w=True):
+        return self._xform(Cmat, False, want_w)
+
+    def inverse(self, T):
+        return self._xform(T, True)
+
+    def quant_reorder(self, T, steps):
+        """int32 Q[k] = floor(T[order[k]] / step + 0.5)  (encode_3dgs.py:204,210,215)."""
+        _need_cuda(T, "T")
+        T = T.to(torch.float32).contiguous()
+        D = T.shape[1]
+        st = _steps(steps, D)
+        Q = torch.empty((self.N, D), dtype=torch.int32, device=T.device)
+        with torch.cuda.device(T.device):
+            check(_lib.lib().raht_quant_reorder(self._h, C.c_void_p(T.data_ptr()), D, D, st, len(st),
+                                                C.c_void_p(Q.data_ptr()), D, _stream()))
+        return Q
+
+    def dequant_unreorder(self, Q, steps):
+        """float32 T[order[k]] = Q[k] * step  (encode_3dgs.py:261,267-268)."""
+        _need_cuda(Q, "Q")
+        Q = Q.to(torch.int32).contiguous()
+        D = Q.shape[1]
+        st = _steps(steps, D)
+        T = torch.empty((self.N, D), dtype=torch.float32, device=Q.device)
+        with torch.cuda.device(Q.device):
+            check(_lib.lib().raht_dequant_unreorder(self._h, C.c_void_p(Q.data_ptr()), D, D, st, len(st),
+                                                    C.c_void_p(T.data_ptr()), D, _stream()))
+        return T
+
+
+def _steps(steps, D):
+    if isinstance(steps, (int, float)):
+        steps = [float(steps)]
+    steps = [float(s) for s in steps]
+    if len(steps) not in (1, D):
+        raise ValueError("steps must be a scalar or have D entries")
+    return (C.c_float * len(steps))(*steps)
+
+
+# ---------------------------------------------------------------------------------------------------
+# plan tokens: what RAHT_param hands back in place of the reference's List / Flags / weights
+# ---------------------------------------------------------------------------------------------------
+def _token(plan):
+    t = torch.tensor([_MAGIC, plan.id], dtype=torch.int64, device=plan.device)
+    t._raht_plan = plan
+    return t
+
+
+def plan_of(lst):
+    """Recover the RahtPlan from what the driver passes back as List (or Flags / weights)."""
+    if isinstance(lst, RahtPlan):
+        return lst
+    tok = lst[0] if isinstance(lst, (list, tuple)) else lst
+    p = getattr(tok, "_raht_plan", None)
+    if p is not None:
+        return p
+    if isinstance(tok, torch.Tensor) and tok.numel() == 2 and tok.dtype == torch.int64:
+        magic, pid = tok.cpu().tolist()          # token was copied: fall back to its contents
+        if magic == _MAGIC and pid in _plans:
+            return _plans[pid]
+    raise RuntimeError("raht-3dgs-codec_amd: List/Flags/weights must be the plan tokens returned by "
+                       "RAHT_param_reorder_fast of this package (reference-shaped lists are not accepted; "
+                       "build the plan from V with RAHT_param_reorder_fast)")
+
+
+@torch.no_grad()
+def RAHT_param_reorder_fast(V, minV, width, depth):
+    """Drop-in for reference python/RAHT_param.py:190-279 (call site encode_3dgs.py:149).
+
+    V: (N, 3) tensor holding integer voxel coordinates, Morton-sorted, unique, on the GPU.
+    Returns (List, Flags, weights, order_RAGFT); the three lists hold one opaque plan token each.
+    """
+    plan = RahtPlan.from_coords(V, minV, width, depth)
+    _plans[plan.id] = plan
+    while len(_plans) > _PLAN_CACHE:
+        _plans.popitem(last=False)
+    return [_token(plan)], [_token(plan)], [_token(plan)], plan.order_RAGFT
+
+
+@torch.no_grad()
+def RAHT2_optimized(Cmat, List, Flags, weights, one_based=False):
+    """Drop-in for reference python/RAHT.py:252-336 (call site encode_3dgs.py:159). Returns (T, w)."""
+    if one_based:
+        raise ValueError("one_based lists are a MATLAB convention; plan tokens are index-free")
+    return plan_of(List).forward(Cmat, want_w=True)
+
+
+@torch.no_grad()
+def inverse_RAHT_optimized(T, List, Flags, weights, one_based=False):
+    """Drop-in for reference python/iRAHT.py:40-114 (call site encode_3dgs.py:274). Returns C."""
+    if one_based:
+        raise ValueError("one_based lists are a MATLAB convention; plan tokens are index-free")
+    return plan_of(List).inverse(T)
+
+
+raht_fn = {
+    "RAHT": RAHT2_optimized,
+    "iRAHT": inverse_RAHT_optimized,
+    "RAHT_param": RAHT_param_reorder_fast,
+}
+
+
+# ---------------------------------------------------------------------------------------------------
+# voxelizer (reference python/voxelize_pc.py)
+# ---------------------------------------------------------------------------------------------------
+@torch.no_grad()
+def get_morton_code(V, J):
+    """Drop-in for reference python/voxelize_pc.py:25-59. V: (N, 3) integer tensor on the GPU."""
+    _need_cuda(V, "V")
+    V = V.to(torch.int64).contiguous()
+    out = torch.empty(V.shape[0], dtype=torch.int64, device=V.device)
+    with torch.cuda.device(V.device):
+        check(_lib.lib().raht_morton(C.c_void_p(V.data_ptr()), V.shape[0], int(J), C.c_void_p(out.data_ptr()),
+                                     _stream()))
+    return out
+
+
+@torch.no_grad()
+def sort_keys(keys, nbits=64):
+    """Stable LSD radix sort of Morton keys on device -> (keys_sorted, idx)."""
+    _need_cuda(keys, "keys")
+    k = keys.contiguous()
+    ko = torch.empty_like(k)
+    idx = torch.empty(k.shape[0], dtype=torch.int64, device=k.device)
+    with torch.cuda.device(k.device):
+        check(_lib.lib().raht_sort_keys(C.c_void_p(k.data_ptr()), k.shape[0], int(nbits), C.c_void_p(ko.data_ptr()),
+                                        C.c_void_p(idx.data_ptr()), _stream()))
+    return ko, idx
+
+
+@torch.no_grad()
+def voxelize_pc_batched(PC, vmin=None, width=None, J=10, device="cuda", residuals=True):
+    """Drop-in for reference python/voxelize_pc.py:62-172.
+
+    Returns (PCvox, PCsorted, voxel_indices, DeltaPC, info) like the reference. PCvox,
+    voxel_indices, info['sort_idx'] and the sorted Morton keys (info['keys_sorted'], extra) come
+    from the HIP voxelizer; PCsorted / DeltaPC are secondary outputs derived from them with two
+    torch gathers (``residuals=False`` skips DeltaPC).
+    """
+    PC = PC.to(device)
+    _need_cuda(PC, "PC")
+    PC = PC.to(torch.float32).contiguous()
+    N, ld = PC.shape
+    d = ld - 3
+    dev = PC.device
+    keys = torch.empty(N, dtype=torch.int64, device=dev)
+    idx = torch.empty(N, dtype=torch.int64, device=dev)
+    vidx = torch.empty(N, dtype=torch.int64, device=dev)
+    pcv = torch.empty((N, ld), dtype=torch.float32, device=dev)
+    nvox = C.c_int64()
+    vmin_out = (C.c_float * 3)()
+    w_out, vs_out = C.c_double(), C.c_double()
+    vm = None
+    if vmin is not None:
+        vm = (C.c_float * 3)(*[float(x) for x in (vmin.detach().cpu().tolist() if isinstance(vmin, torch.Tensor) else vmin)])
+    with torch.cuda.device(dev):
+        check(_lib.lib().raht_voxelize(C.c_void_p(PC.data_ptr()), ld, N, d, vm, -1.0 if width is None else float(width),
+                                       int(J), C.c_void_p(keys.data_ptr()), C.c_void_p(idx.data_ptr()),
+                                       C.c_void_p(vidx.data_ptr()), C.c_void_p(pcv.data_ptr()), None, C.byref(nvox),
+                                       vmin_out, C.byref(w_out), C.byref(vs_out), _stream()))
+    nv = nvox.value
+    voxel_indices = vidx[:nv]
+    PCvox = pcv[:nv]
+    PCsorted = PC[idx]
+    vmin_t = torch.tensor(list(vmin_out), dtype=torch.float32, device=dev)
+    DeltaPC = None
+    if residuals:
+        V0 = PCsorted[:, :3] - vmin_t.unsqueeze(0)
+        DeltaV = V0 - vs_out.value * torch.floor(V0 / vs_out.value)          # voxelize_pc.py:110-111
+        if d > 0:
+            counts = torch.diff(torch.cat([voxel_indices, torch.tensor([N], device=dev)]))
+            vid = torch.repeat_interleave(torch.arange(nv, device=dev), counts)
+            DeltaC = PCsorted[:, 3:] - PCvox[:, 3:][vid]                      # voxelize_pc.py:147-148
+            DeltaPC = torch.cat([DeltaV, DeltaC], dim=1)
+        else:
+            DeltaPC = DeltaV
+    info = {"Nvox": nv, "voxel_size": vs_out.value, "vmin": vmin_t, "width": w_out.value, "N": N,
+            "sort_idx": idx, "keys_sorted": keys}
+    return PCvox, PCsorted, voxel_indices, DeltaPC, info

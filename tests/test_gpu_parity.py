@@ -1,0 +1,340 @@
+"""GPU parity tests: the HIP path (through the C ABI) against golden vectors from the reference and
+against the CPU oracle on seeded inputs. Run on the MI355X box with ``pytest -m gpu``.
+
+Bars (SURVEY.md 8c / DESIGN.md):
+  integers (Morton keys, List/Flags/weights, order_RAGFT, w, voxel indices/coords)  bit-exact
+  float64 kernels vs reference                                                       rtol = atol = 1e-12
+  float32 kernels vs float64 reference, per column c:
+      max|T32 - T64| <= 2e-6 * max|T64[:, c]|      rms <= 1e-6 * rms(T64[:, c])  (floor 1e-30)
+      fwd -> inv round trip <= 1e-5 * max|C|
+  quantized ints: mismatches only +-1 and only next to a rounding tie of the reference value
+"""
+import numpy as np
+import pytest
+
+from .conftest import golden_names, load_golden
+
+pytestmark = pytest.mark.gpu
+
+TRANSFORM = golden_names(exclude_prefix="vox_")
+VOX = golden_names(prefix="vox_")
+ENGINES = [("tile", 0), ("tile", 64), ("tile", 128), ("level", 0)]
+
+
+@pytest.fixture(scope="module")
+def rt():
+    import torch
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    import raht_3dgs_codec_amd as R
+    from raht_3dgs_codec_amd import _lib
+    _lib.lib()                      # must load: no fallback
+    return R
+
+
+def _dev(a, dtype=None):
+    import torch
+    t = torch.from_numpy(np.ascontiguousarray(a))
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.cuda()
+
+
+def _plan(R, g, engine="tile", tile_rows=0):
+    import torch
+    J = int(g["J"])
+    V = _dev(g["V"].astype(np.float64))
+    p = R.RahtPlan.from_coords(V, torch.zeros(3, dtype=torch.float64), 2 ** J, J)
+    p.set_engine(engine, tile_rows)
+    return p
+
+
+def _check_f32(T32, T64, what):
+    T32 = np.asarray(T32, dtype=np.float64)
+    colmax = np.abs(T64).max(axis=0)
+    err = np.abs(T32 - T64).max(axis=0)
+    assert np.all(err <= 2e-6 * np.maximum(colmax, 1e-30)), (what, float((err / np.maximum(colmax, 1e-30)).max()))
+    rms = np.sqrt(((T32 - T64) ** 2).mean(axis=0))
+    ref = np.sqrt((T64 ** 2).mean(axis=0))
+    assert np.all(rms <= 1e-6 * np.maximum(ref, 1e-30)), (what, float((rms / np.maximum(ref, 1e-30)).max()))
+
+
+# ------------------------------------------------------------------------------------------------ plan
+@pytest.mark.parametrize("name", TRANSFORM)
+def test_plan_lists_and_order_match_reference(rt, name):
+    g = load_golden(name)
+    p = _plan(rt, g)
+    List, Flags, weights = p.export_lists()
+    assert len(List) == len(g["List"])
+    for l in range(len(List)):
+        assert np.array_equal(List[l].numpy(), g["List"][l]), f"List[{l}]"
+        assert np.array_equal(Flags[l].numpy(), g["Flags"][l]), f"Flags[{l}]"
+        assert np.array_equal(weights[l].numpy(), g["weights"][l]), f"weights[{l}]"
+    keys, lvl, wl, wr = p.arrays()
+    assert np.array_equal(keys, g["morton"])
+    N = g["V"].shape[0]
+    order = p.order_RAGFT.cpu().numpy()
+    assert np.array_equal(np.sort(order), np.arange(N))
+    ref_sane = (not bool(g["order_is_none"])) and np.array_equal(np.sort(g["order"]), np.arange(N))
+    if ref_sane:
+        assert np.array_equal(order, g["order"])
+    # sum of pairs = N - 1; every row but row 0 is a right sibling exactly once
+    assert lvl[0] == 255 and np.all(lvl[1:] < 64)
+    assert np.all(wl[1:] >= 1) and np.all(wr[1:] >= 1)
+
+
+def test_plan_tokens_behave_like_the_reference_lists(rt):
+    """The drivers re-map the lists with .to(device) and pass them back opaquely (encode_3dgs.py:153-159)."""
+    import torch
+    g = load_golden("n1000_j10_d14")
+    J = int(g["J"])
+    V = _dev(g["V"].astype(np.float64))
+    origin = torch.tensor([0, 0, 0], dtype=V.dtype, device="cuda")
+    ListC, FlagsC, weightsC, order = rt.raht_fn["RAHT_param"](V, origin, 2 ** J, J)
+    ListC = [t.to(device="cuda", non_blocking=True) for t in ListC]
+    FlagsC = [t.to(device="cuda", non_blocking=True) for t in FlagsC]
+    weightsC = [t.to(device="cuda", non_blocking=True) for t in weightsC]
+    C = _dev(g["C"].astype(np.float64))
+    Coeff, w = rt.raht_fn["RAHT"](C, ListC, FlagsC, weightsC)
+    assert Coeff.dtype == torch.float64 and w.shape == (C.shape[0], 1)
+    np.testing.assert_allclose(Coeff.cpu().numpy(), g["T"], rtol=1e-12, atol=1e-12)
+    Crec = rt.raht_fn["iRAHT"](Coeff, ListC, FlagsC, weightsC)
+    assert torch.allclose(C, Crec, rtol=1e-5, atol=1e-8)              # encode_3dgs.py:195 (strict)
+    assert np.array_equal(order.cpu().numpy(), g["order"])
+    # a copied token (different storage) still resolves through its contents
+    Coeff2, _ = rt.raht_fn["RAHT"](C, [ListC[0].clone()], FlagsC, weightsC)
+    assert torch.equal(Coeff, Coeff2)
+
+
+# ------------------------------------------------------------------------------------------- transform
+@pytest.mark.parametrize("engine,tile_rows", ENGINES)
+@pytest.mark.parametrize("name", TRANSFORM)
+def test_forward_inverse_f64(rt, name, engine, tile_rows):
+    g = load_golden(name)
+    p = _plan(rt, g, engine, tile_rows)
+    C = _dev(g["C"].astype(np.float64))
+    T, w = p.forward(C)
+    np.testing.assert_allclose(T.cpu().numpy(), g["T"], rtol=1e-12, atol=1e-12)
+    assert np.array_equal(w.cpu().numpy().reshape(-1), g["w"])
+    Crec = p.inverse(T)
+    np.testing.assert_allclose(Crec.cpu().numpy(), g["C"].astype(np.float64), rtol=1e-12,
+                               atol=1e-12 * max(1.0, float(np.abs(g["C"]).max())))
+
+
+@pytest.mark.parametrize("engine,tile_rows", ENGINES)
+@pytest.mark.parametrize("name", TRANSFORM)
+def test_forward_inverse_f32(rt, name, engine, tile_rows):
+    g = load_golden(name)
+    p = _plan(rt, g, engine, tile_rows)
+    C = _dev(g["C"])
+    T, w = p.forward(C)
+    _check_f32(T.cpu().numpy(), g["T"], name)
+    assert np.array_equal(w.cpu().numpy().reshape(-1).astype(np.float64), g["w"])
+    Crec = p.inverse(T).cpu().numpy()
+    assert np.abs(Crec - g["C"]).max() <= 1e-5 * max(float(np.abs(g["C"]).max()), 1e-30)
+    # inverse of the REFERENCE coefficients (decoder side on its own)
+    C2 = p.inverse(_dev(g["T"].astype(np.float32))).cpu().numpy()
+    assert np.abs(C2 - g["C"]).max() <= 1e-5 * max(float(np.abs(g["C"]).max()), 1e-30)
+
+
+def test_strided_and_unaligned_rows(rt):
+    import torch
+    g = load_golden("n2000_j10_d59")
+    p = _plan(rt, g)
+    N, D = g["C"].shape
+    big = torch.zeros((N, 64), dtype=torch.float32, device="cuda")
+    big[:, :D] = _dev(g["C"])
+    T1, _ = p.forward(big[:, :D])                 # row stride 64
+    T0, _ = p.forward(_dev(g["C"]))
+    assert torch.equal(T0, T1)
+    flat = torch.zeros(N * D + 1, dtype=torch.float32, device="cuda")
+    flat[1:] = _dev(g["C"]).reshape(-1)
+    T2, _ = p.forward(flat[1:].view(N, D))        # base pointer only 4-byte aligned
+    assert torch.equal(T0, T2)
+    assert torch.equal(p.inverse(T0), p.inverse(flat[1:].view(N, D) * 0 + T0))
+
+
+def test_many_channels_are_chunked(rt):
+    """D > 64 is split into channel chunks (the transform is independent per channel)."""
+    import torch
+    g = load_golden("n1000_j10_d14")
+    p = _plan(rt, g)
+    C14 = _dev(g["C"].astype(np.float64))
+    C = torch.cat([C14] * 10, dim=1)[:, :131].contiguous()
+    T, _ = p.forward(C)
+    ref = np.concatenate([g["T"]] * 10, axis=1)[:, :131]
+    np.testing.assert_allclose(T.cpu().numpy(), ref, rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(p.inverse(T).cpu().numpy(), C.cpu().numpy(), rtol=1e-12, atol=1e-12)
+
+
+# ---------------------------------------------------------------------------------------------- quant
+@pytest.mark.parametrize("name", [n for n in TRANSFORM if any(k.startswith("q_step") for k in load_golden(n))])
+def test_quantize_reorder_and_back(rt, name):
+    g = load_golden(name)
+    p = _plan(rt, g)
+    T, _ = p.forward(_dev(g["C"]))
+    order = g["order"]
+    for key in [k for k in g if k.startswith("q_step")]:
+        step = float(key[len("q_step"):])
+        Q = p.quant_reorder(T, step).cpu().numpy()
+        ref = g[key]
+        bad = np.argwhere(Q != ref)
+        pre = g["T"][order] / step + 0.5
+        scale = np.abs(g["T"]).max(axis=0) / step
+        for r, c in bad:
+            assert abs(int(Q[r, c]) - int(ref[r, c])) == 1
+            # fp32 coefficient error (<= 2e-6 of the column max) can only flip values that close to a tie
+            assert abs(pre[r, c] - np.round(pre[r, c])) <= 4e-6 * max(scale[c], 1.0), (key, r, c)
+        # decoder side from the reference integers
+        Td = p.dequant_unreorder(_dev(ref), step)
+        Crec = p.inverse(Td).cpu().numpy()
+        ref_rec = g["crec_step" + key[len("q_step"):]]
+        assert np.abs(Crec - ref_rec).max() <= 1e-5 * max(float(np.abs(ref_rec).max()), 1.0)
+    # per-channel steps
+    D = g["C"].shape[1]
+    steps = [1.0 + 0.5 * c for c in range(D)]
+    Qc = p.quant_reorder(T, steps).cpu().numpy()
+    Tn = T.cpu().numpy()
+    exp = np.floor(Tn[order] / np.asarray(steps, np.float32) + np.float32(0.5)).astype(np.int32)
+    assert np.array_equal(Qc, exp)
+
+
+# ------------------------------------------------------------------------------------------- voxelizer
+@pytest.mark.parametrize("name", VOX)
+def test_voxelize(rt, name):
+    g = load_golden(name)
+    vmin = None if g["vmin_in"].size == 0 else g["vmin_in"].tolist()
+    width = None if float(g["width_in"]) < 0 else float(g["width_in"])
+    J = int(g["J"])
+    PC = _dev(g["PC"])
+    PCvox, PCsorted, vidx, DeltaPC, info = rt.voxelize_pc_batched(PC, vmin, width, J, device="cuda")
+    assert info["Nvox"] == int(g["Nvox"])
+    assert np.array_equal(info["keys_sorted"].cpu().numpy().view(np.uint64), g["keys_sorted"])
+    assert np.array_equal(vidx.cpu().numpy(), g["voxel_indices"])
+    assert np.array_equal(info["vmin"].cpu().numpy(), g["vmin"])
+    assert info["width"] == float(g["width"]) and info["voxel_size"] == float(g["voxel_size"])
+    pv = PCvox.cpu().numpy()
+    assert np.array_equal(pv[:, :3], g["PCvox"][:, :3])
+    np.testing.assert_allclose(pv[:, 3:], g["PCvox"][:, 3:], rtol=2e-6, atol=1e-6)
+    idx = info["sort_idx"].cpu().numpy()
+    assert np.array_equal(np.sort(idx), np.arange(g["PC"].shape[0]))
+    assert np.array_equal(g["morton"][idx], g["keys_sorted"])
+    # stable: equal keys keep their input order
+    same = g["keys_sorted"][1:] == g["keys_sorted"][:-1]
+    assert np.all(idx[1:][same] > idx[:-1][same])
+    assert np.array_equal(PCsorted.cpu().numpy(), g["PC"][idx])
+    m = rt.get_morton_code(_dev(g["Vint"].astype(np.int64)), J).cpu().numpy().view(np.uint64)
+    assert np.array_equal(m, g["morton"])
+
+
+def test_voxelize_matches_oracle_bitwise(rt, oracle):
+    """Same stable order and sequential float32 sums as the C oracle -> means are bit-identical."""
+    rng = np.random.default_rng(5)
+    PC = np.concatenate([rng.normal(0, 1, (50000, 3)), rng.normal(0, 1, (50000, 7))], axis=1).astype(np.float32)
+    r = oracle.voxelize(PC, 7)
+    PCvox, _, vidx, _, info = rt.voxelize_pc_batched(_dev(PC), None, None, 7, device="cuda", residuals=False)
+    assert info["Nvox"] == r["Nvox"] and r["Nvox"] < 50000
+    assert np.array_equal(info["sort_idx"].cpu().numpy(), r["sort_idx"])
+    assert np.array_equal(vidx.cpu().numpy(), r["voxel_indices"])
+    assert np.array_equal(PCvox.cpu().numpy(), r["PCvox"])
+
+
+def test_radix_sort_60bit_keys(rt):
+    import torch
+    rng = np.random.default_rng(11)
+    k = rng.integers(0, 1 << 60, size=300001, dtype=np.int64)
+    k[::7] = k[3]                                       # many duplicates -> stability matters
+    ks, idx = rt.sort_keys(_dev(k), nbits=60)
+    o = np.argsort(k, kind="stable")
+    assert np.array_equal(idx.cpu().numpy(), o)
+    assert np.array_equal(ks.cpu().numpy(), k[o])
+
+
+# ------------------------------------------------------------------------------------------ edge cases
+def test_rejects_bad_input(rt):
+    import torch
+    g = load_golden("n1000_j10_d14")
+    J = int(g["J"])
+    V = g["V"].astype(np.float64)
+    z = torch.zeros(3, dtype=torch.float64)
+    with pytest.raises(rt.RahtError) as e:
+        rt.RahtPlan.from_coords(_dev(V[::-1].copy()), z, 2 ** J, J)          # unsorted
+    assert e.value.code == -2
+    Vd = V.copy(); Vd[500] = Vd[499]
+    with pytest.raises(rt.RahtError) as e:
+        rt.RahtPlan.from_coords(_dev(Vd), z, 2 ** J, J)                      # duplicate voxel
+    assert e.value.code == -2 and "row 500" in str(e.value)
+    Vb = V.copy(); Vb[-1, 0] = 2 ** J
+    with pytest.raises(rt.RahtError) as e:
+        rt.RahtPlan.from_coords(_dev(Vb), z, 2 ** J, J)                      # out of bounds
+    assert e.value.code == -3
+    with pytest.raises(RuntimeError):
+        rt.RAHT_param_reorder_fast(torch.from_numpy(V), z, 2 ** J, J)        # CPU tensor: no CPU path
+    p = rt.RahtPlan.from_coords(_dev(V), z, 2 ** J, J)
+    with pytest.raises(ValueError):
+        p.forward(torch.zeros((5, 3), device="cuda"))
+
+
+def test_single_point(rt):
+    import torch
+    p = rt.RahtPlan.from_coords(torch.zeros((1, 3), dtype=torch.float64, device="cuda"), [0, 0, 0], 2, 1)
+    C = torch.tensor([[1.5, -2.0]], device="cuda")
+    T, w = p.forward(C)
+    assert torch.equal(T, C) and w.item() == 1.0 and p.order_RAGFT.tolist() == [0]
+    assert torch.equal(p.inverse(T), C)
+
+
+# ------------------------------------------------------------------------ oracle on larger seeded inputs
+@pytest.mark.parametrize("n,J,D,seed", [(60000, 10, 59, 3), (200000, 12, 14, 4), (30000, 18, 3, 5)])
+def test_against_oracle_seeded(rt, oracle, n, J, D, seed):
+    import torch
+    from raht_3dgs_codec_amd import synth
+    V, keys, C = synth.scene(n, J, D, seed)
+    po = oracle.raht_param(V.astype(np.float64), np.zeros(3), 2 ** J, J)
+    To, wo = oracle.raht_fwd(C.astype(np.float64), po)
+    p = rt.RahtPlan.from_coords(_dev(V.astype(np.float64)), [0, 0, 0], 2 ** J, J)
+    assert np.array_equal(p.order_RAGFT.cpu().numpy(), po.order)
+    assert p.levels == po.nlevels
+    T, w = p.forward(_dev(C))
+    _check_f32(T.cpu().numpy(), To, "seeded")
+    assert np.array_equal(w.cpu().numpy().reshape(-1).astype(np.float64), wo.reshape(-1))
+    T64, _ = p.forward(_dev(C.astype(np.float64)))
+    np.testing.assert_allclose(T64.cpu().numpy(), To, rtol=1e-12, atol=1e-12)
+    p.set_engine("level")
+    Tl, _ = p.forward(_dev(C))
+    _check_f32(Tl.cpu().numpy(), To, "seeded-level")
+    st = p.stage_stats(4, D)
+    assert st["valid"] and st["rows_per_stage"][0] == V.shape[0]
+
+
+# ------------------------------------------------------- full-size, size-independent properties (cfg3)
+def test_full_size_properties_cfg3(rt):
+    """3M-Gaussian, 59-channel scene: round trip, Parseval, DC coefficient, linearity."""
+    import torch
+    from raht_3dgs_codec_amd import synth
+    n, J, D, seed = synth.CONFIGS["cfg3"]
+    V, keys, C = synth.scene(n, J, D, seed)
+    N = V.shape[0]
+    p = rt.RahtPlan.from_keys(_dev(keys.view(np.int64)), 3 * J)
+    Cd = _dev(C)
+    T, w = p.forward(Cd)
+    Crec = p.inverse(T)
+    cmax = Cd.abs().max().item()
+    assert (Crec - Cd).abs().max().item() <= 1e-5 * cmax                      # encode_3dgs.py:186-195
+    e_in = (Cd.double() ** 2).sum(dim=0)
+    e_out = (T.double() ** 2).sum(dim=0)
+    assert torch.allclose(e_in, e_out, rtol=1e-5)                             # energy, encode_3dgs.py:183-184
+    dc = Cd.double().sum(dim=0) / np.sqrt(N)
+    assert torch.allclose(T[0].double(), dc, rtol=1e-4, atol=1e-4 * dc.abs().max().item())   # utils.py:46-57
+    assert w[0].item() == float(N)
+    X = torch.roll(Cd, 1, dims=0)
+    Tx, _ = p.forward(X)
+    Tsum, _ = p.forward(Cd + 2 * X)
+    scale = T.abs().max().item()
+    assert (Tsum - (T + 2 * Tx)).abs().max().item() <= 2e-5 * scale            # linearity
+    order = p.order_RAGFT
+    assert torch.equal(torch.sort(order)[0], torch.arange(N, device="cuda"))
+    Q = p.quant_reorder(T, 0.01)
+    Td = p.dequant_unreorder(Q, 0.01)
+    assert (Td - T).abs().max().item() <= 0.005 * 1.0001 + 1e-6 * scale
+    st = p.stage_stats(4, D)
+    assert st["valid"] and len(st["rows_per_stage"]) <= 6
