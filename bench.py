@@ -1,0 +1,254 @@
+#!/usr/bin/env python3
+"""bench.py -- M-Gaussians/s for the RAHT hot path on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One step = one pass of the codec's transform path over one scene that is already resident in HBM:
+forward RAHT -> quantize + reorder -> dequantize + un-reorder -> inverse RAHT (BASELINE.json
+configs[2]: "~3M Gaussians, SH deg 3 (59 ch), fwd+inv + quantize").  `--no-quant` times fwd+inv
+only.  N > 1: every rank owns one Morton-prefix shard of an N-times larger scene (weak scaling);
+the top three octree levels are stitched with one small all-gather over RCCL per direction.
+
+Prints ONE JSON line (rank 0) with the driver's contract fields plus `roofline` (dominant kernel,
+HIP-event timed, algorithmic bytes) and `cpu_baseline` (the C oracle on the host cores).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8 TB/s; ~6.3 TB/s copy ceiling)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="cfg3", choices=["cfg3", "cfg2"])
+    ap.add_argument("--no-quant", action="store_true", help="time forward + inverse only")
+    ap.add_argument("--engine", default="tile", choices=["tile", "level"])
+    ap.add_argument("--tile-rows", type=int, default=0)
+    ap.add_argument("--quant-step", type=float, default=0.01)
+    ap.add_argument("--skip-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-repeats", type=int, default=2)
+    return ap.parse_args()
+
+
+def cpu_baseline(V, C32, J, repeats):
+    """The C oracle (scalar restatement of the reference, float64 like the reference) on this host."""
+    from oracle import oracle as orc
+    orc.lib()
+    p = orc.raht_param(V.astype(np.float64), np.zeros(3), 2 ** J, J)
+    C64 = C32.astype(np.float64)
+    best = None
+    for _ in range(max(1, repeats)):
+        t0 = time.perf_counter()
+        T, _ = orc.raht_fwd(C64, p)
+        R = orc.raht_inv(T, p)
+        dt = time.perf_counter() - t0
+        best = dt if best is None else min(best, dt)
+    err = float(np.abs(R - C64).max())
+    return V.shape[0] / best / 1e6, best, err
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        if rank == 0:
+            print(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}; launch through torch.distributed.run", file=sys.stderr)
+        if world == 1 and a.gpus > 1:
+            sys.exit(2)
+    assert torch.cuda.is_available(), "bench.py needs an MI355X"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+
+    import raht_3dgs_codec_amd as R
+    from raht_3dgs_codec_amd import _lib, synth
+    L = _lib.lib()                                     # fails loudly if the HIP library is missing
+
+    n_draws, J, D, seed = synth.CONFIGS[a.workload]
+    # ---- synthetic scene (host, seeded), one Morton-prefix shard per rank ----
+    if world == 1:
+        V, keys, Ch = synth.scene(n_draws, J, D, seed)
+    else:
+        per = 512 // world
+        V, keys, Ch = synth.scene(n_draws, J, D, seed + 100 * rank, prefix_range=(rank * per, (rank + 1) * per, 9))
+    N = V.shape[0]
+    Cd = torch.from_numpy(Ch).to(dev)
+    kd = torch.from_numpy(keys.view(np.int64)).to(dev)
+    steps_arr = (C.c_float * 1)(a.quant_step)
+
+    if world == 1:
+        plan = R.RahtPlan.from_keys(kd, 3 * J)
+        plan.set_engine(a.engine, a.tile_rows)
+        T = torch.empty_like(Cd)
+        Q = torch.empty((N, D), dtype=torch.int32, device=dev)
+        Td = torch.empty_like(Cd)
+        Crec = torch.empty_like(Cd)
+        h = plan._h
+        vp = C.c_void_p
+
+        def s_():
+            return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+        def fwd():
+            _lib.check(L.raht_fwd(h, vp(Cd.data_ptr()), D, D, vp(T.data_ptr()), D, None, s_()))
+
+        def quant():
+            _lib.check(L.raht_quant_reorder(h, vp(T.data_ptr()), D, D, steps_arr, 1, vp(Q.data_ptr()), D, s_()))
+
+        def dequant():
+            _lib.check(L.raht_dequant_unreorder(h, vp(Q.data_ptr()), D, D, steps_arr, 1, vp(Td.data_ptr()), D, s_()))
+
+        def inv(src):
+            _lib.check(L.raht_inv(h, vp(src.data_ptr()), D, D, vp(Crec.data_ptr()), D, s_()))
+
+        if a.no_quant:
+            def step():
+                fwd(); inv(T)
+        else:
+            def step():
+                fwd(); quant(); dequant(); inv(Td)
+        total_rows = N
+    else:
+        from raht_3dgs_codec_amd import sharded
+        sh = sharded.ShardedRaht(kd, 3 * J, prefix_bits=9)
+        qs = None if a.no_quant else a.quant_step
+
+        def step():
+            sh.step(Cd, qs)
+        total_rows = None
+
+    # ---- correctness gate: never report a number for a wrong transform ----
+    if world == 1:
+        fwd(); inv(T)
+        torch.cuda.synchronize()
+        rt_err = (Crec - Cd).abs().max().item() / Cd.abs().max().item()
+        assert rt_err <= 1e-5, f"round trip error {rt_err}"
+    else:
+        rt_err = sh.roundtrip_error(Cd)
+        assert rt_err <= 1e-5, f"round trip error {rt_err}"
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+
+    for _ in range(a.warmup):
+        step()
+    barrier(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    torch.cuda.synchronize(); barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        import torch.distributed as dist
+        tt = torch.tensor([dt, float(N)], dtype=torch.float64, device=dev)
+        tmax = tt.clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        tsum = tt.clone(); dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+        dt = tmax[0].item()
+        total_rows = int(tsum[1].item())
+    ms_per_step = dt / a.steps * 1e3
+    value = total_rows / (dt / a.steps) / 1e6
+
+    out = {
+        "metric": "M-Gaussians/s fwd+inv RAHT, 59-ch SH3 3DGS" if a.workload == "cfg3" else "M-Gaussians/s fwd+inv RAHT, 14-ch SH0 3DGS",
+        "value": round(value, 2), "unit": "M-Gaussians/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {
+            "workload": (f"{a.workload}: {total_rows} Gaussians ({n_draws} draws/GPU, J={J}, {D} channels), "
+                         + ("fwd + inv RAHT" if a.no_quant else "fwd RAHT + quantize/reorder + dequantize/un-reorder + inv RAHT")),
+            "rows_per_gpu": N, "channels": D, "depth_J": J, "engine": a.engine, "quantize": not a.no_quant,
+            "parallelism": "1 GPU" if world == 1 else f"morton-prefix sharded x{world}, top-3-octree-level all-gather (RCCL)",
+            "roundtrip_rel_err": rt_err,
+        },
+    }
+
+    if rank == 0 and world == 1:
+        # ---- per-stage breakdown (HIP events on the launch stream) ----
+        def timed(fn, reps):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                fn()
+            e1.record(); e1.synchronize()
+            return e0.elapsed_time(e1) / reps
+
+        reps = max(5, a.steps)
+        br = {"fwd_ms": timed(fwd, reps), "inv_ms": timed(lambda: inv(T), reps)}
+        if not a.no_quant:
+            br["quant_reorder_ms"] = timed(quant, reps)
+            br["dequant_unreorder_ms"] = timed(dequant, reps)
+        out["breakdown_ms"] = {k: round(v, 4) for k, v in br.items()}
+        st = plan.stage_stats(4, D)
+        out["config"]["tile_rows"] = st["tile_rows"]
+        out["config"]["active_rows_per_stage"] = st["rows_per_stage"]
+
+        # ---- roofline of the dominant kernel: stage-0 LDS-tile kernel, forward and inverse ----
+        # ALGORITHMIC bytes per launch (per direction): read N*D*4 + write N*D*4 + 8 B/row of plan
+        alg = 8.0 * N * D + 8.0 * N
+        if a.engine == "tile":
+            def k_fwd():
+                _lib.check(L.raht_debug_run_stage(h, 0, 0, vp(Cd.data_ptr()), D, D, vp(T.data_ptr()), D, s_()))
+
+            def k_inv():
+                _lib.check(L.raht_debug_run_stage(h, 1, 0, vp(T.data_ptr()), D, D, vp(Crec.data_ptr()), D, s_()))
+            k_fwd(); k_inv()
+            tf, ti = timed(k_fwd, reps), timed(k_inv, reps)
+            traffic = None
+            tp = os.path.join(ROOT, "profiles", "traffic.json")
+            if os.path.exists(tp):
+                try:
+                    traffic = json.load(open(tp)).get(a.workload, {}).get("tile_kernel_fwd_stage0_bytes")
+                except Exception:
+                    traffic = None
+            out["roofline"] = {"kernel": "raht::tile_kernel<float, false, true> (forward, stage 0)", "bound": "hbm",
+                               "achieved": round(alg / (tf * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": round(alg / (tf * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": traffic,
+                               "alg_bytes_per_launch": alg, "avg_launch_ms": round(tf, 4)}
+            out["roofline_inv"] = {"kernel": "raht::tile_kernel<float, true, true> (inverse, stage 0)", "bound": "hbm",
+                                   "achieved": round(alg / (ti * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                   "frac": round(alg / (ti * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                   "alg_bytes_per_launch": alg, "avg_launch_ms": round(ti, 4)}
+        # whole fwd+inv against the whole-path algorithmic bytes (16 N D + 16 N)
+        tot = br["fwd_ms"] + br["inv_ms"]
+        out["path_hbm"] = {"alg_bytes_fwd_inv": 2 * alg, "fwd_inv_ms": round(tot, 4),
+                           "achieved_GBs": round(2 * alg / (tot * 1e-3) / 1e9, 1),
+                           "frac_of_peak": round(2 * alg / (tot * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                           "fwd_inv_only_MGs": round(N / (tot * 1e-3) / 1e6, 1)}
+
+        if not a.skip_cpu_baseline:
+            v, secs, err = cpu_baseline(V, Ch, J, a.cpu_repeats)
+            out["cpu_baseline"] = {"value": round(v, 4), "unit": "M-Gaussians/s", "cores": 1, "kind": "port",
+                                   "sample": (f"the full {a.workload} scene ({N} rows x {D} ch), fwd+inv RAHT only, float64, "
+                                              f"best of {a.cpu_repeats}, {secs:.2f} s per pass; scalar C oracle (oracle/raht_oracle.c)"),
+                                   "roundtrip_abs_err": err}
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

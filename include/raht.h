@@ -132,6 +132,11 @@ int raht_inv(const raht_plan *plan, const float *T, int64_t ldt, int D, float *C
 int raht_inv_f64(const raht_plan *plan, const double *T, int64_t ldt, int D, double *C, int64_t ldc,
                  raht_stream_t stream);
 
+/* Profiling aid: enqueue ONE stage of the float32 tile schedule (stage 0 is the HBM-heavy launch).
+ * Not a transform by itself; bench.py uses it to time the dominant kernel with HIP events. */
+int raht_debug_run_stage(const raht_plan *plan, int inverse, int stage, const float *src, int64_t ld_src,
+                         int D, float *dst, int64_t ld_dst, raht_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Quantize + reorder / dequantize + un-reorder (driver-inline in the reference,
  * python/encode_3dgs.py:204 floor(x/step+0.5), :210 index_select(0, order_RAGFT), :215 int32;

@@ -131,7 +131,10 @@ struct TileArgs {
     const int64_t *wsum;
 };
 
-template <typename T, bool INV>
+// IDENT = true is stage 0 (the tile is rows [e0, e0 + R) of the matrix itself: the HBM-heavy
+// launch); IDENT = false are the gathered later stages. Separate instantiations keep the two
+// apart in rocprof kernel statistics.
+template <typename T, bool INV, bool IDENT>
 __global__ __launch_bounds__(256) void tile_kernel(const TileArgs<T> A)
 {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -160,7 +163,7 @@ __global__ __launch_bounds__(256) void tile_kernel(const TileArgs<T> A)
 
     const int64_t e0 = (int64_t)blockIdx.x * R;
     const int nt = (int)min((int64_t)R, A.n_entries - e0);
-    const bool ident = (A.rows == nullptr);
+    constexpr bool ident = IDENT;
     const int64_t start_row = ident ? e0 : (int64_t)A.rows[e0];
     const int64_t end_row = (e0 + R < A.n_entries) ? (ident ? e0 + R : (int64_t)A.rows[e0 + R]) : A.N;
     const bool fast = ident && A.vec_ok;                  // contiguous 16-byte path
@@ -345,7 +348,9 @@ static int launch_tile_stage(const raht_plan *p, const Schedule &sc, int k, cons
 {
     static bool attr_set = false;
     if (!attr_set) {
-        RAHT_HIP_CHECK(hipFuncSetAttribute((const void *)tile_kernel<T, INV>,
+        RAHT_HIP_CHECK(hipFuncSetAttribute((const void *)tile_kernel<T, INV, true>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        RAHT_HIP_CHECK(hipFuncSetAttribute((const void *)tile_kernel<T, INV, false>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
@@ -359,7 +364,10 @@ static int launch_tile_stage(const raht_plan *p, const Schedule &sc, int k, cons
     A.lvl = p->lvl; A.wl = p->wl; A.wr = p->wr; A.wsum = p->wsum;
     const int nchunks = (D + Dc - 1) / Dc;
     const size_t lds = tile_lds_bytes(sc.tile_rows, (int)sizeof(T), Dc);
-    hipLaunchKernelGGL((tile_kernel<T, INV>), dim3((unsigned)st.n_tiles, (unsigned)nchunks), dim3(256), lds, s, A);
+    if (st.rows == nullptr)
+        hipLaunchKernelGGL((tile_kernel<T, INV, true>), dim3((unsigned)st.n_tiles, (unsigned)nchunks), dim3(256), lds, s, A);
+    else
+        hipLaunchKernelGGL((tile_kernel<T, INV, false>), dim3((unsigned)st.n_tiles, (unsigned)nchunks), dim3(256), lds, s, A);
     RAHT_HIP_CHECK(hipGetLastError());
     return RAHT_OK;
 }
@@ -453,6 +461,24 @@ int raht_inv_f64(const raht_plan *plan, const double *T, int64_t ldt, int D, dou
                  raht_stream_t stream)
 {
     return run_transform<double, true>(plan, T, ldt, D, C, ldc, nullptr, (hipStream_t)stream);
+}
+
+/* Profiling aid: enqueue ONE stage of the float32 tile schedule (stage 0 = the HBM-heavy launch).
+ * Results are only meaningful as part of a full transform; bench.py uses this to time the dominant
+ * kernel in isolation with HIP events. */
+int raht_debug_run_stage(const raht_plan *cp, int inverse, int stage, const float *src, int64_t ld_src, int D,
+                         float *dst, int64_t ld_dst, raht_stream_t stream)
+{
+    raht_plan *p = const_cast<raht_plan *>(cp);
+    if (!p || !src || !dst || D < 1) { set_error("raht_debug_run_stage: bad argument"); return RAHT_ERR_INVALID; }
+    const int Dc = pick_chunk_channels(4, D);
+    const int R = pick_tile_rows(p, 4, Dc);
+    if (R == 0) { set_error("raht_debug_run_stage: no tile size"); return RAHT_ERR_UNSUPPORTED; }
+    const Schedule *sc = nullptr;
+    RAHT_RET(get_schedule(p, R, (hipStream_t)stream, &sc));
+    if (stage < 0 || stage >= (int)sc->stages.size()) { set_error("raht_debug_run_stage: stage out of range"); return RAHT_ERR_INVALID; }
+    if (inverse) return launch_tile_stage<float, true>(p, *sc, stage, src, ld_src, dst, ld_dst, D, Dc, (hipStream_t)stream);
+    return launch_tile_stage<float, false>(p, *sc, stage, src, ld_src, dst, ld_dst, D, Dc, (hipStream_t)stream);
 }
 
 }  // extern "C"

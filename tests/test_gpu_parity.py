@@ -298,7 +298,9 @@ def test_against_oracle_seeded(rt, oracle, n, J, D, seed):
     _check_f32(T.cpu().numpy(), To, "seeded")
     assert np.array_equal(w.cpu().numpy().reshape(-1).astype(np.float64), wo.reshape(-1))
     T64, _ = p.forward(_dev(C.astype(np.float64)))
-    np.testing.assert_allclose(T64.cpu().numpy(), To, rtol=1e-12, atol=1e-12)
+    # 1e-12 relative to the column scale (xyz columns carry a DC of ~1e5 next to entries near 0)
+    colmax = np.abs(To).max(axis=0, keepdims=True)
+    assert np.all(np.abs(T64.cpu().numpy() - To) <= 1e-12 * np.maximum(colmax, 1.0) + 1e-12 * np.abs(To))
     p.set_engine("level")
     Tl, _ = p.forward(_dev(C))
     _check_f32(Tl.cpu().numpy(), To, "seeded-level")
