@@ -43,6 +43,8 @@ def parse():
     ap.add_argument("--quant-step", type=float, default=0.01)
     ap.add_argument("--skip-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-repeats", type=int, default=2)
+    ap.add_argument("--unfused", action="store_true", help="quantize / dequantize as separate passes")
+    ap.add_argument("--ablate", type=int, default=0, help="kernel-timing experiment for the roofline probe only (0 = real kernel)")
     return ap.parse_args()
 
 
@@ -121,12 +123,21 @@ def main():
         def inv(src):
             _lib.check(L.raht_inv(h, vp(src.data_ptr()), D, D, vp(Crec.data_ptr()), D, s_()))
 
+        def fwd_quant():
+            _lib.check(L.raht_fwd_quant(h, vp(Cd.data_ptr()), D, D, steps_arr, 1, vp(Q.data_ptr()), D, s_()))
+
+        def dequant_inv():
+            _lib.check(L.raht_dequant_inv(h, vp(Q.data_ptr()), D, D, steps_arr, 1, vp(Crec.data_ptr()), D, s_()))
+
         if a.no_quant:
             def step():
                 fwd(); inv(T)
-        else:
+        elif a.unfused:
             def step():
                 fwd(); quant(); dequant(); inv(Td)
+        else:
+            def step():
+                fwd_quant(); dequant_inv()
         total_rows = N
     else:
         from raht_3dgs_codec_amd import sharded
@@ -177,7 +188,8 @@ def main():
         "dtype": "f32", "data": "synthetic",
         "config": {
             "workload": (f"{a.workload}: {total_rows} Gaussians ({n_draws} draws/GPU, J={J}, {D} channels), "
-                         + ("fwd + inv RAHT" if a.no_quant else "fwd RAHT + quantize/reorder + dequantize/un-reorder + inv RAHT")),
+                         + ("fwd + inv RAHT" if a.no_quant else "fwd RAHT + quantize/reorder + dequantize/un-reorder + inv RAHT"
+                            + (" (separate passes)" if a.unfused else " (quantization fused into the transform kernels)"))),
             "rows_per_gpu": N, "channels": D, "depth_J": J, "engine": a.engine, "quantize": not a.no_quant,
             "parallelism": "1 GPU" if world == 1 else f"morton-prefix sharded x{world}, top-3-octree-level all-gather (RCCL)",
             "roundtrip_rel_err": rt_err,
@@ -199,6 +211,8 @@ def main():
         if not a.no_quant:
             br["quant_reorder_ms"] = timed(quant, reps)
             br["dequant_unreorder_ms"] = timed(dequant, reps)
+            br["fwd_quant_fused_ms"] = timed(fwd_quant, reps)
+            br["dequant_inv_fused_ms"] = timed(dequant_inv, reps)
         out["breakdown_ms"] = {k: round(v, 4) for k, v in br.items()}
         st = plan.stage_stats(4, D)
         out["config"]["tile_rows"] = st["tile_rows"]
@@ -209,10 +223,10 @@ def main():
         alg = 8.0 * N * D + 8.0 * N
         if a.engine == "tile":
             def k_fwd():
-                _lib.check(L.raht_debug_run_stage(h, 0, 0, vp(Cd.data_ptr()), D, D, vp(T.data_ptr()), D, s_()))
+                _lib.check(L.raht_debug_run_stage(h, 0, 0, vp(Cd.data_ptr()), D, D, vp(T.data_ptr()), D, a.ablate, s_()))
 
             def k_inv():
-                _lib.check(L.raht_debug_run_stage(h, 1, 0, vp(T.data_ptr()), D, D, vp(Crec.data_ptr()), D, s_()))
+                _lib.check(L.raht_debug_run_stage(h, 1, 0, vp(T.data_ptr()), D, D, vp(Crec.data_ptr()), D, a.ablate, s_()))
             k_fwd(); k_inv()
             tf, ti = timed(k_fwd, reps), timed(k_inv, reps)
             traffic = None
@@ -222,11 +236,11 @@ def main():
                     traffic = json.load(open(tp)).get(a.workload, {}).get("tile_kernel_fwd_stage0_bytes")
                 except Exception:
                     traffic = None
-            out["roofline"] = {"kernel": "raht::tile_kernel<float, false, true> (forward, stage 0)", "bound": "hbm",
+            out["roofline"] = {"kernel": "raht::tile_kernel<float, false, true, false> (forward, stage 0)", "bound": "hbm",
                                "achieved": round(alg / (tf * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": round(alg / (tf * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": traffic,
                                "alg_bytes_per_launch": alg, "avg_launch_ms": round(tf, 4)}
-            out["roofline_inv"] = {"kernel": "raht::tile_kernel<float, true, true> (inverse, stage 0)", "bound": "hbm",
+            out["roofline_inv"] = {"kernel": "raht::tile_kernel<float, true, true, false> (inverse, stage 0)", "bound": "hbm",
                                    "achieved": round(alg / (ti * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                    "frac": round(alg / (ti * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                                    "alg_bytes_per_launch": alg, "avg_launch_ms": round(ti, 4)}

@@ -14,7 +14,8 @@
  *   - all data pointers are DEVICE pointers (HBM) unless a parameter says "host";
  *   - `stream` is a hipStream_t passed as void* (NULL = the null stream). Transform entry points
  *     (raht_fwd*, raht_inv*, raht_quant*, raht_dequant*) only enqueue kernels on `stream`: no
- *     allocation, no host synchronisation, safe to capture in a hipGraph. Plan construction and
+ *     host synchronisation and, after the first call for a given (element type, D) or after
+ *     raht_plan_prepare, no allocation: safe to capture in a hipGraph. Plan construction and
  *     raht_voxelize allocate and synchronise `stream` (they size outputs from device counts);
  *   - the caller owns every data buffer; a plan is an opaque handle owning its own HBM;
  *   - rows of C / T are the points in Morton order, row-major, `ld*` = row stride in ELEMENTS;
@@ -132,10 +133,27 @@ int raht_inv(const raht_plan *plan, const float *T, int64_t ldt, int D, float *C
 int raht_inv_f64(const raht_plan *plan, const double *T, int64_t ldt, int D, double *C, int64_t ldc,
                  raht_stream_t stream);
 
+/* Fused variants for the float32 tile engine: the coefficient matrix T is never materialised.
+ *   raht_fwd_quant   = raht_fwd + raht_quant_reorder      (encode_3dgs.py:159,204,210,215)
+ *   raht_dequant_inv = raht_dequant_unreorder + raht_inv  (encode_3dgs.py:261,267-268,274)
+ * Same results as the two-call sequences (identical float32 arithmetic). */
+int raht_fwd_quant(const raht_plan *plan, const float *C, int64_t ldc, int D, const float *steps,
+                   int n_steps, int32_t *Q, int64_t ldq, raht_stream_t stream);
+int raht_dequant_inv(const raht_plan *plan, const int32_t *Q, int64_t ldq, int D, const float *steps,
+                     int n_steps, float *C, int64_t ldc, raht_stream_t stream);
+
+/* Pre-build the tile schedule and the per-stage workspaces for (elem_size in {4, 8}, D). The
+ * first transform with a new (element type, D) does this implicitly (allocating and synchronising
+ * once); after raht_plan_prepare the transform entry points only enqueue kernels (hipGraph-safe).
+ * A plan owns its workspaces: do not run transforms of one plan concurrently on several streams. */
+int raht_plan_prepare(raht_plan *plan, int elem_size, int D, raht_stream_t stream);
+
 /* Profiling aid: enqueue ONE stage of the float32 tile schedule (stage 0 is the HBM-heavy launch).
- * Not a transform by itself; bench.py uses it to time the dominant kernel with HIP events. */
+ * Not a transform by itself; bench.py uses it to time the dominant kernel with HIP events.
+ * ablate: 0 = the real kernel; 1 = skip the butterflies; 2 = also skip merge resolution (a pure
+ * staged copy) -- timing experiments only, the output is then not a transform. */
 int raht_debug_run_stage(const raht_plan *plan, int inverse, int stage, const float *src, int64_t ld_src,
-                         int D, float *dst, int64_t ld_dst, raht_stream_t stream);
+                         int D, float *dst, int64_t ld_dst, int ablate, raht_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Quantize + reorder / dequantize + un-reorder (driver-inline in the reference,

@@ -21,7 +21,7 @@ EXPORTS = [
     "raht_last_error", "raht_version", "raht_plan_create", "raht_plan_create_from_keys",
     "raht_plan_destroy", "raht_plan_size", "raht_plan_nbits", "raht_plan_set_engine",
     "raht_plan_levels", "raht_plan_export_level", "raht_plan_order", "raht_plan_arrays",
-    "raht_plan_copy_array", "raht_plan_stage_stats", "raht_fwd", "raht_fwd_f64", "raht_inv", "raht_inv_f64", "raht_debug_run_stage",
+    "raht_plan_copy_array", "raht_plan_stage_stats", "raht_fwd", "raht_fwd_f64", "raht_inv", "raht_inv_f64", "raht_debug_run_stage", "raht_fwd_quant", "raht_dequant_inv", "raht_plan_prepare",
     "raht_quant_reorder", "raht_dequant_unreorder", "raht_voxelize", "raht_morton", "raht_sort_keys",
 ]
 
@@ -80,7 +80,10 @@ def lib():
         f.argtypes = [vp, vp, i64, i32, vp, i64, vp, vp]
     for f in (L.raht_inv, L.raht_inv_f64):
         f.argtypes = [vp, vp, i64, i32, vp, i64, vp]
-    L.raht_debug_run_stage.argtypes = [vp, i32, i32, vp, i64, i32, vp, i64, vp]
+    L.raht_debug_run_stage.argtypes = [vp, i32, i32, vp, i64, i32, vp, i64, i32, vp]
+    L.raht_fwd_quant.argtypes = [vp, vp, i64, i32, C.POINTER(C.c_float), i32, vp, i64, vp]
+    L.raht_dequant_inv.argtypes = [vp, vp, i64, i32, C.POINTER(C.c_float), i32, vp, i64, vp]
+    L.raht_plan_prepare.argtypes = [vp, i32, i32, vp]
     L.raht_quant_reorder.argtypes = [vp, vp, i64, i32, C.POINTER(C.c_float), i32, vp, i64, vp]
     L.raht_dequant_unreorder.argtypes = [vp, vp, i64, i32, C.POINTER(C.c_float), i32, vp, i64, vp]
     L.raht_voxelize.argtypes = [vp, i64, i64, i32, C.POINTER(C.c_float), dbl, i32, vp, vp, vp, vp, vp,

@@ -13,6 +13,8 @@
 
 namespace raht {
 
+__global__ void compact_scatter_kernel(const uint32_t *in, const uint32_t *flag, const uint32_t *pos, uint32_t *out, int64_t n);
+
 static thread_local char g_err[512] = "";
 
 void set_error(const char *fmt, ...)
@@ -151,6 +153,12 @@ __global__ void order_bucket_kernel(const uint8_t *__restrict__ lvl, int64_t N, 
     bucket[i] = (i == 0) ? 0 : (uint8_t)(1 + (20 - (int)lvl[i] / 3));
 }
 
+__global__ void invert_perm_kernel(const uint32_t *__restrict__ order, int64_t N, uint32_t *__restrict__ inv)
+{
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < N) inv[order[k]] = (uint32_t)k;
+}
+
 __global__ void level_bucket_kernel(const uint8_t *__restrict__ lvl, int64_t N, uint8_t *__restrict__ bucket)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -183,34 +191,66 @@ int pick_chunk_channels(int elem_size, int D)
     return (D + nchunks - 1) / nchunks;
 }
 
-size_t tile_lds_bytes(int R, int elem_size, int Dc)
+size_t tile_lds_bytes(int R, int elem_size, int Dc, bool ident, bool qm)
 {
-    // data tile + per-slot metadata (row id, wl, wr, a, b, partner, merge list, level) + histograms
+    // data tile + per-slot butterfly record (16 B float / 24 B double), row id (later stages only),
+    // Q position (fused quantization only), flag + histograms (1 KiB) + survivor slot list
+    // (R x uint16) + the inverse's survivor prefetch area (12 rows)
+    // (must match the carve-up in transform.hip: tile_kernel)
     size_t data = ((size_t)R * Dc * elem_size + 15) & ~(size_t)15;
-    size_t meta = (size_t)R * (4 + 4 + 4 + 2 * elem_size + 2 + 2 + 1);
-    return data + ((meta + 15) & ~(size_t)15) + 1024;
+    size_t meta = (size_t)R * ((elem_size == 4 ? 16 : 24) + (ident ? 0 : 4) + (qm ? 4 : 0) + 1);
+    size_t surv = ((size_t)R * 2 + 15) & ~(size_t)15;
+    return data + ((meta + 15) & ~(size_t)15) + 1024 + surv + (size_t)12 * Dc * elem_size;
 }
 
 int pick_tile_rows(const raht_plan *plan, int elem_size, int Dc)
 {
     if (plan->tile_rows_override > 0) return plan->tile_rows_override;
-    static const int cand[] = {512, 384, 256, 192, 128};
-    const size_t budget = 78 * 1024;      // two blocks per CU out of 160 KiB of LDS
-    for (int R : cand) {
-        if (R > 256 && Dc > 32) continue;
-        if (tile_lds_bytes(R, elem_size, Dc) <= budget) return R;
-    }
+    // Three 512-thread workgroups per CU. gfx950 hands out its 160 KiB of LDS in 128 granules of
+    // 1280 bytes, so each workgroup may use 42 granules. Measured best on MI355X for the
+    // 59-channel float32 case (R = 192); see DESIGN.md for the sweep.
+    const size_t budget = (size_t)42 * 1280;
+    for (int R = 512; R >= 64; R -= 32)
+        if (tile_lds_bytes(R, elem_size, Dc, true, elem_size == 4) <= budget) return R;
     return 0;
 }
 
 static void free_schedule(Schedule &sc)
 {
-    for (auto &st : sc.stages)
+    for (auto &st : sc.stages) {
         if (st.rows) (void)hipFree(st.rows);
+        if (st.surv_off) (void)hipFree(st.surv_off);
+        if (st.ws) (void)hipFree(st.ws);
+    }
     sc.stages.clear();
 }
 
-int get_schedule(raht_plan *plan, int R, hipStream_t s, const Schedule **out)
+int ensure_workspace(Schedule *sc, size_t row_bytes)
+{
+    if (row_bytes <= sc->ws_row_bytes) return RAHT_OK;
+    for (size_t k = 1; k < sc->stages.size(); ++k) {
+        Stage &st = sc->stages[k];
+        if (st.ws) { (void)hipFree(st.ws); st.ws = nullptr; }
+        if (hipMalloc(&st.ws, row_bytes * (size_t)st.n_entries) != hipSuccess) {
+            set_error("workspace allocation failed (%zu bytes)", row_bytes * (size_t)st.n_entries);
+            sc->ws_row_bytes = 0;
+            return RAHT_ERR_NOMEM;
+        }
+    }
+    sc->ws_row_bytes = row_bytes;
+    return RAHT_OK;
+}
+
+__global__ void tile_start_kernel(const uint32_t *__restrict__ pos, int64_t n, int R, int64_t n_tiles,
+                                  uint32_t total, uint32_t *__restrict__ surv_off)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t > n_tiles) return;
+    surv_off[t] = (t < n_tiles) ? pos[t * R] : total;
+    (void)n;
+}
+
+int get_schedule(raht_plan *plan, int R, hipStream_t s, Schedule **out)
 {
     for (auto &sc : plan->schedules)
         if (sc.tile_rows == R) { *out = &sc; return RAHT_OK; }
@@ -218,8 +258,10 @@ int get_schedule(raht_plan *plan, int R, hipStream_t s, const Schedule **out)
     sc.tile_rows = R;
     sc.valid = true;
     const int64_t N = plan->N;
-    uint32_t *flag = nullptr;
+    uint32_t *flag = nullptr, *pos = nullptr, *dtotal = nullptr;
     RAHT_HIP_CHECK(hipMalloc(&flag, sizeof(uint32_t) * (size_t)N));
+    RAHT_HIP_CHECK(hipMalloc(&pos, sizeof(uint32_t) * (size_t)N));
+    RAHT_HIP_CHECK(hipMalloc(&dtotal, sizeof(uint32_t)));
     uint32_t *rows = nullptr;      // rows of the current stage (nullptr = identity)
     int64_t n = N;
     int rc = RAHT_OK;
@@ -228,33 +270,40 @@ int get_schedule(raht_plan *plan, int R, hipStream_t s, const Schedule **out)
         st.n_entries = n;
         st.n_tiles = ceil_div(n, R);
         st.rows = rows;
-        sc.stages.push_back(st);
-        if (n <= R) break;                                   // a single tile finishes the tree
+        if (n <= R) { sc.stages.push_back(st); break; }      // a single tile finishes the tree
         hipLaunchKernelGGL(stage_survivor_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, s,
                            rows, n, R, N, plan->wl, plan->wr, flag);
-        uint32_t *next = nullptr;
-        if (hipMalloc(&next, sizeof(uint32_t) * (size_t)n) != hipSuccess) { rc = RAHT_ERR_NOMEM; break; }
-        int64_t cnt = 0;
-        rc = compact_u32(rows, flag, next, n, &cnt, s);
-        if (rc != RAHT_OK) { (void)hipFree(next); break; }
+        rc = exclusive_scan_u32(flag, pos, n, dtotal, s);
+        if (rc != RAHT_OK) break;
+        uint32_t cnt32 = 0;
+        if (hipMemcpyAsync(&cnt32, dtotal, sizeof(uint32_t), hipMemcpyDeviceToHost, s) != hipSuccess ||
+            hipStreamSynchronize(s) != hipSuccess) { rc = RAHT_ERR_HIP; break; }
+        const int64_t cnt = cnt32;
         if (cnt >= n || k == 23) {                           // no progress: pathological key pattern
-            (void)hipFree(next);
+            sc.stages.push_back(st);
             sc.valid = false;
             break;
         }
-        // shrink the allocation for long-lived schedules
-        uint32_t *fit = nullptr;
-        if (hipMalloc(&fit, sizeof(uint32_t) * (size_t)cnt) == hipSuccess) {
-            (void)hipMemcpyAsync(fit, next, sizeof(uint32_t) * (size_t)cnt, hipMemcpyDeviceToDevice, s);
-            (void)hipStreamSynchronize(s);
-            (void)hipFree(next);
-            next = fit;
-        }
+        if (hipMalloc(&st.surv_off, sizeof(uint32_t) * (size_t)(st.n_tiles + 1)) != hipSuccess) { rc = RAHT_ERR_NOMEM; break; }
+        hipLaunchKernelGGL(tile_start_kernel, dim3((unsigned)ceil_div(st.n_tiles + 1, 256)), dim3(256), 0, s,
+                           pos, n, R, st.n_tiles, cnt32, st.surv_off);
+        uint32_t *next = nullptr;
+        if (hipMalloc(&next, sizeof(uint32_t) * (size_t)cnt) != hipSuccess) { rc = RAHT_ERR_NOMEM; break; }
+        hipLaunchKernelGGL(compact_scatter_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, s, rows,
+                           flag, pos, next, n);
+        sc.stages.push_back(st);
         rows = next;
         n = cnt;
     }
-    (void)hipFree(flag);
-    if (rc != RAHT_OK) { free_schedule(sc); set_error("schedule build failed"); return rc; }
+    hipError_t e = hipStreamSynchronize(s);
+    (void)hipFree(flag); (void)hipFree(pos); (void)hipFree(dtotal);
+    if (rc == RAHT_OK && e != hipSuccess) rc = RAHT_ERR_HIP;
+    if (rc != RAHT_OK) {
+        if (!sc.stages.empty() && sc.stages.back().rows != rows && rows) (void)hipFree(rows);
+        free_schedule(sc);
+        set_error("schedule build failed");
+        return rc;
+    }
     plan->schedules.push_back(sc);
     *out = &plan->schedules.back();
     return RAHT_OK;
@@ -303,6 +352,8 @@ static int finish_plan(raht_plan *p, const int64_t *leaf_weights, hipStream_t s)
     RAHT_HIP_CHECK(hipMalloc(&p->level_rows, sizeof(uint32_t) * (size_t)N));
     hipLaunchKernelGGL(order_bucket_kernel, dim3(gb), dim3(256), 0, s, p->lvl, N, bucket);
     RAHT_RET(bucket_sort_u8(bucket, p->order, N, 5, nullptr, s));
+    RAHT_HIP_CHECK(hipMalloc(&p->inv_order, sizeof(uint32_t) * (size_t)N));
+    hipLaunchKernelGGL(invert_perm_kernel, dim3(gb), dim3(256), 0, s, p->order, N, p->inv_order);
     hipLaunchKernelGGL(level_bucket_kernel, dim3(gb), dim3(256), 0, s, p->lvl, N, bucket);
     RAHT_RET(bucket_sort_u8(bucket, p->level_rows, N, 6, boff, s));
     RAHT_HIP_CHECK(hipMemcpyAsync(p->level_off, boff, sizeof(uint32_t) * 65, hipMemcpyDeviceToHost, s));
@@ -325,8 +376,8 @@ static int finish_plan(raht_plan *p, const int64_t *leaf_weights, hipStream_t s)
     }
     RAHT_HIP_CHECK(hipGetLastError());
     // Build the default schedule now so that float32 transforms with D <= 64 never allocate.
-    const Schedule *sc = nullptr;
-    RAHT_RET(get_schedule(p, 256, s, &sc));
+    Schedule *sc = nullptr;
+    RAHT_RET(get_schedule(p, pick_tile_rows(p, 4, 59), s, &sc));
     return RAHT_OK;
 }
 
@@ -413,6 +464,7 @@ int raht_plan_destroy(raht_plan *p)
     if (p->wr) (void)hipFree(p->wr);
     if (p->wsum) (void)hipFree(p->wsum);
     if (p->order) (void)hipFree(p->order);
+    if (p->inv_order) (void)hipFree(p->inv_order);
     if (p->level_rows) (void)hipFree(p->level_rows);
     delete p;
     return RAHT_OK;
@@ -514,7 +566,7 @@ int raht_plan_stage_stats(raht_plan *p, int elem_size, int D, int *n_stages, int
     const int Dc = pick_chunk_channels(elem_size, D);
     const int R = pick_tile_rows(p, elem_size, Dc);
     if (R == 0) { set_error("no tile size fits"); return RAHT_ERR_UNSUPPORTED; }
-    const Schedule *sc = nullptr;
+    Schedule *sc = nullptr;
     RAHT_RET(get_schedule(p, R, nullptr, &sc));
     *n_stages = sc->valid ? (int)sc->stages.size() : -(int)sc->stages.size();
     if (tile_rows) *tile_rows = R;

@@ -61,13 +61,17 @@ int compact_u32(const uint32_t *in, const uint32_t *flag, uint32_t *out, int64_t
 struct Stage {
     int64_t n_entries = 0;   // active rows entering this stage
     int64_t n_tiles = 0;
-    uint32_t *rows = nullptr;  // device; nullptr for stage 0 (identity)
+    uint32_t *rows = nullptr;      // device; nullptr for stage 0 (identity)
+    uint32_t *surv_off = nullptr;  // device uint32[n_tiles + 1]: index (in the NEXT stage's entry
+                                   // list) of the first survivor of every tile; nullptr on the last stage
+    void *ws = nullptr;            // device workspace holding this stage's entries (stages >= 1)
 };
 
 struct Schedule {
     int tile_rows = 0;
     bool valid = false;        // false: tile stages cannot finish the tree -> use the level engine
     std::vector<Stage> stages;
+    size_t ws_row_bytes = 0;   // bytes per workspace row currently allocated (D * elem_size)
 };
 
 }  // namespace raht
@@ -82,6 +86,7 @@ struct raht_plan {
     int32_t *wr = nullptr;       // device
     int64_t *wsum = nullptr;     // device int64[N+1] prefix of leaf weights, or nullptr (all ones)
     uint32_t *order = nullptr;   // device, order_RAGFT
+    uint32_t *inv_order = nullptr;  // device, inverse permutation: inv_order[order[k]] = k
     uint32_t *level_rows = nullptr;          // device, rows 1..N-1 stably sorted by lvl
     uint32_t level_off[RAHT_MAX_LEVELS + 1]; // host, start of every level inside level_rows
     int engine = RAHT_ENGINE_TILE;
@@ -92,8 +97,12 @@ struct raht_plan {
 
 namespace raht {
 // Tile schedule for `tile_rows` rows per tile (built on first use, cached in the plan).
-int get_schedule(raht_plan *plan, int tile_rows, hipStream_t s, const Schedule **out);
+int get_schedule(raht_plan *plan, int tile_rows, hipStream_t s, Schedule **out);
+// Make sure the per-stage workspaces of `sc` hold rows of at least row_bytes bytes (allocates on
+// first use / growth only).
+int ensure_workspace(Schedule *sc, size_t row_bytes);
 // Rows per LDS tile for an element size / channel count (0 = does not fit).
 int pick_tile_rows(const raht_plan *plan, int elem_size, int chunk_channels);
 int pick_chunk_channels(int elem_size, int D);
+size_t tile_lds_bytes(int R, int elem_size, int Dc, bool ident, bool qm);
 }  // namespace raht

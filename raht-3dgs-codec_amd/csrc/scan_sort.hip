@@ -293,9 +293,8 @@ int bucket_sort_u8(const uint8_t *bucket, uint32_t *perm_out, int64_t n, int bit
 // ------------------------------------------------------------------------------------------------
 // Stream compaction.
 // ------------------------------------------------------------------------------------------------
-__global__ void compact_scatter_kernel(const uint32_t *__restrict__ in, const uint32_t *__restrict__ flag,
-                                       const uint32_t *__restrict__ pos, uint32_t *__restrict__ out,
-                                       int64_t n)
+__global__ void compact_scatter_kernel(const uint32_t *in, const uint32_t *flag, const uint32_t *pos,
+                                       uint32_t *out, int64_t n)
 {
     const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j < n && flag[j]) out[pos[j]] = in ? in[j] : (uint32_t)j;

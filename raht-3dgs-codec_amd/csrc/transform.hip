@@ -19,9 +19,13 @@
 // Bandwidth-bound integer/fp32 work: no MFMA by design (3 flops per 4 bytes).
 #include "raht_common.h"
 
+#include <algorithm>
+#include <cstdlib>
+#include <type_traits>
+
 namespace raht {
 
-size_t tile_lds_bytes(int R, int elem_size, int Dc);
+size_t tile_lds_bytes(int R, int elem_size, int Dc, bool ident, bool qm);
 
 template <typename T> struct Vec16;
 template <> struct Vec16<float> { typedef float4 type; static constexpr int n = 4; };
@@ -109,14 +113,43 @@ __global__ __launch_bounds__(256) void level_pass_kernel(T *__restrict__ data, i
 
 // ------------------------------------------------------------------------------------------------
 // TILE engine
+//
+// Data flow (K stages; stage k has n_k "entries" = rows still carrying a live low-pass value,
+// n_0 = N; a tile = R consecutive entries):
+//
+//   forward  stage k: read its entries CONTIGUOUSLY (k = 0: the caller's C, k >= 1: workspace
+//            ws_k, entry order) -> butterflies in LDS -> rows finalised here go to T[row] (or,
+//            fused, quantized to Q[inv_order[row]]); the few survivors go, compacted, to ws_{k+1}.
+//   inverse  stage k (K-1 ... 0): rows finalised at this stage come from T[row] (or, fused,
+//            dequantized from Q[inv_order[row]]); its survivors were produced by stage k+1 and sit
+//            contiguously in ws_{k+1} (prefetched at kernel start) -> butterflies, levels
+//            descending -> the whole tile is written CONTIGUOUSLY to ws_k (k >= 1) or to C (k = 0).
+//
+// So every large transfer is a coalesced contiguous span; only finalised rows of stages >= 1 (a
+// few % of N) and the fused Q rows are row-granular (236-byte segments at D = 59).
 // ------------------------------------------------------------------------------------------------
+constexpr int MAX_STEP_CH = 256;
+struct StepTable {
+    int n;                         // 0 = no quantization, 1 = one step, D = per channel
+    float v[MAX_STEP_CH];
+};
+struct NoSteps { int n; };
+
 template <typename T>
 struct TileArgs {
-    const T *src;        // pristine input (fwd: C, inv: T)
-    int64_t ld_src;
-    T *dst;              // output, also the carrier of intermediate low-pass rows between stages
-    int64_t ld_dst;
-    const uint32_t *rows;  // active rows of this stage (nullptr: identity, stage 0)
+    const T *in;         // fwd: this stage's entries, entry order (stage 0: C; k >= 1: ws_k)
+    int64_t ld_in;
+    T *fin;              // row-indexed coefficient matrix T (fwd: output, inv: input)
+    int64_t ld_fin;
+    T *wsn;              // ws_{k+1}: survivors of this stage, entry order of stage k+1 (fwd out / inv in)
+    T *out;              // inv: this stage's entries, entry order (stage 0: C; k >= 1: ws_k)
+    int64_t ld_out;
+    int64_t ld_ws;       // row stride of the workspaces (= D)
+    int32_t *Q;          // fused quantization: row-permuted integer coefficients (fwd out / inv in)
+    int64_t ldq;
+    const uint32_t *inv_order;
+    const uint32_t *rows;      // active rows of this stage (nullptr: identity, stage 0)
+    const uint32_t *surv_off;  // [n_tiles + 1] first survivor index per tile (nullptr on the last stage)
     int64_t n_entries;
     int64_t N;
     int R;
@@ -124,20 +157,65 @@ struct TileArgs {
     int Dc;              // channels per chunk (blockIdx.y selects the chunk)
     int lp_shift;        // log2 of the lane-group size (>= Dc, power of two, <= 64)
     int last_stage;      // this is the top stage of the schedule
-    int vec_ok;          // stage 0 fast path allowed (contiguous rows, 16-byte aligned bases)
+    int vec_io;          // the entry-ordered side (in / out) is contiguous and 16-byte aligned
+    int vec_fin;         // stage 0 only: T rows [e0, e0+R) are contiguous and aligned (bulk path)
+    int dbg;             // profiling ablations (raht_debug_run_stage only): 1 = skip butterflies,
+                         // 2 = skip merge resolution too (pure staged copy). Always 0 in transforms.
     const uint8_t *lvl;
     const int32_t *wl;
     const int32_t *wr;
     const int64_t *wsum;
 };
 
-// IDENT = true is stage 0 (the tile is rows [e0, e0 + R) of the matrix itself: the HBM-heavy
-// launch); IDENT = false are the gathered later stages. Separate instantiations keep the two
-// apart in rocprof kernel statistics.
-template <typename T, bool INV, bool IDENT>
-__global__ __launch_bounds__(256) void tile_kernel(const TileArgs<T> A)
+// One butterfly, resolved: LDS element offsets of the partner (low-pass) row and of the own
+// (high-pass) row, plus the two coefficients.
+template <typename T> struct MRec;
+template <> struct __align__(16) MRec<float> { uint32_t po; uint32_t jo; float a; float b; };
+template <> struct __align__(8) MRec<double> { uint32_t po; uint32_t jo; double a; double b; };
+
+constexpr int TILE_MAX_SLOTS = 2;      // slots per thread: R <= 2 * blockDim
+constexpr int TILE_GATHER_U = 16;      // rows in flight per wave in the inverse's row-granular gathers
+constexpr int TILE_FWD_U = 8;          // same for the forward's strided-row loads
+constexpr int TILE_ROUND_U = 4;        // butterflies in flight per lane group in a round
+constexpr int TILE_PRE_ROWS = 12;      // survivor rows prefetched by the inverse before flags are known
+
+template <typename T, typename V>
+__device__ __forceinline__ void bulk_copy16(const V *__restrict__ g4, V *__restrict__ l4, int nvec, int tid, int nthreads)
+{
+    for (int v0 = tid; v0 < nvec; v0 += 8 * nthreads) {           // 8 x 16 B in flight per lane
+        V x0, x1, x2, x3, x4, x5, x6, x7;
+        const int i1 = v0 + nthreads, i2 = v0 + 2 * nthreads, i3 = v0 + 3 * nthreads, i4 = v0 + 4 * nthreads,
+                  i5 = v0 + 5 * nthreads, i6 = v0 + 6 * nthreads, i7 = v0 + 7 * nthreads;
+        x0 = g4[v0];
+        if (i1 < nvec) x1 = g4[i1];
+        if (i2 < nvec) x2 = g4[i2];
+        if (i3 < nvec) x3 = g4[i3];
+        if (i4 < nvec) x4 = g4[i4];
+        if (i5 < nvec) x5 = g4[i5];
+        if (i6 < nvec) x6 = g4[i6];
+        if (i7 < nvec) x7 = g4[i7];
+        l4[v0] = x0;
+        if (i1 < nvec) l4[i1] = x1;
+        if (i2 < nvec) l4[i2] = x2;
+        if (i3 < nvec) l4[i3] = x3;
+        if (i4 < nvec) l4[i4] = x4;
+        if (i5 < nvec) l4[i5] = x5;
+        if (i6 < nvec) l4[i6] = x6;
+        if (i7 < nvec) l4[i7] = x7;
+    }
+}
+
+// IDENT = true is stage 0 (entries are the rows themselves: the HBM-heavy launch); IDENT = false
+// are the later, much smaller stages. QM = true fuses quantize+reorder (forward) / un-reorder+
+// dequantize (inverse). Separate instantiations keep them apart in rocprof kernel statistics.
+// launch bounds: three 512-thread workgroups per CU = 6 waves per SIMD for float32 (<= 80 VGPRs)
+template <typename T, bool INV, bool IDENT, bool QM>
+__global__ __launch_bounds__(512, (sizeof(T) == 4 ? 6 : 4)) void tile_kernel(const TileArgs<T> A,
+                                                   const typename std::conditional<QM, StepTable, NoSteps>::type ST)
 {
     extern __shared__ __align__(16) unsigned char smem[];
+    typedef typename Vec16<T>::type V16;
+    constexpr int VN = Vec16<T>::n;
     const int R = A.R;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int nthreads = blockDim.x, nw = nthreads >> 6;
@@ -147,88 +225,131 @@ __global__ __launch_bounds__(256) void tile_kernel(const TileArgs<T> A)
     // ---- LDS carve-up (must match tile_lds_bytes) ----
     size_t off = ((size_t)R * A.Dc * sizeof(T) + 15) & ~(size_t)15;
     T *tile = (T *)smem;
-    T *sa = (T *)(smem + off); off += (size_t)R * sizeof(T);
-    T *sb = (T *)(smem + off); off += (size_t)R * sizeof(T);
-    int32_t *srow = (int32_t *)(smem + off); off += (size_t)R * 4;
-    int32_t *swl = (int32_t *)(smem + off); off += (size_t)R * 4;
-    int32_t *swr = (int32_t *)(smem + off); off += (size_t)R * 4;
-    uint16_t *spart = (uint16_t *)(smem + off); off += (size_t)R * 2;
-    uint16_t *smlist = (uint16_t *)(smem + off); off += (size_t)R * 2;
-    uint8_t *slv = (uint8_t *)(smem + off); off += (size_t)R;
+    MRec<T> *mrec = (MRec<T> *)(smem + off); off += (size_t)R * sizeof(MRec<T>);
+    int32_t *srow = (int32_t *)(smem + off); if (!IDENT) off += (size_t)R * 4;   // stage 0: row = e0 + slot
+    int32_t *sdst = (int32_t *)(smem + off); if (QM) off += (size_t)R * 4;       // position of the row in Q
+    uint8_t *sflag = (uint8_t *)(smem + off); off += (size_t)R;      // 0 survivor, 1 merged here, 2 final root
     off = (off + 15) & ~(size_t)15;
     uint32_t *hist = (uint32_t *)(smem + off);            // [64]
     uint32_t *loff = hist + 64;                           // [64]
     uint32_t *cursor = hist + 128;                        // [64]
     uint32_t *lmask = hist + 192;                         // [2]
+    uint32_t *scnt = hist + 196;                          // [32] survivors per (slot chunk, wave)
+    off += 1024;
+    uint16_t *ssurv = (uint16_t *)(smem + off);           // [R] slots of this tile's survivors, by rank
+    off += ((size_t)R * 2 + 15) & ~(size_t)15;
+    T *spre = (T *)(smem + off);                          // inverse: [TILE_PRE_ROWS * Dc] survivor prefetch
 
     const int64_t e0 = (int64_t)blockIdx.x * R;
     const int nt = (int)min((int64_t)R, A.n_entries - e0);
-    constexpr bool ident = IDENT;
-    const int64_t start_row = ident ? e0 : (int64_t)A.rows[e0];
-    const int64_t end_row = (e0 + R < A.n_entries) ? (ident ? e0 + R : (int64_t)A.rows[e0 + R]) : A.N;
-    const bool fast = ident && A.vec_ok;                  // contiguous 16-byte path
+    const int64_t start_row = IDENT ? e0 : (int64_t)A.rows[e0];
+    const int64_t end_row = (e0 + R < A.n_entries) ? (IDENT ? e0 + R : (int64_t)A.rows[e0 + R]) : A.N;
+    uint32_t surv_base = 0, surv_cnt = 0;
+    if (A.surv_off) { surv_base = A.surv_off[blockIdx.x]; surv_cnt = A.surv_off[blockIdx.x + 1] - surv_base; }
 
-    // ---- 1. stage-0 bulk load: the tile is one contiguous span of src ----
-    if (fast) {
-        typedef typename Vec16<T>::type V;
-        constexpr int VN = Vec16<T>::n;
-        const T *gsrc = A.src + e0 * A.ld_src;
-        const int nelem = nt * Dc;
-        const int nvec = nelem / VN;
-        const V *g4 = (const V *)gsrc;
-        V *l4 = (V *)tile;
-        int v = tid;
-        for (; v + 3 * nthreads < nvec; v += 4 * nthreads) {      // 4 loads in flight per lane
-            const V x0 = g4[v], x1 = g4[v + nthreads], x2 = g4[v + 2 * nthreads], x3 = g4[v + 3 * nthreads];
-            l4[v] = x0; l4[v + nthreads] = x1; l4[v + 2 * nthreads] = x2; l4[v + 3 * nthreads] = x3;
-        }
-        for (; v < nvec; v += nthreads) l4[v] = g4[v];
-        for (int e = nvec * VN + tid; e < nelem; e += nthreads) tile[e] = gsrc[e];
-    }
-
-    // ---- 2. per-slot metadata ----
     if (tid < 64) hist[tid] = 0;
-    for (int j = tid; j < nt; j += nthreads) {
-        const int64_t r = ident ? e0 + j : (int64_t)A.rows[e0 + j];
-        srow[j] = (int32_t)r;
-        swl[j] = A.wl[r];
-        swr[j] = A.wr[r];
-        slv[j] = A.lvl[r];
-    }
-    __syncthreads();
 
-    // ---- 3. which slots merge here, their partner slot and butterfly coefficients ----
-    for (int j = tid; j < nt; j += nthreads) {
-        const int64_t r = srow[j];
-        const int l = swl[j], rr = swr[j];
-        const bool merged = (r > 0) && (r - l >= start_row) && (r + rr <= end_row);
-        uint16_t part = 0xffffu;
-        if (merged) {
-            int p;
-            if (ident) {
-                p = j - l;
-            } else {                                     // partner row r - l is an active row of this tile
-                const int32_t want = (int32_t)(r - l);
-                int lo = 0, hi = j - 1;
-                while (lo < hi) {
-                    const int mid = (lo + hi) >> 1;
-                    if (srow[mid] < want) lo = mid + 1; else hi = mid;
-                }
-                p = lo;
-            }
-            part = (uint16_t)p;
-            double w0, w1;
-            pair_weights(r, l, rr, A.wsum, w0, w1);
-            const double den = w0 + w1;
-            sa[j] = (T)sqrt(w0 / den);
-            sb[j] = (T)sqrt(w1 / den);
-            atomicAdd(&hist[slv[j]], 1u);
+    // ---- P0a. per-slot plan metadata -> registers (issued first: latency hides under the bulk load)
+    int32_t m_row[TILE_MAX_SLOTS], m_wl[TILE_MAX_SLOTS], m_wr[TILE_MAX_SLOTS], m_pos[TILE_MAX_SLOTS];
+    int m_lv[TILE_MAX_SLOTS];
+#pragma unroll
+    for (int s = 0; s < TILE_MAX_SLOTS; ++s) {
+        const int j = tid + s * nthreads;
+        m_row[s] = 0; m_wl[s] = 0; m_wr[s] = 0; m_lv[s] = 0; m_pos[s] = 0;
+        if (j < nt) {
+            const int64_t r = IDENT ? e0 + j : (int64_t)A.rows[e0 + j];
+            m_row[s] = (int32_t)r;
+            m_wl[s] = A.wl[r];
+            m_wr[s] = A.wr[r];
+            m_lv[s] = A.lvl[r];
+            m_pos[s] = QM ? (int32_t)A.inv_order[r] : (int32_t)r;    // where the final coefficient lives
         }
-        spart[j] = part;
     }
-    __syncthreads();
 
-    // ---- 4. bucket the merging slots by level (counting sort in LDS) ----
+    // ---- P0b. bulk transfers whose addresses do not depend on the plan metadata ----
+    bool bulk_done = false;                   // tile already holds every slot's input
+    if (!INV) {
+        if (A.vec_io) {                       // the stage's entries are one contiguous span
+            bulk_copy16<T, V16>((const V16 *)(A.in + e0 * A.ld_in), (V16 *)tile, (nt * Dc) / VN, tid, nthreads);
+            for (int e = ((nt * Dc) / VN) * VN + tid; e < nt * Dc; e += nthreads) tile[e] = A.in[e0 * A.ld_in + e];
+        } else {                              // strided rows / channel chunk
+            for (int j0 = wid * TILE_FWD_U; j0 < nt; j0 += nw * TILE_FWD_U) {
+                T v[TILE_FWD_U];
+#pragma unroll
+                for (int u = 0; u < TILE_FWD_U; ++u)
+                    if (j0 + u < nt && lane < Dc) v[u] = A.in[(e0 + j0 + u) * A.ld_in + c_base + lane];
+#pragma unroll
+                for (int u = 0; u < TILE_FWD_U; ++u)
+                    if (j0 + u < nt && lane < Dc) tile[(j0 + u) * Dc + lane] = v[u];
+            }
+        }
+        bulk_done = true;
+    } else {
+        if (IDENT && !QM && A.vec_fin) {      // stage 0: coefficient rows [e0, e0+nt) of T are contiguous
+            bulk_copy16<T, V16>((const V16 *)(A.fin + e0 * A.ld_fin), (V16 *)tile, (nt * Dc) / VN, tid, nthreads);
+            for (int e = ((nt * Dc) / VN) * VN + tid; e < nt * Dc; e += nthreads) tile[e] = A.fin[e0 * A.ld_fin + e];
+            bulk_done = true;
+        }
+        // survivors of this tile were produced by the stage above: one contiguous chunk of ws_{k+1}
+        const int npre = (int)min(surv_cnt, (uint32_t)TILE_PRE_ROWS) * Dc;
+        for (int e = tid; e < npre; e += nthreads) {
+            const int rr = e / Dc, cc = e - rr * Dc;
+            spre[e] = A.wsn[(int64_t)(surv_base + rr) * A.ld_ws + c_base + cc];
+        }
+    }
+#pragma unroll
+    for (int s = 0; s < TILE_MAX_SLOTS; ++s) {
+        const int j = tid + s * nthreads;
+        if (j < nt) { if (!IDENT) srow[j] = m_row[s]; if (QM) sdst[j] = m_pos[s]; }
+    }
+    __syncthreads();                                                       // sync #1
+
+    // inverse without a bulk path: gather every slot's coefficient row now (survivor slots get
+    // overwritten in P3b) -- the addresses only need sdst
+    if (INV && !bulk_done) {
+        for (int j0 = wid * TILE_GATHER_U; j0 < nt; j0 += nw * TILE_GATHER_U) {
+            T v[TILE_GATHER_U];
+#pragma unroll
+            for (int u = 0; u < TILE_GATHER_U; ++u) {
+                if (j0 + u < nt && lane < Dc) {
+                    if (QM) v[u] = (T)A.Q[(int64_t)sdst[j0 + u] * A.ldq + c_base + lane];
+                    else v[u] = A.fin[(IDENT ? e0 + j0 + u : (int64_t)srow[j0 + u]) * A.ld_fin + c_base + lane];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < TILE_GATHER_U; ++u) {
+                if (j0 + u < nt && lane < Dc) {
+                    T x = v[u];
+                    if constexpr (QM) x = x * (T)ST.v[ST.n == 1 ? 0 : c_base + lane];   // encode_3dgs.py:261
+                    tile[(j0 + u) * Dc + lane] = x;
+                }
+            }
+        }
+    }
+
+    // ---- P1. which slots merge inside this tile; level histogram; survivor ranks ----
+    bool m_merged[TILE_MAX_SLOTS];
+    int m_rank[TILE_MAX_SLOTS];
+    const uint64_t lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+#pragma unroll
+    for (int s = 0; s < TILE_MAX_SLOTS; ++s) {
+        const int j = tid + s * nthreads;
+        m_merged[s] = false;
+        bool surv = false;
+        if (j < nt && !(A.dbg & 2)) {
+            const int64_t r = m_row[s];
+            m_merged[s] = (r > 0) && (r - m_wl[s] >= start_row) && (r + m_wr[s] <= end_row);
+            surv = !m_merged[s];
+            sflag[j] = m_merged[s] ? 1 : (A.last_stage ? 2 : 0);
+            if (m_merged[s]) atomicAdd(&hist[m_lv[s]], 1u);
+        }
+        const uint64_t bal = __ballot(surv);
+        m_rank[s] = __popcll(bal & lt);
+        if (lane == 0 && s * nw + wid < 32) scnt[s * nw + wid] = (uint32_t)__popcll(bal);
+    }
+    __syncthreads();                                                       // sync #2
+
+    // ---- P2. level offsets (wave 0); survivor destinations ----
     if (wid == 0) {
         const uint32_t c = hist[lane];
         uint32_t inc = c;
@@ -242,81 +363,168 @@ __global__ __launch_bounds__(256) void tile_kernel(const TileArgs<T> A)
         const uint64_t m = __ballot(c > 0);
         if (lane == 0) { lmask[0] = (uint32_t)m; lmask[1] = (uint32_t)(m >> 32); }
     }
-    __syncthreads();
-    for (int j = tid; j < nt; j += nthreads) {
-        if (spart[j] != 0xffffu) {
-            const uint32_t pos = atomicAdd(&cursor[slv[j]], 1u);
-            smlist[pos] = (uint16_t)j;
-        }
-    }
-
-    // ---- 5. row-wise loads (gathered stages, strided / unaligned stage 0, inverse patches) ----
-    // forward : stage 0 reads src, later stages read the low-pass rows carried in dst
-    // inverse : rows finalised by THIS stage still hold pristine coefficients in src; rows that
-    //           survive this stage were already rewritten by the stages above it (unless this is
-    //           the top stage) and are read from dst
-    {
-        const bool need_all = !fast;
-        if (need_all || (INV && !A.last_stage)) {
-            for (int j = wid; j < nt; j += nw) {
-                const bool survivor = (spart[j] == 0xffffu);
-                bool from_dst;
-                if (!INV) from_dst = !ident;
-                else from_dst = survivor && !A.last_stage;
-                if (!need_all && !from_dst) continue;     // already in LDS from the bulk load
-                const int64_t r = srow[j];
-                const T *gp = from_dst ? (A.dst + r * A.ld_dst + c_base) : (A.src + r * A.ld_src + c_base);
-                if (lane < Dc) tile[j * Dc + lane] = gp[lane];
+    if (!A.last_stage) {
+#pragma unroll
+        for (int s = 0; s < TILE_MAX_SLOTS; ++s) {
+            const int j = tid + s * nthreads;
+            if (j < nt && !m_merged[s] && !(A.dbg & 2)) {
+                uint32_t before = 0;
+                for (int q = 0; q < s * nw + wid; ++q) before += scnt[q];
+                const uint32_t rk = before + (uint32_t)m_rank[s];            // rank among this tile's survivors
+                ssurv[rk] = (uint16_t)j;
             }
         }
     }
-    __syncthreads();
+    __syncthreads();                                                       // sync #3
 
-    // ---- 6. butterflies, one round per level present ----
+    // ---- P3a. resolve every butterfly of this tile into a record, bucketed by level ----
+#pragma unroll
+    for (int s = 0; s < TILE_MAX_SLOTS; ++s) {
+        const int j = tid + s * nthreads;
+        if (j < nt && m_merged[s]) {
+            const int64_t r = m_row[s];
+            const int l = m_wl[s];
+            int p;
+            if (IDENT) {
+                p = j - l;
+            } else {                                     // partner row r - l is an active row of this tile
+                const int32_t want = (int32_t)(r - l);
+                int lo = 0, hi = j - 1;
+                while (lo < hi) {
+                    const int mid = (lo + hi) >> 1;
+                    if (srow[mid] < want) lo = mid + 1; else hi = mid;
+                }
+                p = lo;
+            }
+            double w0, w1;
+            pair_weights(r, l, m_wr[s], A.wsum, w0, w1);
+            const double den = w0 + w1;
+            MRec<T> rec;
+            rec.po = (uint32_t)(p * Dc);
+            rec.jo = (uint32_t)(j * Dc);
+            rec.a = (T)sqrt(w0 / den);                    // RAHT.py:321-322
+            rec.b = (T)sqrt(w1 / den);
+            const uint32_t pos = atomicAdd(&cursor[m_lv[s]], 1u);
+            mrec[pos] = rec;
+        }
+    }
+    // ---- P3b. inverse: drop the survivors' low-pass rows (from the stage above) into their slots
+    if (INV && !A.last_stage && !(A.dbg & 2)) {
+        for (uint32_t q0 = wid * 4; q0 < surv_cnt; q0 += nw * 4) {
+            T v[4]; int jj[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const uint32_t q = q0 + u;
+                jj[u] = (q < surv_cnt) ? (int)ssurv[q] : -1;
+                if (jj[u] >= 0 && lane < Dc)
+                    v[u] = (q < (uint32_t)TILE_PRE_ROWS) ? spre[q * Dc + lane]
+                                                         : A.wsn[(int64_t)(surv_base + q) * A.ld_ws + c_base + lane];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (jj[u] >= 0 && lane < Dc) tile[jj[u] * Dc + lane] = v[u];
+        }
+    }
+    __syncthreads();                                                       // sync #4
+
+    // ---- P4. butterflies, one round per level present ----
     {
         const int Lp = 1 << A.lp_shift;
         const int gpw = 64 >> A.lp_shift;
         const int g = lane >> A.lp_shift, c = lane & (Lp - 1);
+        const uint32_t stride = (uint32_t)(nw * gpw);
         uint64_t mask = ((uint64_t)lmask[1] << 32) | lmask[0];
+        if (A.dbg & 1) mask = 0;
         while (mask) {
             const int l = INV ? (63 - __clzll((long long)mask)) : (__ffsll((long long)mask) - 1);
             mask &= ~(1ull << l);
             const uint32_t base = loff[l], cnt = hist[l];
-            for (uint32_t mb = wid * gpw; mb < cnt; mb += nw * gpw) {
-                const uint32_t m = mb + g;
-                if (m < cnt && c < Dc) {
-                    const int j = smlist[base + m];
-                    const int p = spart[j];
-                    const T a = sa[j], b = sb[j];
-                    const T x0 = tile[p * Dc + c], x1 = tile[j * Dc + c];
+            const uint32_t cc = (uint32_t)min(c, Dc - 1);         // idle lanes read a valid column
+            // branch-free body: reads are clamped to valid records (redundant, harmless), only
+            // the writes are predicated -> TILE_ROUND_U independent LDS chains in flight per lane
+            for (uint32_t mb = wid * gpw + g; mb < cnt + g; mb += stride * TILE_ROUND_U) {
+                uint32_t ip[TILE_ROUND_U], ij[TILE_ROUND_U];
+                T ca[TILE_ROUND_U], cb[TILE_ROUND_U], x0[TILE_ROUND_U], x1[TILE_ROUND_U];
+#pragma unroll
+                for (int u = 0; u < TILE_ROUND_U; ++u) {
+                    const uint32_t m = min(mb + u * stride, cnt - 1);
+                    const MRec<T> rec = mrec[base + m];
+                    ip[u] = rec.po + cc;
+                    ij[u] = rec.jo + cc;
+                    ca[u] = rec.a; cb[u] = rec.b;
+                }
+#pragma unroll
+                for (int u = 0; u < TILE_ROUND_U; ++u) { x0[u] = tile[ip[u]]; x1[u] = tile[ij[u]]; }
+#pragma unroll
+                for (int u = 0; u < TILE_ROUND_U; ++u) {
+                    T lo, hi;
                     if (!INV) {                           // RAHT.py:331-332
-                        tile[p * Dc + c] = a * x0 + b * x1;
-                        tile[j * Dc + c] = a * x1 - b * x0;
+                        lo = ca[u] * x0[u] + cb[u] * x1[u];
+                        hi = ca[u] * x1[u] - cb[u] * x0[u];
                     } else {                              // iRAHT.py:108-109
-                        tile[p * Dc + c] = a * x0 - b * x1;
-                        tile[j * Dc + c] = b * x0 + a * x1;
+                        lo = ca[u] * x0[u] - cb[u] * x1[u];
+                        hi = cb[u] * x0[u] + ca[u] * x1[u];
                     }
+                    if ((mb + u * stride < cnt) && (c < Dc)) { tile[ip[u]] = lo; tile[ij[u]] = hi; }
                 }
             }
             __syncthreads();
         }
     }
 
-    // ---- 7. write back ----
-    if (fast) {
-        typedef typename Vec16<T>::type V;
-        constexpr int VN = Vec16<T>::n;
-        T *gdst = A.dst + e0 * A.ld_dst;
-        const int nelem = nt * Dc;
-        const int nvec = nelem / VN;
-        V *g4 = (V *)gdst;
-        const V *l4 = (const V *)tile;
-        for (int v = tid; v < nvec; v += nthreads) g4[v] = l4[v];
-        for (int e = nvec * VN + tid; e < nelem; e += nthreads) gdst[e] = tile[e];
+    // ---- P5. write back ----
+    if (INV) {
+        // the whole tile, entry order: stage 0 -> C rows [e0, e0+nt); stage k -> ws_k
+        if (A.vec_io) {
+            V16 *g4 = (V16 *)(A.out + e0 * A.ld_out);
+            const V16 *l4 = (const V16 *)tile;
+            const int nvec = (nt * Dc) / VN;
+            for (int v = tid; v < nvec; v += nthreads) g4[v] = l4[v];
+            for (int e = nvec * VN + tid; e < nt * Dc; e += nthreads) A.out[e0 * A.ld_out + e] = tile[e];
+        } else {
+            for (int j = wid; j < nt; j += nw)
+                if (lane < Dc) A.out[(e0 + j) * A.ld_out + c_base + lane] = tile[j * Dc + lane];
+        }
     } else {
-        for (int j = wid; j < nt; j += nw) {
-            const int64_t r = srow[j];
-            if (lane < Dc) A.dst[r * A.ld_dst + c_base + lane] = tile[j * Dc + lane];
+        const bool bulk_fin = IDENT && !QM && A.vec_fin;
+        if (bulk_fin) {
+            // stage 0: T rows [e0, e0+nt) in one span (survivor rows are rewritten by later stages)
+            V16 *g4 = (V16 *)(A.fin + e0 * A.ld_fin);
+            const V16 *l4 = (const V16 *)tile;
+            const int nvec = (nt * Dc) / VN;
+            for (int v = tid; v < nvec; v += nthreads) g4[v] = l4[v];
+            for (int e = nvec * VN + tid; e < nt * Dc; e += nthreads) A.fin[e0 * A.ld_fin + e] = tile[e];
+        }
+        // survivors (a few per tile): compacted into ws_{k+1} in rank order
+        if (!A.last_stage && !(A.dbg & 2)) {
+            for (uint32_t q = wid; q < surv_cnt; q += nw) {
+                const int j = ssurv[q];
+                if (lane < Dc) A.wsn[(int64_t)(surv_base + q) * A.ld_ws + c_base + lane] = tile[j * Dc + lane];
+            }
+        }
+        // rows finalised here, row-granular (later stages, strided T, or fused quantization)
+        if (!bulk_fin) {
+            for (int j0 = wid * 4; j0 < nt; j0 += nw * 4) {
+                int fl[4]; int64_t d[4]; T x[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int j = min(j0 + u, nt - 1);
+                    fl[u] = (A.dbg & 2) ? 1 : sflag[j];
+                    d[u] = QM ? (int64_t)sdst[j] : (IDENT ? e0 + j : (int64_t)srow[j]);
+                    x[u] = tile[j * Dc + min(lane, Dc - 1)];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (j0 + u < nt && fl[u] != 0 && lane < Dc) {
+                        if constexpr (QM) {
+                            const float st = ST.v[ST.n == 1 ? 0 : c_base + lane];
+                            A.Q[d[u] * A.ldq + c_base + lane] = (int32_t)floorf((float)x[u] / st + 0.5f);  // encode_3dgs.py:204,210,215
+                        } else {
+                            A.fin[d[u] * A.ld_fin + c_base + lane] = x[u];
+                        }
+                    }
+                }
+            }
         }
     }
 }
@@ -335,6 +543,17 @@ __global__ void node_weight_kernel(const int32_t *__restrict__ wl, const int32_t
     w[i] = (T)(w0 + w1);
 }
 
+static int tile_threads()
+{
+    static int t = 0;
+    if (t == 0) {
+        const char *e = getenv("RAHT_TILE_THREADS");      // tuning knob: 512 (default), 256 or 128
+        const int v = e ? atoi(e) : 512;
+        t = (v == 128 || v == 256 || v == 512) ? v : 512;
+    }
+    return t;
+}
+
 static int lp_shift_for(int Dc)
 {
     int s = 0;
@@ -342,34 +561,78 @@ static int lp_shift_for(int Dc)
     return s;
 }
 
-template <typename T, bool INV>
-static int launch_tile_stage(const raht_plan *p, const Schedule &sc, int k, const T *src, int64_t ld_src,
-                             T *dst, int64_t ld_dst, int D, int Dc, hipStream_t s)
+// What one direction of the transform reads / writes.
+template <typename T>
+struct XformIO {
+    const T *src = nullptr; int64_t ld_src = 0;     // fwd: C             inv: T (unless quantized)
+    T *dst = nullptr; int64_t ld_dst = 0;           // fwd: T (unless q)  inv: C
+    int32_t *Q = nullptr; int64_t ldq = 0;          // fused quantization (fwd out / inv in)
+    const float *steps = nullptr; int n_steps = 0;
+};
+
+template <typename T, bool INV, bool IDENT, bool QM>
+static int launch_tile_one(const TileArgs<T> &A, const XformIO<T> &io, dim3 grid, int threads, size_t lds, hipStream_t s)
 {
     static bool attr_set = false;
     if (!attr_set) {
-        RAHT_HIP_CHECK(hipFuncSetAttribute((const void *)tile_kernel<T, INV, true>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        RAHT_HIP_CHECK(hipFuncSetAttribute((const void *)tile_kernel<T, INV, false>,
+        RAHT_HIP_CHECK(hipFuncSetAttribute((const void *)tile_kernel<T, INV, IDENT, QM>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
-    const Stage &st = sc.stages[(size_t)k];
-    TileArgs<T> A;
-    A.src = src; A.ld_src = ld_src; A.dst = dst; A.ld_dst = ld_dst;
-    A.rows = st.rows; A.n_entries = st.n_entries; A.N = p->N; A.R = sc.tile_rows;
-    A.D = D; A.Dc = Dc; A.lp_shift = lp_shift_for(Dc);
-    A.last_stage = (k == (int)sc.stages.size() - 1) ? 1 : 0;
-    A.vec_ok = (Dc == D && ld_src == D && ld_dst == D && ((uintptr_t)src % 16 == 0) && ((uintptr_t)dst % 16 == 0)) ? 1 : 0;
-    A.lvl = p->lvl; A.wl = p->wl; A.wr = p->wr; A.wsum = p->wsum;
-    const int nchunks = (D + Dc - 1) / Dc;
-    const size_t lds = tile_lds_bytes(sc.tile_rows, (int)sizeof(T), Dc);
-    if (st.rows == nullptr)
-        hipLaunchKernelGGL((tile_kernel<T, INV, true>), dim3((unsigned)st.n_tiles, (unsigned)nchunks), dim3(256), lds, s, A);
-    else
-        hipLaunchKernelGGL((tile_kernel<T, INV, false>), dim3((unsigned)st.n_tiles, (unsigned)nchunks), dim3(256), lds, s, A);
+    if constexpr (QM) {
+        StepTable st;
+        st.n = io.n_steps;
+        for (int c = 0; c < io.n_steps; ++c) st.v[c] = io.steps[c];
+        hipLaunchKernelGGL((tile_kernel<T, INV, IDENT, true>), grid, dim3(threads), lds, s, A, st);
+    } else {
+        NoSteps ns{0};
+        hipLaunchKernelGGL((tile_kernel<T, INV, IDENT, false>), grid, dim3(threads), lds, s, A, ns);
+    }
     RAHT_HIP_CHECK(hipGetLastError());
     return RAHT_OK;
+}
+
+template <typename T, bool INV, bool QM>
+static int launch_tile_stage(const raht_plan *p, const Schedule &sc, int k, const XformIO<T> &io, int D, int Dc,
+                             hipStream_t s, int dbg = 0)
+{
+    const Stage &st = sc.stages[(size_t)k];
+    const int K = (int)sc.stages.size();
+    TileArgs<T> A;
+    A.rows = st.rows; A.surv_off = st.surv_off; A.n_entries = st.n_entries; A.N = p->N; A.R = sc.tile_rows;
+    A.D = D; A.Dc = Dc; A.lp_shift = lp_shift_for(Dc);
+    A.last_stage = (k == K - 1) ? 1 : 0;
+    A.lvl = p->lvl; A.wl = p->wl; A.wr = p->wr; A.wsum = p->wsum;
+    A.inv_order = p->inv_order; A.Q = io.Q; A.ldq = io.ldq;
+    A.dbg = dbg;
+    A.ld_ws = D;
+    A.wsn = (k + 1 < K) ? (T *)sc.stages[(size_t)k + 1].ws : nullptr;
+    T *ws_k = (k >= 1) ? (T *)st.ws : nullptr;
+    const bool one_chunk = (Dc == D);
+    auto aligned = [](const void *q) { return ((uintptr_t)q % 16) == 0; };
+    if (!INV) {
+        A.in = (k == 0) ? io.src : ws_k; A.ld_in = (k == 0) ? io.ld_src : D;
+        A.fin = io.dst; A.ld_fin = io.ld_dst;
+        A.out = nullptr; A.ld_out = 0;
+        A.vec_io = (one_chunk && A.ld_in == D && aligned(A.in)) ? 1 : 0;
+        A.vec_fin = (k == 0 && one_chunk && io.dst && io.ld_dst == D && aligned(io.dst)) ? 1 : 0;
+    } else {
+        A.in = nullptr; A.ld_in = 0;
+        A.fin = const_cast<T *>(io.src); A.ld_fin = io.ld_src;
+        A.out = (k == 0) ? io.dst : ws_k; A.ld_out = (k == 0) ? io.ld_dst : D;
+        A.vec_io = (one_chunk && A.ld_out == D && aligned(A.out)) ? 1 : 0;
+        A.vec_fin = (k == 0 && one_chunk && io.src && io.ld_src == D && aligned(io.src)) ? 1 : 0;
+    }
+    const int nchunks = (D + Dc - 1) / Dc;
+    const size_t lds = tile_lds_bytes(sc.tile_rows, (int)sizeof(T), Dc, st.rows == nullptr, QM);
+    const int threads = tile_threads();
+    if (sc.tile_rows > TILE_MAX_SLOTS * threads) {
+        set_error("tile_rows %d too large for %d threads", sc.tile_rows, threads);
+        return RAHT_ERR_UNSUPPORTED;
+    }
+    const dim3 grid((unsigned)st.n_tiles, (unsigned)nchunks);
+    if (st.rows == nullptr) return launch_tile_one<T, INV, true, QM>(A, io, grid, threads, lds, s);
+    return launch_tile_one<T, INV, false, QM>(A, io, grid, threads, lds, s);
 }
 
 template <typename T, bool INV>
@@ -396,6 +659,24 @@ static int run_level_engine(const raht_plan *p, const T *src, int64_t ld_src, T 
     return RAHT_OK;
 }
 
+// Tile schedule (+ workspaces) for this element type / channel count; nullptr -> use the level engine.
+template <typename T>
+static int tile_setup(raht_plan *p, int D, hipStream_t s, Schedule **sc_out, int *Dc_out)
+{
+    *sc_out = nullptr;
+    if (p->engine == RAHT_ENGINE_LEVEL) return RAHT_OK;
+    const int Dc = pick_chunk_channels((int)sizeof(T), D);
+    const int R = pick_tile_rows(p, (int)sizeof(T), Dc);
+    if (R == 0) return RAHT_OK;
+    Schedule *sc = nullptr;
+    RAHT_RET(get_schedule(p, R, s, &sc));
+    if (!sc->valid) return RAHT_OK;                   // pathological key pattern, see plan.hip
+    RAHT_RET(ensure_workspace(sc, (size_t)D * sizeof(T)));
+    *sc_out = sc;
+    *Dc_out = Dc;
+    return RAHT_OK;
+}
+
 template <typename T, bool INV>
 static int run_transform(const raht_plan *cp, const T *src, int64_t ld_src, int D, T *dst, int64_t ld_dst,
                          T *w, hipStream_t s)
@@ -403,26 +684,19 @@ static int run_transform(const raht_plan *cp, const T *src, int64_t ld_src, int 
     raht_plan *p = const_cast<raht_plan *>(cp);
     if (!p || !src || !dst) { set_error("raht transform: NULL argument"); return RAHT_ERR_INVALID; }
     if (D < 1 || ld_src < D || ld_dst < D) { set_error("raht transform: bad D/ld (D=%d ld_src=%lld ld_dst=%lld)", D, (long long)ld_src, (long long)ld_dst); return RAHT_ERR_INVALID; }
-    int rc = RAHT_OK;
-    bool use_level = (p->engine == RAHT_ENGINE_LEVEL);
-    const Schedule *sc = nullptr;
+    Schedule *sc = nullptr;
     int Dc = 0;
-    if (!use_level) {
-        Dc = pick_chunk_channels((int)sizeof(T), D);
-        const int R = pick_tile_rows(p, (int)sizeof(T), Dc);
-        if (R == 0) use_level = true;
-        else {
-            RAHT_RET(get_schedule(p, R, s, &sc));
-            if (!sc->valid) use_level = true;              // pathological key pattern, see plan.hip
-        }
-    }
-    if (use_level) {
+    RAHT_RET(tile_setup<T>(p, D, s, &sc, &Dc));
+    int rc = RAHT_OK;
+    if (!sc) {
         rc = run_level_engine<T, INV>(p, src, ld_src, dst, ld_dst, D, s);
     } else {
+        XformIO<T> io;
+        io.src = src; io.ld_src = ld_src; io.dst = dst; io.ld_dst = ld_dst;
         const int K = (int)sc->stages.size();
         for (int q = 0; q < K && rc == RAHT_OK; ++q) {
             const int k = INV ? K - 1 - q : q;
-            rc = launch_tile_stage<T, INV>(p, *sc, k, src, ld_src, dst, ld_dst, D, Dc, s);
+            rc = launch_tile_stage<T, INV, false>(p, *sc, k, io, D, Dc, s);
         }
     }
     if (rc == RAHT_OK && w) {
@@ -431,6 +705,15 @@ static int run_transform(const raht_plan *cp, const T *src, int64_t ld_src, int 
         RAHT_HIP_CHECK(hipGetLastError());
     }
     return rc;
+}
+
+static int check_steps(const float *steps, int n_steps, int D)
+{
+    if (!steps || !(n_steps == 1 || n_steps == D)) { set_error("quant: n_steps must be 1 or D"); return RAHT_ERR_INVALID; }
+    if (n_steps > MAX_STEP_CH) { set_error("quant: per-channel steps support D <= %d", MAX_STEP_CH); return RAHT_ERR_UNSUPPORTED; }
+    for (int c = 0; c < n_steps; ++c)
+        if (!(steps[c] > 0.0f)) { set_error("quant: step[%d] must be > 0", c); return RAHT_ERR_INVALID; }
+    return RAHT_OK;
 }
 
 }  // namespace raht
@@ -463,22 +746,74 @@ int raht_inv_f64(const raht_plan *plan, const double *T, int64_t ldt, int D, dou
     return run_transform<double, true>(plan, T, ldt, D, C, ldc, nullptr, (hipStream_t)stream);
 }
 
+/* Fused forward RAHT + quantize + reorder: Q[k, c] = floor(T[order[k], c] / step_c + 0.5) without
+ * ever materialising T (encode_3dgs.py:159,204,210,215 in one pass). */
+int raht_fwd_quant(const raht_plan *cp, const float *C, int64_t ldc, int D, const float *steps, int n_steps,
+                   int32_t *Q, int64_t ldq, raht_stream_t stream)
+{
+    raht_plan *p = const_cast<raht_plan *>(cp);
+    hipStream_t s = (hipStream_t)stream;
+    if (!p || !C || !Q || D < 1 || ldc < D || ldq < D) { set_error("raht_fwd_quant: bad argument"); return RAHT_ERR_INVALID; }
+    RAHT_RET(check_steps(steps, n_steps, D));
+    Schedule *sc = nullptr;
+    int Dc = 0;
+    RAHT_RET(tile_setup<float>(p, D, s, &sc, &Dc));
+    if (!sc) { set_error("raht_fwd_quant needs the tile engine (use raht_fwd + raht_quant_reorder)"); return RAHT_ERR_UNSUPPORTED; }
+    XformIO<float> io;
+    io.src = C; io.ld_src = ldc; io.Q = Q; io.ldq = ldq; io.steps = steps; io.n_steps = n_steps;
+    const int K = (int)sc->stages.size();
+    for (int k = 0; k < K; ++k) RAHT_RET((launch_tile_stage<float, false, true>(p, *sc, k, io, D, Dc, s)));
+    return RAHT_OK;
+}
+
+/* Fused un-reorder + dequantize + inverse RAHT (encode_3dgs.py:261,267-268,274 in one pass). */
+int raht_dequant_inv(const raht_plan *cp, const int32_t *Q, int64_t ldq, int D, const float *steps, int n_steps,
+                     float *C, int64_t ldc, raht_stream_t stream)
+{
+    raht_plan *p = const_cast<raht_plan *>(cp);
+    hipStream_t s = (hipStream_t)stream;
+    if (!p || !C || !Q || D < 1 || ldc < D || ldq < D) { set_error("raht_dequant_inv: bad argument"); return RAHT_ERR_INVALID; }
+    RAHT_RET(check_steps(steps, n_steps, D));
+    Schedule *sc = nullptr;
+    int Dc = 0;
+    RAHT_RET(tile_setup<float>(p, D, s, &sc, &Dc));
+    if (!sc) { set_error("raht_dequant_inv needs the tile engine (use raht_dequant_unreorder + raht_inv)"); return RAHT_ERR_UNSUPPORTED; }
+    XformIO<float> io;
+    io.dst = C; io.ld_dst = ldc; io.Q = const_cast<int32_t *>(Q); io.ldq = ldq; io.steps = steps; io.n_steps = n_steps;
+    const int K = (int)sc->stages.size();
+    for (int k = K - 1; k >= 0; --k) RAHT_RET((launch_tile_stage<float, true, true>(p, *sc, k, io, D, Dc, s)));
+    return RAHT_OK;
+}
+
+/* Pre-build the tile schedule and workspaces for (elem_size, D) so that later transform calls
+ * neither allocate nor synchronise (e.g. before hipGraph capture). */
+int raht_plan_prepare(raht_plan *p, int elem_size, int D, raht_stream_t stream)
+{
+    if (!p || (elem_size != 4 && elem_size != 8) || D < 1) { set_error("raht_plan_prepare: bad argument"); return RAHT_ERR_INVALID; }
+    Schedule *sc = nullptr;
+    int Dc = 0;
+    if (elem_size == 4) return tile_setup<float>(p, D, (hipStream_t)stream, &sc, &Dc);
+    return tile_setup<double>(p, D, (hipStream_t)stream, &sc, &Dc);
+}
+
 /* Profiling aid: enqueue ONE stage of the float32 tile schedule (stage 0 = the HBM-heavy launch).
  * Results are only meaningful as part of a full transform; bench.py uses this to time the dominant
  * kernel in isolation with HIP events. */
 int raht_debug_run_stage(const raht_plan *cp, int inverse, int stage, const float *src, int64_t ld_src, int D,
-                         float *dst, int64_t ld_dst, raht_stream_t stream)
+                         float *dst, int64_t ld_dst, int ablate, raht_stream_t stream)
 {
     raht_plan *p = const_cast<raht_plan *>(cp);
+    hipStream_t s = (hipStream_t)stream;
     if (!p || !src || !dst || D < 1) { set_error("raht_debug_run_stage: bad argument"); return RAHT_ERR_INVALID; }
-    const int Dc = pick_chunk_channels(4, D);
-    const int R = pick_tile_rows(p, 4, Dc);
-    if (R == 0) { set_error("raht_debug_run_stage: no tile size"); return RAHT_ERR_UNSUPPORTED; }
-    const Schedule *sc = nullptr;
-    RAHT_RET(get_schedule(p, R, (hipStream_t)stream, &sc));
+    Schedule *sc = nullptr;
+    int Dc = 0;
+    RAHT_RET(tile_setup<float>(p, D, s, &sc, &Dc));
+    if (!sc) { set_error("raht_debug_run_stage: tile engine unavailable"); return RAHT_ERR_UNSUPPORTED; }
     if (stage < 0 || stage >= (int)sc->stages.size()) { set_error("raht_debug_run_stage: stage out of range"); return RAHT_ERR_INVALID; }
-    if (inverse) return launch_tile_stage<float, true>(p, *sc, stage, src, ld_src, dst, ld_dst, D, Dc, (hipStream_t)stream);
-    return launch_tile_stage<float, false>(p, *sc, stage, src, ld_src, dst, ld_dst, D, Dc, (hipStream_t)stream);
+    XformIO<float> io;
+    io.src = src; io.ld_src = ld_src; io.dst = dst; io.ld_dst = ld_dst;
+    if (inverse) return launch_tile_stage<float, true, false>(p, *sc, stage, io, D, Dc, s, ablate);
+    return launch_tile_stage<float, false, false>(p, *sc, stage, io, D, Dc, s, ablate);
 }
 
 }  // extern "C"

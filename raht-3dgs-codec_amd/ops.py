@@ -193,6 +193,38 @@ class RahtPlan:
     def inverse(self, T):
         return self._xform(T, True)
 
+    def prepare(self, D, dtype=torch.float32):
+        """Pre-build schedule + workspaces so later calls only enqueue kernels (hipGraph-safe)."""
+        es = 8 if dtype == torch.float64 else 4
+        with torch.cuda.device(self.device):
+            check(_lib.lib().raht_plan_prepare(self._h, es, int(D), _stream()))
+
+    def forward_quant(self, Cmat, steps):
+        """Fused forward RAHT + quantize + reorder -> int32 Q (T is never materialised)."""
+        _need_cuda(Cmat, "C")
+        X = Cmat.to(torch.float32)
+        if X.stride(1) != 1 or X.stride(0) < X.shape[1]:
+            X = X.contiguous()
+        D = X.shape[1]
+        st = _steps(steps, D)
+        Q = torch.empty((self.N, D), dtype=torch.int32, device=X.device)
+        with torch.cuda.device(X.device):
+            check(_lib.lib().raht_fwd_quant(self._h, C.c_void_p(X.data_ptr()), X.stride(0), D, st, len(st),
+                                            C.c_void_p(Q.data_ptr()), D, _stream()))
+        return Q
+
+    def dequant_inverse(self, Q, steps):
+        """Fused un-reorder + dequantize + inverse RAHT -> float32 C."""
+        _need_cuda(Q, "Q")
+        Q = Q.to(torch.int32).contiguous()
+        D = Q.shape[1]
+        st = _steps(steps, D)
+        out = torch.empty((self.N, D), dtype=torch.float32, device=Q.device)
+        with torch.cuda.device(Q.device):
+            check(_lib.lib().raht_dequant_inv(self._h, C.c_void_p(Q.data_ptr()), D, D, st, len(st),
+                                              C.c_void_p(out.data_ptr()), D, _stream()))
+        return out
+
     def quant_reorder(self, T, steps):
         """int32 Q[k] = floor(T[order[k]] / step + 0.5)  (encode_3dgs.py:204,210,215)."""
         _need_cuda(T, "T")

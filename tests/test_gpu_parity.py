@@ -198,6 +198,35 @@ def test_quantize_reorder_and_back(rt, name):
     assert np.array_equal(Qc, exp)
 
 
+@pytest.mark.parametrize("tile_rows", [0, 64, 128])
+@pytest.mark.parametrize("name", ["n257_j3_d11", "n1000_j10_d14", "n1500_j12_d56", "n3000_j18_d3", "early_root_j10", "n8_cube_j1"])
+def test_fused_quant_equals_two_call_sequence(rt, name, tile_rows):
+    """raht_fwd_quant == raht_fwd + raht_quant_reorder and raht_dequant_inv == dequant + raht_inv, bit for bit."""
+    import torch
+    g = load_golden(name)
+    p = _plan(rt, g, "tile", tile_rows)
+    C = _dev(g["C"])
+    D = C.shape[1]
+    for steps in (1.0, 0.37, [0.5 + 0.25 * c for c in range(D)]):
+        T, _ = p.forward(C)
+        Q2 = p.quant_reorder(T, steps)
+        Q1 = p.forward_quant(C, steps)
+        assert torch.equal(Q1, Q2)
+        C2 = p.inverse(p.dequant_unreorder(Q2, steps))
+        C1 = p.dequant_inverse(Q1, steps)
+        assert torch.equal(C1, C2)
+
+
+def test_fused_quant_strided_input(rt):
+    import torch
+    g = load_golden("n2000_j10_d59")
+    p = _plan(rt, g)
+    N, D = g["C"].shape
+    big = torch.zeros((N, 64), dtype=torch.float32, device="cuda")
+    big[:, :D] = _dev(g["C"])
+    assert torch.equal(p.forward_quant(big[:, :D], 0.01), p.forward_quant(_dev(g["C"]), 0.01))
+
+
 # ------------------------------------------------------------------------------------------- voxelizer
 @pytest.mark.parametrize("name", VOX)
 def test_voxelize(rt, name):
@@ -338,5 +367,7 @@ def test_full_size_properties_cfg3(rt):
     Q = p.quant_reorder(T, 0.01)
     Td = p.dequant_unreorder(Q, 0.01)
     assert (Td - T).abs().max().item() <= 0.005 * 1.0001 + 1e-6 * scale
+    assert torch.equal(p.forward_quant(Cd, 0.01), Q)                          # fused == two-call
+    assert torch.equal(p.dequant_inverse(Q, 0.01), p.inverse(Td))
     st = p.stage_stats(4, D)
     assert st["valid"] and len(st["rows_per_stage"]) <= 6
