@@ -9,6 +9,7 @@
 #include "raht_common.h"
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 
 namespace raht {
@@ -151,6 +152,12 @@ __global__ void order_bucket_kernel(const uint8_t *__restrict__ lvl, int64_t N, 
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N) return;
     bucket[i] = (i == 0) ? 0 : (uint8_t)(1 + (20 - (int)lvl[i] / 3));
+}
+
+__global__ void order_to_identity_kernel(uint32_t *order, int64_t N)
+{
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < N) order[k] = (uint32_t)k;
 }
 
 __global__ void invert_perm_kernel(const uint32_t *__restrict__ order, int64_t N, uint32_t *__restrict__ inv)
@@ -352,6 +359,8 @@ static int finish_plan(raht_plan *p, const int64_t *leaf_weights, hipStream_t s)
     RAHT_HIP_CHECK(hipMalloc(&p->level_rows, sizeof(uint32_t) * (size_t)N));
     hipLaunchKernelGGL(order_bucket_kernel, dim3(gb), dim3(256), 0, s, p->lvl, N, bucket);
     RAHT_RET(bucket_sort_u8(bucket, p->order, N, 5, nullptr, s));
+    if (getenv("RAHT_DEBUG_IDENTITY_ORDER"))      // timing experiments only: order_RAGFT := identity
+        hipLaunchKernelGGL(order_to_identity_kernel, dim3(gb), dim3(256), 0, s, p->order, N);
     RAHT_HIP_CHECK(hipMalloc(&p->inv_order, sizeof(uint32_t) * (size_t)N));
     hipLaunchKernelGGL(invert_perm_kernel, dim3(gb), dim3(256), 0, s, p->order, N, p->inv_order);
     hipLaunchKernelGGL(level_bucket_kernel, dim3(gb), dim3(256), 0, s, p->lvl, N, bucket);

@@ -173,7 +173,7 @@ template <typename T> struct MRec;
 template <> struct __align__(16) MRec<float> { uint32_t po; uint32_t jo; float a; float b; };
 template <> struct __align__(8) MRec<double> { uint32_t po; uint32_t jo; double a; double b; };
 
-constexpr int TILE_MAX_SLOTS = 2;      // slots per thread: R <= 2 * blockDim
+constexpr int TILE_MAX_SLOTS = 2;      // slots per thread (template SLOTS = 1 or 2): R <= SLOTS * blockDim
 constexpr int TILE_GATHER_U = 16;      // rows in flight per wave in the inverse's row-granular gathers
 constexpr int TILE_FWD_U = 8;          // same for the forward's strided-row loads
 constexpr int TILE_ROUND_U = 4;        // butterflies in flight per lane group in a round
@@ -205,11 +205,47 @@ __device__ __forceinline__ void bulk_copy16(const V *__restrict__ g4, V *__restr
     }
 }
 
+// Plan metadata of one tile, held in registers (slot j = tid + s * blockDim). The persistent tile
+// loop loads the NEXT tile's metadata while the current tile's butterflies run, so no tile waits on
+// an HBM round trip before it can issue its own data loads.
+template <int SLOTS>
+struct TileMeta {
+    int32_t row[SLOTS], wl[SLOTS], wr[SLOTS], pos[SLOTS];
+    int lv[SLOTS];
+    int64_t start_row, end_row;
+    uint32_t surv_base, surv_cnt;
+};
+
+template <typename T, bool IDENT, bool QM, int SLOTS>
+__device__ __forceinline__ void load_tile_meta(const TileArgs<T> &A, int64_t t, int tid, int nthreads, TileMeta<SLOTS> &M)
+{
+    const int R = A.R;
+    const int64_t e0 = t * R;
+    const int nt = (int)min((int64_t)R, A.n_entries - e0);
+    M.start_row = IDENT ? e0 : (int64_t)A.rows[e0];
+    M.end_row = (e0 + R < A.n_entries) ? (IDENT ? e0 + R : (int64_t)A.rows[e0 + R]) : A.N;
+    M.surv_base = 0; M.surv_cnt = 0;
+    if (A.surv_off) { M.surv_base = A.surv_off[t]; M.surv_cnt = A.surv_off[t + 1] - M.surv_base; }
+#pragma unroll
+    for (int s = 0; s < SLOTS; ++s) {
+        const int j = tid + s * nthreads;
+        M.row[s] = 0; M.wl[s] = 0; M.wr[s] = 0; M.lv[s] = 0; M.pos[s] = 0;
+        if (j < nt) {
+            const int64_t r = IDENT ? e0 + j : (int64_t)A.rows[e0 + j];
+            M.row[s] = (int32_t)r;
+            M.wl[s] = A.wl[r];
+            M.wr[s] = A.wr[r];
+            M.lv[s] = A.lvl[r];
+            M.pos[s] = QM ? (int32_t)A.inv_order[r] : (int32_t)r;    // where the final coefficient lives
+        }
+    }
+}
+
 // IDENT = true is stage 0 (entries are the rows themselves: the HBM-heavy launch); IDENT = false
 // are the later, much smaller stages. QM = true fuses quantize+reorder (forward) / un-reorder+
 // dequantize (inverse). Separate instantiations keep them apart in rocprof kernel statistics.
 // launch bounds: three 512-thread workgroups per CU = 6 waves per SIMD for float32 (<= 80 VGPRs)
-template <typename T, bool INV, bool IDENT, bool QM>
+template <typename T, bool INV, bool IDENT, bool QM, int SLOTS>
 __global__ __launch_bounds__(512, (sizeof(T) == 4 ? 6 : 4)) void tile_kernel(const TileArgs<T> A,
                                                    const typename std::conditional<QM, StepTable, NoSteps>::type ST)
 {
@@ -217,7 +253,7 @@ __global__ __launch_bounds__(512, (sizeof(T) == 4 ? 6 : 4)) void tile_kernel(con
     typedef typename Vec16<T>::type V16;
     constexpr int VN = Vec16<T>::n;
     const int R = A.R;
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int tid0 = threadIdx.x;
     const int nthreads = blockDim.x, nw = nthreads >> 6;
     const int c_base = blockIdx.y * A.Dc;
     const int Dc = min(A.Dc, A.D - c_base);
@@ -240,31 +276,34 @@ __global__ __launch_bounds__(512, (sizeof(T) == 4 ? 6 : 4)) void tile_kernel(con
     off += ((size_t)R * 2 + 15) & ~(size_t)15;
     T *spre = (T *)(smem + off);                          // inverse: [TILE_PRE_ROWS * Dc] survivor prefetch
 
-    const int64_t e0 = (int64_t)blockIdx.x * R;
+    // quantization step of this lane's channel (row-granular paths map lane -> channel): one
+    // kernarg read at kernel start instead of one inside every gather / scatter iteration
+    float my_step = 1.0f;
+    if constexpr (QM) my_step = ST.v[ST.n == 1 ? 0 : c_base + min(tid0 & 63, Dc - 1)];
+
+    // ---- persistent loop over this workgroup's tiles; metadata of the next tile is prefetched ----
+    const int64_t n_tiles = (A.n_entries + R - 1) / R;
+    TileMeta<SLOTS> M;
+    if ((int64_t)blockIdx.x < n_tiles) load_tile_meta<T, IDENT, QM, SLOTS>(A, blockIdx.x, tid0, nthreads, M);
+    for (int64_t tile_id = blockIdx.x; tile_id < n_tiles; tile_id += gridDim.x) {
+    // Re-derive the lane-dependent indices every iteration from an opaque copy of the thread id:
+    // otherwise the compiler hoists dozens of lane-dependent addresses out of this long loop body
+    // and spills them (register budget: 80 VGPRs for three workgroups per CU).
+    int tid = tid0;
+    asm volatile("" : "+v"(tid));
+    const int lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int64_t e0 = tile_id * R;
     const int nt = (int)min((int64_t)R, A.n_entries - e0);
-    const int64_t start_row = IDENT ? e0 : (int64_t)A.rows[e0];
-    const int64_t end_row = (e0 + R < A.n_entries) ? (IDENT ? e0 + R : (int64_t)A.rows[e0 + R]) : A.N;
-    uint32_t surv_base = 0, surv_cnt = 0;
-    if (A.surv_off) { surv_base = A.surv_off[blockIdx.x]; surv_cnt = A.surv_off[blockIdx.x + 1] - surv_base; }
-
-    if (tid < 64) hist[tid] = 0;
-
-    // ---- P0a. per-slot plan metadata -> registers (issued first: latency hides under the bulk load)
-    int32_t m_row[TILE_MAX_SLOTS], m_wl[TILE_MAX_SLOTS], m_wr[TILE_MAX_SLOTS], m_pos[TILE_MAX_SLOTS];
-    int m_lv[TILE_MAX_SLOTS];
+    const int64_t start_row = M.start_row, end_row = M.end_row;
+    const uint32_t surv_base = M.surv_base, surv_cnt = M.surv_cnt;
+    int32_t m_row[SLOTS], m_wl[SLOTS], m_wr[SLOTS], m_pos[SLOTS];
+    int m_lv[SLOTS];
 #pragma unroll
-    for (int s = 0; s < TILE_MAX_SLOTS; ++s) {
-        const int j = tid + s * nthreads;
-        m_row[s] = 0; m_wl[s] = 0; m_wr[s] = 0; m_lv[s] = 0; m_pos[s] = 0;
-        if (j < nt) {
-            const int64_t r = IDENT ? e0 + j : (int64_t)A.rows[e0 + j];
-            m_row[s] = (int32_t)r;
-            m_wl[s] = A.wl[r];
-            m_wr[s] = A.wr[r];
-            m_lv[s] = A.lvl[r];
-            m_pos[s] = QM ? (int32_t)A.inv_order[r] : (int32_t)r;    // where the final coefficient lives
-        }
+    for (int s = 0; s < SLOTS; ++s) {
+        m_row[s] = M.row[s]; m_wl[s] = M.wl[s]; m_wr[s] = M.wr[s]; m_pos[s] = M.pos[s]; m_lv[s] = M.lv[s];
     }
+    if (tid < 64) hist[tid] = 0;
 
     // ---- P0b. bulk transfers whose addresses do not depend on the plan metadata ----
     bool bulk_done = false;                   // tile already holds every slot's input
@@ -273,11 +312,12 @@ __global__ __launch_bounds__(512, (sizeof(T) == 4 ? 6 : 4)) void tile_kernel(con
             bulk_copy16<T, V16>((const V16 *)(A.in + e0 * A.ld_in), (V16 *)tile, (nt * Dc) / VN, tid, nthreads);
             for (int e = ((nt * Dc) / VN) * VN + tid; e < nt * Dc; e += nthreads) tile[e] = A.in[e0 * A.ld_in + e];
         } else {                              // strided rows / channel chunk
+            const int cl = min(lane, Dc - 1);                // clamped: loads are unconditional
             for (int j0 = wid * TILE_FWD_U; j0 < nt; j0 += nw * TILE_FWD_U) {
                 T v[TILE_FWD_U];
 #pragma unroll
                 for (int u = 0; u < TILE_FWD_U; ++u)
-                    if (j0 + u < nt && lane < Dc) v[u] = A.in[(e0 + j0 + u) * A.ld_in + c_base + lane];
+                    v[u] = A.in[(e0 + min(j0 + u, nt - 1)) * A.ld_in + c_base + cl];
 #pragma unroll
                 for (int u = 0; u < TILE_FWD_U; ++u)
                     if (j0 + u < nt && lane < Dc) tile[(j0 + u) * Dc + lane] = v[u];
@@ -298,7 +338,7 @@ __global__ __launch_bounds__(512, (sizeof(T) == 4 ? 6 : 4)) void tile_kernel(con
         }
     }
 #pragma unroll
-    for (int s = 0; s < TILE_MAX_SLOTS; ++s) {
+    for (int s = 0; s < SLOTS; ++s) {
         const int j = tid + s * nthreads;
         if (j < nt) { if (!IDENT) srow[j] = m_row[s]; if (QM) sdst[j] = m_pos[s]; }
     }
@@ -307,32 +347,41 @@ __global__ __launch_bounds__(512, (sizeof(T) == 4 ? 6 : 4)) void tile_kernel(con
     // inverse without a bulk path: gather every slot's coefficient row now (survivor slots get
     // overwritten in P3b) -- the addresses only need sdst
     if (INV && !bulk_done) {
+        const int cl = min(lane, Dc - 1);
         for (int j0 = wid * TILE_GATHER_U; j0 < nt; j0 += nw * TILE_GATHER_U) {
-            T v[TILE_GATHER_U];
+            // Branch-free: every load is unconditional from a clamped (valid) address, raw values
+            // stay in registers until all TILE_GATHER_U loads of the wave are in flight; only the
+            // LDS stores are predicated. (Predicated loads compile to one exec-mask region each
+            // with its own s_waitcnt, i.e. TILE_GATHER_U serialised HBM round trips.)
+            typedef typename std::conditional<QM, int32_t, T>::type RawT;
+            int64_t src_row[TILE_GATHER_U];
 #pragma unroll
             for (int u = 0; u < TILE_GATHER_U; ++u) {
-                if (j0 + u < nt && lane < Dc) {
-                    if (QM) v[u] = (T)A.Q[(int64_t)sdst[j0 + u] * A.ldq + c_base + lane];
-                    else v[u] = A.fin[(IDENT ? e0 + j0 + u : (int64_t)srow[j0 + u]) * A.ld_fin + c_base + lane];
-                }
+                const int j = min(j0 + u, nt - 1);
+                if constexpr (QM) src_row[u] = (int64_t)sdst[j];
+                else src_row[u] = IDENT ? e0 + j : (int64_t)srow[j];
+            }
+            RawT v[TILE_GATHER_U];
+#pragma unroll
+            for (int u = 0; u < TILE_GATHER_U; ++u) {
+                if constexpr (QM) v[u] = A.Q[src_row[u] * A.ldq + c_base + cl];
+                else v[u] = A.fin[src_row[u] * A.ld_fin + c_base + cl];
             }
 #pragma unroll
             for (int u = 0; u < TILE_GATHER_U; ++u) {
-                if (j0 + u < nt && lane < Dc) {
-                    T x = v[u];
-                    if constexpr (QM) x = x * (T)ST.v[ST.n == 1 ? 0 : c_base + lane];   // encode_3dgs.py:261
-                    tile[(j0 + u) * Dc + lane] = x;
-                }
+                T x = (T)v[u];
+                if constexpr (QM) x = x * (T)my_step;                                     // encode_3dgs.py:261
+                if (j0 + u < nt && lane < Dc) tile[(j0 + u) * Dc + lane] = x;
             }
         }
     }
 
     // ---- P1. which slots merge inside this tile; level histogram; survivor ranks ----
-    bool m_merged[TILE_MAX_SLOTS];
-    int m_rank[TILE_MAX_SLOTS];
+    bool m_merged[SLOTS];
+    int m_rank[SLOTS];
     const uint64_t lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
 #pragma unroll
-    for (int s = 0; s < TILE_MAX_SLOTS; ++s) {
+    for (int s = 0; s < SLOTS; ++s) {
         const int j = tid + s * nthreads;
         m_merged[s] = false;
         bool surv = false;
@@ -365,7 +414,7 @@ __global__ __launch_bounds__(512, (sizeof(T) == 4 ? 6 : 4)) void tile_kernel(con
     }
     if (!A.last_stage) {
 #pragma unroll
-        for (int s = 0; s < TILE_MAX_SLOTS; ++s) {
+        for (int s = 0; s < SLOTS; ++s) {
             const int j = tid + s * nthreads;
             if (j < nt && !m_merged[s] && !(A.dbg & 2)) {
                 uint32_t before = 0;
@@ -379,7 +428,7 @@ __global__ __launch_bounds__(512, (sizeof(T) == 4 ? 6 : 4)) void tile_kernel(con
 
     // ---- P3a. resolve every butterfly of this tile into a record, bucketed by level ----
 #pragma unroll
-    for (int s = 0; s < TILE_MAX_SLOTS; ++s) {
+    for (int s = 0; s < SLOTS; ++s) {
         const int j = tid + s * nthreads;
         if (j < nt && m_merged[s]) {
             const int64_t r = m_row[s];
@@ -410,22 +459,26 @@ __global__ __launch_bounds__(512, (sizeof(T) == 4 ? 6 : 4)) void tile_kernel(con
     }
     // ---- P3b. inverse: drop the survivors' low-pass rows (from the stage above) into their slots
     if (INV && !A.last_stage && !(A.dbg & 2)) {
+        const int cl = min(lane, Dc - 1);
         for (uint32_t q0 = wid * 4; q0 < surv_cnt; q0 += nw * 4) {
             T v[4]; int jj[4];
 #pragma unroll
+            for (int u = 0; u < 4; ++u) jj[u] = (int)ssurv[min(q0 + u, surv_cnt - 1)];
+#pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const uint32_t q = q0 + u;
-                jj[u] = (q < surv_cnt) ? (int)ssurv[q] : -1;
-                if (jj[u] >= 0 && lane < Dc)
-                    v[u] = (q < (uint32_t)TILE_PRE_ROWS) ? spre[q * Dc + lane]
-                                                         : A.wsn[(int64_t)(surv_base + q) * A.ld_ws + c_base + lane];
+                const uint32_t q = min(q0 + u, surv_cnt - 1);
+                if (q0 + 3 < (uint32_t)TILE_PRE_ROWS) v[u] = spre[q * Dc + cl];      // wave-uniform choice
+                else v[u] = A.wsn[(int64_t)(surv_base + q) * A.ld_ws + c_base + cl];
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u)
-                if (jj[u] >= 0 && lane < Dc) tile[jj[u] * Dc + lane] = v[u];
+                if (q0 + u < surv_cnt && lane < Dc) tile[jj[u] * Dc + lane] = v[u];
         }
     }
     __syncthreads();                                                       // sync #4
+
+    // prefetch the next tile's plan metadata: the loads stay in flight during the butterflies
+    if (tile_id + gridDim.x < n_tiles) load_tile_meta<T, IDENT, QM, SLOTS>(A, tile_id + gridDim.x, tid, nthreads, M);
 
     // ---- P4. butterflies, one round per level present ----
     {
@@ -517,8 +570,7 @@ __global__ __launch_bounds__(512, (sizeof(T) == 4 ? 6 : 4)) void tile_kernel(con
                 for (int u = 0; u < 4; ++u) {
                     if (j0 + u < nt && fl[u] != 0 && lane < Dc) {
                         if constexpr (QM) {
-                            const float st = ST.v[ST.n == 1 ? 0 : c_base + lane];
-                            A.Q[d[u] * A.ldq + c_base + lane] = (int32_t)floorf((float)x[u] / st + 0.5f);  // encode_3dgs.py:204,210,215
+                            A.Q[d[u] * A.ldq + c_base + lane] = (int32_t)floorf((float)x[u] / my_step + 0.5f);  // encode_3dgs.py:204,210,215
                         } else {
                             A.fin[d[u] * A.ld_fin + c_base + lane] = x[u];
                         }
@@ -527,6 +579,8 @@ __global__ __launch_bounds__(512, (sizeof(T) == 4 ? 6 : 4)) void tile_kernel(con
             }
         }
     }
+    __syncthreads();              // LDS is reused by the next tile
+    }                             // persistent tile loop
 }
 
 // node weights of RAHT.py:325-328: after its own butterfly a right sibling carries w0 + w1 and is
@@ -554,6 +608,25 @@ static int tile_threads()
     return t;
 }
 
+static int device_cus()
+{
+    static int n = 0;
+    if (n == 0) {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) == hipSuccess &&
+            hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) n = v;
+        else n = 256;                                       // MI355X
+    }
+    return n;
+}
+
+static bool persist_enabled()
+{
+    static int v = -1;
+    if (v < 0) { const char *e = getenv("RAHT_TILE_PERSIST"); v = (e && atoi(e) == 0) ? 0 : 1; }
+    return v == 1;
+}
+
 static int lp_shift_for(int Dc)
 {
     int s = 0;
@@ -570,12 +643,12 @@ struct XformIO {
     const float *steps = nullptr; int n_steps = 0;
 };
 
-template <typename T, bool INV, bool IDENT, bool QM>
+template <typename T, bool INV, bool IDENT, bool QM, int SLOTS>
 static int launch_tile_one(const TileArgs<T> &A, const XformIO<T> &io, dim3 grid, int threads, size_t lds, hipStream_t s)
 {
     static bool attr_set = false;
     if (!attr_set) {
-        RAHT_HIP_CHECK(hipFuncSetAttribute((const void *)tile_kernel<T, INV, IDENT, QM>,
+        RAHT_HIP_CHECK(hipFuncSetAttribute((const void *)tile_kernel<T, INV, IDENT, QM, SLOTS>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
@@ -583,10 +656,10 @@ static int launch_tile_one(const TileArgs<T> &A, const XformIO<T> &io, dim3 grid
         StepTable st;
         st.n = io.n_steps;
         for (int c = 0; c < io.n_steps; ++c) st.v[c] = io.steps[c];
-        hipLaunchKernelGGL((tile_kernel<T, INV, IDENT, true>), grid, dim3(threads), lds, s, A, st);
+        hipLaunchKernelGGL((tile_kernel<T, INV, IDENT, true, SLOTS>), grid, dim3(threads), lds, s, A, st);
     } else {
         NoSteps ns{0};
-        hipLaunchKernelGGL((tile_kernel<T, INV, IDENT, false>), grid, dim3(threads), lds, s, A, ns);
+        hipLaunchKernelGGL((tile_kernel<T, INV, IDENT, false, SLOTS>), grid, dim3(threads), lds, s, A, ns);
     }
     RAHT_HIP_CHECK(hipGetLastError());
     return RAHT_OK;
@@ -630,9 +703,18 @@ static int launch_tile_stage(const raht_plan *p, const Schedule &sc, int k, cons
         set_error("tile_rows %d too large for %d threads", sc.tile_rows, threads);
         return RAHT_ERR_UNSUPPORTED;
     }
-    const dim3 grid((unsigned)st.n_tiles, (unsigned)nchunks);
-    if (st.rows == nullptr) return launch_tile_one<T, INV, true, QM>(A, io, grid, threads, lds, s);
-    return launch_tile_one<T, INV, false, QM>(A, io, grid, threads, lds, s);
+    // persistent workgroups: as many as the chip keeps resident (LDS granules of 1280 B, 32 waves
+    // per CU), each walking tiles blockIdx.x, blockIdx.x + gridDim.x, ...
+    const int per_cu = std::max(1, std::min((int)(128 / ((lds + 1279) / 1280)), 32 / (threads / 64)));
+    const int64_t resident = (int64_t)per_cu * device_cus();
+    const int64_t gx = persist_enabled() ? std::min<int64_t>(st.n_tiles, std::max<int64_t>(1, resident / nchunks)) : st.n_tiles;
+    const dim3 grid((unsigned)gx, (unsigned)nchunks);
+    const bool one = sc.tile_rows <= threads;
+    if (st.rows == nullptr)
+        return one ? launch_tile_one<T, INV, true, QM, 1>(A, io, grid, threads, lds, s)
+                   : launch_tile_one<T, INV, true, QM, 2>(A, io, grid, threads, lds, s);
+    return one ? launch_tile_one<T, INV, false, QM, 1>(A, io, grid, threads, lds, s)
+               : launch_tile_one<T, INV, false, QM, 2>(A, io, grid, threads, lds, s);
 }
 
 template <typename T, bool INV>
