@@ -84,6 +84,22 @@ int raht_plan_create(const void *V, int v_dtype, int64_t N, const double minV[3]
 int raht_plan_create_from_keys(const uint64_t *keys_sorted, int64_t N, int nbits,
                                const int64_t *leaf_weights, raht_stream_t stream, raht_plan **out);
 
+/* Truncated trees (Morton-prefix sharded scenes): butterflies at binary levels >= top_level are
+ * NOT performed by this plan's transforms; the rows that still carry a low-pass value afterwards
+ * ("roots": row 0 and every row whose level is >= top_level, i.e. the first row of every
+ * top-level prefix node) are stitched by the caller's top stage. Default top_level = 64 (whole
+ * tree, one root = the DC row). Call before the first transform; rebuilds the tile schedules.
+ *   raht_plan_roots           : number of roots and (optionally) their rows, ascending, into a
+ *                               DEVICE int64[n_roots] buffer;
+ *   raht_plan_set_root_buffer : DEVICE buffer of n_roots x D elements of the transform's type
+ *                               (row stride D), or NULL. When set, forward transforms write the roots'
+ *                               low-pass rows there (and, in the fused-quantization entry, leave
+ *                               their Q rows untouched), inverse transforms read the roots from
+ *                               there instead of from T / Q. */
+int raht_plan_set_top_level(raht_plan *plan, int top_level, raht_stream_t stream);
+int raht_plan_roots(const raht_plan *plan, int64_t *n_roots, int64_t *rows_dev, raht_stream_t stream);
+int raht_plan_set_root_buffer(raht_plan *plan, void *buf_dev);
+
 int raht_plan_destroy(raht_plan *plan);
 int64_t raht_plan_size(const raht_plan *plan);          /* N */
 int raht_plan_nbits(const raht_plan *plan);             /* 3 * depth */

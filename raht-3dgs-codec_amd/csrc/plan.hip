@@ -178,6 +178,7 @@ __global__ void level_bucket_kernel(const uint8_t *__restrict__ lvl, int64_t N, 
 // [r - wl, r + wr) lies inside the tile's row range; otherwise it survives to the next stage.
 __global__ void stage_survivor_kernel(const uint32_t *__restrict__ rows, int64_t n, int R, int64_t N,
                                       const int32_t *__restrict__ wl, const int32_t *__restrict__ wr,
+                                      const uint8_t *__restrict__ lvl, int top_level,
                                       uint32_t *__restrict__ survivor)
 {
     const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -187,7 +188,7 @@ __global__ void stage_survivor_kernel(const uint32_t *__restrict__ rows, int64_t
     const int64_t j0 = t * R, j1 = j0 + R;
     const int64_t start = rows ? rows[j0] : j0;
     const int64_t end = (j1 < n) ? (rows ? (int64_t)rows[j1] : j1) : N;
-    const bool merged = (r > 0) && (r - wl[r] >= start) && (r + wr[r] <= end);
+    const bool merged = (r > 0) && ((int)lvl[r] < top_level) && (r - wl[r] >= start) && (r + wr[r] <= end);
     survivor[j] = merged ? 0u : 1u;
 }
 
@@ -277,16 +278,16 @@ int get_schedule(raht_plan *plan, int R, hipStream_t s, Schedule **out)
         st.n_entries = n;
         st.n_tiles = ceil_div(n, R);
         st.rows = rows;
-        if (n <= R) { sc.stages.push_back(st); break; }      // a single tile finishes the tree
         hipLaunchKernelGGL(stage_survivor_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, s,
-                           rows, n, R, N, plan->wl, plan->wr, flag);
+                           rows, n, R, N, plan->wl, plan->wr, plan->lvl, plan->top_level, flag);
         rc = exclusive_scan_u32(flag, pos, n, dtotal, s);
         if (rc != RAHT_OK) break;
         uint32_t cnt32 = 0;
         if (hipMemcpyAsync(&cnt32, dtotal, sizeof(uint32_t), hipMemcpyDeviceToHost, s) != hipSuccess ||
             hipStreamSynchronize(s) != hipSuccess) { rc = RAHT_ERR_HIP; break; }
         const int64_t cnt = cnt32;
-        if (cnt >= n || k == 23) {                           // no progress: pathological key pattern
+        const bool last = (cnt == plan->n_roots);            // only the roots are left: tree finished
+        if (!last && (cnt >= n || k == 23)) {                // no progress: pathological key pattern
             sc.stages.push_back(st);
             sc.valid = false;
             break;
@@ -294,6 +295,7 @@ int get_schedule(raht_plan *plan, int R, hipStream_t s, Schedule **out)
         if (hipMalloc(&st.surv_off, sizeof(uint32_t) * (size_t)(st.n_tiles + 1)) != hipSuccess) { rc = RAHT_ERR_NOMEM; break; }
         hipLaunchKernelGGL(tile_start_kernel, dim3((unsigned)ceil_div(st.n_tiles + 1, 256)), dim3(256), 0, s,
                            pos, n, R, st.n_tiles, cnt32, st.surv_off);
+        if (last) { sc.stages.push_back(st); break; }
         uint32_t *next = nullptr;
         if (hipMalloc(&next, sizeof(uint32_t) * (size_t)cnt) != hipSuccess) { rc = RAHT_ERR_NOMEM; break; }
         hipLaunchKernelGGL(compact_scatter_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, s, rows,
@@ -314,6 +316,33 @@ int get_schedule(raht_plan *plan, int R, hipStream_t s, Schedule **out)
     plan->schedules.push_back(sc);
     *out = &plan->schedules.back();
     return RAHT_OK;
+}
+
+// ---- roots: rows that still carry a low-pass value when the (possibly truncated) tree is done ----
+__global__ void root_flag_kernel(const uint8_t *__restrict__ lvl, int64_t N, int top_level, uint32_t *__restrict__ flag)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < N) flag[i] = (i == 0 || (int)lvl[i] >= top_level) ? 1u : 0u;
+}
+
+static int compute_roots(raht_plan *p, hipStream_t s)
+{
+    if (p->root_rows) { (void)hipFree(p->root_rows); p->root_rows = nullptr; }
+    uint32_t *flag = nullptr, *tmp = nullptr;
+    RAHT_HIP_CHECK(hipMalloc(&flag, sizeof(uint32_t) * (size_t)p->N));
+    RAHT_HIP_CHECK(hipMalloc(&tmp, sizeof(uint32_t) * (size_t)p->N));
+    hipLaunchKernelGGL(root_flag_kernel, dim3((unsigned)ceil_div(p->N, 256)), dim3(256), 0, s, p->lvl, p->N,
+                       p->top_level, flag);
+    int64_t cnt = 0;
+    int rc = compact_u32(nullptr, flag, tmp, p->N, &cnt, s);
+    if (rc == RAHT_OK) {
+        p->n_roots = cnt;
+        if (hipMalloc(&p->root_rows, sizeof(uint32_t) * (size_t)cnt) != hipSuccess) rc = RAHT_ERR_NOMEM;
+        else if (hipMemcpy(p->root_rows, tmp, sizeof(uint32_t) * (size_t)cnt, hipMemcpyDeviceToDevice) != hipSuccess) rc = RAHT_ERR_HIP;
+    }
+    (void)hipFree(flag);
+    (void)hipFree(tmp);
+    return rc;
 }
 
 // ---- plan construction ---------------------------------------------------------------------------
@@ -384,6 +413,7 @@ static int finish_plan(raht_plan *p, const int64_t *leaf_weights, hipStream_t s)
         RAHT_HIP_CHECK(hipMemcpy(p->wsum, ps.data(), sizeof(int64_t) * ((size_t)N + 1), hipMemcpyHostToDevice));
     }
     RAHT_HIP_CHECK(hipGetLastError());
+    RAHT_RET(compute_roots(p, s));
     // Build the default schedule now so that float32 transforms with D <= 64 never allocate.
     Schedule *sc = nullptr;
     RAHT_RET(get_schedule(p, pick_tile_rows(p, 4, 59), s, &sc));
@@ -474,6 +504,7 @@ int raht_plan_destroy(raht_plan *p)
     if (p->wsum) (void)hipFree(p->wsum);
     if (p->order) (void)hipFree(p->order);
     if (p->inv_order) (void)hipFree(p->inv_order);
+    if (p->root_rows) (void)hipFree(p->root_rows);
     if (p->level_rows) (void)hipFree(p->level_rows);
     delete p;
     return RAHT_OK;
@@ -556,6 +587,35 @@ int raht_plan_arrays(const raht_plan *p, const uint64_t **keys, const uint8_t **
     if (lvl) *lvl = p->lvl;
     if (wl) *wl = p->wl;
     if (wr) *wr = p->wr;
+    return RAHT_OK;
+}
+
+int raht_plan_set_top_level(raht_plan *p, int top_level, raht_stream_t stream)
+{
+    if (!p || top_level < 1 || top_level > 64) { set_error("raht_plan_set_top_level: bad argument"); return RAHT_ERR_INVALID; }
+    if (top_level == p->top_level) return RAHT_OK;
+    for (auto &sc : p->schedules) free_schedule(sc);
+    p->schedules.clear();
+    p->top_level = top_level;
+    return compute_roots(p, (hipStream_t)stream);
+}
+
+int raht_plan_roots(const raht_plan *p, int64_t *n_roots, int64_t *rows_dev, raht_stream_t stream)
+{
+    if (!p || !n_roots) { set_error("raht_plan_roots: NULL argument"); return RAHT_ERR_INVALID; }
+    *n_roots = p->n_roots;
+    if (rows_dev) {
+        hipLaunchKernelGGL(order_to_i64_kernel, dim3((unsigned)ceil_div(p->n_roots, 256)), dim3(256), 0,
+                           (hipStream_t)stream, p->root_rows, p->n_roots, rows_dev);
+        RAHT_HIP_CHECK(hipGetLastError());
+    }
+    return RAHT_OK;
+}
+
+int raht_plan_set_root_buffer(raht_plan *p, void *buf_dev)
+{
+    if (!p) return RAHT_ERR_INVALID;
+    p->root_buf = buf_dev;
     return RAHT_OK;
 }
 

@@ -89,6 +89,10 @@ struct raht_plan {
     uint32_t *inv_order = nullptr;  // device, inverse permutation: inv_order[order[k]] = k
     uint32_t *level_rows = nullptr;          // device, rows 1..N-1 stably sorted by lvl
     uint32_t level_off[RAHT_MAX_LEVELS + 1]; // host, start of every level inside level_rows
+    int top_level = 64;          // butterflies at binary levels >= top_level are NOT performed
+    int64_t n_roots = 1;         // row 0 plus every row whose level is >= top_level
+    uint32_t *root_rows = nullptr;   // device, ascending
+    void *root_buf = nullptr;    // caller-owned device buffer (n_roots x D), see raht_plan_set_root_buffer
     int engine = RAHT_ENGINE_TILE;
     int tile_rows_override = 0;
     std::vector<raht::Schedule> schedules;   // cache keyed by tile_rows

@@ -165,6 +165,9 @@ struct TileArgs {
     const int32_t *wl;
     const int32_t *wr;
     const int64_t *wsum;
+    int top_level;       // butterflies at levels >= top_level are left to the caller (sharded scenes)
+    T *root_buf;         // optional compact (n_roots x D) buffer: forward writes the rows still carrying
+                         // a low-pass value there, inverse reads them from there (nullptr: T / Q rows)
 };
 
 // One butterfly, resolved: LDS element offsets of the partner (low-pass) row and of the own
@@ -331,7 +334,8 @@ __global__ __launch_bounds__(512, (sizeof(T) == 4 ? 6 : 4)) void tile_kernel(con
             bulk_done = true;
         }
         // survivors of this tile were produced by the stage above: one contiguous chunk of ws_{k+1}
-        const int npre = (int)min(surv_cnt, (uint32_t)TILE_PRE_ROWS) * Dc;
+        // (the top stage has no stage above it: its survivors are the roots, handled in P3b)
+        const int npre = A.last_stage ? 0 : (int)min(surv_cnt, (uint32_t)TILE_PRE_ROWS) * Dc;
         for (int e = tid; e < npre; e += nthreads) {
             const int rr = e / Dc, cc = e - rr * Dc;
             spre[e] = A.wsn[(int64_t)(surv_base + rr) * A.ld_ws + c_base + cc];
@@ -387,7 +391,7 @@ __global__ __launch_bounds__(512, (sizeof(T) == 4 ? 6 : 4)) void tile_kernel(con
         bool surv = false;
         if (j < nt && !(A.dbg & 2)) {
             const int64_t r = m_row[s];
-            m_merged[s] = (r > 0) && (r - m_wl[s] >= start_row) && (r + m_wr[s] <= end_row);
+            m_merged[s] = (r > 0) && (m_lv[s] < A.top_level) && (r - m_wl[s] >= start_row) && (r + m_wr[s] <= end_row);
             surv = !m_merged[s];
             sflag[j] = m_merged[s] ? 1 : (A.last_stage ? 2 : 0);
             if (m_merged[s]) atomicAdd(&hist[m_lv[s]], 1u);
@@ -412,7 +416,7 @@ __global__ __launch_bounds__(512, (sizeof(T) == 4 ? 6 : 4)) void tile_kernel(con
         const uint64_t m = __ballot(c > 0);
         if (lane == 0) { lmask[0] = (uint32_t)m; lmask[1] = (uint32_t)(m >> 32); }
     }
-    if (!A.last_stage) {
+    {
 #pragma unroll
         for (int s = 0; s < SLOTS; ++s) {
             const int j = tid + s * nthreads;
@@ -473,6 +477,13 @@ __global__ __launch_bounds__(512, (sizeof(T) == 4 ? 6 : 4)) void tile_kernel(con
 #pragma unroll
             for (int u = 0; u < 4; ++u)
                 if (q0 + u < surv_cnt && lane < Dc) tile[jj[u] * Dc + lane] = v[u];
+        }
+    }
+    // top stage of the inverse: the roots' low-pass values may come from a compact caller buffer
+    if (INV && A.last_stage && A.root_buf && !(A.dbg & 2)) {
+        for (uint32_t q = wid; q < surv_cnt; q += nw) {
+            const int j = ssurv[q];
+            if (lane < Dc) tile[j * Dc + lane] = A.root_buf[(int64_t)(surv_base + q) * A.D + c_base + lane];
         }
     }
     __syncthreads();                                                       // sync #4
@@ -548,11 +559,14 @@ __global__ __launch_bounds__(512, (sizeof(T) == 4 ? 6 : 4)) void tile_kernel(con
             for (int v = tid; v < nvec; v += nthreads) g4[v] = l4[v];
             for (int e = nvec * VN + tid; e < nt * Dc; e += nthreads) A.fin[e0 * A.ld_fin + e] = tile[e];
         }
-        // survivors (a few per tile): compacted into ws_{k+1} in rank order
-        if (!A.last_stage && !(A.dbg & 2)) {
+        // survivors (a few per tile): compacted into ws_{k+1} in rank order; at the top stage the
+        // survivors are the roots, optionally exported to the caller's compact root buffer
+        if (!(A.dbg & 2) && (!A.last_stage || A.root_buf)) {
+            T *dstb = A.last_stage ? A.root_buf : A.wsn;
+            const int64_t ldb = A.last_stage ? (int64_t)A.D : A.ld_ws;
             for (uint32_t q = wid; q < surv_cnt; q += nw) {
                 const int j = ssurv[q];
-                if (lane < Dc) A.wsn[(int64_t)(surv_base + q) * A.ld_ws + c_base + lane] = tile[j * Dc + lane];
+                if (lane < Dc) dstb[(int64_t)(surv_base + q) * ldb + c_base + lane] = tile[j * Dc + lane];
             }
         }
         // rows finalised here, row-granular (later stages, strided T, or fused quantization)
@@ -568,7 +582,10 @@ __global__ __launch_bounds__(512, (sizeof(T) == 4 ? 6 : 4)) void tile_kernel(con
                 }
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
-                    if (j0 + u < nt && fl[u] != 0 && lane < Dc) {
+                    // fused quantization + root buffer: the roots' coefficients are produced (and
+                    // quantized) by the caller's top-level stage, not here
+                    const bool skip_root = QM && A.root_buf && fl[u] == 2;
+                    if (j0 + u < nt && fl[u] != 0 && !skip_root && lane < Dc) {
                         if constexpr (QM) {
                             A.Q[d[u] * A.ldq + c_base + lane] = (int32_t)floorf((float)x[u] / my_step + 0.5f);  // encode_3dgs.py:204,210,215
                         } else {
@@ -623,7 +640,9 @@ static int device_cus()
 static bool persist_enabled()
 {
     static int v = -1;
-    if (v < 0) { const char *e = getenv("RAHT_TILE_PERSIST"); v = (e && atoi(e) == 0) ? 0 : 1; }
+    // default off: one tile per workgroup measured faster (3155 vs 2857 M-Gaussians/s on the fused
+    // cfg3 step); persistent workgroups start in lock-step and pay a tail
+    if (v < 0) { const char *e = getenv("RAHT_TILE_PERSIST"); v = (e && atoi(e) == 1) ? 1 : 0; }
     return v == 1;
 }
 
@@ -677,6 +696,7 @@ static int launch_tile_stage(const raht_plan *p, const Schedule &sc, int k, cons
     A.last_stage = (k == K - 1) ? 1 : 0;
     A.lvl = p->lvl; A.wl = p->wl; A.wr = p->wr; A.wsum = p->wsum;
     A.inv_order = p->inv_order; A.Q = io.Q; A.ldq = io.ldq;
+    A.top_level = p->top_level; A.root_buf = (T *)p->root_buf;
     A.dbg = dbg;
     A.ld_ws = D;
     A.wsn = (k + 1 < K) ? (T *)sc.stages[(size_t)k + 1].ws : nullptr;
@@ -717,6 +737,18 @@ static int launch_tile_stage(const raht_plan *p, const Schedule &sc, int k, cons
                : launch_tile_one<T, INV, false, QM, 2>(A, io, grid, threads, lds, s);
 }
 
+template <typename T>
+__global__ void root_rows_kernel(T *__restrict__ mat, int64_t ld, int D, const uint32_t *__restrict__ rows,
+                                 int64_t n_roots, T *__restrict__ buf, int to_buf)
+{
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n_roots * D) return;
+    const int64_t q = e / D;
+    const int c = (int)(e - q * D);
+    if (to_buf) buf[e] = mat[(int64_t)rows[q] * ld + c];
+    else mat[(int64_t)rows[q] * ld + c] = buf[e];
+}
+
 template <typename T, bool INV>
 static int run_level_engine(const raht_plan *p, const T *src, int64_t ld_src, T *dst, int64_t ld_dst,
                             int D, hipStream_t s)
@@ -726,10 +758,15 @@ static int run_level_engine(const raht_plan *p, const T *src, int64_t ld_src, T 
         const unsigned gb = (unsigned)std::min<int64_t>(ceil_div(total, 256), 8192);
         hipLaunchKernelGGL(copy_rows_kernel<T>, dim3(gb), dim3(256), 0, s, src, ld_src, dst, ld_dst, p->N, D);
     }
+    const unsigned gr = (unsigned)ceil_div(p->n_roots * D, 256);
+    if (INV && p->root_buf)
+        hipLaunchKernelGGL(root_rows_kernel<T>, dim3(gr), dim3(256), 0, s, dst, ld_dst, D, p->root_rows, p->n_roots,
+                           (T *)p->root_buf, 0);
     const int lps = lp_shift_for(std::min(D, 64));
     const int gpw = 64 >> lps;
-    for (int q = 0; q <= p->max_level; ++q) {
-        const int l = INV ? p->max_level - q : q;
+    const int top = std::min(p->max_level, p->top_level - 1);
+    for (int q = 0; q <= top; ++q) {
+        const int l = INV ? top - q : q;
         const uint32_t cnt = p->level_off[l + 1] - p->level_off[l];
         if (cnt == 0) continue;                                  // RAHT.py:304-305
         const int64_t steps = ceil_div(cnt, gpw * 4);
@@ -737,6 +774,9 @@ static int run_level_engine(const raht_plan *p, const T *src, int64_t ld_src, T 
         hipLaunchKernelGGL((level_pass_kernel<T, INV>), dim3(gb), dim3(256), 0, s, dst, ld_dst, D,
                            p->level_rows + p->level_off[l], cnt, p->wl, p->wr, p->wsum, lps);
     }
+    if (!INV && p->root_buf)
+        hipLaunchKernelGGL(root_rows_kernel<T>, dim3(gr), dim3(256), 0, s, dst, ld_dst, D, p->root_rows, p->n_roots,
+                           (T *)p->root_buf, 1);
     RAHT_HIP_CHECK(hipGetLastError());
     return RAHT_OK;
 }

@@ -58,6 +58,18 @@ class RahtPlan:
         self.id = _next_id[0]
         _next_id[0] += 1
         self._order = None
+        self._inv_order = None
+        self._roots = None
+
+    @property
+    def inv_order(self):
+        """Inverse permutation of order_RAGFT: position of row i in the reordered coefficient list."""
+        if self._inv_order is None:
+            o = self.order_RAGFT
+            inv = torch.empty_like(o)
+            inv[o] = torch.arange(self.N, dtype=torch.int64, device=o.device)
+            self._inv_order = inv
+        return self._inv_order
 
     # -- construction ---------------------------------------------------------------------------
     @staticmethod
@@ -82,7 +94,7 @@ class RahtPlan:
         return RahtPlan(h, V.device)
 
     @staticmethod
-    def from_keys(keys_sorted, nbits, leaf_weights=None):
+    def from_keys(keys_sorted, nbits, leaf_weights=None, top_level=None):
         _need_cuda(keys_sorted, "keys_sorted")
         k = keys_sorted.contiguous()
         if k.dtype not in (torch.int64, torch.uint64):
@@ -96,7 +108,42 @@ class RahtPlan:
             check(_lib.lib().raht_plan_create_from_keys(C.c_void_p(k.data_ptr()), k.shape[0], int(nbits),
                                                         C.c_void_p(lw.data_ptr()) if lw is not None else None,
                                                         _stream(), C.byref(h)))
-        return RahtPlan(h, k.device)
+        p = RahtPlan(h, k.device)
+        if top_level is not None:
+            p.set_top_level(top_level)
+        return p
+
+    # -- truncated trees / roots (Morton-prefix sharded scenes) -----------------------------------
+    def set_top_level(self, top_level):
+        """Butterflies at binary levels >= top_level are left to the caller's top stage."""
+        with torch.cuda.device(self.device):
+            check(_lib.lib().raht_plan_set_top_level(self._h, int(top_level), _stream()))
+        self._roots = None
+
+    @property
+    def root_rows(self):
+        """int64 device tensor: rows that still carry a low-pass value after a forward transform."""
+        if getattr(self, "_roots", None) is None:
+            n = C.c_int64()
+            check(_lib.lib().raht_plan_roots(self._h, C.byref(n), None, None))
+            r = torch.empty(n.value, dtype=torch.int64, device=self.device)
+            with torch.cuda.device(self.device):
+                check(_lib.lib().raht_plan_roots(self._h, C.byref(n), C.c_void_p(r.data_ptr()), _stream()))
+            self._roots = r
+        return self._roots
+
+    @property
+    def n_roots(self):
+        return int(self.root_rows.shape[0])
+
+    def _set_roots_buffer(self, buf, D, dtype):
+        if buf is None:
+            check(_lib.lib().raht_plan_set_root_buffer(self._h, None))
+            return
+        _need_cuda(buf, "roots")
+        if buf.dtype != dtype or tuple(buf.shape) != (self.n_roots, D) or not buf.is_contiguous():
+            raise ValueError(f"roots buffer must be a contiguous ({self.n_roots}, {D}) {dtype} tensor")
+        check(_lib.lib().raht_plan_set_root_buffer(self._h, C.c_void_p(buf.data_ptr())))
 
     def __del__(self):
         try:
@@ -163,7 +210,7 @@ class RahtPlan:
         return dict(valid=n.value > 0, tile_rows=tr.value, rows_per_stage=[int(rows[i]) for i in range(k)])
 
     # -- transforms -----------------------------------------------------------------------------
-    def _xform(self, X, inverse, want_w=False):
+    def _xform(self, X, inverse, want_w=False, roots=None):
         _need_cuda(X, "C" if not inverse else "T")
         if X.dim() != 2 or X.shape[0] != self.N:
             raise ValueError(f"expected ({self.N}, D) tensor, got {tuple(X.shape)}")
@@ -176,6 +223,15 @@ class RahtPlan:
         w = torch.empty((self.N, 1), dtype=X.dtype, device=X.device) if want_w else None
         L = _lib.lib()
         f64 = X.dtype == torch.float64
+        self._set_roots_buffer(roots, D, X.dtype)
+        try:
+            self._run(L, X, out, w, D, inverse, f64)
+        finally:
+            if roots is not None:
+                self._set_roots_buffer(None, D, X.dtype)
+        return (out, w) if want_w else out
+
+    def _run(self, L, X, out, w, D, inverse, f64):
         with torch.cuda.device(X.device):
             if not inverse:
                 fn = L.raht_fwd_f64 if f64 else L.raht_fwd
@@ -185,13 +241,14 @@ class RahtPlan:
                 fn = L.raht_inv_f64 if f64 else L.raht_inv
                 check(fn(self._h, C.c_void_p(X.data_ptr()), X.stride(0), D, C.c_void_p(out.data_ptr()), D,
                          _stream()))
-        return (out, w) if want_w else out
 
-    def forward(self, Cmat, want_w=True):
-        return self._xform(Cmat, False, want_w)
+    def forward(self, Cmat, want_w=True, roots=None):
+        """roots: optional (n_roots, D) output buffer receiving the rows that still carry a low-pass."""
+        return self._xform(Cmat, False, want_w, roots)
 
-    def inverse(self, T):
-        return self._xform(T, True)
+    def inverse(self, T, roots=None):
+        """roots: optional (n_roots, D) buffer the root rows are read from instead of T."""
+        return self._xform(T, True, False, roots)
 
     def prepare(self, D, dtype=torch.float32):
         """Pre-build schedule + workspaces so later calls only enqueue kernels (hipGraph-safe)."""
@@ -199,7 +256,7 @@ class RahtPlan:
         with torch.cuda.device(self.device):
             check(_lib.lib().raht_plan_prepare(self._h, es, int(D), _stream()))
 
-    def forward_quant(self, Cmat, steps):
+    def forward_quant(self, Cmat, steps, roots=None):
         """Fused forward RAHT + quantize + reorder -> int32 Q (T is never materialised)."""
         _need_cuda(Cmat, "C")
         X = Cmat.to(torch.float32)
@@ -208,21 +265,31 @@ class RahtPlan:
         D = X.shape[1]
         st = _steps(steps, D)
         Q = torch.empty((self.N, D), dtype=torch.int32, device=X.device)
-        with torch.cuda.device(X.device):
-            check(_lib.lib().raht_fwd_quant(self._h, C.c_void_p(X.data_ptr()), X.stride(0), D, st, len(st),
-                                            C.c_void_p(Q.data_ptr()), D, _stream()))
+        self._set_roots_buffer(roots, D, torch.float32)
+        try:
+            with torch.cuda.device(X.device):
+                check(_lib.lib().raht_fwd_quant(self._h, C.c_void_p(X.data_ptr()), X.stride(0), D, st, len(st),
+                                                C.c_void_p(Q.data_ptr()), D, _stream()))
+        finally:
+            if roots is not None:
+                self._set_roots_buffer(None, D, torch.float32)
         return Q
 
-    def dequant_inverse(self, Q, steps):
+    def dequant_inverse(self, Q, steps, roots=None):
         """Fused un-reorder + dequantize + inverse RAHT -> float32 C."""
         _need_cuda(Q, "Q")
         Q = Q.to(torch.int32).contiguous()
         D = Q.shape[1]
         st = _steps(steps, D)
         out = torch.empty((self.N, D), dtype=torch.float32, device=Q.device)
-        with torch.cuda.device(Q.device):
-            check(_lib.lib().raht_dequant_inv(self._h, C.c_void_p(Q.data_ptr()), D, D, st, len(st),
-                                              C.c_void_p(out.data_ptr()), D, _stream()))
+        self._set_roots_buffer(roots, D, torch.float32)
+        try:
+            with torch.cuda.device(Q.device):
+                check(_lib.lib().raht_dequant_inv(self._h, C.c_void_p(Q.data_ptr()), D, D, st, len(st),
+                                                  C.c_void_p(out.data_ptr()), D, _stream()))
+        finally:
+            if roots is not None:
+                self._set_roots_buffer(None, D, torch.float32)
         return out
 
     def quant_reorder(self, T, steps):

@@ -371,3 +371,96 @@ def test_full_size_properties_cfg3(rt):
     assert torch.equal(p.dequant_inverse(Q, 0.01), p.inverse(Td))
     st = p.stage_stats(4, D)
     assert st["valid"] and len(st["rows_per_stage"]) <= 6
+
+
+# ------------------------------------------------------------- truncated trees, roots, sharded scenes
+@pytest.mark.parametrize("engine,tile_rows", [("tile", 0), ("tile", 64), ("level", 0)])
+def test_truncated_plan_roots_and_weights(rt, engine, tile_rows):
+    """top_level cut + compact root buffer + weighted leaves, against the numpy formulation."""
+    import torch
+    from raht_3dgs_codec_amd import synth
+    from tests.numpy_ops import NumpyPlan
+    V, keys, C = synth.scene(40000, 8, 7, seed=9)
+    nbits, top = 24, 15
+    kd = _dev(keys.view(np.int64))
+    ref = NumpyPlan(torch.from_numpy(keys.view(np.int64).copy()), nbits, top_level=top)
+    p = rt.RahtPlan.from_keys(kd, nbits, top_level=top)
+    p.set_engine(engine, tile_rows)
+    assert np.array_equal(p.root_rows.cpu().numpy(), ref.root_rows.numpy()) and p.n_roots > 100
+    C64 = torch.from_numpy(C.astype(np.float64))
+    r_ref = torch.empty((ref.n_roots, 7), dtype=torch.float64)
+    T_ref = ref.forward(C64, roots=r_ref)
+    roots = torch.empty((p.n_roots, 7), dtype=torch.float64, device="cuda")
+    T = p.forward(C64.cuda(), want_w=False, roots=roots)
+    scale = float(T_ref.abs().max())
+    np.testing.assert_allclose(T.cpu().numpy(), T_ref.numpy(), rtol=1e-12, atol=1e-12 * scale)
+    np.testing.assert_allclose(roots.cpu().numpy(), r_ref.numpy(), rtol=1e-12, atol=1e-12 * scale)
+    # inverse reads the roots from the buffer, not from T
+    T2 = T.clone()
+    T2[p.root_rows] = 123.0
+    np.testing.assert_allclose(p.inverse(T2, roots=roots).cpu().numpy(), C.astype(np.float64), rtol=1e-11, atol=1e-11 * scale)
+    # weighted leaves (what the top stage of a sharded scene uses)
+    rng = np.random.default_rng(3)
+    tk = np.unique(rng.integers(0, 512, size=300)).astype(np.int64)
+    tw = rng.integers(1, 100000, size=tk.shape[0]).astype(np.int64)
+    X = rng.normal(size=(tk.shape[0], 5))
+    wp = rt.RahtPlan.from_keys(_dev(tk), 9, leaf_weights=_dev(tw))
+    wp.set_engine(engine, tile_rows)
+    wr = NumpyPlan(torch.from_numpy(tk), 9, leaf_weights=torch.from_numpy(tw))
+    Tw, w = wp.forward(_dev(X))
+    np.testing.assert_allclose(Tw.cpu().numpy(), wr.forward(torch.from_numpy(X)).numpy(), rtol=1e-12, atol=1e-12)
+    assert w[0].item() == float(tw.sum())
+    np.testing.assert_allclose(wp.inverse(Tw).cpu().numpy(), X, rtol=1e-11, atol=1e-11)
+
+
+def test_sharded_driver_single_rank_equals_plain_plan(rt):
+    import torch
+    from raht_3dgs_codec_amd import sharded, synth
+    V, keys, C = synth.scene(120000, 11, 59, seed=21)
+    kd = _dev(keys.view(np.int64))
+    Cd = _dev(C)
+    sh = sharded.ShardedRaht(kd, 33, prefix_bits=9)
+    p = rt.RahtPlan.from_keys(kd, 33)
+    T0, _ = p.forward(Cd)
+    T1 = sh.forward(Cd)
+    assert sh.n_roots > 50 and sh.total_rows == keys.shape[0]
+    scale = T0.abs().max(dim=0)[0]
+    assert bool(((T1 - T0).abs().max(dim=0)[0] <= 2e-6 * scale).all())
+    assert (sh.inverse(T1) - Cd).abs().max().item() <= 1e-5 * Cd.abs().max().item()
+    Q0, Q1 = p.forward_quant(Cd, 0.01), sh.forward_quant(Cd, 0.01)
+    assert (Q0 != Q1).float().mean().item() < 1e-5 and (Q0 - Q1).abs().max().item() <= 1
+    R1 = sh.dequant_inverse(Q1, 0.01)
+    assert (R1 - p.dequant_inverse(Q0, 0.01)).abs().max().item() <= 0.02
+
+
+def test_two_prefix_shards_stitched_by_the_top_stage(rt, oracle):
+    """Emulates two ranks on one GPU: shard-local truncated transforms + one weighted top tree ==
+    the oracle's transform of the whole scene."""
+    import torch
+    from raht_3dgs_codec_amd import synth
+    J, D = 9, 11
+    V, keys, C = synth.scene(90000, J, D, seed=31)
+    nbits, pb = 3 * J, 9
+    po = oracle.raht_param(V.astype(np.float64), np.zeros(3), 2 ** J, J)
+    To, _ = oracle.raht_fwd(C.astype(np.float64), po)
+    pref = (keys >> np.uint64(nbits - pb)).astype(np.int64)
+    cut = int(np.searchsorted(pref, 200))
+    shards = [(0, cut), (cut, keys.shape[0])]
+    plans, roots, metas = [], [], []
+    for a, b in shards:
+        pl = rt.RahtPlan.from_keys(_dev(keys[a:b].view(np.int64)), nbits, top_level=nbits - pb)
+        rb = torch.empty((pl.n_roots, D), dtype=torch.float32, device="cuda")
+        Tl = pl.forward(_dev(C[a:b]), want_w=False, roots=rb)
+        rr = pl.root_rows.cpu().numpy()
+        cnt = np.diff(np.concatenate([rr, [b - a]]))
+        plans.append((pl, Tl, rr)); roots.append(rb); metas.append((pref[a:b][rr], cnt))
+    tp = np.concatenate([m[0] for m in metas]); tc = np.concatenate([m[1] for m in metas])
+    top = rt.RahtPlan.from_keys(_dev(tp.astype(np.int64)), pb, leaf_weights=_dev(tc.astype(np.int64)))
+    Ttop = top.forward(torch.cat(roots), want_w=False)
+    off = 0
+    for (pl, Tl, rr), (a, b) in zip(plans, shards):
+        Tl[pl.root_rows] = Ttop[off: off + len(rr)]
+        off += len(rr)
+        # tolerance relative to the WHOLE scene's column scale (the DC lives in one shard only)
+        err = np.abs(Tl.cpu().numpy().astype(np.float64) - To[a:b]).max(axis=0)
+        assert np.all(err <= 2e-6 * np.abs(To).max(axis=0)), float((err / np.abs(To).max(axis=0)).max())

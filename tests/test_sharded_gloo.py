@@ -1,0 +1,109 @@
+"""World-size-2 (and 3) gloo tests of the Morton-prefix sharded RAHT on CPU.
+
+The host-side logic under test is raht_3dgs_codec_amd.sharded.ShardedRaht: prefix-range shards,
+root directory exchange, ONE all-gather per direction, replicated weighted top tree, write-back of
+the rank's own top coefficients. The shard-local arithmetic is injected (tests/numpy_ops.py) because
+the product's local ops are GPU-only; the result is checked against the C oracle run on the WHOLE
+scene, i.e. against the reference's unsharded transform."""
+import os
+import socket
+import sys
+import traceback
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, J, n, D, q):
+    try:
+        sys.path.insert(0, ROOT)
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        from raht_3dgs_codec_amd import sharded, synth
+        from tests.numpy_ops import NumpyLocalOps
+        from oracle import oracle as orc
+
+        V, keys, C = synth.scene(n, J, D, seed=77)            # the whole scene, same on every rank
+        nbits, pb = 3 * J, 9
+        pref = (keys >> np.uint64(nbits - pb)).astype(np.int64)
+        per = (1 << pb) // world
+        lo, hi = rank * per, ((rank + 1) * per if rank < world - 1 else 1 << pb)
+        mine = np.nonzero((pref >= lo) & (pref < hi))[0]
+        assert mine.size > 0 and np.all(np.diff(mine) == 1)
+        k_loc = torch.from_numpy(keys[mine].view(np.int64).copy())
+        C_loc = torch.from_numpy(C[mine].astype(np.float64))
+
+        sh = sharded.ShardedRaht(k_loc, nbits, prefix_bits=pb, local_ops=NumpyLocalOps)
+        assert sh.world == world and sh.total_rows == keys.shape[0]
+
+        # reference: the oracle on the WHOLE scene
+        po = orc.raht_param(V.astype(np.float64), np.zeros(3), 2 ** J, J)
+        To, _ = orc.raht_fwd(C.astype(np.float64), po)
+
+        T = sh.forward(C_loc)
+        np.testing.assert_allclose(T.numpy(), To[mine], rtol=1e-11, atol=1e-11 * np.abs(To).max())
+        R = sh.inverse(T)
+        np.testing.assert_allclose(R.numpy(), C[mine].astype(np.float64), rtol=1e-11, atol=1e-11)
+
+        # quantized path: dequantized coefficients of this shard == quantized oracle coefficients
+        step = 0.05
+        Q = sh.forward_quant(C_loc, step)
+        Tq = torch.empty_like(T)
+        Tq[sh.plan.order_RAGFT] = Q.to(torch.float64) * step
+        ref = np.floor(To[mine] / step + 0.5) * step
+        bad = np.abs(Tq.numpy() - ref) > 1e-9
+        assert bad.mean() < 1e-4            # only rounding ties may differ
+        Rq = sh.dequant_inverse(Q, step)
+        assert float((Rq - C_loc).abs().max()) < 40 * step
+        # orthonormal transform: global error energy == global quantization error energy
+        e_loc = torch.tensor([float(((Rq - C_loc) ** 2).sum()), float(((Tq - T) ** 2).sum())], dtype=torch.float64)
+        dist.all_reduce(e_loc)
+        assert abs(e_loc[0].item() - e_loc[1].item()) <= 1e-6 * max(e_loc[1].item(), 1e-30)
+        dist.barrier()
+        dist.destroy_process_group()
+        q.put((rank, "ok"))
+    except Exception:
+        q.put((rank, traceback.format_exc()))
+
+
+@pytest.mark.parametrize("world,J,n,D", [(2, 6, 6000, 5), (2, 10, 4000, 14), (3, 5, 3000, 3)])
+def test_sharded_matches_unsharded_oracle(world, J, n, D):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, J, n, D, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, msg in res:
+        assert msg == "ok", f"rank {rank}:\n{msg}"
+
+
+def test_single_process_degenerates_to_plain_transform():
+    """world = 1 (no process group): the sharded driver is just local + top stages."""
+    sys.path.insert(0, ROOT)
+    from raht_3dgs_codec_amd import sharded, synth
+    from tests.numpy_ops import NumpyLocalOps, NumpyPlan
+    V, keys, C = synth.scene(3000, 7, 4, seed=5)
+    k = torch.from_numpy(keys.view(np.int64).copy())
+    Cd = torch.from_numpy(C.astype(np.float64))
+    sh = sharded.ShardedRaht(k, 21, prefix_bits=9, local_ops=NumpyLocalOps)
+    full = NumpyPlan(k, 21)
+    np.testing.assert_allclose(sh.forward(Cd).numpy(), full.forward(Cd).numpy(), rtol=1e-12, atol=1e-12)
+    assert sh.roundtrip_error(Cd) < 1e-12
