@@ -222,25 +222,33 @@ def main():
         # ALGORITHMIC bytes per launch (per direction): read N*D*4 + write N*D*4 + 8 B/row of plan
         alg = 8.0 * N * D + 8.0 * N
         if a.engine == "tile":
+            fused = not (a.no_quant or a.unfused)
+            qp, qs = (vp(Q.data_ptr()), a.quant_step) if fused else (None, 0.0)
+
             def k_fwd():
-                _lib.check(L.raht_debug_run_stage(h, 0, 0, vp(Cd.data_ptr()), D, D, vp(T.data_ptr()), D, a.ablate, s_()))
+                _lib.check(L.raht_debug_run_stage(h, 0, 0, vp(Cd.data_ptr()), D, D, vp(T.data_ptr()), D, qp, D, qs,
+                                                  a.ablate, s_()))
 
             def k_inv():
-                _lib.check(L.raht_debug_run_stage(h, 1, 0, vp(T.data_ptr()), D, D, vp(Crec.data_ptr()), D, a.ablate, s_()))
+                _lib.check(L.raht_debug_run_stage(h, 1, 0, vp(T.data_ptr()), D, D, vp(Crec.data_ptr()), D, qp, D, qs,
+                                                  a.ablate, s_()))
             k_fwd(); k_inv()
             tf, ti = timed(k_fwd, reps), timed(k_inv, reps)
             traffic = None
             tp = os.path.join(ROOT, "profiles", "traffic.json")
             if os.path.exists(tp):
                 try:
-                    traffic = json.load(open(tp)).get(a.workload, {}).get("tile_kernel_fwd_stage0_bytes")
+                    traffic = json.load(open(tp)).get(a.workload, {}).get("fused" if fused else "plain", {}).get("fwd_stage0_bytes")
                 except Exception:
                     traffic = None
-            out["roofline"] = {"kernel": "raht::tile_kernel<float, false, true, false> (forward, stage 0)", "bound": "hbm",
+            tq = "true" if fused else "false"
+            out["roofline"] = {"kernel": f"raht::tile_kernel<float, false, true, {tq}, 1> (forward, stage 0"
+                                         + (", fused quantize+reorder)" if fused else ")"), "bound": "hbm",
                                "achieved": round(alg / (tf * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": round(alg / (tf * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": traffic,
                                "alg_bytes_per_launch": alg, "avg_launch_ms": round(tf, 4)}
-            out["roofline_inv"] = {"kernel": "raht::tile_kernel<float, true, true, false> (inverse, stage 0)", "bound": "hbm",
+            out["roofline_inv"] = {"kernel": f"raht::tile_kernel<float, true, true, {tq}, 1> (inverse, stage 0"
+                                             + (", fused un-reorder+dequantize)" if fused else ")"), "bound": "hbm",
                                    "achieved": round(alg / (ti * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                    "frac": round(alg / (ti * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                                    "alg_bytes_per_launch": alg, "avg_launch_ms": round(ti, 4)}

@@ -166,10 +166,13 @@ int raht_plan_prepare(raht_plan *plan, int elem_size, int D, raht_stream_t strea
 
 /* Profiling aid: enqueue ONE stage of the float32 tile schedule (stage 0 is the HBM-heavy launch).
  * Not a transform by itself; bench.py uses it to time the dominant kernel with HIP events.
+ *   Q == NULL : plain kernels   (forward: mat = C in, mat2 = T out;  inverse: mat = T in, mat2 = C out)
+ *   Q != NULL : fused-quantization kernels (forward: mat = C in, Q out;  inverse: Q in, mat2 = C out)
  * ablate: 0 = the real kernel; 1 = skip the butterflies; 2 = also skip merge resolution (a pure
  * staged copy) -- timing experiments only, the output is then not a transform. */
-int raht_debug_run_stage(const raht_plan *plan, int inverse, int stage, const float *src, int64_t ld_src,
-                         int D, float *dst, int64_t ld_dst, int ablate, raht_stream_t stream);
+int raht_debug_run_stage(const raht_plan *plan, int inverse, int stage, const float *mat, int64_t ld_mat,
+                         int D, float *mat2, int64_t ld_mat2, int32_t *Q, int64_t ldq, float step,
+                         int ablate, raht_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Quantize + reorder / dequantize + un-reorder (driver-inline in the reference,

@@ -83,7 +83,7 @@ def lib():
         f.argtypes = [vp, vp, i64, i32, vp, i64, vp, vp]
     for f in (L.raht_inv, L.raht_inv_f64):
         f.argtypes = [vp, vp, i64, i32, vp, i64, vp]
-    L.raht_debug_run_stage.argtypes = [vp, i32, i32, vp, i64, i32, vp, i64, i32, vp]
+    L.raht_debug_run_stage.argtypes = [vp, i32, i32, vp, i64, i32, vp, i64, vp, i64, C.c_float, i32, vp]
     L.raht_fwd_quant.argtypes = [vp, vp, i64, i32, C.POINTER(C.c_float), i32, vp, i64, vp]
     L.raht_dequant_inv.argtypes = [vp, vp, i64, i32, C.POINTER(C.c_float), i32, vp, i64, vp]
     L.raht_plan_prepare.argtypes = [vp, i32, i32, vp]

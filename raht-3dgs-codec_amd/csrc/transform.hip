@@ -920,22 +920,37 @@ int raht_plan_prepare(raht_plan *p, int elem_size, int D, raht_stream_t stream)
 
 /* Profiling aid: enqueue ONE stage of the float32 tile schedule (stage 0 = the HBM-heavy launch).
  * Results are only meaningful as part of a full transform; bench.py uses this to time the dominant
- * kernel in isolation with HIP events. */
-int raht_debug_run_stage(const raht_plan *cp, int inverse, int stage, const float *src, int64_t ld_src, int D,
-                         float *dst, int64_t ld_dst, int ablate, raht_stream_t stream)
+ * kernel in isolation with HIP events. Q != NULL selects the fused-quantization kernels
+ * (forward: mat = C in, Q out; inverse: Q in, mat = C out), Q == NULL the plain ones
+ * (forward: mat = C in, mat2 = T out; inverse: mat = T in, mat2 = C out). */
+int raht_debug_run_stage(const raht_plan *cp, int inverse, int stage, const float *mat, int64_t ld_mat, int D,
+                         float *mat2, int64_t ld_mat2, int32_t *Q, int64_t ldq, float step, int ablate,
+                         raht_stream_t stream)
 {
     raht_plan *p = const_cast<raht_plan *>(cp);
     hipStream_t s = (hipStream_t)stream;
-    if (!p || !src || !dst || D < 1) { set_error("raht_debug_run_stage: bad argument"); return RAHT_ERR_INVALID; }
+    if (!p || D < 1 || (!Q && (!mat || !mat2)) || (Q && !(inverse ? (const void *)mat2 : (const void *)mat))) {
+        set_error("raht_debug_run_stage: bad argument");
+        return RAHT_ERR_INVALID;
+    }
     Schedule *sc = nullptr;
     int Dc = 0;
     RAHT_RET(tile_setup<float>(p, D, s, &sc, &Dc));
     if (!sc) { set_error("raht_debug_run_stage: tile engine unavailable"); return RAHT_ERR_UNSUPPORTED; }
     if (stage < 0 || stage >= (int)sc->stages.size()) { set_error("raht_debug_run_stage: stage out of range"); return RAHT_ERR_INVALID; }
     XformIO<float> io;
-    io.src = src; io.ld_src = ld_src; io.dst = dst; io.ld_dst = ld_dst;
-    if (inverse) return launch_tile_stage<float, true, false>(p, *sc, stage, io, D, Dc, s, ablate);
-    return launch_tile_stage<float, false, false>(p, *sc, stage, io, D, Dc, s, ablate);
+    if (!Q) {
+        io.src = mat; io.ld_src = ld_mat; io.dst = mat2; io.ld_dst = ld_mat2;
+        if (inverse) return launch_tile_stage<float, true, false>(p, *sc, stage, io, D, Dc, s, ablate);
+        return launch_tile_stage<float, false, false>(p, *sc, stage, io, D, Dc, s, ablate);
+    }
+    io.Q = Q; io.ldq = ldq; io.steps = &step; io.n_steps = 1;
+    if (inverse) {
+        io.dst = mat2; io.ld_dst = ld_mat2;
+        return launch_tile_stage<float, true, true>(p, *sc, stage, io, D, Dc, s, ablate);
+    }
+    io.src = mat; io.ld_src = ld_mat;
+    return launch_tile_stage<float, false, true>(p, *sc, stage, io, D, Dc, s, ablate);
 }
 
 }  // extern "C"
