@@ -42,6 +42,7 @@ def parse():
     ap.add_argument("--tile-rows", type=int, default=0)
     ap.add_argument("--quant-step", type=float, default=0.01)
     ap.add_argument("--skip-cpu-baseline", action="store_true")
+    ap.add_argument("--skip-prelude", action="store_true", help="do not time plan build / sort / voxelizer")
     ap.add_argument("--cpu-repeats", type=int, default=2)
     ap.add_argument("--unfused", action="store_true", help="quantize / dequantize as separate passes")
     ap.add_argument("--ablate", type=int, default=0, help="kernel-timing experiment for the roofline probe only (0 = real kernel)")
@@ -258,6 +259,33 @@ def main():
                            "achieved_GBs": round(2 * alg / (tot * 1e-3) / 1e9, 1),
                            "frac_of_peak": round(2 * alg / (tot * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                            "fwd_inv_only_MGs": round(N / (tot * 1e-3) / 1e6, 1)}
+
+        # ---- prelude stages, reported separately: plan build, radix sort, voxelizer ----
+        if not a.skip_prelude:
+            def wall(fn, reps=3):
+                best = None
+                for _ in range(reps):
+                    torch.cuda.synchronize(); t = time.perf_counter(); fn(); torch.cuda.synchronize()
+                    dtt = time.perf_counter() - t
+                    best = dtt if best is None else min(best, dtt)
+                return best * 1e3
+            pre = {}
+            pre["plan_from_sorted_keys_ms"] = wall(lambda: R.RahtPlan.from_keys(kd, 3 * J))
+            g = torch.Generator(device=dev); g.manual_seed(1)
+            perm = torch.randperm(N, device=dev, generator=g)
+            ku = kd[perm].contiguous()
+            pre["radix_sort_%dbit_ms" % (3 * J)] = wall(lambda: R.sort_keys(ku, nbits=3 * J))
+            k60 = (ku << (60 - 3 * J)) | (ku & ((1 << (60 - 3 * J)) - 1))
+            pre["radix_sort_60bit_ms"] = wall(lambda: R.sort_keys(k60, nbits=60))
+            pre["torch_sort_int64_ms"] = wall(lambda: torch.sort(ku))
+            # voxelizer on the unsorted cloud: xyz (voxel centres) + the D-3 (or D) attribute columns
+            xyz = torch.from_numpy(V.astype(np.float32)).to(dev)[perm] + 0.5
+            PC = torch.cat([xyz, Cd[perm][:, : min(D, 56)]], dim=1).contiguous()
+            pre["voxelize_ms"] = wall(lambda: R.voxelize_pc_batched(PC, [0.0, 0.0, 0.0], float(2 ** J), J, device=dev, residuals=False))
+            pre["voxelize_points"] = N
+            pre["voxelize_columns"] = int(PC.shape[1])
+            out["prelude_ms"] = {k: (round(v, 3) if isinstance(v, float) else v) for k, v in pre.items()}
+            del PC, xyz, ku, k60, perm
 
         if not a.skip_cpu_baseline:
             v, secs, err = cpu_baseline(V, Ch, J, a.cpu_repeats)

@@ -82,30 +82,16 @@ __global__ void morton_i64_kernel(const int64_t *__restrict__ V, int64_t N, uint
 
 // ---- lvl[] -------------------------------------------------------------------------------------
 __global__ void level_kernel(const uint64_t *__restrict__ keys, int64_t N, int nbits,
-                             uint8_t *__restrict__ lvl, PlanErr *err, int *max_level)
+                             uint8_t *__restrict__ lvl, PlanErr *err)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    int l = -1;                                  // every lane reaches the wave reduction below
-    if (i < N) {
-        const uint64_t k = keys[i];
-        if (nbits < 64 && (k >> nbits) != 0) report(err, RAHT_ERR_BOUNDS, i);
-        if (i == 0) {
-            lvl[0] = 255;
-        } else {
-            const uint64_t p = keys[i - 1];
-            if (k <= p) {
-                report(err, RAHT_ERR_UNSORTED, i);
-                lvl[i] = 0;
-            } else {
-                l = 63 - __clzll((long long)(k ^ p));
-                lvl[i] = (uint8_t)l;
-            }
-        }
-    }
-    int m = l;                                   // one atomic per wave
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) m = max(m, __shfl_xor(m, d, 64));
-    if ((threadIdx.x & 63) == 0 && m >= 0) atomicMax(max_level, m);
+    if (i >= N) return;
+    const uint64_t k = keys[i];
+    if (nbits < 64 && (k >> nbits) != 0) report(err, RAHT_ERR_BOUNDS, i);
+    if (i == 0) { lvl[0] = 255; return; }
+    const uint64_t p = keys[i - 1];
+    if (k <= p) { report(err, RAHT_ERR_UNSORTED, i); lvl[i] = 0; return; }
+    lvl[i] = (uint8_t)(63 - __clzll((long long)(k ^ p)));
 }
 
 // ---- wl[], wr[] --------------------------------------------------------------------------------
@@ -266,10 +252,9 @@ int get_schedule(raht_plan *plan, int R, hipStream_t s, Schedule **out)
     sc.tile_rows = R;
     sc.valid = true;
     const int64_t N = plan->N;
-    uint32_t *flag = nullptr, *pos = nullptr, *dtotal = nullptr;
-    RAHT_HIP_CHECK(hipMalloc(&flag, sizeof(uint32_t) * (size_t)N));
-    RAHT_HIP_CHECK(hipMalloc(&pos, sizeof(uint32_t) * (size_t)N));
-    RAHT_HIP_CHECK(hipMalloc(&dtotal, sizeof(uint32_t)));
+    Scratch buf(sizeof(uint32_t) * (2 * (size_t)N + 1));
+    if (!buf.ok()) return RAHT_ERR_NOMEM;
+    uint32_t *flag = buf.as<uint32_t>(), *pos = flag + N, *dtotal = pos + N;
     uint32_t *rows = nullptr;      // rows of the current stage (nullptr = identity)
     int64_t n = N;
     int rc = RAHT_OK;
@@ -305,7 +290,6 @@ int get_schedule(raht_plan *plan, int R, hipStream_t s, Schedule **out)
         n = cnt;
     }
     hipError_t e = hipStreamSynchronize(s);
-    (void)hipFree(flag); (void)hipFree(pos); (void)hipFree(dtotal);
     if (rc == RAHT_OK && e != hipSuccess) rc = RAHT_ERR_HIP;
     if (rc != RAHT_OK) {
         if (!sc.stages.empty() && sc.stages.back().rows != rows && rows) (void)hipFree(rows);
@@ -328,21 +312,18 @@ __global__ void root_flag_kernel(const uint8_t *__restrict__ lvl, int64_t N, int
 static int compute_roots(raht_plan *p, hipStream_t s)
 {
     if (p->root_rows) { (void)hipFree(p->root_rows); p->root_rows = nullptr; }
-    uint32_t *flag = nullptr, *tmp = nullptr;
-    RAHT_HIP_CHECK(hipMalloc(&flag, sizeof(uint32_t) * (size_t)p->N));
-    RAHT_HIP_CHECK(hipMalloc(&tmp, sizeof(uint32_t) * (size_t)p->N));
+    Scratch buf(sizeof(uint32_t) * 2 * (size_t)p->N);
+    if (!buf.ok()) return RAHT_ERR_NOMEM;
+    uint32_t *flag = buf.as<uint32_t>(), *tmp = flag + p->N;
     hipLaunchKernelGGL(root_flag_kernel, dim3((unsigned)ceil_div(p->N, 256)), dim3(256), 0, s, p->lvl, p->N,
                        p->top_level, flag);
     int64_t cnt = 0;
-    int rc = compact_u32(nullptr, flag, tmp, p->N, &cnt, s);
-    if (rc == RAHT_OK) {
-        p->n_roots = cnt;
-        if (hipMalloc(&p->root_rows, sizeof(uint32_t) * (size_t)cnt) != hipSuccess) rc = RAHT_ERR_NOMEM;
-        else if (hipMemcpy(p->root_rows, tmp, sizeof(uint32_t) * (size_t)cnt, hipMemcpyDeviceToDevice) != hipSuccess) rc = RAHT_ERR_HIP;
-    }
-    (void)hipFree(flag);
-    (void)hipFree(tmp);
-    return rc;
+    RAHT_RET(compact_u32(nullptr, flag, tmp, p->N, &cnt, s));
+    p->n_roots = cnt;
+    RAHT_HIP_CHECK(hipMalloc(&p->root_rows, sizeof(uint32_t) * (size_t)cnt));
+    RAHT_HIP_CHECK(hipMemcpyAsync(p->root_rows, tmp, sizeof(uint32_t) * (size_t)cnt, hipMemcpyDeviceToDevice, s));
+    RAHT_HIP_CHECK(hipStreamSynchronize(s));
+    return RAHT_OK;
 }
 
 // ---- plan construction ---------------------------------------------------------------------------
@@ -350,24 +331,34 @@ static int finish_plan(raht_plan *p, const int64_t *leaf_weights, hipStream_t s)
 {
     const int64_t N = p->N;
     const unsigned gb = (unsigned)ceil_div(N, 256);
-    PlanErr *derr = nullptr;
-    int *dmax = nullptr;
-    RAHT_HIP_CHECK(hipMalloc(&derr, sizeof(PlanErr)));
-    RAHT_HIP_CHECK(hipMalloc(&dmax, sizeof(int)));
+    Scratch tmp(sizeof(PlanErr) + sizeof(uint32_t) * 65 + (size_t)N);     // error word | bucket offsets | bucket ids
+    if (!tmp.ok()) return RAHT_ERR_NOMEM;
+    PlanErr *derr = tmp.as<PlanErr>();
+    uint32_t *boff = (uint32_t *)((char *)tmp.ptr() + sizeof(PlanErr));
+    uint8_t *bucket = (uint8_t *)(boff + 65);
     PlanErr h0 = {0, 0xffffffffu};
-    int hm = -1;
     RAHT_HIP_CHECK(hipMemcpyAsync(derr, &h0, sizeof(h0), hipMemcpyHostToDevice, s));
-    RAHT_HIP_CHECK(hipMemcpyAsync(dmax, &hm, sizeof(hm), hipMemcpyHostToDevice, s));
     RAHT_HIP_CHECK(hipMalloc(&p->lvl, (size_t)N));
     RAHT_HIP_CHECK(hipMalloc(&p->wl, sizeof(int32_t) * (size_t)N));
     RAHT_HIP_CHECK(hipMalloc(&p->wr, sizeof(int32_t) * (size_t)N));
-    hipLaunchKernelGGL(level_kernel, dim3(gb), dim3(256), 0, s, p->keys, N, p->nbits, p->lvl, derr, dmax);
+    RAHT_HIP_CHECK(hipMalloc(&p->order, sizeof(uint32_t) * (size_t)N));
+    RAHT_HIP_CHECK(hipMalloc(&p->inv_order, sizeof(uint32_t) * (size_t)N));
+    RAHT_HIP_CHECK(hipMalloc(&p->level_rows, sizeof(uint32_t) * (size_t)N));
+    hipLaunchKernelGGL(level_kernel, dim3(gb), dim3(256), 0, s, p->keys, N, p->nbits, p->lvl, derr);
+    // everything below is enqueued speculatively; the error word is checked at the single sync
+    hipLaunchKernelGGL(extent_kernel, dim3(gb), dim3(256), 0, s, p->keys, N, p->lvl, p->wl, p->wr);
+    // order_RAGFT and the per-level row buckets: two stable bucket sorts
+    hipLaunchKernelGGL(order_bucket_kernel, dim3(gb), dim3(256), 0, s, p->lvl, N, bucket);
+    RAHT_RET(bucket_sort_u8(bucket, p->order, N, 5, nullptr, s));
+    if (getenv("RAHT_DEBUG_IDENTITY_ORDER"))      // timing experiments only: order_RAGFT := identity
+        hipLaunchKernelGGL(order_to_identity_kernel, dim3(gb), dim3(256), 0, s, p->order, N);
+    hipLaunchKernelGGL(invert_perm_kernel, dim3(gb), dim3(256), 0, s, p->order, N, p->inv_order);
+    hipLaunchKernelGGL(level_bucket_kernel, dim3(gb), dim3(256), 0, s, p->lvl, N, bucket);
+    RAHT_RET(bucket_sort_u8(bucket, p->level_rows, N, 6, boff, s));
     PlanErr he;
     RAHT_HIP_CHECK(hipMemcpyAsync(&he, derr, sizeof(he), hipMemcpyDeviceToHost, s));
-    RAHT_HIP_CHECK(hipMemcpyAsync(&hm, dmax, sizeof(hm), hipMemcpyDeviceToHost, s));
+    RAHT_HIP_CHECK(hipMemcpyAsync(p->level_off, boff, sizeof(uint32_t) * 65, hipMemcpyDeviceToHost, s));
     RAHT_HIP_CHECK(hipStreamSynchronize(s));
-    (void)hipFree(derr);
-    (void)hipFree(dmax);
     if (he.code != 0) {
         if (he.code == RAHT_ERR_UNSORTED)
             set_error("Morton keys are not strictly increasing at row %u (input must be Morton-sorted "
@@ -376,28 +367,9 @@ static int finish_plan(raht_plan *p, const int64_t *leaf_weights, hipStream_t s)
             set_error("coordinate / key out of bounds at row %u for depth %d", he.row, p->nbits / 3);
         return he.code;
     }
-    p->max_level = hm;
-    hipLaunchKernelGGL(extent_kernel, dim3(gb), dim3(256), 0, s, p->keys, N, p->lvl, p->wl, p->wr);
-
-    // order_RAGFT and the per-level row buckets: two stable bucket sorts
-    uint8_t *bucket = nullptr;
-    uint32_t *boff = nullptr;
-    RAHT_HIP_CHECK(hipMalloc(&bucket, (size_t)N));
-    RAHT_HIP_CHECK(hipMalloc(&boff, sizeof(uint32_t) * 65));
-    RAHT_HIP_CHECK(hipMalloc(&p->order, sizeof(uint32_t) * (size_t)N));
-    RAHT_HIP_CHECK(hipMalloc(&p->level_rows, sizeof(uint32_t) * (size_t)N));
-    hipLaunchKernelGGL(order_bucket_kernel, dim3(gb), dim3(256), 0, s, p->lvl, N, bucket);
-    RAHT_RET(bucket_sort_u8(bucket, p->order, N, 5, nullptr, s));
-    if (getenv("RAHT_DEBUG_IDENTITY_ORDER"))      // timing experiments only: order_RAGFT := identity
-        hipLaunchKernelGGL(order_to_identity_kernel, dim3(gb), dim3(256), 0, s, p->order, N);
-    RAHT_HIP_CHECK(hipMalloc(&p->inv_order, sizeof(uint32_t) * (size_t)N));
-    hipLaunchKernelGGL(invert_perm_kernel, dim3(gb), dim3(256), 0, s, p->order, N, p->inv_order);
-    hipLaunchKernelGGL(level_bucket_kernel, dim3(gb), dim3(256), 0, s, p->lvl, N, bucket);
-    RAHT_RET(bucket_sort_u8(bucket, p->level_rows, N, 6, boff, s));
-    RAHT_HIP_CHECK(hipMemcpyAsync(p->level_off, boff, sizeof(uint32_t) * 65, hipMemcpyDeviceToHost, s));
-    RAHT_HIP_CHECK(hipStreamSynchronize(s));
-    (void)hipFree(bucket);
-    (void)hipFree(boff);
+    p->max_level = -1;                              // highest level that has a pair (bucket 63 = row 0)
+    for (int l = 0; l < 63; ++l)
+        if (p->level_off[l + 1] > p->level_off[l]) p->max_level = l;
 
     if (leaf_weights) {
         // prefix sums of the leaf weights on the host: weighted plans are tiny (<= 512 rows when

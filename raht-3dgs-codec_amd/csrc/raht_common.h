@@ -36,6 +36,24 @@ void set_error(const char *fmt, ...);
 
 static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+// Device scratch memory from a thread-local grow-only pool: plan / sort / voxelizer temporaries are
+// reused across calls instead of paying hipMalloc + hipFree (each a device synchronisation) per use.
+// Stream-ordered reuse is safe because every user of the pool runs its work on the caller's stream
+// in program order and the pool is per host thread.
+class Scratch {
+public:
+    explicit Scratch(size_t bytes);
+    ~Scratch();
+    Scratch(const Scratch &) = delete;
+    Scratch &operator=(const Scratch &) = delete;
+    void *ptr() const { return p_; }
+    template <typename T> T *as() const { return (T *)p_; }
+    bool ok() const { return p_ != nullptr; }
+private:
+    void *p_ = nullptr;
+    int slot_ = -1;
+};
+
 // ---- device primitives (scan_sort.hip) ---------------------------------------------------------
 // Exclusive prefix sum of n uint32 values, in place allowed (out may equal in). `total` (device
 // uint32*, may be NULL) receives the sum. Allocates its own small workspace (plan/voxelize time

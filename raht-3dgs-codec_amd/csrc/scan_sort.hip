@@ -9,6 +9,47 @@
 namespace raht {
 
 // ------------------------------------------------------------------------------------------------
+// Scratch pool
+// ------------------------------------------------------------------------------------------------
+struct PoolBlock { void *p; size_t bytes; bool used; };
+static thread_local std::vector<PoolBlock> g_pool;
+
+Scratch::Scratch(size_t bytes)
+{
+    if (bytes == 0) bytes = 16;
+    int best = -1;
+    for (int i = 0; i < (int)g_pool.size(); ++i)
+        if (!g_pool[(size_t)i].used && g_pool[(size_t)i].bytes >= bytes &&
+            (best < 0 || g_pool[(size_t)i].bytes < g_pool[(size_t)best].bytes)) best = i;
+    if (best < 0) {
+        // recycle the largest free block that is too small, else grow the pool
+        int victim = -1;
+        for (int i = 0; i < (int)g_pool.size(); ++i)
+            if (!g_pool[(size_t)i].used && (victim < 0 || g_pool[(size_t)i].bytes > g_pool[(size_t)victim].bytes)) victim = i;
+        void *q = nullptr;
+        const size_t want = bytes + bytes / 4;                 // head-room against slow growth
+        if (victim >= 0 && g_pool.size() >= 24) {
+            (void)hipFree(g_pool[(size_t)victim].p);
+            if (hipMalloc(&q, want) != hipSuccess) { g_pool.erase(g_pool.begin() + victim); set_error("scratch: out of device memory (%zu bytes)", want); return; }
+            g_pool[(size_t)victim] = {q, want, false};
+            best = victim;
+        } else {
+            if (hipMalloc(&q, want) != hipSuccess) { set_error("scratch: out of device memory (%zu bytes)", want); return; }
+            g_pool.push_back({q, want, false});
+            best = (int)g_pool.size() - 1;
+        }
+    }
+    g_pool[(size_t)best].used = true;
+    p_ = g_pool[(size_t)best].p;
+    slot_ = best;
+}
+
+Scratch::~Scratch()
+{
+    if (slot_ >= 0 && slot_ < (int)g_pool.size()) g_pool[(size_t)slot_].used = false;
+}
+
+// ------------------------------------------------------------------------------------------------
 // Exclusive scan (3 kernels, recursive on the block sums).
 // ------------------------------------------------------------------------------------------------
 constexpr int SCAN_THREADS = 256;
@@ -107,23 +148,17 @@ int exclusive_scan_u32(const uint32_t *in, uint32_t *out, int64_t n, uint32_t *t
         if (total) RAHT_HIP_CHECK(hipMemsetAsync(total, 0, sizeof(uint32_t), s));
         return RAHT_OK;
     }
-    // workspace: nb + nb/2048 + ... entries
-    int64_t wsn = 0;
+    // workspace: nb + nb/2048 + ... entries, plus one word to keep in[n-1] (out may alias in)
+    int64_t wsn = 1;
     for (int64_t m = ceil_div(n, SCAN_BLOCK); m > 1; m = ceil_div(m, SCAN_BLOCK)) wsn += m;
-    uint32_t *ws = nullptr;
-    uint32_t *last_in = nullptr;
-    if (wsn > 0) RAHT_HIP_CHECK(hipMalloc(&ws, sizeof(uint32_t) * (size_t)wsn));
-    if (total) {
-        // keep in[n-1] (out may alias in)
-        RAHT_HIP_CHECK(hipMalloc(&last_in, sizeof(uint32_t)));
+    Scratch ws(sizeof(uint32_t) * (size_t)wsn);
+    if (!ws.ok()) return RAHT_ERR_NOMEM;
+    uint32_t *last_in = ws.as<uint32_t>();
+    if (total)
         RAHT_HIP_CHECK(hipMemcpyAsync(last_in, in + (n - 1), sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
-    }
-    int rc = scan_rec(in, out, n, ws, s);
+    int rc = scan_rec(in, out, n, ws.as<uint32_t>() + 1, s);
     if (rc == RAHT_OK && total)
         hipLaunchKernelGGL(scan_total_kernel, dim3(1), dim3(1), 0, s, last_in, out + (n - 1), total);
-    // The stream-ordered frees below are safe: hipFree synchronises with outstanding work.
-    if (ws) (void)hipFree(ws);
-    if (last_in) (void)hipFree(last_in);
     RAHT_HIP_CHECK(hipGetLastError());
     return rc;
 }
@@ -235,6 +270,8 @@ __global__ __launch_bounds__(RP_THREADS) void radix_scatter_kernel(
     }
 }
 
+__global__ void store_u32_kernel(uint32_t *p, uint32_t v) { *p = v; }
+
 template <typename KeyT>
 static int radix_pass_impl(const KeyT *keys_in, const uint32_t *vals_in, KeyT *keys_out,
                            uint32_t *vals_out, int64_t n, int shift, int bits, uint32_t *bucket_off,
@@ -244,19 +281,18 @@ static int radix_pass_impl(const KeyT *keys_in, const uint32_t *vals_in, KeyT *k
     if (bits < 1 || bits > 8) { set_error("radix pass: bits=%d", bits); return RAHT_ERR_INVALID; }
     const uint32_t nb = (uint32_t)ceil_div(n, RP_BLOCK);
     const uint32_t nd = 1u << bits;
-    uint32_t *ghist = nullptr;
-    RAHT_HIP_CHECK(hipMalloc(&ghist, sizeof(uint32_t) * (size_t)nd * nb));
+    Scratch gh(sizeof(uint32_t) * (size_t)nd * nb);
+    if (!gh.ok()) return RAHT_ERR_NOMEM;
+    uint32_t *ghist = gh.as<uint32_t>();
     hipLaunchKernelGGL(radix_hist_kernel<KeyT>, dim3(nb), dim3(RP_THREADS), 0, s, keys_in, n, shift,
                        nd - 1u, ghist, nb);
     int rc = exclusive_scan_u32(ghist, ghist, (int64_t)nd * nb, nullptr, s);
-    if (rc != RAHT_OK) { (void)hipFree(ghist); return rc; }
+    if (rc != RAHT_OK) return rc;
     if (bucket_off) {
         // start of bucket d = goffs[d * nb + 0]; end sentinel = n
         RAHT_HIP_CHECK(hipMemcpy2DAsync(bucket_off, sizeof(uint32_t), ghist, sizeof(uint32_t) * nb,
                                         sizeof(uint32_t), nd, hipMemcpyDeviceToDevice, s));
-        const uint32_t n32 = (uint32_t)n;
-        RAHT_HIP_CHECK(hipMemcpyAsync(bucket_off + nd, &n32, sizeof(uint32_t), hipMemcpyHostToDevice, s));
-        RAHT_HIP_CHECK(hipStreamSynchronize(s));   // n32 lives on this stack frame
+        hipLaunchKernelGGL(store_u32_kernel, dim3(1), dim3(1), 0, s, bucket_off + nd, (uint32_t)n);
     }
     if (vals_in) {
         if (keys_out)
@@ -274,7 +310,6 @@ static int radix_pass_impl(const KeyT *keys_in, const uint32_t *vals_in, KeyT *k
                                s, keys_in, vals_in, keys_out, vals_out, n, shift, bits, ghist, nb);
     }
     RAHT_HIP_CHECK(hipGetLastError());
-    (void)hipFree(ghist);
     return RAHT_OK;
 }
 
@@ -305,21 +340,19 @@ int compact_u32(const uint32_t *in, const uint32_t *flag, uint32_t *out, int64_t
 {
     *count_host = 0;
     if (n <= 0) return RAHT_OK;
-    uint32_t *pos = nullptr, *total = nullptr;
-    RAHT_HIP_CHECK(hipMalloc(&pos, sizeof(uint32_t) * (size_t)n));
-    RAHT_HIP_CHECK(hipMalloc(&total, sizeof(uint32_t)));
-    int rc = exclusive_scan_u32(flag, pos, n, total, s);
+    Scratch pos(sizeof(uint32_t) * ((size_t)n + 1));
+    if (!pos.ok()) return RAHT_ERR_NOMEM;
+    uint32_t *total = pos.as<uint32_t>() + n;
+    int rc = exclusive_scan_u32(flag, pos.as<uint32_t>(), n, total, s);
     if (rc == RAHT_OK) {
         hipLaunchKernelGGL(compact_scatter_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, s, in,
-                           flag, pos, out, n);
+                           flag, pos.as<uint32_t>(), out, n);
         uint32_t t = 0;
         hipError_t e = hipMemcpyAsync(&t, total, sizeof(uint32_t), hipMemcpyDeviceToHost, s);
         if (e == hipSuccess) e = hipStreamSynchronize(s);
         if (e != hipSuccess) { set_error("compact: %s", hipGetErrorString(e)); rc = RAHT_ERR_HIP; }
         *count_host = t;
     }
-    (void)hipFree(pos);
-    (void)hipFree(total);
     return rc;
 }
 

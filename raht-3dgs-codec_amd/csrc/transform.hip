@@ -569,28 +569,48 @@ __global__ __launch_bounds__(512, (sizeof(T) == 4 ? 6 : 4)) void tile_kernel(con
                 if (lane < Dc) dstb[(int64_t)(surv_base + q) * ldb + c_base + lane] = tile[j * Dc + lane];
             }
         }
-        // rows finalised here, row-granular (later stages, strided T, or fused quantization)
+        // rows finalised here, row-granular (later stages, strided T, or fused quantization).
+        // Each wave owns a contiguous run of rows; lane l fetches the flag / destination of the
+        // run's l-th row ONCE (vector LDS read), rows are then walked with readlane broadcasts and
+        // batched data reads. (Reading the wave-uniform flag / destination per row from LDS makes
+        // hipcc emit a serialised ds_read -> s_waitcnt -> v_readfirstlane -> branch chain per row.)
         if (!bulk_fin) {
-            for (int j0 = wid * 4; j0 < nt; j0 += nw * 4) {
-                int fl[4]; int64_t d[4]; T x[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int j = min(j0 + u, nt - 1);
-                    fl[u] = (A.dbg & 2) ? 1 : sflag[j];
-                    d[u] = QM ? (int64_t)sdst[j] : (IDENT ? e0 + j : (int64_t)srow[j]);
-                    x[u] = tile[j * Dc + min(lane, Dc - 1)];
+            const int RW = (nt + nw - 1) / nw;                    // rows per wave
+            const int cl = min(lane, Dc - 1);
+            if (RW <= 64) {
+                const int jb = wid * RW;
+                int fl_v = 0, d_v = 0;
+                if (lane < RW && jb + lane < nt) {
+                    const int j = jb + lane;
+                    fl_v = (A.dbg & 2) ? 1 : (int)sflag[j];
+                    d_v = QM ? sdst[j] : (IDENT ? (int)(e0 + j) : srow[j]);
+                    if (QM && A.root_buf && fl_v == 2) fl_v = 0;  // roots are quantized by the caller's top stage
                 }
+                for (int u0 = 0; u0 < RW; u0 += 8) {
+                    T x[8];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    // fused quantization + root buffer: the roots' coefficients are produced (and
-                    // quantized) by the caller's top-level stage, not here
-                    const bool skip_root = QM && A.root_buf && fl[u] == 2;
-                    if (j0 + u < nt && fl[u] != 0 && !skip_root && lane < Dc) {
-                        if constexpr (QM) {
-                            A.Q[d[u] * A.ldq + c_base + lane] = (int32_t)floorf((float)x[u] / my_step + 0.5f);  // encode_3dgs.py:204,210,215
-                        } else {
-                            A.fin[d[u] * A.ld_fin + c_base + lane] = x[u];
+                    for (int u = 0; u < 8; ++u) x[u] = tile[min(jb + u0 + u, nt - 1) * Dc + cl];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int fl = __builtin_amdgcn_readlane(fl_v, (u0 + u) & 63);
+                        const int64_t d = (int64_t)__builtin_amdgcn_readlane(d_v, (u0 + u) & 63);
+                        if (u0 + u < RW && jb + u0 + u < nt && fl != 0 && lane < Dc) {
+                            if constexpr (QM)       // encode_3dgs.py:204,210,215
+                                A.Q[d * A.ldq + c_base + lane] = (int32_t)floorf((float)x[u] / my_step + 0.5f);
+                            else
+                                A.fin[d * A.ld_fin + c_base + lane] = x[u];
                         }
+                    }
+                }
+            } else {                                              // very large tiles: plain loop
+                for (int j = wid; j < nt; j += nw) {
+                    int fl = (A.dbg & 2) ? 1 : (int)sflag[j];
+                    if (QM && A.root_buf && fl == 2) fl = 0;
+                    const int64_t d = QM ? (int64_t)sdst[j] : (IDENT ? e0 + j : (int64_t)srow[j]);
+                    if (fl != 0 && lane < Dc) {
+                        const T xx = tile[j * Dc + lane];
+                        if constexpr (QM) A.Q[d * A.ldq + c_base + lane] = (int32_t)floorf((float)xx / my_step + 0.5f);
+                        else A.fin[d * A.ld_fin + c_base + lane] = xx;
                     }
                 }
             }

@@ -90,8 +90,11 @@ __global__ void u32_to_i64_kernel(const uint32_t *__restrict__ in, int64_t n, in
     if (i < n) out[i] = (int64_t)in[i];
 }
 
-// One wave per voxel, lanes = output columns (3 coordinates + d attributes). Members are summed
-// sequentially in sorted order (same order as a CPU scatter_add_, voxelize_pc.py:140-144).
+// Per-voxel attribute mean. A wave takes 16 voxels per iteration: lanes fetch the 16 (+1) voxel
+// starts, first-member indices and keys with vector loads, then the first-member rows are loaded 8 at
+// a time (lanes = attribute columns) so that several HBM round trips overlap; further members (rare:
+// most voxels hold one point) are added sequentially in sorted order -- the same order as a CPU
+// scatter_add_ (voxelize_pc.py:140-144), so the float32 sums are bit-reproducible.
 __global__ __launch_bounds__(256) void voxel_mean_kernel(const float *__restrict__ PC, int64_t ld, int64_t N, int d,
                                                          const uint64_t *__restrict__ keys_sorted,
                                                          const uint32_t *__restrict__ sort_idx,
@@ -102,22 +105,43 @@ __global__ __launch_bounds__(256) void voxel_mean_kernel(const float *__restrict
     const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
     const int ldo = 3 + d;
-    for (int64_t v = wave; v < nvox; v += nwaves) {
-        const int64_t s = vstart[v];
-        const int64_t e = (v + 1 < nvox) ? (int64_t)vstart[v + 1] : N;
-        const uint64_t key = keys_sorted[s];
-        const uint32_t x = vx_compact3(key >> 2), y = vx_compact3(key >> 1), z = vx_compact3(key);
-        if (lane < 3) {
-            const uint32_t cv = lane == 0 ? x : (lane == 1 ? y : z);
-            if (PCvox) PCvox[v * ldo + lane] = (float)cv;         // :152,:155
-            if (Vvox) Vvox[v * 3 + lane] = (int64_t)cv;
+    for (int64_t v0 = wave * 16; v0 < nvox; v0 += nwaves * 16) {
+        const int64_t vi = v0 + lane;
+        const uint32_t vs = (lane <= 16 && vi < nvox) ? vstart[vi] : (uint32_t)N;
+        uint32_t first = 0, klo = 0, khi = 0;
+        if (lane < 16 && vi < nvox) {
+            first = sort_idx[vs];
+            const uint64_t k = keys_sorted[vs];
+            klo = (uint32_t)k; khi = (uint32_t)(k >> 32);
         }
-        if (PCvox && d > 0) {
-            const float cnt = (float)(e - s);                     // :137
-            for (int c = lane; c < d; c += 64) {
-                float acc = 0.0f;
-                for (int64_t i = s; i < e; ++i) acc += PC[(int64_t)sort_idx[i] * ld + 3 + c];
-                PCvox[v * ldo + 3 + c] = __fdiv_rn(acc, cnt);     // :144
+        // integer voxel coordinates from the key (:152,:155)
+        if (lane < 16 && vi < nvox) {
+            const uint64_t key = ((uint64_t)khi << 32) | klo;
+            const uint32_t x = vx_compact3(key >> 2), y = vx_compact3(key >> 1), z = vx_compact3(key);
+            if (PCvox) { PCvox[vi * ldo + 0] = (float)x; PCvox[vi * ldo + 1] = (float)y; PCvox[vi * ldo + 2] = (float)z; }
+            if (Vvox) { Vvox[vi * 3 + 0] = x; Vvox[vi * 3 + 1] = y; Vvox[vi * 3 + 2] = z; }
+        }
+        if (!PCvox || d == 0) continue;
+        for (int c0 = 0; c0 < d; c0 += 64) {
+            const int c = c0 + lane;
+            const int cc = min(c, d - 1);
+            for (int u0 = 0; u0 < 16; u0 += 8) {
+                float acc[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const uint32_t i0 = (uint32_t)__builtin_amdgcn_readlane((int)first, u0 + u);
+                    acc[u] = PC[(int64_t)i0 * ld + 3 + cc];
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int64_t v = v0 + u0 + u;
+                    if (v >= nvox) break;                                      // wave-uniform
+                    const int64_t s = (uint32_t)__builtin_amdgcn_readlane((int)vs, u0 + u);
+                    const int64_t e = (uint32_t)__builtin_amdgcn_readlane((int)vs, u0 + u + 1);
+                    float a = acc[u];
+                    for (int64_t i = s + 1; i < e; ++i) a += PC[(int64_t)sort_idx[i] * ld + 3 + cc];
+                    if (c < d) PCvox[v * ldo + 3 + c] = __fdiv_rn(a, (float)(e - s));   // :137,:144
+                }
             }
         }
     }
@@ -128,12 +152,10 @@ static int sort_keys_u32idx(const uint64_t *keys_in, int64_t N, int nbits, uint6
 {
     // LSD passes of 8 bits; ping-pong between two (key, index) buffers, last pass lands in *_out
     const int npass = std::max(1, (nbits + 7) / 8);
-    uint64_t *ktmp = nullptr;
-    uint32_t *itmp = nullptr;
-    if (npass > 1) {
-        RAHT_HIP_CHECK(hipMalloc(&ktmp, sizeof(uint64_t) * (size_t)N));
-        RAHT_HIP_CHECK(hipMalloc(&itmp, sizeof(uint32_t) * (size_t)N));
-    }
+    Scratch tmp(npass > 1 ? (sizeof(uint64_t) + sizeof(uint32_t)) * (size_t)N : 16);
+    if (!tmp.ok()) return RAHT_ERR_NOMEM;
+    uint64_t *ktmp = tmp.as<uint64_t>();
+    uint32_t *itmp = (uint32_t *)(ktmp + N);
     const uint64_t *kin = keys_in;
     const uint32_t *iin = nullptr;
     int rc = RAHT_OK;
@@ -146,8 +168,6 @@ static int sort_keys_u32idx(const uint64_t *keys_in, int64_t N, int nbits, uint6
         kin = ko;
         iin = io;
     }
-    if (ktmp) (void)hipFree(ktmp);
-    if (itmp) (void)hipFree(itmp);
     return rc;
 }
 
@@ -164,13 +184,13 @@ int raht_sort_keys(const uint64_t *keys_in, int64_t N, int nbits, uint64_t *keys
     if (N == 0) return RAHT_OK;
     if (N >= ((int64_t)1 << 31)) { set_error("raht_sort_keys: N too large"); return RAHT_ERR_INVALID; }
     hipStream_t s = (hipStream_t)stream;
-    uint32_t *idx32 = nullptr;
-    RAHT_HIP_CHECK(hipMalloc(&idx32, sizeof(uint32_t) * (size_t)N));
+    Scratch ib(sizeof(uint32_t) * (size_t)N);
+    if (!ib.ok()) return RAHT_ERR_NOMEM;
+    uint32_t *idx32 = ib.as<uint32_t>();
     int rc = sort_keys_u32idx(keys_in, N, nbits, keys_out, idx32, s);
     if (rc == RAHT_OK && idx_out)
         hipLaunchKernelGGL(u32_to_i64_kernel, dim3((unsigned)ceil_div(N, 256)), dim3(256), 0, s, idx32, N, idx_out);
-    hipError_t e = hipStreamSynchronize(s);
-    (void)hipFree(idx32);
+    hipError_t e = hipStreamSynchronize(s);       // idx32 returns to the pool when this frame ends
     if (e != hipSuccess) { set_error("raht_sort_keys: %s", hipGetErrorString(e)); return RAHT_ERR_HIP; }
     return rc;
 }
@@ -187,8 +207,9 @@ int raht_voxelize(const float *PC, int64_t ldpc, int64_t N, int d, const float *
     double width = width_in;
     // ---- vmin / width (voxelize_pc.py:87-95) ----
     const int nb = (int)std::min<int64_t>(ceil_div(N, 256), 1024);
-    float *part = nullptr;
-    RAHT_HIP_CHECK(hipMalloc(&part, sizeof(float) * 4 * (size_t)nb));
+    Scratch partb(sizeof(float) * 4 * (size_t)nb);
+    if (!partb.ok()) return RAHT_ERR_NOMEM;
+    float *part = partb.as<float>();
     std::vector<float> hp((size_t)nb * 4);
     if (vmin_in) { vmin[0] = vmin_in[0]; vmin[1] = vmin_in[1]; vmin[2] = vmin_in[2]; }
     else {
@@ -209,47 +230,33 @@ int raht_voxelize(const float *PC, int64_t ldpc, int64_t N, int d, const float *
         for (int b = 1; b < nb; ++b) m = std::fmax(m, hp[(size_t)b * 4 + 3]);
         width = (double)m;
     }
-    (void)hipFree(part);
     if (!(width > 0)) { set_error("raht_voxelize: width must be > 0 (got %g)", width); return RAHT_ERR_INVALID; }
     const double voxel_size = width / (double)((uint64_t)1 << J);   // :97
     const float vs = (float)voxel_size;
 
     // ---- keys, sort ----
-    uint64_t *keys = nullptr, *ks = keys_sorted;
-    uint32_t *idx = nullptr, *flag = nullptr, *vstart = nullptr;
-    bool own_ks = false;
-    int rc = RAHT_OK;
+    Scratch kb(sizeof(uint64_t) * 2 * (size_t)N), ib(sizeof(uint32_t) * 3 * (size_t)N);
+    if (!kb.ok() || !ib.ok()) return RAHT_ERR_NOMEM;
+    uint64_t *keys = kb.as<uint64_t>();
+    uint64_t *ks = keys_sorted ? keys_sorted : keys + N;
+    uint32_t *idx = ib.as<uint32_t>(), *flag = idx + N, *vstart = flag + N;
     int64_t nv = 0;
-    do {
-        if (hipMalloc(&keys, sizeof(uint64_t) * (size_t)N) != hipSuccess) { rc = RAHT_ERR_NOMEM; break; }
-        if (!ks) { if (hipMalloc(&ks, sizeof(uint64_t) * (size_t)N) != hipSuccess) { rc = RAHT_ERR_NOMEM; break; } own_ks = true; }
-        if (hipMalloc(&idx, sizeof(uint32_t) * (size_t)N) != hipSuccess) { rc = RAHT_ERR_NOMEM; break; }
-        if (hipMalloc(&flag, sizeof(uint32_t) * (size_t)N) != hipSuccess) { rc = RAHT_ERR_NOMEM; break; }
-        if (hipMalloc(&vstart, sizeof(uint32_t) * (size_t)N) != hipSuccess) { rc = RAHT_ERR_NOMEM; break; }
+    {
         const unsigned gb = (unsigned)ceil_div(N, 256);
         hipLaunchKernelGGL(vox_keys_kernel, dim3(gb), dim3(256), 0, s, PC, ldpc, N, vmin[0], vmin[1], vmin[2], vs, J, keys);
-        rc = sort_keys_u32idx(keys, N, 3 * J, ks, idx, s);
-        if (rc != RAHT_OK) break;
+        RAHT_RET(sort_keys_u32idx(keys, N, 3 * J, ks, idx, s));
         hipLaunchKernelGGL(boundary_kernel, dim3(gb), dim3(256), 0, s, ks, N, flag);
-        rc = compact_u32(nullptr, flag, vstart, N, &nv, s);
-        if (rc != RAHT_OK) break;
+        RAHT_RET(compact_u32(nullptr, flag, vstart, N, &nv, s));
         if (PCvox || Vvox) {
-            const unsigned gv = (unsigned)std::min<int64_t>(ceil_div(nv, 4), 4096);
+            const unsigned gv = (unsigned)std::min<int64_t>(ceil_div(nv, 64), 8192);
             hipLaunchKernelGGL(voxel_mean_kernel, dim3(gv), dim3(256), 0, s, PC, ldpc, N, d, ks, idx, vstart, nv, PCvox, Vvox);
         }
         if (sort_idx) hipLaunchKernelGGL(u32_to_i64_kernel, dim3(gb), dim3(256), 0, s, idx, N, sort_idx);
         if (voxel_indices) hipLaunchKernelGGL(u32_to_i64_kernel, dim3((unsigned)ceil_div(nv, 256)), dim3(256), 0, s, vstart, nv, voxel_indices);
         hipError_t e = hipStreamSynchronize(s);
         if (e == hipSuccess) e = hipGetLastError();
-        if (e != hipSuccess) { set_error("raht_voxelize: %s", hipGetErrorString(e)); rc = RAHT_ERR_HIP; }
-    } while (0);
-    if (rc == RAHT_ERR_NOMEM) set_error("raht_voxelize: out of device memory");
-    if (keys) (void)hipFree(keys);
-    if (own_ks && ks) (void)hipFree(ks);
-    if (idx) (void)hipFree(idx);
-    if (flag) (void)hipFree(flag);
-    if (vstart) (void)hipFree(vstart);
-    if (rc != RAHT_OK) return rc;
+        if (e != hipSuccess) { set_error("raht_voxelize: %s", hipGetErrorString(e)); return RAHT_ERR_HIP; }
+    }
     *n_vox = nv;
     if (vmin_out) { vmin_out[0] = vmin[0]; vmin_out[1] = vmin[1]; vmin_out[2] = vmin[2]; }
     if (width_out) *width_out = width;
