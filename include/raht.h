@@ -104,8 +104,11 @@ int raht_plan_destroy(raht_plan *plan);
 int64_t raht_plan_size(const raht_plan *plan);          /* N */
 int raht_plan_nbits(const raht_plan *plan);             /* 3 * depth */
 
-/* Engine / tile-size selection (tile_rows = 0 keeps the automatic choice). */
+/* Engine / tile-size selection (tile_rows = 0 keeps the automatic choice). tile_rows applies to
+ * stage 0 (the HBM-heavy launch); raht_plan_set_tail_tile sets the geometry of the later, small
+ * stages: rows per tile and channels per chunk (0 = automatic: 1024 rows x 32 float32 channels). */
 int raht_plan_set_engine(raht_plan *plan, int engine, int tile_rows);
+int raht_plan_set_tail_tile(raht_plan *plan, int tail_rows, int tail_channels);
 
 /* Reference-shaped views, for parity tests and the drivers' DEBUG save_lists
  * (reference python/encode_3dgs.py:165). HOST output buffers.

@@ -209,11 +209,34 @@ int pick_tile_rows(const raht_plan *plan, int elem_size, int Dc)
     return 0;
 }
 
+void pick_tail_geometry(const raht_plan *plan, int elem_size, int D, int stage0_rows, int *tail_rows, int *tail_chunk)
+{
+    // Later stages hold a few % of the rows. Default: the same geometry as stage 0, trimmed so that
+    // three workgroups still fit per CU with the slightly larger later-stage LDS layout (row ids).
+    // Much larger chunked tiles (e.g. 1024 x 32) cut the number of stages but measured slower on cfg3
+    // (one workgroup per CU, no overlap): 1.02 vs 0.955 ms per fused step.
+    int Dc = std::min(D, 64), R = stage0_rows;
+    if (D > 64) Dc = pick_chunk_channels(elem_size, D);
+    if (plan->tail_chunk_override > 0) Dc = std::min(plan->tail_chunk_override, std::min(D, 64));
+    if (plan->tail_rows_override > 0) {
+        R = plan->tail_rows_override;
+        while (R > 64 && tile_lds_bytes(R, elem_size, Dc, false, elem_size == 4) > (size_t)128 * 1280) R -= 64;
+    } else {
+        while (R > 64 && tile_lds_bytes(R, elem_size, Dc, false, elem_size == 4) > (size_t)42 * 1280) R -= 8;
+    }
+    *tail_rows = R;
+    *tail_chunk = Dc;
+}
+
 static void free_schedule(Schedule &sc)
 {
     for (auto &st : sc.stages) {
         if (st.rows) (void)hipFree(st.rows);
         if (st.surv_off) (void)hipFree(st.surv_off);
+        if (st.e_wl) (void)hipFree(st.e_wl);
+        if (st.e_wr) (void)hipFree(st.e_wr);
+        if (st.e_lvl) (void)hipFree(st.e_lvl);
+        if (st.e_pos) (void)hipFree(st.e_pos);
         if (st.ws) (void)hipFree(st.ws);
     }
     sc.stages.clear();
@@ -244,12 +267,24 @@ __global__ void tile_start_kernel(const uint32_t *__restrict__ pos, int64_t n, i
     (void)n;
 }
 
-int get_schedule(raht_plan *plan, int R, hipStream_t s, Schedule **out)
+__global__ void gather_meta_kernel(const uint32_t *__restrict__ rows, int64_t n, const int32_t *__restrict__ wl,
+                                   const int32_t *__restrict__ wr, const uint8_t *__restrict__ lvl,
+                                   const uint32_t *__restrict__ inv_order, int32_t *__restrict__ e_wl,
+                                   int32_t *__restrict__ e_wr, uint8_t *__restrict__ e_lvl, uint32_t *__restrict__ e_pos)
+{
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    const uint32_t r = rows[j];
+    e_wl[j] = wl[r]; e_wr[j] = wr[r]; e_lvl[j] = lvl[r]; e_pos[j] = inv_order[r];
+}
+
+int get_schedule(raht_plan *plan, int R0, int R1, hipStream_t s, Schedule **out)
 {
     for (auto &sc : plan->schedules)
-        if (sc.tile_rows == R) { *out = &sc; return RAHT_OK; }
+        if (sc.tile_rows == R0 && sc.tail_rows == R1) { *out = &sc; return RAHT_OK; }
     Schedule sc;
-    sc.tile_rows = R;
+    sc.tile_rows = R0;
+    sc.tail_rows = R1;
     sc.valid = true;
     const int64_t N = plan->N;
     Scratch buf(sizeof(uint32_t) * (2 * (size_t)N + 1));
@@ -259,10 +294,18 @@ int get_schedule(raht_plan *plan, int R, hipStream_t s, Schedule **out)
     int64_t n = N;
     int rc = RAHT_OK;
     for (int k = 0; k < 24; ++k) {
+        const int R = (k == 0) ? R0 : R1;
         Stage st;
         st.n_entries = n;
         st.n_tiles = ceil_div(n, R);
         st.rows = rows;
+        st.tile_rows = R;
+        if (rows) {
+            if (hipMalloc(&st.e_wl, sizeof(int32_t) * (size_t)n) != hipSuccess || hipMalloc(&st.e_wr, sizeof(int32_t) * (size_t)n) != hipSuccess ||
+                hipMalloc(&st.e_lvl, (size_t)n) != hipSuccess || hipMalloc(&st.e_pos, sizeof(uint32_t) * (size_t)n) != hipSuccess) { rc = RAHT_ERR_NOMEM; sc.stages.push_back(st); break; }
+            hipLaunchKernelGGL(gather_meta_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, s, rows, n, plan->wl,
+                               plan->wr, plan->lvl, plan->inv_order, st.e_wl, st.e_wr, st.e_lvl, st.e_pos);
+        }
         hipLaunchKernelGGL(stage_survivor_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, s,
                            rows, n, R, N, plan->wl, plan->wr, plan->lvl, plan->top_level, flag);
         rc = exclusive_scan_u32(flag, pos, n, dtotal, s);
@@ -388,7 +431,10 @@ static int finish_plan(raht_plan *p, const int64_t *leaf_weights, hipStream_t s)
     RAHT_RET(compute_roots(p, s));
     // Build the default schedule now so that float32 transforms with D <= 64 never allocate.
     Schedule *sc = nullptr;
-    RAHT_RET(get_schedule(p, pick_tile_rows(p, 4, 59), s, &sc));
+    const int R0 = pick_tile_rows(p, 4, 59);
+    int R1 = 0, Dc1 = 0;
+    pick_tail_geometry(p, 4, 59, R0, &R1, &Dc1);
+    RAHT_RET(get_schedule(p, R0, R1, s, &sc));
     return RAHT_OK;
 }
 
@@ -484,6 +530,17 @@ int raht_plan_destroy(raht_plan *p)
 
 int64_t raht_plan_size(const raht_plan *p) { return p ? p->N : -1; }
 int raht_plan_nbits(const raht_plan *p) { return p ? p->nbits : -1; }
+
+int raht_plan_set_tail_tile(raht_plan *p, int tail_rows, int tail_channels)
+{
+    if (!p || tail_rows < 0 || tail_rows > 1024 || (tail_rows & 3) || tail_channels < 0 || tail_channels > 64) {
+        set_error("raht_plan_set_tail_tile: rows must be a multiple of 4 in [0, 1024], channels in [0, 64]");
+        return RAHT_ERR_INVALID;
+    }
+    p->tail_rows_override = tail_rows;
+    p->tail_chunk_override = tail_channels;
+    return RAHT_OK;
+}
 
 int raht_plan_set_engine(raht_plan *p, int engine, int tile_rows)
 {
@@ -608,7 +665,9 @@ int raht_plan_stage_stats(raht_plan *p, int elem_size, int D, int *n_stages, int
     const int R = pick_tile_rows(p, elem_size, Dc);
     if (R == 0) { set_error("no tile size fits"); return RAHT_ERR_UNSUPPORTED; }
     Schedule *sc = nullptr;
-    RAHT_RET(get_schedule(p, R, nullptr, &sc));
+    int R1 = 0, Dc1 = 0;
+    pick_tail_geometry(p, elem_size, D, R, &R1, &Dc1);
+    RAHT_RET(get_schedule(p, R, R1, nullptr, &sc));
     *n_stages = sc->valid ? (int)sc->stages.size() : -(int)sc->stages.size();
     if (tile_rows) *tile_rows = R;
     for (int k = 0; k < (int)sc->stages.size() && k < max_stages; ++k)

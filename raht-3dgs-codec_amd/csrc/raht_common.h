@@ -83,10 +83,17 @@ struct Stage {
     uint32_t *surv_off = nullptr;  // device uint32[n_tiles + 1]: index (in the NEXT stage's entry
                                    // list) of the first survivor of every tile; nullptr on the last stage
     void *ws = nullptr;            // device workspace holding this stage's entries (stages >= 1)
+    int tile_rows = 0;             // rows per tile of THIS stage
+    // entry-ordered copies of the plan metadata (stages >= 1): one contiguous, single-latency load
+    // per tile instead of rows[] -> wl/wr/lvl/inv_order[row] chains. nullptr on stage 0 (entry = row).
+    int32_t *e_wl = nullptr, *e_wr = nullptr;
+    uint8_t *e_lvl = nullptr;
+    uint32_t *e_pos = nullptr;
 };
 
 struct Schedule {
-    int tile_rows = 0;
+    int tile_rows = 0;         // rows per tile of stage 0 (cache key, with tail_rows)
+    int tail_rows = 0;         // rows per tile of the stages >= 1
     bool valid = false;        // false: tile stages cannot finish the tree -> use the level engine
     std::vector<Stage> stages;
     size_t ws_row_bytes = 0;   // bytes per workspace row currently allocated (D * elem_size)
@@ -113,13 +120,18 @@ struct raht_plan {
     void *root_buf = nullptr;    // caller-owned device buffer (n_roots x D), see raht_plan_set_root_buffer
     int engine = RAHT_ENGINE_TILE;
     int tile_rows_override = 0;
+    int tail_rows_override = 0;  // rows per tile of the later stages (0 = automatic)
+    int tail_chunk_override = 0; // channels per chunk of the later stages (0 = automatic)
     std::vector<raht::Schedule> schedules;   // cache keyed by tile_rows
     std::vector<uint8_t> lvl_host;           // lazily downloaded for export_level
 };
 
 namespace raht {
 // Tile schedule for `tile_rows` rows per tile (built on first use, cached in the plan).
-int get_schedule(raht_plan *plan, int tile_rows, hipStream_t s, Schedule **out);
+int get_schedule(raht_plan *plan, int tile_rows, int tail_rows, hipStream_t s, Schedule **out);
+// Tile geometry of the later (small, latency-bound) stages: as many rows as one workgroup per CU can
+// stage, in channel chunks.
+void pick_tail_geometry(const raht_plan *plan, int elem_size, int D, int stage0_rows, int *tail_rows, int *tail_chunk);
 // Make sure the per-stage workspaces of `sc` hold rows of at least row_bytes bytes (allocates on
 // first use / growth only).
 int ensure_workspace(Schedule *sc, size_t row_bytes);

@@ -234,12 +234,15 @@ __device__ __forceinline__ void load_tile_meta(const TileArgs<T> &A, int64_t t, 
         const int j = tid + s * nthreads;
         M.row[s] = 0; M.wl[s] = 0; M.wr[s] = 0; M.lv[s] = 0; M.pos[s] = 0;
         if (j < nt) {
+            // A.wl / wr / lvl / inv_order are ENTRY-ordered for this stage (stage 0: entry = row,
+            // the plan arrays themselves; later stages: per-stage gathered copies), so all five
+            // loads are contiguous and independent of each other
             const int64_t r = IDENT ? e0 + j : (int64_t)A.rows[e0 + j];
             M.row[s] = (int32_t)r;
-            M.wl[s] = A.wl[r];
-            M.wr[s] = A.wr[r];
-            M.lv[s] = A.lvl[r];
-            M.pos[s] = QM ? (int32_t)A.inv_order[r] : (int32_t)r;    // where the final coefficient lives
+            M.wl[s] = A.wl[e0 + j];
+            M.wr[s] = A.wr[e0 + j];
+            M.lv[s] = A.lvl[e0 + j];
+            M.pos[s] = QM ? (int32_t)A.inv_order[e0 + j] : (int32_t)r;    // where the final coefficient lives
         }
     }
 }
@@ -705,17 +708,24 @@ static int launch_tile_one(const TileArgs<T> &A, const XformIO<T> &io, dim3 grid
 }
 
 template <typename T, bool INV, bool QM>
-static int launch_tile_stage(const raht_plan *p, const Schedule &sc, int k, const XformIO<T> &io, int D, int Dc,
+static int launch_tile_stage(const raht_plan *p, const Schedule &sc, int k, const XformIO<T> &io, int D, int Dc0,
                              hipStream_t s, int dbg = 0)
 {
     const Stage &st = sc.stages[(size_t)k];
+    int Dc = Dc0;
+    if (k >= 1) {                                    // later stages: large tiles, channel chunks
+        int r1 = 0;
+        pick_tail_geometry(p, (int)sizeof(T), D, sc.tile_rows, &r1, &Dc);
+    }
     const int K = (int)sc.stages.size();
     TileArgs<T> A;
-    A.rows = st.rows; A.surv_off = st.surv_off; A.n_entries = st.n_entries; A.N = p->N; A.R = sc.tile_rows;
+    A.rows = st.rows; A.surv_off = st.surv_off; A.n_entries = st.n_entries; A.N = p->N; A.R = st.tile_rows;
     A.D = D; A.Dc = Dc; A.lp_shift = lp_shift_for(Dc);
     A.last_stage = (k == K - 1) ? 1 : 0;
-    A.lvl = p->lvl; A.wl = p->wl; A.wr = p->wr; A.wsum = p->wsum;
-    A.inv_order = p->inv_order; A.Q = io.Q; A.ldq = io.ldq;
+    A.wsum = p->wsum;
+    if (st.rows) { A.lvl = st.e_lvl; A.wl = st.e_wl; A.wr = st.e_wr; A.inv_order = st.e_pos; }
+    else { A.lvl = p->lvl; A.wl = p->wl; A.wr = p->wr; A.inv_order = p->inv_order; }
+    A.Q = io.Q; A.ldq = io.ldq;
     A.top_level = p->top_level; A.root_buf = (T *)p->root_buf;
     A.dbg = dbg;
     A.ld_ws = D;
@@ -737,10 +747,10 @@ static int launch_tile_stage(const raht_plan *p, const Schedule &sc, int k, cons
         A.vec_fin = (k == 0 && one_chunk && io.src && io.ld_src == D && aligned(io.src)) ? 1 : 0;
     }
     const int nchunks = (D + Dc - 1) / Dc;
-    const size_t lds = tile_lds_bytes(sc.tile_rows, (int)sizeof(T), Dc, st.rows == nullptr, QM);
+    const size_t lds = tile_lds_bytes(st.tile_rows, (int)sizeof(T), Dc, st.rows == nullptr, QM);
     const int threads = tile_threads();
-    if (sc.tile_rows > TILE_MAX_SLOTS * threads) {
-        set_error("tile_rows %d too large for %d threads", sc.tile_rows, threads);
+    if (st.tile_rows > TILE_MAX_SLOTS * threads) {
+        set_error("tile_rows %d too large for %d threads", st.tile_rows, threads);
         return RAHT_ERR_UNSUPPORTED;
     }
     // persistent workgroups: as many as the chip keeps resident (LDS granules of 1280 B, 32 waves
@@ -749,7 +759,7 @@ static int launch_tile_stage(const raht_plan *p, const Schedule &sc, int k, cons
     const int64_t resident = (int64_t)per_cu * device_cus();
     const int64_t gx = persist_enabled() ? std::min<int64_t>(st.n_tiles, std::max<int64_t>(1, resident / nchunks)) : st.n_tiles;
     const dim3 grid((unsigned)gx, (unsigned)nchunks);
-    const bool one = sc.tile_rows <= threads;
+    const bool one = st.tile_rows <= threads;
     if (st.rows == nullptr)
         return one ? launch_tile_one<T, INV, true, QM, 1>(A, io, grid, threads, lds, s)
                    : launch_tile_one<T, INV, true, QM, 2>(A, io, grid, threads, lds, s);
@@ -811,7 +821,9 @@ static int tile_setup(raht_plan *p, int D, hipStream_t s, Schedule **sc_out, int
     const int R = pick_tile_rows(p, (int)sizeof(T), Dc);
     if (R == 0) return RAHT_OK;
     Schedule *sc = nullptr;
-    RAHT_RET(get_schedule(p, R, s, &sc));
+    int R1 = 0, Dc1 = 0;
+    pick_tail_geometry(p, (int)sizeof(T), D, R, &R1, &Dc1);
+    RAHT_RET(get_schedule(p, R, R1, s, &sc));
     if (!sc->valid) return RAHT_OK;                   // pathological key pattern, see plan.hip
     RAHT_RET(ensure_workspace(sc, (size_t)D * sizeof(T)));
     *sc_out = sc;
