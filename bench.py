@@ -44,6 +44,8 @@ def parse():
     ap.add_argument("--skip-cpu-baseline", action="store_true")
     ap.add_argument("--skip-prelude", action="store_true", help="do not time plan build / sort / voxelizer")
     ap.add_argument("--cpu-repeats", type=int, default=2)
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="collective backend for --gpus > 1 (gloo: ranks may share one GPU; testing only)")
     ap.add_argument("--unfused", action="store_true", help="quantize / dequantize as separate passes")
     ap.add_argument("--ablate", type=int, default=0, help="kernel-timing experiment for the roofline probe only (0 = real kernel)")
     return ap.parse_args()
@@ -77,11 +79,15 @@ def main():
         if world == 1 and a.gpus > 1:
             sys.exit(2)
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
+    local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if a.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
 
     import raht_3dgs_codec_amd as R
     from raht_3dgs_codec_amd import _lib, synth
@@ -174,7 +180,7 @@ def main():
     dt = time.perf_counter() - t0
     if world > 1:
         import torch.distributed as dist
-        tt = torch.tensor([dt, float(N)], dtype=torch.float64, device=dev)
+        tt = torch.tensor([dt, float(N)], dtype=torch.float64, device=dev if a.backend == "nccl" else "cpu")
         tmax = tt.clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         tsum = tt.clone(); dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
         dt = tmax[0].item()
@@ -192,7 +198,7 @@ def main():
                          + ("fwd + inv RAHT" if a.no_quant else "fwd RAHT + quantize/reorder + dequantize/un-reorder + inv RAHT"
                             + (" (separate passes)" if a.unfused else " (quantization fused into the transform kernels)"))),
             "rows_per_gpu": N, "channels": D, "depth_J": J, "engine": a.engine, "quantize": not a.no_quant,
-            "parallelism": "1 GPU" if world == 1 else f"morton-prefix sharded x{world}, top-3-octree-level all-gather (RCCL)",
+            "parallelism": "1 GPU" if world == 1 else f"morton-prefix sharded x{world}, top-3-octree-level all-gather ({'RCCL' if a.backend == 'nccl' else 'gloo, TEST ONLY'})",
             "roundtrip_rel_err": rt_err,
         },
     }

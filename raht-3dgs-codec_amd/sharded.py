@@ -71,6 +71,12 @@ class ShardedRaht:
         """all-gather a (rows, cols) tensor -> (world * rows, cols)."""
         if self.world == 1:
             return x
+        if x.is_cuda and self.dist.get_backend(self.group) == "gloo":
+            # test / debugging configuration (several ranks sharing one GPU): stage through the host
+            xc = x.contiguous().cpu()
+            outc = torch.empty((self.world * rows, x.shape[1]), dtype=x.dtype)
+            self.dist.all_gather_into_tensor(outc, xc, group=self.group)
+            return outc.to(x.device)
         out = torch.empty((self.world * rows, x.shape[1]), dtype=x.dtype, device=x.device)
         self.dist.all_gather_into_tensor(out, x.contiguous(), group=self.group)
         return out
