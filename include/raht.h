@@ -215,6 +215,37 @@ int raht_morton(const int64_t *V, int64_t N, int J, uint64_t *keys, raht_stream_
 int raht_sort_keys(const uint64_t *keys_in, int64_t N, int nbits, uint64_t *keys_out,
                    int64_t *idx_out, raht_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * RLGR entropy stage: adaptive Run-Length / Golomb-Rice coder, byte-exact with the
+ * reference's vendored PyRLGR (python/PyRLGR/src/libs/rlgr/membuf.cpp:258-423, call sites
+ * python/encode_3dgs.py:229-245). HOST pointers throughout: the coder is sequential and stays on
+ * the CPU (as in the reference), but works on strided int32 columns of the quantized coefficient
+ * matrix and codes the D channels on a pool of host threads.
+ *   raht_rlgr_bound           : bytes that always suffice for n symbols
+ *   raht_rlgr_encode          : == m = membuf(); m.rlgrWrite(seq, flag); m.close(); m.get_buffer()
+ *   raht_rlgr_decode          : == membuf(buf).rlgrRead(n, flag)
+ *   raht_rlgr_encode_channels : symbol n of channel c is Q[n * sym_stride + c * chan_stride] (row-major
+ *                               N x D matrix: sym_stride = ld, chan_stride = 1; channel-major D x N as
+ *                               produced by raht_transpose_i32: sym_stride = 1, chan_stride = N);
+ *                               stream of channel c -> out + c * cap_per_channel, nbytes[c];
+ *                               nthreads <= 0 = all host cores
+ *   raht_rlgr_decode_channels : the inverse.
+ *   raht_transpose_i32        : DEVICE int32 transpose (rows x cols, ld_in) -> (cols x rows, ld_out)
+ *                               so that the host coder gets contiguous channels after the D2H copy. */
+int64_t raht_rlgr_bound(int64_t n);
+int raht_rlgr_encode(const int32_t *seq, int64_t n, int64_t stride, int flag_signed, uint8_t *out,
+                     int64_t cap, int64_t *nbytes);
+int raht_rlgr_decode(const uint8_t *buf, int64_t nbytes, int64_t n, int flag_signed, int32_t *seq,
+                     int64_t stride);
+int raht_rlgr_encode_channels(const int32_t *Q, int64_t N, int D, int64_t sym_stride, int64_t chan_stride,
+                              int flag_signed, uint8_t *out, int64_t cap_per_channel, int64_t *nbytes,
+                              int nthreads);
+int raht_rlgr_decode_channels(const uint8_t *bufs, int64_t cap_per_channel, const int64_t *nbytes,
+                              int64_t N, int D, int flag_signed, int32_t *Q, int64_t sym_stride,
+                              int64_t chan_stride, int nthreads);
+int raht_transpose_i32(const int32_t *in, int64_t ld_in, int64_t rows, int64_t cols, int32_t *out,
+                       int64_t ld_out, raht_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

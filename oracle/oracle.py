@@ -65,6 +65,9 @@ def lib():
     L.orc_quant_reorder.argtypes = [vp, i64, i32, dbl, vp, vp]
     L.orc_dequant_unreorder.argtypes = [vp, i64, i32, dbl, vp, vp]
     L.orc_voxelize.argtypes = [vp, i64, i32, vp, dbl, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    L.orc_rlgr_encode.argtypes = [vp, i64, i32, vp, i64]
+    L.orc_rlgr_encode.restype = i64
+    L.orc_rlgr_decode.argtypes = [vp, i64, i64, i32, vp]
     _lib = L
     return L
 
@@ -189,3 +192,22 @@ def voxelize(PC, J, vmin=None, width=None):
     return dict(keys_sorted=keys, sort_idx=idx, voxel_indices=vi[:n].copy(), PCvox=pcv[:n].copy(),
                 Vvox=vvox[:n].copy(), Nvox=n, vmin=vmin_out, width=w_out.value,
                 voxel_size=vs_out.value)
+
+
+def rlgr_encode(seq, flag_signed=1):
+    """bytes of membuf().rlgrWrite(seq, flag); close(); get_buffer()  (PyRLGR membuf.cpp:340-423)."""
+    seq = np.ascontiguousarray(seq, dtype=np.int64)
+    cap = 16 + 9 * seq.shape[0]
+    out = np.empty(cap, dtype=np.uint8)
+    n = lib().orc_rlgr_encode(_ptr(seq), seq.shape[0], int(flag_signed), _ptr(out), cap)
+    if n < 0:
+        raise ValueError("orc_rlgr_encode: buffer too small")
+    return out[:n].copy()
+
+
+def rlgr_decode(buf, N, flag_signed=1):
+    """membuf(buf).rlgrRead(N, flag)  (PyRLGR membuf.cpp:258-338)."""
+    buf = np.ascontiguousarray(buf, dtype=np.uint8)
+    seq = np.empty(N, dtype=np.int64)
+    lib().orc_rlgr_decode(_ptr(buf), buf.shape[0], int(N), int(flag_signed), _ptr(seq))
+    return seq

@@ -393,3 +393,197 @@ int orc_voxelize(const float *PC, int64_t N, int d, const float *vmin_in, double
     *voxel_size_out = voxel_size;
     return 0;
 }
+
+/* ---------------------------------------------------------------- PyRLGR membuf.cpp
+ * Literal restatement of the bit buffer (membuf.cpp:74-189) and of the coder (:228-423). */
+#define ORC_L 4
+#define ORC_U0 3
+#define ORC_D0 1
+#define ORC_U1 2
+#define ORC_D1 1
+#define ORC_MASK(k) ((((uint64_t)1) << (k)) - 1)
+
+typedef struct {
+    uint64_t data;
+    uint8_t bits;
+    uint8_t *buf;          /* write: output, read: input */
+    int64_t cap, size, pos;
+    int overflow;
+} orc_membuf;
+
+static void mb_flush(orc_membuf *m)                         /* :74-86 */
+{
+    while (m->bits >= 8) {
+        m->bits -= 8;
+        uint8_t byte = (uint8_t)((m->data >> m->bits) & 0xff);
+        if (m->size < m->cap) m->buf[m->size] = byte; else m->overflow = 1;
+        m->size++;
+        m->pos++;
+    }
+}
+
+static void mb_fill(orc_membuf *m)                          /* :89-104 */
+{
+    while (m->bits <= 56) {
+        if (m->pos < m->size) {
+            uint8_t byte = m->buf[m->pos++];
+            m->data = (m->data << 8) + byte;
+            m->bits += 8;
+        } else return;
+    }
+}
+
+static uint8_t mb_read1(orc_membuf *m)                      /* :106-112 */
+{
+    if (!m->bits) mb_fill(m);
+    m->bits--;
+    return (uint8_t)((m->data >> m->bits) & 1u);
+}
+
+static uint64_t mb_read(orc_membuf *m, uint8_t bits)        /* :114-126 */
+{
+    if (bits > 56) {
+        uint64_t d = mb_read(m, (uint8_t)(bits - 32)) << 32;
+        return d + mb_read(m, 32);
+    }
+    mb_fill(m);
+    m->bits -= bits;
+    return (m->data >> m->bits) & ORC_MASK(bits);
+}
+
+static void mb_write1(orc_membuf *m, uint8_t bit)           /* :161-170 */
+{
+    m->data <<= 1;
+    if (bit) m->data++;
+    m->bits++;
+    if (m->bits >= 8) mb_flush(m);
+}
+
+static void mb_write(orc_membuf *m, uint64_t data, uint8_t bits)   /* :172-184 */
+{
+    if (bits > 56) {
+        mb_write(m, data >> 32, (uint8_t)(bits - 32));
+        mb_write(m, data & ORC_MASK(32), 32);
+        return;
+    }
+    m->data = (m->data << bits) + data;
+    m->bits += bits;
+    mb_flush(m);
+}
+
+static void mb_close(orc_membuf *m)                         /* :47-58 */
+{
+    uint8_t r = m->bits % 8;
+    if (r) mb_write(m, 0, (uint8_t)(8 - r)); else mb_flush(m);
+}
+
+static uint64_t mb_gr_read(orc_membuf *m, uint8_t bits)     /* :228-240 */
+{
+    uint64_t p = 0;
+    while (mb_read1(m)) {
+        p++;
+        if (p >= 32) return mb_read(m, 32);
+    }
+    return (p << bits) + mb_read(m, bits);
+}
+
+static void mb_gr_write(orc_membuf *m, uint64_t data, uint8_t bits)   /* :242-256 */
+{
+    uint64_t p = data >> bits;
+    if (p < 32) {
+        mb_write(m, ORC_MASK(p + 1) - 1, (uint8_t)(p + 1));
+        mb_write(m, data & ORC_MASK(bits), bits);
+    } else {
+        mb_write(m, ORC_MASK(32), 32);
+        mb_write(m, data, 32);
+    }
+}
+
+static uint64_t s2u(int64_t v) { return v < 0 ? (((uint64_t)(-v)) << 1) - 1 : ((uint64_t)v) << 1; }   /* :4-14 */
+static int64_t u2s(uint64_t v) { int64_t d = (int64_t)(v >> 1); return (v & 1) ? -d - 1 : d; }          /* :16-23 */
+
+#define ADAPT_KRP(p)                                                         \
+    do {                                                                     \
+        if (p) { k_RP += (p) - 1; if (k_RP > 32 * ORC_L) k_RP = 32 * ORC_L; } \
+        else { if (k_RP < 2) k_RP = 0; else k_RP -= 2; }                     \
+    } while (0)
+
+int64_t orc_rlgr_encode(const int64_t *seq, int64_t N, int flag_signed, uint8_t *out, int64_t cap)
+{
+    orc_membuf mb; memset(&mb, 0, sizeof(mb));
+    mb.buf = out; mb.cap = cap;
+    uint64_t u = 0, k_P = 0, k_RP = 2 * ORC_L, m = 0, k = 0, k_R, p;        /* :343-349 */
+    for (int64_t n = 0; n < N; ++n) {                                      /* :351 */
+        u = flag_signed ? s2u(seq[n]) : (uint64_t)seq[n];
+        k = k_P / ORC_L;
+        k_R = k_RP / ORC_L;
+        if (k) {                                                           /* run mode :356-383 */
+            if (u) {
+                u--;
+                mb_write1(&mb, 0);
+                mb_write(&mb, m, (uint8_t)k);
+                mb_gr_write(&mb, u, (uint8_t)k_R);
+                p = u >> k_R;
+                ADAPT_KRP(p);
+                if (k_P < ORC_D1) k_P = 0; else k_P -= ORC_D1;
+                m = 0;
+            } else {
+                m++;
+                if (m == ((uint64_t)1 << k)) {
+                    mb_write1(&mb, 1);
+                    k_P += ORC_U1;
+                    m = 0;
+                }
+            }
+        } else {                                                           /* no-run mode :384-407 */
+            mb_gr_write(&mb, u, (uint8_t)k_R);
+            p = u >> k_R;
+            ADAPT_KRP(p);
+            if (u) { if (k_P < ORC_D0) k_P = 0; else k_P -= ORC_D0; }
+            else k_P += ORC_U0;
+            m = 0;
+        }
+    }
+    if (k && !u) {                                                         /* :410-413 */
+        mb_write1(&mb, 0);
+        mb_write(&mb, m, (uint8_t)(k_P / ORC_L));
+    }
+    mb_close(&mb);
+    return mb.overflow ? -1 : mb.size;
+}
+
+int orc_rlgr_decode(const uint8_t *buf, int64_t nbytes, int64_t N, int flag_signed, int64_t *seq)
+{
+    orc_membuf mb; memset(&mb, 0, sizeof(mb));
+    mb.buf = (uint8_t *)buf; mb.size = nbytes;
+    uint64_t u, k_P = 0, k_RP = 2 * ORC_L, m = 0, k, k_R, p;                /* :261-268 */
+    int64_t n = 0;
+    while (n < N) {                                                        /* :270 */
+        k = k_P / ORC_L;
+        k_R = k_RP / ORC_L;
+        if (k) {                                                           /* run mode :274-307 */
+            m = 0;
+            while (mb_read1(&mb)) {
+                m += (uint64_t)1 << k;
+                k_P += ORC_U1;
+                k = k_P / ORC_L;
+            }
+            m += mb_read(&mb, (uint8_t)k);
+            while (m-- && n < N) seq[n++] = 0;
+            if (n >= N) break;
+            u = mb_gr_read(&mb, (uint8_t)k_R);
+            seq[n++] = flag_signed ? u2s(u + 1) : (int64_t)(u + 1);
+            p = u >> k_R;
+            ADAPT_KRP(p);
+            if (k_P < ORC_D1) k_P = 0; else k_P -= ORC_D1;
+        } else {                                                           /* no-run mode :308-329 */
+            u = mb_gr_read(&mb, (uint8_t)k_R);
+            seq[n++] = flag_signed ? u2s(u) : (int64_t)u;
+            p = u >> k_R;
+            ADAPT_KRP(p);
+            if (u) { if (k_P < ORC_D0) k_P = 0; else k_P -= ORC_D0; }
+            else k_P += ORC_U0;
+        }
+    }
+    return 0;
+}

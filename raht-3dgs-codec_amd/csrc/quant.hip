@@ -53,6 +53,26 @@ __global__ __launch_bounds__(256) void dequant_unreorder_kernel(const int32_t *_
     }
 }
 
+// int32 matrix transpose through an LDS tile (64 rows x 64 columns, padded): row-major N x D  <->
+// channel-major D x N, so that the entropy stage reads / writes contiguous channels. Both global
+// sides are coalesced (lanes along the contiguous dimension).
+__global__ __launch_bounds__(256) void transpose_i32_kernel(const int32_t *__restrict__ in, int64_t ld_in, int64_t rows,
+                                                            int64_t cols, int32_t *__restrict__ out, int64_t ld_out)
+{
+    __shared__ int32_t t[64][65];
+    const int64_t r0 = (int64_t)blockIdx.x * 64, c0 = (int64_t)blockIdx.y * 64;
+    const int lx = threadIdx.x & 63, ly = threadIdx.x >> 6;            // 64 x 4
+    for (int k = ly; k < 64; k += 4) {
+        const int64_t r = r0 + k, c = c0 + lx;
+        if (r < rows && c < cols) t[k][lx] = in[r * ld_in + c];
+    }
+    __syncthreads();
+    for (int k = ly; k < 64; k += 4) {
+        const int64_t c = c0 + k, r = r0 + lx;                         // out is cols x rows
+        if (r < rows && c < cols) out[c * ld_out + r] = t[lx][k];
+    }
+}
+
 static int fill_steps(StepTable &t, const float *steps, int n_steps, int D)
 {
     if (!steps || !(n_steps == 1 || n_steps == D)) { set_error("quant: n_steps must be 1 or D"); return RAHT_ERR_INVALID; }
@@ -93,6 +113,17 @@ int raht_dequant_unreorder(const raht_plan *p, const int32_t *Q, int64_t ldq, in
     const unsigned gb = (unsigned)std::min<int64_t>(ceil_div(p->N, 4), 4096);
     hipLaunchKernelGGL(dequant_unreorder_kernel, dim3(gb), dim3(256), 0, (hipStream_t)stream, Q, ldq, D,
                        p->order, p->N, st, T, ldt);
+    RAHT_HIP_CHECK(hipGetLastError());
+    return RAHT_OK;
+}
+
+int raht_transpose_i32(const int32_t *in, int64_t ld_in, int64_t rows, int64_t cols, int32_t *out, int64_t ld_out,
+                       raht_stream_t stream)
+{
+    if (!in || !out || rows < 0 || cols < 0 || ld_in < cols || ld_out < rows) { set_error("raht_transpose_i32: bad argument"); return RAHT_ERR_INVALID; }
+    if (rows == 0 || cols == 0) return RAHT_OK;
+    const dim3 grid((unsigned)ceil_div(rows, 64), (unsigned)ceil_div(cols, 64));
+    hipLaunchKernelGGL(transpose_i32_kernel, grid, dim3(256), 0, (hipStream_t)stream, in, ld_in, rows, cols, out, ld_out);
     RAHT_HIP_CHECK(hipGetLastError());
     return RAHT_OK;
 }

@@ -1,0 +1,329 @@
+// rlgr.hip -- host-side adaptive Run-Length / Golomb-Rice entropy coder (Malvar 2006), byte-exact
+// with the reference's vendored PyRLGR (reference python/PyRLGR/src/libs/rlgr/membuf.cpp:258-423,
+// parameters L=4, U0=3, D0=1, U1=2, D1=1 of membuf.h:18-22).  SURVEY.md 8f-1: the stage right after
+// the RAHT hot path (reference python/encode_3dgs.py:219-245).
+//
+// What is different from the reference: it works directly on strided int32 coefficient columns (the
+// reference goes tensor -> numpy -> Python list -> std::vector<int64_t> per channel,
+// encode_3dgs.py:215-234), writes into caller buffers, and codes the D channels of a matrix on a
+// pool of host threads (channels are independent streams). The bit stream is identical.
+// Host code only (no kernels): RLGR is a sequential adaptive coder; the north star keeps the entropy
+// stage on the CPU.
+#include <stdint.h>
+#include <string.h>
+
+#include <algorithm>
+#include <atomic>
+#include <thread>
+#include <vector>
+
+#include "raht_common.h"
+
+namespace raht {
+namespace rlgr {
+
+constexpr uint64_t L = 4, U0 = 3, D0 = 1, U1 = 2, D1 = 1;
+
+// MSB-first bit writer with a 64-bit accumulator (same byte stream as membuf::write/flush).
+struct BitWriter {
+    uint8_t *out;
+    int64_t cap, size = 0;
+    uint64_t acc = 0;        // pending bits, right-aligned
+    int nbits = 0;           // < 8 after every put
+    bool overflow = false;
+
+    inline void put(uint64_t v, int bits)                 // bits <= 56, v < 2^bits
+    {
+        acc = (acc << bits) | v;
+        nbits += bits;
+        while (nbits >= 8) {
+            nbits -= 8;
+            if (size < cap) out[size] = (uint8_t)(acc >> nbits);
+            else overflow = true;
+            ++size;
+        }
+        acc &= (nbits ? ((1ull << nbits) - 1) : 0);
+    }
+    inline void put_wide(uint64_t v, int bits)            // membuf.cpp:172-184 (split above 56 bits)
+    {
+        if (bits > 56) { put(v >> 32, bits - 32); put(v & 0xffffffffull, 32); }
+        else put(bits ? (v & ((bits == 64) ? ~0ull : ((1ull << bits) - 1))) : 0, bits);
+    }
+    inline void golomb_rice(uint64_t u, int k)            // membuf.cpp:242-256
+    {
+        const uint64_t p = u >> k;
+        if (p < 32) {
+            put((1ull << (p + 1)) - 2, (int)p + 1);       // p ones, one zero
+            put(k ? (u & ((1ull << k) - 1)) : 0, k);
+        } else {
+            put(0xffffffffull, 32);                       // escape: 32 ones, then 32 raw bits
+            put(u & 0xffffffffull, 32);
+        }
+    }
+    inline void close() { if (nbits) put(0, 8 - nbits); } // membuf.cpp:47-58
+};
+
+struct BitReader {
+    const uint8_t *in;
+    int64_t size, pos = 0;
+    uint64_t acc = 0;
+    int nbits = 0;
+
+    inline void fill()
+    {
+        while (nbits <= 56 && pos < size) { acc = (acc << 8) | in[pos++]; nbits += 8; }
+    }
+    inline uint32_t bit()
+    {
+        if (!nbits) { fill(); if (!nbits) return 0; }     // past the end: zeros (the reference underflows)
+        --nbits;
+        return (uint32_t)((acc >> nbits) & 1u);
+    }
+    inline uint64_t get(int bits)                         // bits <= 56
+    {
+        if (!bits) return 0;
+        fill();
+        if (nbits < bits) { const int miss = bits - nbits; acc <<= miss; nbits += miss; }   // zero padding
+        nbits -= bits;
+        return (acc >> nbits) & ((1ull << bits) - 1);
+    }
+    inline uint64_t get_wide(int bits)
+    {
+        if (bits > 56) { const uint64_t hi = get(bits - 32) << 32; return hi + get(32); }
+        return get(bits);
+    }
+    inline uint64_t golomb_rice(int k)                    // membuf.cpp:228-240
+    {
+        uint64_t p = 0;
+        while (bit()) { if (++p >= 32) return get(32); }
+        return (p << k) + get(k);
+    }
+};
+
+static inline uint64_t s2u(int64_t v) { return v < 0 ? (((uint64_t)(-v)) << 1) - 1 : ((uint64_t)v) << 1; }
+static inline int64_t u2s(uint64_t v) { const int64_t d = (int64_t)(v >> 1); return (v & 1) ? -d - 1 : d; }
+
+#define RLGR_ADAPT_KRP(p)                                            \
+    do {                                                             \
+        if (p) { k_RP += (p) - 1; if (k_RP > 32 * L) k_RP = 32 * L; } \
+        else { k_RP = (k_RP < 2) ? 0 : k_RP - 2; }                   \
+    } while (0)
+
+static int64_t encode(const int32_t *seq, int64_t n, int64_t stride, int flag_signed, uint8_t *out, int64_t cap)
+{
+    BitWriter w;
+    w.out = out; w.cap = cap;
+    uint64_t u = 0, k_P = 0, k_RP = 2 * L, m = 0, k = 0;
+    for (int64_t i = 0; i < n; ++i) {                     // membuf.cpp:351-408
+        const int64_t v = seq[i * stride];
+        u = flag_signed ? s2u(v) : (uint64_t)(uint32_t)v;
+        k = k_P / L;
+        const uint64_t k_R = k_RP / L;
+        if (k) {                                          // run mode
+            if (u) {
+                --u;
+                w.put(0, 1);
+                w.put_wide(m, (int)k);
+                w.golomb_rice(u, (int)k_R);
+                const uint64_t p = u >> k_R;
+                RLGR_ADAPT_KRP(p);
+                k_P = (k_P < D1) ? 0 : k_P - D1;
+                m = 0;
+            } else if (++m == (1ull << k)) {
+                w.put(1, 1);
+                k_P += U1;
+                m = 0;
+            }
+        } else {                                          // no-run mode
+            w.golomb_rice(u, (int)k_R);
+            const uint64_t p = u >> k_R;
+            RLGR_ADAPT_KRP(p);
+            if (u) k_P = (k_P < D0) ? 0 : k_P - D0;
+            else k_P += U0;
+            m = 0;
+        }
+    }
+    if (n > 0 && k && !u) {                               // membuf.cpp:410-413: flush the open run
+        w.put(0, 1);
+        w.put_wide(m, (int)(k_P / L));
+    }
+    w.close();
+    return w.overflow ? -1 : w.size;
+}
+
+static void decode(const uint8_t *buf, int64_t nbytes, int64_t n, int flag_signed, int32_t *seq, int64_t stride)
+{
+    BitReader r;
+    r.in = buf; r.size = nbytes;
+    uint64_t k_P = 0, k_RP = 2 * L;
+    int64_t i = 0;
+    while (i < n) {                                       // membuf.cpp:270-331
+        uint64_t k = k_P / L;
+        const uint64_t k_R = k_RP / L;
+        if (k) {
+            uint64_t m = 0;
+            while (r.bit()) {
+                m += 1ull << k;
+                k_P += U1;
+                k = k_P / L;
+                if (m > (uint64_t)n) break;                // corrupt stream guard
+            }
+            m += r.get_wide((int)k);
+            while (m-- && i < n) seq[(i++) * stride] = 0;
+            if (i >= n) break;
+            const uint64_t u = r.golomb_rice((int)k_R);
+            seq[(i++) * stride] = (int32_t)(flag_signed ? u2s(u + 1) : (int64_t)(u + 1));
+            const uint64_t p = u >> k_R;
+            RLGR_ADAPT_KRP(p);
+            k_P = (k_P < D1) ? 0 : k_P - D1;
+        } else {
+            const uint64_t u = r.golomb_rice((int)k_R);
+            seq[(i++) * stride] = (int32_t)(flag_signed ? u2s(u) : (int64_t)u);
+            const uint64_t p = u >> k_R;
+            RLGR_ADAPT_KRP(p);
+            if (u) k_P = (k_P < D0) ? 0 : k_P - D0;
+            else k_P += U0;
+        }
+    }
+}
+
+template <typename F>
+static void parallel_channels(int D, int nthreads, F fn)
+{
+    nthreads = std::min(nthreads, D);
+    if (nthreads <= 1) { for (int c = 0; c < D; ++c) fn(c); return; }
+    std::atomic<int> next(0);
+    std::vector<std::thread> pool;
+    for (int t = 0; t < nthreads; ++t)
+        pool.emplace_back([&]() { for (int c = next++; c < D; c = next++) fn(c); });
+    for (auto &t : pool) t.join();
+}
+
+}  // namespace rlgr
+}  // namespace raht
+
+using namespace raht;
+
+extern "C" {
+
+int64_t raht_rlgr_bound(int64_t n)
+{
+    // worst case per symbol: run prefix (1 + k <= 33 bits) + escape (64 bits) -> 13 bytes; + flush
+    return 16 + 13 * (n > 0 ? n : 0);
+}
+
+int raht_rlgr_encode(const int32_t *seq, int64_t n, int64_t stride, int flag_signed, uint8_t *out, int64_t cap,
+                     int64_t *nbytes)
+{
+    if ((!seq && n > 0) || !out || !nbytes || n < 0 || stride < 1) { set_error("raht_rlgr_encode: bad argument"); return RAHT_ERR_INVALID; }
+    const int64_t r = rlgr::encode(seq, n, stride, flag_signed, out, cap);
+    if (r < 0) { set_error("raht_rlgr_encode: output buffer too small (use raht_rlgr_bound)"); return RAHT_ERR_NOMEM; }
+    *nbytes = r;
+    return RAHT_OK;
+}
+
+int raht_rlgr_decode(const uint8_t *buf, int64_t nbytes, int64_t n, int flag_signed, int32_t *seq, int64_t stride)
+{
+    if ((!buf && nbytes > 0) || (!seq && n > 0) || n < 0 || nbytes < 0 || stride < 1) { set_error("raht_rlgr_decode: bad argument"); return RAHT_ERR_INVALID; }
+    rlgr::decode(buf, nbytes, n, flag_signed, seq, stride);
+    return RAHT_OK;
+}
+
+}  // extern "C" (helpers below have C++ linkage)
+namespace raht { namespace rlgr {
+// Blocked, threaded transpose of an N x D row-major int32 matrix into D contiguous channels (and
+// back). Coding a strided column makes every thread stream the whole matrix through its caches.
+static void transpose_to_channels(const int32_t *Q, int64_t N, int D, int64_t ldq, int32_t *T, int nthreads)
+{
+    const int64_t B = 2048;
+    const int64_t nblk = (N + B - 1) / B;
+    std::atomic<int64_t> next(0);
+    auto work = [&]() {
+        for (int64_t b = next++; b < nblk; b = next++) {
+            const int64_t r0 = b * B, r1 = std::min(N, r0 + B);
+            for (int c0 = 0; c0 < D; c0 += 16)
+                for (int64_t r = r0; r < r1; ++r) {
+                    const int32_t *row = Q + r * ldq;
+                    for (int c = c0; c < std::min(D, c0 + 16); ++c) T[(int64_t)c * N + r] = row[c];
+                }
+        }
+    };
+    if (nthreads <= 1) { work(); return; }
+    std::vector<std::thread> pool;
+    for (int t = 0; t < nthreads; ++t) pool.emplace_back(work);
+    for (auto &t : pool) t.join();
+}
+
+static void transpose_from_channels(const int32_t *T, int64_t N, int D, int32_t *Q, int64_t ldq, int nthreads)
+{
+    const int64_t B = 2048;
+    const int64_t nblk = (N + B - 1) / B;
+    std::atomic<int64_t> next(0);
+    auto work = [&]() {
+        for (int64_t b = next++; b < nblk; b = next++) {
+            const int64_t r0 = b * B, r1 = std::min(N, r0 + B);
+            for (int c0 = 0; c0 < D; c0 += 16)
+                for (int64_t r = r0; r < r1; ++r) {
+                    int32_t *row = Q + r * ldq;
+                    for (int c = c0; c < std::min(D, c0 + 16); ++c) row[c] = T[(int64_t)c * N + r];
+                }
+        }
+    };
+    if (nthreads <= 1) { work(); return; }
+    std::vector<std::thread> pool;
+    for (int t = 0; t < nthreads; ++t) pool.emplace_back(work);
+    for (auto &t : pool) t.join();
+}
+
+static int resolve_threads(int nthreads, int D)
+{
+    if (nthreads <= 0) nthreads = (int)std::max(1u, std::thread::hardware_concurrency());
+    return std::max(1, std::min(nthreads, std::max(D, 1)));
+}
+}}  // namespace raht::rlgr
+using raht::rlgr::resolve_threads;
+extern "C" {
+
+int raht_rlgr_encode_channels(const int32_t *Q, int64_t N, int D, int64_t sym_stride, int64_t chan_stride,
+                              int flag_signed, uint8_t *out, int64_t cap_per_channel, int64_t *nbytes, int nthreads)
+{
+    if (!Q || !out || !nbytes || N < 0 || D < 1 || sym_stride < 1 || chan_stride < 1 || cap_per_channel < 1) {
+        set_error("raht_rlgr_encode_channels: bad argument");
+        return RAHT_ERR_INVALID;
+    }
+    const int nt = resolve_threads(nthreads, D);
+    std::vector<int32_t> tmp;
+    const int32_t *src = Q;
+    int64_t ss = sym_stride, cs = chan_stride;
+    if (sym_stride != 1 && chan_stride == 1 && D > 1 && N > 4096) {          // row-major: go channel-major first
+        tmp.resize((size_t)N * (size_t)D);
+        rlgr::transpose_to_channels(Q, N, D, sym_stride, tmp.data(), nt);
+        src = tmp.data(); ss = 1; cs = N;
+    }
+    std::atomic<int> bad(0);
+    rlgr::parallel_channels(D, nt, [&](int c) {
+        const int64_t r = rlgr::encode(src + (int64_t)c * cs, N, ss, flag_signed, out + (int64_t)c * cap_per_channel, cap_per_channel);
+        if (r < 0) { bad = 1; nbytes[c] = -1; } else nbytes[c] = r;
+    });
+    if (bad) { set_error("raht_rlgr_encode_channels: cap_per_channel too small (use raht_rlgr_bound)"); return RAHT_ERR_NOMEM; }
+    return RAHT_OK;
+}
+
+int raht_rlgr_decode_channels(const uint8_t *bufs, int64_t cap_per_channel, const int64_t *nbytes, int64_t N, int D,
+                              int flag_signed, int32_t *Q, int64_t sym_stride, int64_t chan_stride, int nthreads)
+{
+    if (!bufs || !nbytes || !Q || N < 0 || D < 1 || sym_stride < 1 || chan_stride < 1) { set_error("raht_rlgr_decode_channels: bad argument"); return RAHT_ERR_INVALID; }
+    const int nt = resolve_threads(nthreads, D);
+    std::vector<int32_t> tmp;
+    int32_t *dst = Q;
+    int64_t ss = sym_stride, cs = chan_stride;
+    const bool via_tmp = (sym_stride != 1 && chan_stride == 1 && D > 1 && N > 4096);
+    if (via_tmp) { tmp.resize((size_t)N * (size_t)D); dst = tmp.data(); ss = 1; cs = N; }
+    rlgr::parallel_channels(D, nt, [&](int c) {
+        rlgr::decode(bufs + (int64_t)c * cap_per_channel, nbytes[c], N, flag_signed, dst + (int64_t)c * cs, ss);
+    });
+    if (via_tmp) rlgr::transpose_from_channels(tmp.data(), N, D, Q, sym_stride, nt);
+    return RAHT_OK;
+}
+
+}  // extern "C"

@@ -229,5 +229,49 @@ def main():
     voxelize_case("vox_posonly_j5", rng.uniform(0, 1, size=(3000, 3)).astype(np.float32), 5)
 
 
-if __name__ == "__main__":
+if __name__ == "__main__" and os.environ.get("GOLDEN_ONLY", "") == "":
     main()
+
+
+def rlgr_cases():
+    """RLGR byte streams produced by the REFERENCE's own coder (built from its sources by
+    `make -C oracle ref` into oracle/_ref/): inputs and expected bytes only."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(HERE)), "oracle", "_ref"))
+    import rlgr
+    rng = np.random.default_rng(424242)
+
+    def enc(x, flag):
+        m = rlgr.membuf()
+        m.rlgrWrite([int(v) for v in x], flag)
+        m.close()
+        return np.array(m.get_buffer(), dtype=np.uint8)
+
+    cases = {
+        "lap1": (rng.laplace(0, 1, 30000).astype(np.int64), 1),
+        "lap30": (rng.laplace(0, 30, 20000).astype(np.int64), 1),
+        "zeros": (np.zeros(70000, np.int64), 1),
+        "sparse": (((rng.random(60000) < 0.004) * rng.integers(-300, 300, 60000)).astype(np.int64), 1),
+        "escape": (rng.integers(-2 ** 31 + 1, 2 ** 31 - 1, 3000).astype(np.int64), 1),
+        "int32_extremes": (np.array([-2 ** 31, 2 ** 31 - 1, 0, 0, -1, 1, -2 ** 31, 0, 0, 0, 0, 0, 0, 0, 0, 5], np.int64), 1),
+        "single_nonzero": (np.array([7], np.int64), 1),
+        "single_zero": (np.array([0], np.int64), 1),
+        "run_then_values": (np.concatenate([np.zeros(9000, np.int64), rng.laplace(0, 500, 4000).astype(np.int64), np.zeros(333, np.int64)]), 1),
+        "ends_in_open_run": (np.concatenate([rng.laplace(0, 2, 500).astype(np.int64), np.zeros(37, np.int64)]), 1),
+        "unsigned": (rng.integers(0, 12, 8000).astype(np.int64), 0),
+        "dc_then_small": (np.concatenate([[123456], rng.laplace(0, 4, 12000).astype(np.int64)]).astype(np.int64), 1),
+    }
+    out = {}
+    for name, (x, flag) in cases.items():
+        out[name + "__x"] = x.astype(np.int64)
+        out[name + "__flag"] = np.int32(flag)
+        out[name + "__bytes"] = enc(x, flag)
+        # the reference's decoder must invert its own stream
+        r = rlgr.membuf(out[name + "__bytes"].tolist())
+        _, back = r.rlgrRead(len(x), flag)
+        assert back == x.tolist(), name
+    np.savez_compressed(os.path.join(HERE, "rlgr_streams.npz"), **out)
+    print("rlgr_streams:", {k: (len(v[0]), len(out[k + "__bytes"])) for k, v in cases.items()})
+
+
+if __name__ == "__main__" and os.environ.get("GOLDEN_ONLY", "") in ("", "rlgr"):
+    rlgr_cases()
