@@ -1,0 +1,162 @@
+"""Codec driver for voxelized 3DGS frames: the repo's counterpart of the reference's
+python/encode_3dgs.py main loop (:126-411), logging the same 20-column CSV (:70-76, :402-409) so
+that the reference's scripts/summarize_pipeline_runtime.py works on it unchanged.
+
+    prelude (plan) -> forward RAHT -> quantize -> reorder -> [D2H] -> RLGR encode all channels ->
+    RLGR decode -> [H2D] -> dequantize -> un-reorder -> inverse RAHT -> PSNR (all / quats / scales /
+    opacity / colours) -> CSV row per (frame, step)
+
+``fused=True`` (default) uses raht_fwd_quant / raht_dequant_inv: the Quant / Coeff_reorder columns
+are then 0 and their work is inside RAHT_transform_time / iRAHT_time. ``fused=False`` keeps the
+reference's stage boundaries one to one. Everything on the transform side runs through the C ABI on
+the GPU; the entropy stage is the byte-exact host coder (csrc/rlgr.hip).
+"""
+import math
+import os
+import time
+
+import numpy as np
+import torch
+
+from . import rlgr as rlgr_mod
+from .ops import RAHT_param_reorder_fast, plan_of, raht_fn
+
+CSV_HEADER = ("Frame,Quantization_Step,Rate_bpp,"
+              "RAHT_prelude_time,RAHT_transform_time,Quant_time,"
+              "Coeff_reorder_enc_time,Entropy_enc_time,"
+              "Entropy_dec_time,Dequant_time,"
+              "Coeff_reorder_dec_time,iRAHT_time,"
+              "Total_enc_time,Total_dec_time,Pipeline_time,"
+              "PSNR_all,PSNR_quats,PSNR_scales,PSNR_opacity,PSNR_colors")          # encode_3dgs.py:70-76
+
+
+def _sync():
+    torch.cuda.synchronize()
+
+
+def _psnr(a, b):
+    return -10 * math.log10(torch.mean((a - b) ** 2).item() + 1e-10)               # encode_3dgs.py:298-310
+
+
+def encode_frame(V_int, attributes, J, steps, frame=1, device="cuda:0", dtype=torch.float32, fused=True,
+                 nthreads=0, channel_major=True):
+    """One frame through the whole pipeline. Returns a list of dict rows (one per step) with the CSV
+    columns plus ``size_bytes`` and ``C_rec`` (last step) for inspection."""
+    N = V_int.shape[0]
+    C = attributes.to(dtype=dtype).contiguous().to(device)
+    _sync()
+    V = V_int.to(dtype=torch.float64).to(device)                                    # :139-142
+    origin = torch.tensor([0, 0, 0], dtype=V.dtype, device=device)
+
+    t0 = time.time()
+    ListC, FlagsC, weightsC, order_RAGFT = RAHT_param_reorder_fast(V, origin, 2 ** J, J)   # :149
+    _sync()
+    t_prelude = time.time() - t0
+    plan = plan_of(ListC)
+    use_fused = fused and dtype == torch.float32
+
+    Coeff, t_transform = None, 0.0
+    if not use_fused:
+        t0 = time.time()
+        Coeff, _ = raht_fn["RAHT"](C, ListC, FlagsC, weightsC)                      # :159
+        _sync()
+        t_transform = time.time() - t0
+
+    rows = []
+    for step in steps:
+        r = dict(Frame=frame, Quantization_Step=step)
+        # ---------------- encoder ----------------
+        if use_fused:
+            t0 = time.time()
+            coeff_reordered = plan.forward_quant(C, float(step))                    # :159 + :204 + :210 + :215
+            _sync()
+            r["RAHT_transform_time"], r["Quant_time"], r["Coeff_reorder_enc_time"] = time.time() - t0, 0.0, 0.0
+        else:
+            t0 = time.time()
+            Coeff_enc = torch.floor(Coeff / step + 0.5)                             # :204
+            _sync()
+            r["Quant_time"] = time.time() - t0
+            t0 = time.time()
+            coeff_reordered = Coeff_enc.index_select(0, order_RAGFT).to(torch.int32)   # :210, :215
+            _sync()
+            r["Coeff_reorder_enc_time"] = time.time() - t0
+            r["RAHT_transform_time"] = t_transform
+        # device -> host, channel-major so that the entropy coder reads contiguous channels
+        q_dev = rlgr_mod.transpose_on_device(coeff_reordered) if channel_major else coeff_reordered
+        q_cpu = q_dev.cpu().numpy()                                                 # :215-217
+        streams, t_enc = rlgr_mod.encode_channels(q_cpu, 1, nthreads=nthreads, channel_major=channel_major)   # :229-234
+        size_bytes = sum(int(s.shape[0]) for s in streams)                          # :247
+        r["Entropy_enc_time"] = t_enc
+        # ---------------- decoder ----------------
+        q_back, t_dec = rlgr_mod.decode_channels(streams, N, 1, nthreads=nthreads, channel_major=channel_major)   # :237-245
+        assert np.array_equal(q_back, q_cpu), "RLGR roundtrip failed"               # :242-245
+        r["Entropy_dec_time"] = t_dec
+        qd = torch.from_numpy(q_back).to(device)
+        if channel_major:
+            qd = rlgr_mod.transpose_on_device(qd)
+        if use_fused:
+            t0 = time.time()
+            C_rec = plan.dequant_inverse(qd, float(step))                           # :261 + :267-268 + :274
+            _sync()
+            r["iRAHT_time"], r["Dequant_time"], r["Coeff_reorder_dec_time"] = time.time() - t0, 0.0, 0.0
+        else:
+            t0 = time.time()
+            Coeff_dec = qd.to(dtype) * step                                         # :261
+            _sync()
+            r["Dequant_time"] = time.time() - t0
+            t0 = time.time()
+            Coeff_dec = Coeff_dec[torch.argsort(order_RAGFT), :]                     # :267-268
+            _sync()
+            r["Coeff_reorder_dec_time"] = time.time() - t0
+            t0 = time.time()
+            C_rec = raht_fn["iRAHT"](Coeff_dec, ListC, FlagsC, weightsC)            # :274
+            _sync()
+            r["iRAHT_time"] = time.time() - t0
+        # ---------------- bookkeeping (:279-310) ----------------
+        r["RAHT_prelude_time"] = t_prelude
+        r["Total_enc_time"] = r["RAHT_transform_time"] + r["Quant_time"] + r["Coeff_reorder_enc_time"] + r["Entropy_enc_time"]
+        r["Total_dec_time"] = r["Entropy_dec_time"] + r["Dequant_time"] + r["Coeff_reorder_dec_time"] + r["iRAHT_time"]
+        r["Pipeline_time"] = t_prelude + r["Total_enc_time"] + r["Total_dec_time"]
+        r["Rate_bpp"] = size_bytes * 8 / N                                          # :403
+        r["size_bytes"] = size_bytes
+        r["PSNR_all"] = _psnr(C, C_rec)
+        r["PSNR_quats"] = _psnr(C[:, 0:4], C_rec[:, 0:4])
+        r["PSNR_scales"] = _psnr(C[:, 4:7], C_rec[:, 4:7])
+        r["PSNR_opacity"] = _psnr(C[:, 7], C_rec[:, 7])
+        r["PSNR_colors"] = _psnr(C[:, 8:], C_rec[:, 8:])
+        r["C_rec"] = C_rec
+        rows.append(r)
+    return rows
+
+
+def format_row(r):
+    """One CSV line, same formatting as encode_3dgs.py:402-409."""
+    return (f"{r['Frame']},{r['Quantization_Step']},{r['Rate_bpp']:.6f},"
+            f"{r['RAHT_prelude_time']:.6f},{r['RAHT_transform_time']:.6f},{r['Quant_time']:.6f},"
+            f"{r['Coeff_reorder_enc_time']:.6f},{r['Entropy_enc_time']:.6f},"
+            f"{r['Entropy_dec_time']:.6f},{r['Dequant_time']:.6f},"
+            f"{r['Coeff_reorder_dec_time']:.6f},{r['iRAHT_time']:.6f},"
+            f"{r['Total_enc_time']:.6f},{r['Total_dec_time']:.6f},{r['Pipeline_time']:.6f},"
+            f"{r['PSNR_all']:.6f},{r['PSNR_quats']:.6f},{r['PSNR_scales']:.6f},{r['PSNR_opacity']:.6f},{r['PSNR_colors']:.6f}")
+
+
+def encode_3dgs(ply_list, J=10, colorStep=(1, 4, 8, 12, 16, 20, 24, 32, 64), csv_path="../results/runtime_3dgs.csv",
+                device="cuda:0", dtype=torch.float32, fused=True, warmup=True):
+    """Counterpart of the reference script: PLY list in, CSV out (defaults: encode_3dgs.py:29-33,60)."""
+    from .ply_io import read_compressed_3dgs_ply
+    d = os.path.dirname(csv_path)
+    if d:
+        os.makedirs(d, exist_ok=True)
+    lines = [CSV_HEADER]
+    for idx, path in enumerate(ply_list):
+        res = read_compressed_3dgs_ply(path)
+        if res is None:
+            raise RuntimeError(f"Failed to load frame from {path}")
+        V_int, attributes, _, _ = res
+        if warmup and idx == 0:                                                   # :88-118
+            encode_frame(V_int, attributes, J, colorStep[:1], frame=0, device=device, dtype=dtype, fused=fused)
+        for r in encode_frame(V_int, attributes, J, colorStep, frame=idx + 1, device=device, dtype=dtype, fused=fused):
+            lines.append(format_row(r))
+    with open(csv_path, "w") as f:
+        f.write("\n".join(lines) + "\n")
+    return lines

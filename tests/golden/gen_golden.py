@@ -275,3 +275,69 @@ def rlgr_cases():
 
 if __name__ == "__main__" and os.environ.get("GOLDEN_ONLY", "") in ("", "rlgr"):
     rlgr_cases()
+
+
+def pipeline_case():
+    """Replays the reference driver's per-frame loop (python/encode_3dgs.py:126-411) with the
+    reference's own operators, its own RLGR build (oracle/_ref) and its own PLY writer / reader, on a
+    small synthetic voxelized 3DGS frame. Records what the driver logs: bytes per step, PSNRs."""
+    import math
+    import tempfile
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(HERE)), "oracle", "_ref"))
+    import rlgr
+    from data_util import read_compressed_3dgs_ply
+    from quality_eval import save_ply
+
+    rng = np.random.default_rng(777)
+    J = 10
+    V = sorted_unique_voxels(blob_cloud(rng, 2600, J), J)
+    N = V.shape[0]
+    A = gaussian_attrs(rng, N, 56)                      # quats(4) scales(3) opacity(1) colors(48)
+    voxel_size, vmin = 0.0123, torch.tensor([-1.5, 0.25, 3.0])
+
+    # --- PLY round trip through the reference writer / reader (quality_eval.py:18-117, data_util.py:272-382)
+    with tempfile.TemporaryDirectory() as td:
+        path = os.path.join(td, "frame.ply")
+        save_ply(path, torch.from_numpy(V).float(), torch.from_numpy(A[:, 0:4]), torch.from_numpy(A[:, 4:7]),
+                 torch.from_numpy(A[:, 7]), torch.from_numpy(A[:, 8:]), voxel_size=voxel_size, vmin=vmin)
+        ply_bytes = np.frombuffer(open(path, "rb").read(), dtype=np.uint8).copy()
+        Vr, Ar, vs_r, vmin_r = read_compressed_3dgs_ply(path)
+    assert torch.equal(Vr, torch.from_numpy(V)) and np.array_equal(Ar.numpy(), A)
+
+    # --- the driver loop, float64 (encode_3dgs.py:82-83) -------------------------------------------
+    steps = [0.004, 0.02, 0.1, 1]
+    C = Ar.to(torch.float64)
+    Vd = Vr.to(torch.float64)
+    origin = torch.zeros(3, dtype=torch.float64)
+    List, Flags, weights, order = RAHT_param_reorder_fast(Vd, origin, 2 ** J, J)
+    Coeff, _ = RAHT2_optimized(C, List, Flags, weights)
+    out = dict(V=V.astype(np.int32), A=A, J=np.int32(J), voxel_size=np.float64(voxel_size), vmin=vmin.numpy(),
+               ply_bytes=ply_bytes, steps=np.array(steps, dtype=np.float64))
+    size_bytes, psnrs = [], []
+    for s in steps:
+        enc = torch.floor(Coeff / s + 0.5)                             # :204
+        q = enc.index_select(0, order).to(torch.int32).numpy()         # :210-217
+        total = 0
+        dec_cols = []
+        for ch in range(q.shape[1]):                                   # :229-245
+            m = rlgr.membuf(); m.rlgrWrite(q[:, ch].tolist(), 1); m.close()
+            buf = m.get_buffer(); total += len(buf)
+            _, back = rlgr.membuf(buf).rlgrRead(q.shape[0], 1)
+            assert back == q[:, ch].tolist()
+            dec_cols.append(back)
+        dec = torch.from_numpy(np.stack(dec_cols, axis=1).astype(np.int32)).to(torch.float64) * s     # :255-261
+        dec = dec[torch.argsort(order), :]                             # :267-268
+        rec = inverse_RAHT_optimized(dec, List, Flags, weights)        # :274
+
+        def ps(a, b):
+            return -10 * math.log10(torch.mean((a - b) ** 2).item() + 1e-10)   # :298-310
+        psnrs.append([ps(C, rec), ps(C[:, 0:4], rec[:, 0:4]), ps(C[:, 4:7], rec[:, 4:7]), ps(C[:, 7], rec[:, 7]), ps(C[:, 8:], rec[:, 8:])])
+        size_bytes.append(total)
+    out["size_bytes"] = np.array(size_bytes, dtype=np.int64)
+    out["psnr"] = np.array(psnrs, dtype=np.float64)                    # all, quats, scales, opacity, colors
+    np.savez_compressed(os.path.join(HERE, "pipeline_small.npz"), **out)
+    print("pipeline_small: N=%d bytes=%s psnr_all=%s" % (N, size_bytes, [round(p[0], 2) for p in psnrs]))
+
+
+if __name__ == "__main__" and os.environ.get("GOLDEN_ONLY", "") in ("", "pipeline"):
+    pipeline_case()
