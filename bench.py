@@ -36,7 +36,8 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="cfg3", choices=["cfg3", "cfg2"])
+    ap.add_argument("--workload", default="cfg3", choices=["cfg3", "cfg2", "cfg5"],
+                    help="cfg3 = headline (3M x 59); cfg2 = 1M x 14; cfg5 = 50M x 59 single-GPU equivalent, generated on device")
     ap.add_argument("--no-quant", action="store_true", help="time forward + inverse only")
     ap.add_argument("--engine", default="tile", choices=["tile", "level"])
     ap.add_argument("--tile-rows", type=int, default=0)
@@ -95,14 +96,31 @@ def main():
 
     n_draws, J, D, seed = synth.CONFIGS[a.workload]
     # ---- synthetic scene (host, seeded), one Morton-prefix shard per rank ----
-    if world == 1:
+    if a.workload == "cfg5":
+        # 50 M rows: generated on the device (host generation would take minutes); no CPU baseline
+        assert world == 1, "cfg5 is a single-GPU scaling data point"
+        g5 = torch.Generator(device=dev); g5.manual_seed(seed)
+        kraw = torch.randint(0, 1 << (3 * J), (int(n_draws * 1.002),), device=dev, dtype=torch.int64, generator=g5)
+        kd5 = torch.unique(kraw)[:n_draws].contiguous()
+        del kraw
+        keys = None; V = None
+        Ch = None
+        a.skip_cpu_baseline = True; a.skip_prelude = True
+    elif world == 1:
         V, keys, Ch = synth.scene(n_draws, J, D, seed)
     else:
         per = 512 // world
         V, keys, Ch = synth.scene(n_draws, J, D, seed + 100 * rank, prefix_range=(rank * per, (rank + 1) * per, 9))
-    N = V.shape[0]
-    Cd = torch.from_numpy(Ch).to(dev)
-    kd = torch.from_numpy(keys.view(np.int64)).to(dev)
+    if a.workload == "cfg5":
+        N = int(kd5.shape[0])
+        kd = kd5
+        Cd = torch.empty((N, D), dtype=torch.float32, device=dev)
+        for c0 in range(0, D, 8):                               # fill in column blocks: bounded temporaries
+            Cd[:, c0:c0 + 8] = torch.randn((N, min(8, D - c0)), device=dev, generator=g5)
+    else:
+        N = V.shape[0]
+        Cd = torch.from_numpy(Ch).to(dev)
+        kd = torch.from_numpy(keys.view(np.int64)).to(dev)
     steps_arr = (C.c_float * 1)(a.quant_step)
 
     if world == 1:

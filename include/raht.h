@@ -216,6 +216,19 @@ int raht_sort_keys(const uint64_t *keys_in, int64_t N, int nbits, uint64_t *keys
                    int64_t *idx_out, raht_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Per-voxel Gaussian merge. Replaces merge_clusters_cuda / merge_weighted_mean_kernel
+ * (reference cuda/merge_cluster_wrapper.cu:11-116, cuda/merge_cluster.cu:2-111): cluster c owns the
+ * Gaussians cluster_indices[cluster_offsets[c] .. cluster_offsets[c+1]); weight = opacity (or 1);
+ * means / scales / colours = weighted means, quaternion = normalised weighted sum (identity
+ * (0,0,0,1) if the norm is 0), opacity = min(sum, 1); empty clusters produce zeros. DEVICE pointers,
+ * int32 indices / offsets, float32 data, row-major [N,3] [N,4] [N,3] [N] [N,color_dim]. */
+int raht_merge_clusters(const int32_t *cluster_indices, const int32_t *cluster_offsets, int64_t num_clusters,
+                        const float *means, const float *quats, const float *scales, const float *opacities,
+                        const float *colors, int color_dim, int weight_by_opacity, float *merged_means,
+                        float *merged_quats, float *merged_scales, float *merged_opacities,
+                        float *merged_colors, raht_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
  * RLGR entropy stage: adaptive Run-Length / Golomb-Rice coder, byte-exact with the
  * reference's vendored PyRLGR (python/PyRLGR/src/libs/rlgr/membuf.cpp:258-423, call sites
  * python/encode_3dgs.py:229-245). HOST pointers throughout: the coder is sequential and stays on

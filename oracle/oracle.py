@@ -68,6 +68,7 @@ def lib():
     L.orc_rlgr_encode.argtypes = [vp, i64, i32, vp, i64]
     L.orc_rlgr_encode.restype = i64
     L.orc_rlgr_decode.argtypes = [vp, i64, i64, i32, vp]
+    L.orc_merge_clusters.argtypes = [vp, vp, i64, vp, vp, vp, vp, vp, i32, i32, vp, vp, vp, vp, vp]
     _lib = L
     return L
 
@@ -211,3 +212,17 @@ def rlgr_decode(buf, N, flag_signed=1):
     seq = np.empty(N, dtype=np.int64)
     lib().orc_rlgr_decode(_ptr(buf), buf.shape[0], int(N), int(flag_signed), _ptr(seq))
     return seq
+
+
+def merge_clusters(cluster_indices, cluster_offsets, means, quats, scales, opacities, colors, weight_by_opacity=True):
+    """merge_weighted_mean_kernel restated from cuda/merge_cluster.cu:2-111 (PARITY UNPINNED)."""
+    ci = np.ascontiguousarray(cluster_indices, dtype=np.int32)
+    co = np.ascontiguousarray(cluster_offsets, dtype=np.int32)
+    f = lambda a: np.ascontiguousarray(a, dtype=np.float32)   # noqa: E731
+    means, quats, scales, opacities, colors = f(means), f(quats), f(scales), f(opacities), f(colors)
+    K, cd = co.shape[0] - 1, colors.shape[1]
+    out = [np.zeros((K, 3), np.float32), np.zeros((K, 4), np.float32), np.zeros((K, 3), np.float32),
+           np.zeros((K,), np.float32), np.zeros((K, cd), np.float32)]
+    lib().orc_merge_clusters(_ptr(ci), _ptr(co), K, _ptr(means), _ptr(quats), _ptr(scales), _ptr(opacities), _ptr(colors),
+                             cd, 1 if weight_by_opacity else 0, *[_ptr(o) for o in out])
+    return tuple(out)

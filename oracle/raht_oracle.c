@@ -587,3 +587,50 @@ int orc_rlgr_decode(const uint8_t *buf, int64_t nbytes, int64_t N, int flag_sign
     }
     return 0;
 }
+
+/* ---------------------------------------------------------------- cuda/merge_cluster.cu:2-111
+ * PARITY UNPINNED (see raht_oracle.h): restated from the kernel text only. */
+int orc_merge_clusters(const int32_t *ci, const int32_t *co, int64_t K, const float *means, const float *quats,
+                       const float *scales, const float *opac, const float *colors, int cd, int wbo, float *mm,
+                       float *mq, float *ms, float *mo, float *mc)
+{
+    for (int64_t c = 0; c < K; ++c) {
+        const int start = co[c], end = co[c + 1];
+        if (end - start == 0) {                                   /* :26 -- outputs stay zero */
+            for (int k = 0; k < 3; ++k) { mm[c * 3 + k] = 0; ms[c * 3 + k] = 0; }
+            for (int k = 0; k < 4; ++k) mq[c * 4 + k] = 0;
+            mo[c] = 0;
+            for (int k = 0; k < cd; ++k) mc[c * cd + k] = 0;
+            continue;
+        }
+        float ma[3] = {0, 0, 0}, qa[4] = {0, 0, 0, 0}, sa[3] = {0, 0, 0}, osum = 0, tw = 0;
+        for (int i = start; i < end; ++i) {                       /* :38-63 */
+            const int idx = ci[i];
+            const float w = wbo ? opac[idx] : 1.0f;
+            tw += w;
+            for (int k = 0; k < 3; ++k) ma[k] = fmaf(means[idx * 3 + k], w, ma[k]);
+            for (int k = 0; k < 4; ++k) qa[k] = fmaf(quats[idx * 4 + k], w, qa[k]);
+            for (int k = 0; k < 3; ++k) sa[k] = fmaf(scales[idx * 3 + k], w, sa[k]);
+            osum += opac[idx];
+        }
+        const float twd = (tw == 0.0f) ? 1.0f : tw;               /* :66-68 */
+        for (int k = 0; k < 3; ++k) mm[c * 3 + k] = ma[k] / twd;  /* :71-73 */
+        float n2 = qa[0] * qa[0];                                 /* :76-77 */
+        n2 = fmaf(qa[1], qa[1], n2); n2 = fmaf(qa[2], qa[2], n2); n2 = fmaf(qa[3], qa[3], n2);
+        const float nrm = sqrtf(n2);
+        if (nrm > 0.0f) for (int k = 0; k < 4; ++k) mq[c * 4 + k] = qa[k] / nrm;    /* :78-83 */
+        else { mq[c * 4 + 0] = 0; mq[c * 4 + 1] = 0; mq[c * 4 + 2] = 0; mq[c * 4 + 3] = 1.0f; }   /* :84-89 */
+        for (int k = 0; k < 3; ++k) ms[c * 3 + k] = sa[k] / twd;  /* :91-93 */
+        mo[c] = fminf(osum, 1.0f);                                /* :96 */
+        for (int k = 0; k < cd; ++k) {                            /* :98-110 */
+            float acc = 0.0f;
+            for (int i = start; i < end; ++i) {
+                const int idx = ci[i];
+                const float w = wbo ? opac[idx] : 1.0f;
+                acc = fmaf(colors[(int64_t)idx * cd + k], w, acc);
+            }
+            mc[c * cd + k] = (tw > 0.0f) ? acc / tw : 0.0f;
+        }
+    }
+    return 0;
+}

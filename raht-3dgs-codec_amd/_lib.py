@@ -23,7 +23,7 @@ EXPORTS = [
     "raht_plan_levels", "raht_plan_export_level", "raht_plan_order", "raht_plan_arrays",
     "raht_plan_copy_array", "raht_plan_stage_stats", "raht_fwd", "raht_fwd_f64", "raht_inv", "raht_inv_f64", "raht_debug_run_stage", "raht_fwd_quant", "raht_dequant_inv", "raht_plan_prepare",
     "raht_quant_reorder", "raht_dequant_unreorder", "raht_voxelize", "raht_morton", "raht_sort_keys",
-    "raht_rlgr_bound", "raht_rlgr_encode", "raht_rlgr_decode", "raht_rlgr_encode_channels", "raht_rlgr_decode_channels", "raht_transpose_i32",
+    "raht_rlgr_bound", "raht_rlgr_encode", "raht_rlgr_decode", "raht_rlgr_encode_channels", "raht_rlgr_decode_channels", "raht_transpose_i32", "raht_merge_clusters",
 ]
 
 
@@ -101,6 +101,7 @@ def lib():
     L.raht_rlgr_decode.argtypes = [vp, i64, i64, i32, vp, i64]
     L.raht_rlgr_encode_channels.argtypes = [vp, i64, i32, i64, i64, i32, vp, i64, vp, i32]
     L.raht_rlgr_decode_channels.argtypes = [vp, i64, vp, i64, i32, i32, vp, i64, i64, i32]
+    L.raht_merge_clusters.argtypes = [vp, vp, i64, vp, vp, vp, vp, vp, i32, i32, vp, vp, vp, vp, vp, vp]
     L.raht_transpose_i32.argtypes = [vp, i64, i64, i64, vp, i64, vp]
     _lib = L
     return L

@@ -89,4 +89,5 @@ CONFIGS = {
     # name: (n_draws, J, D, seed)         BASELINE.json configs / SURVEY 8d
     "cfg2": (1_000_000, 10, 14, 1),       # ~1M Gaussians, SH deg 0 (~14 attribute channels)
     "cfg3": (3_000_000, 12, 59, 2),       # ~3M Gaussians, SH deg 3 (59 channels) -- headline
+    "cfg5": (50_000_000, 14, 59, 3),      # ~50M Gaussians (BASELINE configs[4] on ONE GPU; bench.py builds it on device)
 }
