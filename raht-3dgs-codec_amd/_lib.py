@@ -74,7 +74,7 @@ def lib():
     L.raht_plan_size.restype = i64
     L.raht_plan_nbits.argtypes = [vp]
     L.raht_plan_set_engine.argtypes = [vp, i32, i32]
-    L.raht_plan_set_tail_tile.argtypes = [vp, i32, i32]
+    L.raht_plan_set_tail_tile.argtypes = [vp, i32, i32, i32]
     L.raht_plan_levels.argtypes = [vp]
     L.raht_plan_export_level.argtypes = [vp, i32, vp, vp, vp, C.POINTER(i64)]
     L.raht_plan_order.argtypes = [vp, vp, vp]

@@ -209,7 +209,8 @@ int pick_tile_rows(const raht_plan *plan, int elem_size, int Dc)
     return 0;
 }
 
-void pick_tail_geometry(const raht_plan *plan, int elem_size, int D, int stage0_rows, int *tail_rows, int *tail_chunk)
+void pick_tail_geometry(const raht_plan *plan, int elem_size, int D, int stage0_rows, int *tail_rows, int *tail_chunk,
+                        int *final_rows)
 {
     // Later stages hold a few % of the rows. Default: the same geometry as stage 0, trimmed so that
     // three workgroups still fit per CU with the slightly larger later-stage LDS layout (row ids).
@@ -226,6 +227,12 @@ void pick_tail_geometry(const raht_plan *plan, int elem_size, int D, int stage0_
     }
     *tail_rows = R;
     *tail_chunk = Dc;
+    // The finishing stage is latency-bound: once few enough entries are left, ONE workgroup with all
+    // 128 LDS granules takes them as a single tile and completes the tree in one launch.
+    int Rf = 512;
+    if (plan->final_rows_override > 0) Rf = plan->final_rows_override;
+    while (Rf > 64 && tile_lds_bytes(Rf, elem_size, Dc, false, elem_size == 4) > (size_t)128 * 1280) Rf -= 64;
+    *final_rows = std::max(Rf, 64);
 }
 
 static void free_schedule(Schedule &sc)
@@ -278,13 +285,14 @@ __global__ void gather_meta_kernel(const uint32_t *__restrict__ rows, int64_t n,
     e_wl[j] = wl[r]; e_wr[j] = wr[r]; e_lvl[j] = lvl[r]; e_pos[j] = inv_order[r];
 }
 
-int get_schedule(raht_plan *plan, int R0, int R1, hipStream_t s, Schedule **out)
+int get_schedule(raht_plan *plan, int R0, int R1, int Rf, hipStream_t s, Schedule **out)
 {
     for (auto &sc : plan->schedules)
-        if (sc.tile_rows == R0 && sc.tail_rows == R1) { *out = &sc; return RAHT_OK; }
+        if (sc.tile_rows == R0 && sc.tail_rows == R1 && sc.final_rows == Rf) { *out = &sc; return RAHT_OK; }
     Schedule sc;
     sc.tile_rows = R0;
     sc.tail_rows = R1;
+    sc.final_rows = Rf;
     sc.valid = true;
     const int64_t N = plan->N;
     Scratch buf(sizeof(uint32_t) * (2 * (size_t)N + 1));
@@ -294,7 +302,8 @@ int get_schedule(raht_plan *plan, int R0, int R1, hipStream_t s, Schedule **out)
     int64_t n = N;
     int rc = RAHT_OK;
     for (int k = 0; k < 24; ++k) {
-        const int R = (k == 0) ? R0 : R1;
+        int R = (k == 0) ? R0 : R1;
+        if (n <= Rf && n > R) R = (int)(ceil_div(n, 64) * 64);   // few entries left: one big tile finishes the tree
         Stage st;
         st.n_entries = n;
         st.n_tiles = ceil_div(n, R);
@@ -432,9 +441,9 @@ static int finish_plan(raht_plan *p, const int64_t *leaf_weights, hipStream_t s)
     // Build the default schedule now so that float32 transforms with D <= 64 never allocate.
     Schedule *sc = nullptr;
     const int R0 = pick_tile_rows(p, 4, 59);
-    int R1 = 0, Dc1 = 0;
-    pick_tail_geometry(p, 4, 59, R0, &R1, &Dc1);
-    RAHT_RET(get_schedule(p, R0, R1, s, &sc));
+    int R1 = 0, Dc1 = 0, Rf = 0;
+    pick_tail_geometry(p, 4, 59, R0, &R1, &Dc1, &Rf);
+    RAHT_RET(get_schedule(p, R0, R1, Rf, s, &sc));
     return RAHT_OK;
 }
 
@@ -531,14 +540,16 @@ int raht_plan_destroy(raht_plan *p)
 int64_t raht_plan_size(const raht_plan *p) { return p ? p->N : -1; }
 int raht_plan_nbits(const raht_plan *p) { return p ? p->nbits : -1; }
 
-int raht_plan_set_tail_tile(raht_plan *p, int tail_rows, int tail_channels)
+int raht_plan_set_tail_tile(raht_plan *p, int tail_rows, int tail_channels, int final_rows)
 {
-    if (!p || tail_rows < 0 || tail_rows > 1024 || (tail_rows & 3) || tail_channels < 0 || tail_channels > 64) {
-        set_error("raht_plan_set_tail_tile: rows must be a multiple of 4 in [0, 1024], channels in [0, 64]");
+    if (!p || tail_rows < 0 || tail_rows > 1024 || (tail_rows & 3) || tail_channels < 0 || tail_channels > 64 ||
+        final_rows < 0 || final_rows > 1024 || (final_rows & 63)) {
+        set_error("raht_plan_set_tail_tile: rows multiple of 4 in [0, 1024], channels in [0, 64], final rows multiple of 64 in [0, 1024]");
         return RAHT_ERR_INVALID;
     }
     p->tail_rows_override = tail_rows;
     p->tail_chunk_override = tail_channels;
+    p->final_rows_override = final_rows;
     return RAHT_OK;
 }
 
@@ -665,9 +676,9 @@ int raht_plan_stage_stats(raht_plan *p, int elem_size, int D, int *n_stages, int
     const int R = pick_tile_rows(p, elem_size, Dc);
     if (R == 0) { set_error("no tile size fits"); return RAHT_ERR_UNSUPPORTED; }
     Schedule *sc = nullptr;
-    int R1 = 0, Dc1 = 0;
-    pick_tail_geometry(p, elem_size, D, R, &R1, &Dc1);
-    RAHT_RET(get_schedule(p, R, R1, nullptr, &sc));
+    int R1 = 0, Dc1 = 0, Rf = 0;
+    pick_tail_geometry(p, elem_size, D, R, &R1, &Dc1, &Rf);
+    RAHT_RET(get_schedule(p, R, R1, Rf, nullptr, &sc));
     *n_stages = sc->valid ? (int)sc->stages.size() : -(int)sc->stages.size();
     if (tile_rows) *tile_rows = R;
     for (int k = 0; k < (int)sc->stages.size() && k < max_stages; ++k)

@@ -94,6 +94,7 @@ struct Stage {
 struct Schedule {
     int tile_rows = 0;         // rows per tile of stage 0 (cache key, with tail_rows)
     int tail_rows = 0;         // rows per tile of the stages >= 1
+    int final_rows = 0;        // a stage with at most this many entries runs as ONE tile and finishes the tree
     bool valid = false;        // false: tile stages cannot finish the tree -> use the level engine
     std::vector<Stage> stages;
     size_t ws_row_bytes = 0;   // bytes per workspace row currently allocated (D * elem_size)
@@ -122,16 +123,18 @@ struct raht_plan {
     int tile_rows_override = 0;
     int tail_rows_override = 0;  // rows per tile of the later stages (0 = automatic)
     int tail_chunk_override = 0; // channels per chunk of the later stages (0 = automatic)
+    int final_rows_override = 0; // single-tile finishing stage up to this many entries (0 = automatic)
     std::vector<raht::Schedule> schedules;   // cache keyed by tile_rows
     std::vector<uint8_t> lvl_host;           // lazily downloaded for export_level
 };
 
 namespace raht {
 // Tile schedule for `tile_rows` rows per tile (built on first use, cached in the plan).
-int get_schedule(raht_plan *plan, int tile_rows, int tail_rows, hipStream_t s, Schedule **out);
+int get_schedule(raht_plan *plan, int tile_rows, int tail_rows, int final_rows, hipStream_t s, Schedule **out);
 // Tile geometry of the later (small, latency-bound) stages: as many rows as one workgroup per CU can
 // stage, in channel chunks.
-void pick_tail_geometry(const raht_plan *plan, int elem_size, int D, int stage0_rows, int *tail_rows, int *tail_chunk);
+void pick_tail_geometry(const raht_plan *plan, int elem_size, int D, int stage0_rows, int *tail_rows, int *tail_chunk,
+                        int *final_rows);
 // Make sure the per-stage workspaces of `sc` hold rows of at least row_bytes bytes (allocates on
 // first use / growth only).
 int ensure_workspace(Schedule *sc, size_t row_bytes);

@@ -714,8 +714,8 @@ static int launch_tile_stage(const raht_plan *p, const Schedule &sc, int k, cons
     const Stage &st = sc.stages[(size_t)k];
     int Dc = Dc0;
     if (k >= 1) {                                    // later stages: large tiles, channel chunks
-        int r1 = 0;
-        pick_tail_geometry(p, (int)sizeof(T), D, sc.tile_rows, &r1, &Dc);
+        int r1 = 0, rf = 0;
+        pick_tail_geometry(p, (int)sizeof(T), D, sc.tile_rows, &r1, &Dc, &rf);
     }
     const int K = (int)sc.stages.size();
     TileArgs<T> A;
@@ -821,9 +821,9 @@ static int tile_setup(raht_plan *p, int D, hipStream_t s, Schedule **sc_out, int
     const int R = pick_tile_rows(p, (int)sizeof(T), Dc);
     if (R == 0) return RAHT_OK;
     Schedule *sc = nullptr;
-    int R1 = 0, Dc1 = 0;
-    pick_tail_geometry(p, (int)sizeof(T), D, R, &R1, &Dc1);
-    RAHT_RET(get_schedule(p, R, R1, s, &sc));
+    int R1 = 0, Dc1 = 0, Rf = 0;
+    pick_tail_geometry(p, (int)sizeof(T), D, R, &R1, &Dc1, &Rf);
+    RAHT_RET(get_schedule(p, R, R1, Rf, s, &sc));
     if (!sc->valid) return RAHT_OK;                   // pathological key pattern, see plan.hip
     RAHT_RET(ensure_workspace(sc, (size_t)D * sizeof(T)));
     *sc_out = sc;

@@ -167,10 +167,10 @@ class RahtPlan:
     def levels(self):
         return int(_lib.lib().raht_plan_levels(self._h))
 
-    def set_engine(self, engine="tile", tile_rows=0, tail_rows=0, tail_channels=0):
+    def set_engine(self, engine="tile", tile_rows=0, tail_rows=0, tail_channels=0, final_rows=0):
         e = {"tile": _lib.ENGINE_TILE, "level": _lib.ENGINE_LEVEL}[engine]
         check(_lib.lib().raht_plan_set_engine(self._h, e, int(tile_rows)))
-        check(_lib.lib().raht_plan_set_tail_tile(self._h, int(tail_rows), int(tail_channels)))
+        check(_lib.lib().raht_plan_set_tail_tile(self._h, int(tail_rows), int(tail_channels), int(final_rows)))
 
     def export_lists(self):
         """Reference-shaped (List, Flags, weights) as CPU tensors (RAHT_param.py:190-279 outputs)."""

@@ -20,7 +20,9 @@ TRANSFORM = golden_names(exclude_prefix="vox_")
 VOX = golden_names(prefix="vox_")
 # (engine, stage-0 tile rows, later-stage tile rows, later-stage channels per chunk); 0 = automatic.
 # Small explicit tiles force multi-stage / multi-tile / channel-chunked schedules on the small fixtures.
-ENGINES = [("tile", 0, 0, 0), ("tile", 64, 64, 0), ("tile", 128, 64, 8), ("tile", 64, 256, 3), ("level", 0, 0, 0)]
+# last entry: finishing single-tile stage up to that many rows (64 keeps the small fixtures multi-stage)
+ENGINES = [("tile", 0, 0, 0, 0), ("tile", 64, 64, 0, 64), ("tile", 128, 64, 8, 64), ("tile", 64, 256, 3, 0), ("tile", 64, 64, 0, 0),
+           ("level", 0, 0, 0, 0)]
 
 
 @pytest.fixture(scope="module")
@@ -41,12 +43,12 @@ def _dev(a, dtype=None):
     return t.cuda()
 
 
-def _plan(R, g, engine="tile", tile_rows=0, tail_rows=0, tail_ch=0):
+def _plan(R, g, engine="tile", tile_rows=0, tail_rows=0, tail_ch=0, final_rows=0):
     import torch
     J = int(g["J"])
     V = _dev(g["V"].astype(np.float64))
     p = R.RahtPlan.from_coords(V, torch.zeros(3, dtype=torch.float64), 2 ** J, J)
-    p.set_engine(engine, tile_rows, tail_rows, tail_ch)
+    p.set_engine(engine, tile_rows, tail_rows, tail_ch, final_rows)
     return p
 
 
@@ -200,13 +202,13 @@ def test_quantize_reorder_and_back(rt, name):
     assert np.array_equal(Qc, exp)
 
 
-@pytest.mark.parametrize("tile_rows,tail_rows,tail_ch", [(0, 0, 0), (64, 64, 0), (128, 64, 8), (64, 256, 3)])
+@pytest.mark.parametrize("tile_rows,tail_rows,tail_ch,final_rows", [(0, 0, 0, 0), (64, 64, 0, 64), (128, 64, 8, 64), (64, 256, 3, 0)])
 @pytest.mark.parametrize("name", ["n257_j3_d11", "n1000_j10_d14", "n1500_j12_d56", "n3000_j18_d3", "early_root_j10", "n8_cube_j1"])
-def test_fused_quant_equals_two_call_sequence(rt, name, tile_rows, tail_rows, tail_ch):
+def test_fused_quant_equals_two_call_sequence(rt, name, tile_rows, tail_rows, tail_ch, final_rows):
     """raht_fwd_quant == raht_fwd + raht_quant_reorder and raht_dequant_inv == dequant + raht_inv, bit for bit."""
     import torch
     g = load_golden(name)
-    p = _plan(rt, g, "tile", tile_rows, tail_rows, tail_ch)
+    p = _plan(rt, g, "tile", tile_rows, tail_rows, tail_ch, final_rows)
     C = _dev(g["C"])
     D = C.shape[1]
     for steps in (1.0, 0.37, [0.5 + 0.25 * c for c in range(D)]):
@@ -376,8 +378,8 @@ def test_full_size_properties_cfg3(rt):
 
 
 # ------------------------------------------------------------- truncated trees, roots, sharded scenes
-@pytest.mark.parametrize("engine,tile_rows,tail_rows,tail_ch", [("tile", 0, 0, 0), ("tile", 64, 64, 0), ("tile", 64, 128, 4), ("level", 0, 0, 0)])
-def test_truncated_plan_roots_and_weights(rt, engine, tile_rows, tail_rows, tail_ch):
+@pytest.mark.parametrize("engine,tile_rows,tail_rows,tail_ch,final_rows", [("tile", 0, 0, 0, 0), ("tile", 64, 64, 0, 64), ("tile", 64, 128, 4, 64), ("level", 0, 0, 0, 0)])
+def test_truncated_plan_roots_and_weights(rt, engine, tile_rows, tail_rows, tail_ch, final_rows):
     """top_level cut + compact root buffer + weighted leaves, against the numpy formulation."""
     import torch
     from raht_3dgs_codec_amd import synth
@@ -387,7 +389,7 @@ def test_truncated_plan_roots_and_weights(rt, engine, tile_rows, tail_rows, tail
     kd = _dev(keys.view(np.int64))
     ref = NumpyPlan(torch.from_numpy(keys.view(np.int64).copy()), nbits, top_level=top)
     p = rt.RahtPlan.from_keys(kd, nbits, top_level=top)
-    p.set_engine(engine, tile_rows, tail_rows, tail_ch)
+    p.set_engine(engine, tile_rows, tail_rows, tail_ch, final_rows)
     assert np.array_equal(p.root_rows.cpu().numpy(), ref.root_rows.numpy()) and p.n_roots > 100
     C64 = torch.from_numpy(C.astype(np.float64))
     r_ref = torch.empty((ref.n_roots, 7), dtype=torch.float64)
@@ -407,7 +409,7 @@ def test_truncated_plan_roots_and_weights(rt, engine, tile_rows, tail_rows, tail
     tw = rng.integers(1, 100000, size=tk.shape[0]).astype(np.int64)
     X = rng.normal(size=(tk.shape[0], 5))
     wp = rt.RahtPlan.from_keys(_dev(tk), 9, leaf_weights=_dev(tw))
-    wp.set_engine(engine, tile_rows, tail_rows, tail_ch)
+    wp.set_engine(engine, tile_rows, tail_rows, tail_ch, final_rows)
     wr = NumpyPlan(torch.from_numpy(tk), 9, leaf_weights=torch.from_numpy(tw))
     Tw, w = wp.forward(_dev(X))
     np.testing.assert_allclose(Tw.cpu().numpy(), wr.forward(torch.from_numpy(X)).numpy(), rtol=1e-12, atol=1e-12)
