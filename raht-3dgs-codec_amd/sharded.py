@@ -55,6 +55,7 @@ class ShardedRaht:
         counts = (ends - self.root_rows).to(torch.int64)
         # exchange the root directory once (prefix id + leaf count per root)
         self.max_roots = 1 << self.prefix_bits
+        self._pads, self._valid_idx, self._root_pos = {}, None, None
         sizes = self._all_gather_rows(torch.tensor([[self.n_roots]], dtype=torch.int64, device=dev), 1).reshape(-1)
         self.sizes = [int(x) for x in sizes.tolist()]
         self.offset = sum(self.sizes[:self.rank])
@@ -82,14 +83,22 @@ class ShardedRaht:
         return out
 
     def _gather_var(self, x):
-        """all-gather per-rank row blocks of different heights (padded to the largest one)."""
+        """all-gather per-rank row blocks of different heights: pad to the largest block, ONE
+        all-gather, then one index_select with a precomputed index picks the valid rows."""
         if self.world == 1:
             return x
         m = max(self.sizes)
-        pad = torch.zeros((m, x.shape[1]), dtype=x.dtype, device=x.device)
-        pad[: x.shape[0]] = x
+        key = (x.dtype, x.shape[1])
+        pad = self._pads.get(key)
+        if pad is None:
+            pad = torch.zeros((m, x.shape[1]), dtype=x.dtype, device=x.device)
+            self._pads[key] = pad
+        pad[: x.shape[0]].copy_(x)
         allp = self._all_gather_rows(pad, m)
-        return torch.cat([allp[r * m: r * m + self.sizes[r]] for r in range(self.world)], dim=0)
+        if self._valid_idx is None:
+            idx = [r * m + i for r in range(self.world) for i in range(self.sizes[r])]
+            self._valid_idx = torch.tensor(idx, dtype=torch.int64, device=x.device)
+        return allp.index_select(0, self._valid_idx)
 
     def _mine(self, allrows):
         return allrows[self.offset: self.offset + self.n_roots].contiguous()
@@ -112,11 +121,16 @@ class ShardedRaht:
         roots = torch.empty((self.n_roots, C.shape[1]), dtype=self.qdt, device=C.device)
         Q = self.plan.forward_quant(C, step, roots=roots)
         top = self._mine(self.top.forward(self._gather_var(roots), want_w=False))
-        Q[self.plan.inv_order[self.root_rows]] = torch.floor(top / step + 0.5).to(torch.int32)
+        Q[self._root_positions()] = torch.floor(top / step + 0.5).to(torch.int32)
         return Q
 
+    def _root_positions(self):
+        if self._root_pos is None:
+            self._root_pos = self.plan.inv_order[self.root_rows].contiguous()
+        return self._root_pos
+
     def dequant_inverse(self, Q, step):
-        roots_c = Q[self.plan.inv_order[self.root_rows]].to(self.qdt) * step
+        roots_c = Q[self._root_positions()].to(self.qdt) * step
         low = self.top.inverse(self._gather_var(roots_c.contiguous()))
         return self.plan.dequant_inverse(Q, step, roots=self._mine(low))
 

@@ -468,3 +468,36 @@ def test_two_prefix_shards_stitched_by_the_top_stage(rt, oracle):
         # tolerance relative to the WHOLE scene's column scale (the DC lives in one shard only)
         err = np.abs(Tl.cpu().numpy().astype(np.float64) - To[a:b]).max(axis=0)
         assert np.all(err <= 2e-6 * np.abs(To).max(axis=0)), float((err / np.abs(To).max(axis=0)).max())
+
+
+def test_transform_entry_points_are_graph_capturable(rt):
+    """After raht_plan_prepare the transform entry points only enqueue kernels on the given stream:
+    they can be captured in a hipGraph (torch.cuda.CUDAGraph) and replayed."""
+    import torch
+    from raht_3dgs_codec_amd import synth
+    V, keys, C = synth.scene(50000, 10, 59, seed=8)
+    p = rt.RahtPlan.from_keys(_dev(keys.view(np.int64)), 30)
+    p.prepare(59)
+    Cd = _dev(C)
+    C0 = Cd.clone()
+    ref_Q = p.forward_quant(Cd, 0.02)
+    ref_R = p.dequant_inverse(ref_Q, 0.02)
+    torch.cuda.synchronize()
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):                     # warm-up on the side stream, as torch recommends
+        p.dequant_inverse(p.forward_quant(Cd, 0.02), 0.02)
+    torch.cuda.current_stream().wait_stream(s)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        Qg = p.forward_quant(Cd, 0.02)
+        Rg = p.dequant_inverse(Qg, 0.02)
+    Cd.add_(1.0)                                   # new input, same buffers
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(Qg, p.forward_quant(Cd, 0.02)) and not torch.equal(Qg, ref_Q)
+    assert torch.equal(Rg, p.dequant_inverse(Qg, 0.02))
+    Cd.copy_(C0)
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(Qg, ref_Q) and torch.equal(Rg, ref_R)
