@@ -129,6 +129,81 @@ def encode_frame(V_int, attributes, J, steps, frame=1, device="cuda:0", dtype=to
     return rows
 
 
+CSV_HEADER_PLY = ("Frame,Quantization_Step,Rate_bpp,RAHT_prelude_time,RAHT_transform_time,Quant_time,"
+                  "Entropy_enc_time,Entropy_dec_time,Dequant_time,iRAHT_time,psnr")           # encode_ply.py:57
+
+
+def rgb_to_yuv(rgb):
+    """RGB -> YUV, BT.709 full range with 128/255 chroma offsets, clipped to [0, 255], float64
+    (same arithmetic as reference python/utils.py:4-33)."""
+    if rgb.ndim != 2 or rgb.shape[1] != 3:
+        raise ValueError("Expected Nx3 tensor")
+    rgb = rgb.to(torch.float64)
+    rgb1 = torch.hstack((rgb / 255.0, torch.ones((rgb.size(0), 1), dtype=torch.float64, device=rgb.device)))
+    Q = torch.tensor([[0.21260000, -0.114572, 0.5],
+                      [0.71520000, -0.385428, -0.454153],
+                      [0.07220000, 0.5, -0.045847],
+                      [0.0, 0.50196078, 0.50196078]], dtype=torch.float64, device=rgb.device)
+    return torch.clamp(rgb1 @ Q, 0.0, 1.0) * 255.0
+
+
+def encode_ply_frame(V_int, Crgb, J, steps=(1, 2, 4, 6, 8, 12, 16, 20, 24, 32, 64), frame=1, device="cuda:0",
+                     dtype=torch.float64, nthreads=0):
+    """RGB point cloud counterpart of the reference's encode_ply.py loop (:102-222): YUV, plan,
+    forward RAHT, per step quantize / Y-PSNR from the coefficients (:148-152, Parseval) / reorder /
+    RLGR Y,U,V / dequantize / un-reorder + inverse RAHT. Returns dict rows (CSV columns of :57 plus
+    ``size_bytes`` and ``C_rec``). float64 by default like the reference (:83 of encode_3dgs.py)."""
+    N = V_int.shape[0]
+    Cyuv = rgb_to_yuv(Crgb.to(torch.float64)).to(dtype).contiguous()
+    C = Cyuv.to(device)
+    V = V_int.to(dtype=torch.float64).to(device)
+    origin = torch.tensor([0, 0, 0], dtype=V.dtype, device=device)
+    t0 = time.time()
+    ListC, FlagsC, weightsC, order_RAGFT = RAHT_param_reorder_fast(V, origin, 2 ** J, J)
+    _sync()
+    t_prelude = time.time() - t0
+    t0 = time.time()
+    Coeff, _ = raht_fn["RAHT"](C, ListC, FlagsC, weightsC)
+    _sync()
+    t_transform = time.time() - t0
+    rows = []
+    for step in steps:
+        r = dict(Frame=frame, Quantization_Step=step, RAHT_prelude_time=t_prelude, RAHT_transform_time=t_transform)
+        t0 = time.time()
+        Coeff_enc = torch.floor(Coeff / step + 0.5)                                 # :148
+        _sync()
+        r["Quant_time"] = time.time() - t0
+        Y_hat = Coeff_enc[:, 0] * step
+        mse = (torch.linalg.norm(Coeff[:, 0].double() - Y_hat.double()) ** 2) / (N * 255 ** 2)     # :150-151
+        r["psnr"] = float(-10 * torch.log10(mse))
+        q_dev = Coeff_enc.index_select(0, order_RAGFT).to(torch.int32)              # :156-157
+        q_cpu = rlgr_mod.transpose_on_device(q_dev).cpu().numpy()
+        streams, r["Entropy_enc_time"] = rlgr_mod.encode_channels(q_cpu, 1, nthreads=nthreads, channel_major=True)   # :164-176
+        q_back, r["Entropy_dec_time"] = rlgr_mod.decode_channels(streams, N, 1, nthreads=nthreads, channel_major=True)
+        assert np.array_equal(q_back, q_cpu), "RLGR roundtrip failed"               # :184-187
+        r["size_bytes"] = sum(int(s.shape[0]) for s in streams)
+        r["Rate_bpp"] = r["size_bytes"] * 8 / N
+        qd = rlgr_mod.transpose_on_device(torch.from_numpy(q_back).to(device))
+        t0 = time.time()
+        Coeff_dec = qd.to(dtype) * step                                             # :202
+        _sync()
+        r["Dequant_time"] = time.time() - t0
+        t0 = time.time()
+        Coeff_dec = Coeff_dec[torch.argsort(order_RAGFT), :]                         # :206-208
+        r["C_rec"] = raht_fn["iRAHT"](Coeff_dec, ListC, FlagsC, weightsC)
+        _sync()
+        r["iRAHT_time"] = time.time() - t0
+        rows.append(r)
+    return rows
+
+
+def format_row_ply(r):
+    """One CSV line, same columns as encode_ply.py:217-220."""
+    return (f"{r['Frame']},{r['Quantization_Step']},{r['Rate_bpp']:.6f},{r['RAHT_prelude_time']:.6f},{r['RAHT_transform_time']:.6f},"
+            f"{r['Quant_time']:.6f},{r['Entropy_enc_time']:.6f},"
+            f"{r['Entropy_dec_time']:.6f},{r['Dequant_time']:.6f},{r['iRAHT_time']:.6f},{r['psnr']:.6f}")
+
+
 def format_row(r):
     """One CSV line, same formatting as encode_3dgs.py:402-409."""
     return (f"{r['Frame']},{r['Quantization_Step']},{r['Rate_bpp']:.6f},"

@@ -341,3 +341,51 @@ def pipeline_case():
 
 if __name__ == "__main__" and os.environ.get("GOLDEN_ONLY", "") in ("", "pipeline"):
     pipeline_case()
+
+
+def encode_ply_case():
+    """BASELINE configs[0]: the reference's encode_ply.py loop (:102-222) on a 10k-point RGB cloud
+    (positions U[0,1)^3 voxelized at J=10, RGB randint(0,256), seed 0), with the
+    reference's rgb_to_yuv (utils.py:4-33), operators and RLGR build. Records bytes and Y-PSNR per step."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(HERE)), "oracle", "_ref"))
+    import rlgr
+    from utils import rgb_to_yuv
+    rng = np.random.default_rng(0)
+    J = 10
+    P = rng.uniform(0, 1, size=(10000, 3))
+    rgb_all = rng.integers(0, 256, size=(10000, 3))
+    Vall = np.floor(P * (1 << J)).astype(np.int64)
+    V, first = np.unique(Vall, axis=0, return_index=True)
+    mc = morton_np(V, J)
+    o = np.argsort(mc, kind="stable")
+    V, rgb = V[o], rgb_all[first][o].astype(np.float32)
+    N = V.shape[0]
+    Cyuv = rgb_to_yuv(torch.from_numpy(rgb).to(torch.float64)).contiguous()
+    Vd = torch.from_numpy(V).to(torch.float64)
+    origin = torch.zeros(3, dtype=torch.float64)
+    List, Flags, weights, order = RAHT_param_reorder_fast(Vd, origin, 2 ** J, J)
+    Coeff, _ = RAHT2_optimized(Cyuv, List, Flags, weights)
+    steps = [1, 2, 4, 6, 8, 12, 16, 20, 24, 32, 64]                 # encode_ply.py:29
+    sizes, psnrs, recs = [], [], {}
+    for s in steps:
+        enc = torch.floor(Coeff / s + 0.5)
+        Y_hat = enc[:, 0] * s
+        mse = (torch.linalg.norm(Coeff[:, 0] - Y_hat) ** 2) / (N * 255 ** 2)      # :150-151
+        psnrs.append(float(-10 * torch.log10(mse)))
+        q = enc.index_select(0, order).to(torch.int32).numpy()
+        total = 0
+        for ch in range(3):
+            m = rlgr.membuf(); m.rlgrWrite(q[:, ch].tolist(), 1); m.close()
+            total += len(m.get_buffer())
+        sizes.append(total)
+        if s in (1, 16):
+            dec = torch.from_numpy(q).to(torch.float64) * s
+            recs[s] = inverse_RAHT_optimized(dec[torch.argsort(order), :], List, Flags, weights).numpy()
+    np.savez_compressed(os.path.join(HERE, "pipeline_ply_rgb.npz"), V=V.astype(np.int32), rgb=rgb, J=np.int32(J),
+                        yuv=Cyuv.numpy(), steps=np.array(steps, dtype=np.float64), size_bytes=np.array(sizes, dtype=np.int64),
+                        psnr_y=np.array(psnrs), crec_step1=recs[1], crec_step16=recs[16])
+    print("pipeline_ply_rgb: N=%d bytes=%s psnr=%s" % (N, sizes, [round(p, 2) for p in psnrs]))
+
+
+if __name__ == "__main__" and os.environ.get("GOLDEN_ONLY", "") in ("", "ply"):
+    encode_ply_case()

