@@ -641,9 +641,9 @@ static int tile_threads()
 {
     static int t = 0;
     if (t == 0) {
-        const char *e = getenv("RAHT_TILE_THREADS");      // tuning knob: 512 (default), 256 or 128
+        const char *e = getenv("RAHT_TILE_THREADS");      // tuning knob: 512 (default) or 256
         const int v = e ? atoi(e) : 512;
-        t = (v == 128 || v == 256 || v == 512) ? v : 512;
+        t = (v == 256 || v == 512) ? v : 512;
     }
     return t;
 }
