@@ -912,7 +912,14 @@ int raht_fwd_quant(const raht_plan *cp, const float *C, int64_t ldc, int D, cons
     Schedule *sc = nullptr;
     int Dc = 0;
     RAHT_RET(tile_setup<float>(p, D, s, &sc, &Dc));
-    if (!sc) { set_error("raht_fwd_quant needs the tile engine (use raht_fwd + raht_quant_reorder)"); return RAHT_ERR_UNSUPPORTED; }
+    if (!sc) {
+        // level engine (selected explicitly, or fallback for pathological key patterns): two passes
+        // through a pooled temporary (stream-ordered reuse; see Scratch in raht_common.h)
+        Scratch tmp(sizeof(float) * (size_t)p->N * (size_t)D);
+        if (!tmp.ok()) return RAHT_ERR_NOMEM;
+        RAHT_RET((run_level_engine<float, false>(p, C, ldc, tmp.as<float>(), D, D, s)));
+        return raht_quant_reorder(p, tmp.as<float>(), D, D, steps, n_steps, Q, ldq, stream);
+    }
     XformIO<float> io;
     io.src = C; io.ld_src = ldc; io.Q = Q; io.ldq = ldq; io.steps = steps; io.n_steps = n_steps;
     const int K = (int)sc->stages.size();
@@ -931,7 +938,12 @@ int raht_dequant_inv(const raht_plan *cp, const int32_t *Q, int64_t ldq, int D, 
     Schedule *sc = nullptr;
     int Dc = 0;
     RAHT_RET(tile_setup<float>(p, D, s, &sc, &Dc));
-    if (!sc) { set_error("raht_dequant_inv needs the tile engine (use raht_dequant_unreorder + raht_inv)"); return RAHT_ERR_UNSUPPORTED; }
+    if (!sc) {
+        Scratch tmp(sizeof(float) * (size_t)p->N * (size_t)D);
+        if (!tmp.ok()) return RAHT_ERR_NOMEM;
+        RAHT_RET(raht_dequant_unreorder(p, Q, ldq, D, steps, n_steps, tmp.as<float>(), D, stream));
+        return run_level_engine<float, true>(p, tmp.as<float>(), D, C, ldc, D, s);
+    }
     XformIO<float> io;
     io.dst = C; io.ld_dst = ldc; io.Q = const_cast<int32_t *>(Q); io.ldq = ldq; io.steps = steps; io.n_steps = n_steps;
     const int K = (int)sc->stages.size();

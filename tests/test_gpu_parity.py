@@ -501,3 +501,49 @@ def test_transform_entry_points_are_graph_capturable(rt):
     g.replay()
     torch.cuda.synchronize()
     assert torch.equal(Qg, ref_Q) and torch.equal(Rg, ref_R)
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_randomised_configurations(rt, seed):
+    """Random N / key width / channel count / dtype / truncation / tile geometry against the numpy
+    formulation of the list-free transform (tests/numpy_ops.py)."""
+    import torch
+    from tests.numpy_ops import NumpyPlan
+    rng = np.random.default_rng(5000 + seed)
+    nbits = int(rng.integers(1, 64))
+    nmax = min(20000, 1 << min(nbits, 20))
+    N = int(rng.integers(1, nmax + 1))
+    D = int(rng.choice([1, 2, 3, 5, 16, 31, 32, 33, 59, 63, 64, 65, 100, 128, 130]))
+    f64 = bool(rng.integers(0, 2))
+    hi = (1 << nbits) - 1
+    if nbits <= 20:
+        keys = np.sort(rng.choice(1 << nbits, size=N, replace=False)).astype(np.int64)
+    else:
+        keys = np.unique(rng.integers(0, hi, size=N + 64, dtype=np.int64, endpoint=True))[:N]
+        N = keys.shape[0]
+    top = int(rng.integers(1, nbits + 1)) if rng.random() < 0.4 else None
+    kt = torch.from_numpy(keys.copy())
+    ref = NumpyPlan(kt, nbits, top_level=top)
+    p = rt.RahtPlan.from_keys(kt.cuda(), nbits, top_level=top)
+    geo = [(0, 0, 0, 0), (64, 64, 0, 64), (128, 64, 8, 64), (64, 128, 5, 128), (192, 0, 0, 0)][int(rng.integers(0, 5))]
+    p.set_engine("tile" if rng.random() < 0.85 else "level", *geo)
+    assert np.array_equal(p.root_rows.cpu().numpy(), ref.root_rows.numpy())
+    C = rng.normal(size=(N, D)) * 10 ** rng.uniform(-2, 3)
+    Cd = torch.from_numpy(C if f64 else C.astype(np.float32)).cuda()
+    roots = torch.empty((p.n_roots, D), dtype=Cd.dtype, device="cuda")
+    T = p.forward(Cd, want_w=False, roots=roots)
+    r_ref = torch.empty((ref.n_roots, D), dtype=torch.float64)
+    T_ref = ref.forward(torch.from_numpy(Cd.cpu().numpy().astype(np.float64)), roots=r_ref).numpy()
+    scale = np.maximum(np.abs(T_ref).max(axis=0), 1e-300)
+    tol = 1e-12 if f64 else 3e-6
+    err = np.abs(T.cpu().numpy().astype(np.float64) - T_ref).max(axis=0) / scale
+    assert err.max() <= tol, (seed, N, D, nbits, top, geo, float(err.max()))
+    assert (np.abs(roots.cpu().numpy().astype(np.float64) - r_ref.numpy()).max(axis=0) / scale).max() <= tol
+    R = p.inverse(T, roots=roots)
+    assert (R - Cd).abs().max().item() <= (1e-11 if f64 else 2e-5) * max(Cd.abs().max().item(), 1e-30)
+    if not f64 and D <= 256:
+        steps = float(10 ** rng.uniform(-3, 0)) * float(np.abs(T_ref).max() + 1e-3) / 1000.0
+        Q1 = p.forward_quant(Cd, steps)
+        Q2 = p.quant_reorder(p.forward(Cd, want_w=False), steps)
+        assert torch.equal(Q1, Q2)
+        assert torch.equal(p.dequant_inverse(Q1, steps), p.inverse(p.dequant_unreorder(Q1, steps)))
