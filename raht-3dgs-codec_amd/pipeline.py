@@ -204,6 +204,32 @@ def format_row_ply(r):
             f"{r['Entropy_dec_time']:.6f},{r['Dequant_time']:.6f},{r['iRAHT_time']:.6f},{r['psnr']:.6f}")
 
 
+def compress_to_nvox(means, quats, scales, opacities, colors, J=10, device="cuda:0", output_ply=None):
+    """N Gaussians -> Nvox voxelized Gaussians: counterpart of the reference's compress_to_nvox
+    (python/test_voxelize_3dgs.py:160-288): voxelize the means (:203), use the sort permutation and
+    the voxel starts as cluster indices / offsets (:225-233), merge all attributes per voxel with
+    opacity weights (:247-257), and optionally save the voxelized frame with integer voxel
+    coordinates and the voxel_size / vmin header comments (:281-288) -- the input format of
+    ``encode_3dgs``. Returns (V_int int64 (Nvox,3), attributes float32 (Nvox, 8 + color_dim), info)."""
+    from .merge import merge_gaussian_clusters_with_indices
+    from .ops import voxelize_pc_batched
+    from .ply_io import save_ply
+    means = means.to(device).float().contiguous()
+    N = means.shape[0]
+    PCvox, _, voxel_indices, _, info = voxelize_pc_batched(means, J=J, device=device, residuals=False)
+    cluster_indices = info["sort_idx"].int()                                       # :225-226
+    cluster_offsets = torch.cat([voxel_indices, torch.tensor([N], dtype=torch.int64, device=means.device)]).int()   # :230-233
+    mm, mq, ms, mo, mc = merge_gaussian_clusters_with_indices(means, quats.to(device), scales.to(device),
+                                                              opacities.to(device), colors.to(device),
+                                                              cluster_indices, cluster_offsets, weight_by_opacity=True)
+    V_int = PCvox[:, :3].long()                                                    # :267
+    attributes = torch.cat([mq, ms, mo.unsqueeze(1), mc], dim=1)                   # layout of data_util.py:366
+    if output_ply is not None:
+        save_ply(output_ply, PCvox[:, :3], mq, ms, mo, mc, voxel_size=info["voxel_size"], vmin=info["vmin"])
+    info = dict(info, merged_means=mm, cluster_indices=cluster_indices, cluster_offsets=cluster_offsets)
+    return V_int, attributes, info
+
+
 def format_row(r):
     """One CSV line, same formatting as encode_3dgs.py:402-409."""
     return (f"{r['Frame']},{r['Quantization_Step']},{r['Rate_bpp']:.6f},"
