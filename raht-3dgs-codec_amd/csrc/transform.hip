@@ -181,6 +181,8 @@ constexpr int TILE_GATHER_U = 16;      // rows in flight per wave in the inverse
 constexpr int TILE_FWD_U = 8;          // same for the forward's strided-row loads
 constexpr int TILE_ROUND_U = 4;        // butterflies in flight per lane group in a round
 constexpr int TILE_PRE_ROWS = 12;      // survivor rows prefetched by the inverse before flags are known
+constexpr int TILE_PF_VEC = 6;         // PIPE: 16-byte vectors per lane holding the next tile's contiguous span
+constexpr int TILE_PF_ROWS = 24;       // PIPE, fused inverse: rows per wave of the next tile gathered ahead
 
 template <typename T, typename V>
 __device__ __forceinline__ void bulk_copy16(const V *__restrict__ g4, V *__restrict__ l4, int nvec, int tid, int nthreads)
@@ -216,10 +218,12 @@ struct TileMeta {
     int32_t row[SLOTS], wl[SLOTS], wr[SLOTS], pos[SLOTS];
     int lv[SLOTS];
     int64_t start_row, end_row;
-    uint32_t surv_base, surv_cnt;
+    uint32_t surv_raw;                 // lane l holds surv_off[t + (l & 1)]: a lane-dependent load, so that hipcc
+                                       // does not scalarise it on the spot (s_waitcnt + v_readfirstlane right
+                                       // after the load would also drain every older load, i.e. the prefetch)
 };
 
-template <typename T, bool IDENT, bool QM, int SLOTS>
+template <typename T, bool IDENT, bool QM, int SLOTS, bool NOPOS = false>
 __device__ __forceinline__ void load_tile_meta(const TileArgs<T> &A, int64_t t, int tid, int nthreads, TileMeta<SLOTS> &M)
 {
     const int R = A.R;
@@ -227,8 +231,8 @@ __device__ __forceinline__ void load_tile_meta(const TileArgs<T> &A, int64_t t, 
     const int nt = (int)min((int64_t)R, A.n_entries - e0);
     M.start_row = IDENT ? e0 : (int64_t)A.rows[e0];
     M.end_row = (e0 + R < A.n_entries) ? (IDENT ? e0 + R : (int64_t)A.rows[e0 + R]) : A.N;
-    M.surv_base = 0; M.surv_cnt = 0;
-    if (A.surv_off) { M.surv_base = A.surv_off[t]; M.surv_cnt = A.surv_off[t + 1] - M.surv_base; }
+    M.surv_raw = 0;
+    if (A.surv_off) M.surv_raw = A.surv_off[t + (tid & 1)];
 #pragma unroll
     for (int s = 0; s < SLOTS; ++s) {
         const int j = tid + s * nthreads;
@@ -242,7 +246,7 @@ __device__ __forceinline__ void load_tile_meta(const TileArgs<T> &A, int64_t t, 
             M.wl[s] = A.wl[e0 + j];
             M.wr[s] = A.wr[e0 + j];
             M.lv[s] = A.lvl[e0 + j];
-            M.pos[s] = QM ? (int32_t)A.inv_order[e0 + j] : (int32_t)r;    // where the final coefficient lives
+            if (!NOPOS) M.pos[s] = QM ? (int32_t)A.inv_order[e0 + j] : (int32_t)r;    // where the final coefficient lives
         }
     }
 }
@@ -251,7 +255,15 @@ __device__ __forceinline__ void load_tile_meta(const TileArgs<T> &A, int64_t t, 
 // are the later, much smaller stages. QM = true fuses quantize+reorder (forward) / un-reorder+
 // dequantize (inverse). Separate instantiations keep them apart in rocprof kernel statistics.
 // launch bounds: three 512-thread workgroups per CU = 6 waves per SIMD for float32 (<= 80 VGPRs)
-template <typename T, bool INV, bool IDENT, bool QM, int SLOTS>
+//
+// PIPE = true (stage 0 only, persistent workgroups): software pipeline across a workgroup's tiles.
+// A tile's life is load -> LDS -> ~20 barrier-separated butterfly rounds -> store, a latency chain of
+// ~18 us of which only the ends touch HBM, and LDS capacity fixes how many tiles a CU holds -- so
+// without overlap INSIDE a workgroup the chip idles at ~3.8 TB/s. With PIPE the NEXT tile's input is
+// fetched into registers (24 VGPRs: the contiguous span as 6 x 16 B per lane, or, for the fused
+// inverse, 24 row-granular Q rows per wave) before the current tile's rounds start, and lands in
+// LDS at the top of the next iteration.
+template <typename T, bool INV, bool IDENT, bool QM, int SLOTS, bool PIPE>
 __global__ __launch_bounds__(512, (sizeof(T) == 4 ? 6 : 4)) void tile_kernel(const TileArgs<T> A,
                                                    const typename std::conditional<QM, StepTable, NoSteps>::type ST)
 {
@@ -290,7 +302,59 @@ __global__ __launch_bounds__(512, (sizeof(T) == 4 ? 6 : 4)) void tile_kernel(con
     // ---- persistent loop over this workgroup's tiles; metadata of the next tile is prefetched ----
     const int64_t n_tiles = (A.n_entries + R - 1) / R;
     TileMeta<SLOTS> M;
-    if ((int64_t)blockIdx.x < n_tiles) load_tile_meta<T, IDENT, QM, SLOTS>(A, blockIdx.x, tid0, nthreads, M);
+    constexpr bool PF_BULK = PIPE && (!INV || !QM);       // next tile = one contiguous span (C, or T rows)
+    constexpr bool PF_GATH = PIPE && INV && QM;           // next tile = rows of Q at inv_order[row]
+    static_assert(!PIPE || (IDENT && SLOTS == 1), "PIPE is a stage-0 mode");
+    V16 pfv0, pfv1, pfv2, pfv3, pfv4, pfv5;               // TILE_PF_VEC named registers (an array ends up in scratch)
+    static_assert(TILE_PF_VEC == 6, "pfv0..pfv5");
+    int32_t pfg[PF_GATH ? TILE_PF_ROWS : 1];
+    int32_t pf_pos = 0;                                   // PF_GATH: Q position of this lane's row, two tiles ahead
+    const T *pf_src = INV ? (const T *)A.fin : A.in;
+    const int64_t pf_ld = INV ? A.ld_fin : A.ld_in;
+    // issue the loads of tile t's contiguous span; unconditional from clamped indices (see P0b)
+    auto pf_issue_bulk = [&](int64_t t, int tid) {
+        const int64_t e0n = t * R;
+        const int ntn = (int)min((int64_t)R, A.n_entries - e0n);
+        const int nvec = (ntn * Dc) / VN;
+        if (nvec > 0) {
+            const V16 *g4 = (const V16 *)(pf_src + e0n * pf_ld);
+            pfv0 = g4[min(tid, nvec - 1)];
+            pfv1 = g4[min(tid + nthreads, nvec - 1)];
+            pfv2 = g4[min(tid + 2 * nthreads, nvec - 1)];
+            pfv3 = g4[min(tid + 3 * nthreads, nvec - 1)];
+            pfv4 = g4[min(tid + 4 * nthreads, nvec - 1)];
+            pfv5 = g4[min(tid + 5 * nthreads, nvec - 1)];
+        }
+    };
+    // issue the row gathers of tile t; sdst[] holds its Q positions (written before the last barrier)
+    auto pf_issue_gather = [&](int64_t t, int tid) {
+        const int lane = tid & 63;
+        const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+        const int64_t e0n = t * R;
+        const int ntn = (int)min((int64_t)R, A.n_entries - e0n);
+        const int RWc = (R + nw - 1) / nw;
+        const int d_v = sdst[min(wid * RWc + min(lane, RWc - 1), ntn - 1)];
+        const int cl = min(lane, Dc - 1);
+#pragma unroll
+        for (int u = 0; u < TILE_PF_ROWS; ++u) {
+            const int64_t d = (int64_t)__builtin_amdgcn_readlane(d_v, u);
+            pfg[u] = A.Q[d * A.ldq + c_base + cl];
+        }
+    };
+    if ((int64_t)blockIdx.x < n_tiles) {
+        load_tile_meta<T, IDENT, QM, SLOTS, PF_GATH>(A, blockIdx.x, tid0, nthreads, M);
+        if constexpr (PF_BULK) pf_issue_bulk(blockIdx.x, tid0);
+        if constexpr (PF_GATH) {
+            const int64_t e00 = (int64_t)blockIdx.x * R;
+            const int nt0 = (int)min((int64_t)R, A.n_entries - e00);
+            if (tid0 < nt0) sdst[tid0] = (int32_t)A.inv_order[e00 + tid0];
+            __syncthreads();
+            pf_issue_gather(blockIdx.x, tid0);
+            __syncthreads();                              // sdst is rewritten at the top of the loop
+            const int64_t t1 = (int64_t)blockIdx.x + gridDim.x;
+            if (t1 < n_tiles) pf_pos = (int32_t)A.inv_order[min(t1 * R + tid0, A.n_entries - 1)];
+        }
+    }
     for (int64_t tile_id = blockIdx.x; tile_id < n_tiles; tile_id += gridDim.x) {
     // Re-derive the lane-dependent indices every iteration from an opaque copy of the thread id:
     // otherwise the compiler hoists dozens of lane-dependent addresses out of this long loop body
@@ -302,7 +366,8 @@ __global__ __launch_bounds__(512, (sizeof(T) == 4 ? 6 : 4)) void tile_kernel(con
     const int64_t e0 = tile_id * R;
     const int nt = (int)min((int64_t)R, A.n_entries - e0);
     const int64_t start_row = M.start_row, end_row = M.end_row;
-    const uint32_t surv_base = M.surv_base, surv_cnt = M.surv_cnt;
+    const uint32_t surv_base = (uint32_t)__builtin_amdgcn_readlane((int)M.surv_raw, 0);
+    const uint32_t surv_cnt = (uint32_t)__builtin_amdgcn_readlane((int)M.surv_raw, 1) - surv_base;
     int32_t m_row[SLOTS], m_wl[SLOTS], m_wr[SLOTS], m_pos[SLOTS];
     int m_lv[SLOTS];
 #pragma unroll
@@ -313,7 +378,35 @@ __global__ __launch_bounds__(512, (sizeof(T) == 4 ? 6 : 4)) void tile_kernel(con
 
     // ---- P0b. bulk transfers whose addresses do not depend on the plan metadata ----
     bool bulk_done = false;                   // tile already holds every slot's input
-    if (!INV) {
+    if constexpr (PF_BULK) {
+        // this tile's span was fetched during the previous tile's rounds; fetch the next one now
+        const int nvec = (nt * Dc) / VN;
+        V16 *l4 = (V16 *)tile;
+        if (tid < nvec) l4[tid] = pfv0;
+        if (tid + nthreads < nvec) l4[tid + nthreads] = pfv1;
+        if (tid + 2 * nthreads < nvec) l4[tid + 2 * nthreads] = pfv2;
+        if (tid + 3 * nthreads < nvec) l4[tid + 3 * nthreads] = pfv3;
+        if (tid + 4 * nthreads < nvec) l4[tid + 4 * nthreads] = pfv4;
+        if (tid + 5 * nthreads < nvec) l4[tid + 5 * nthreads] = pfv5;
+        for (int e = nvec * VN + tid; e < nt * Dc; e += nthreads) tile[e] = pf_src[e0 * pf_ld + e];
+        // every register of this tile's metadata is "used" here, so that its wait sits BEFORE the
+        // prefetch is issued (loads return in order: a later wait would also drain the prefetch)
+        asm volatile("" :: "v"(m_row[0]), "v"(m_wl[0]), "v"(m_wr[0]), "v"(m_pos[0]), "v"(m_lv[0]), "s"(surv_cnt));
+        __builtin_amdgcn_s_waitcnt(0x0F70);               // vmcnt(0): see the metadata prefetch below
+        if (tile_id + gridDim.x < n_tiles) pf_issue_bulk(tile_id + gridDim.x, tid);
+        bulk_done = true;
+    } else if constexpr (PF_GATH) {
+        const int RWc = (R + nw - 1) / nw;
+#pragma unroll
+        for (int u = 0; u < TILE_PF_ROWS; ++u) {
+            const int j = wid * RWc + u;
+            if (u < RWc && j < nt && lane < Dc) tile[j * Dc + lane] = (T)pfg[u] * (T)my_step;   // encode_3dgs.py:261
+        }
+        if (tile_id + gridDim.x < n_tiles && tid < R) sdst[tid] = pf_pos;                     // next tile's Q positions
+        bulk_done = true;
+    }
+    if (PIPE && !INV) {
+    } else if (!INV) {
         if (A.vec_io) {                       // the stage's entries are one contiguous span
             bulk_copy16<T, V16>((const V16 *)(A.in + e0 * A.ld_in), (V16 *)tile, (nt * Dc) / VN, tid, nthreads);
             for (int e = ((nt * Dc) / VN) * VN + tid; e < nt * Dc; e += nthreads) tile[e] = A.in[e0 * A.ld_in + e];
@@ -331,7 +424,7 @@ __global__ __launch_bounds__(512, (sizeof(T) == 4 ? 6 : 4)) void tile_kernel(con
         }
         bulk_done = true;
     } else {
-        if (IDENT && !QM && A.vec_fin) {      // stage 0: coefficient rows [e0, e0+nt) of T are contiguous
+        if (!PIPE && IDENT && !QM && A.vec_fin) {      // stage 0: coefficient rows [e0, e0+nt) of T are contiguous
             bulk_copy16<T, V16>((const V16 *)(A.fin + e0 * A.ld_fin), (V16 *)tile, (nt * Dc) / VN, tid, nthreads);
             for (int e = ((nt * Dc) / VN) * VN + tid; e < nt * Dc; e += nthreads) tile[e] = A.fin[e0 * A.ld_fin + e];
             bulk_done = true;
@@ -347,7 +440,7 @@ __global__ __launch_bounds__(512, (sizeof(T) == 4 ? 6 : 4)) void tile_kernel(con
 #pragma unroll
     for (int s = 0; s < SLOTS; ++s) {
         const int j = tid + s * nthreads;
-        if (j < nt) { if (!IDENT) srow[j] = m_row[s]; if (QM) sdst[j] = m_pos[s]; }
+        if (j < nt) { if (!IDENT) srow[j] = m_row[s]; if (QM && !PF_GATH) sdst[j] = m_pos[s]; }
     }
     __syncthreads();                                                       // sync #1
 
@@ -467,15 +560,30 @@ __global__ __launch_bounds__(512, (sizeof(T) == 4 ? 6 : 4)) void tile_kernel(con
     // ---- P3b. inverse: drop the survivors' low-pass rows (from the stage above) into their slots
     if (INV && !A.last_stage && !(A.dbg & 2)) {
         const int cl = min(lane, Dc - 1);
-        for (uint32_t q0 = wid * 4; q0 < surv_cnt; q0 += nw * 4) {
+        // (a) the first TILE_PRE_ROWS survivors were prefetched into spre: LDS -> LDS, no wait on HBM
+        //     (kept apart from (b): a value that may come from either source makes hipcc wait for
+        //     every outstanding global load, including the next tile's prefetch)
+        const uint32_t n_pre = min(surv_cnt, (uint32_t)TILE_PRE_ROWS);
+        for (uint32_t q0 = wid * 4; q0 < n_pre; q0 += nw * 4) {
             T v[4]; int jj[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) jj[u] = (int)ssurv[min(q0 + u, surv_cnt - 1)];
+            for (int u = 0; u < 4; ++u) {
+                const uint32_t q = min(q0 + u, n_pre - 1);
+                jj[u] = (int)ssurv[q];
+                v[u] = spre[q * Dc + cl];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (q0 + u < n_pre && lane < Dc) tile[jj[u] * Dc + lane] = v[u];
+        }
+        // (b) the rest (tiles with many survivors) straight from the workspace
+        for (uint32_t q0 = TILE_PRE_ROWS + wid * 4; q0 < surv_cnt; q0 += nw * 4) {
+            T v[4]; int jj[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const uint32_t q = min(q0 + u, surv_cnt - 1);
-                if (q0 + 3 < (uint32_t)TILE_PRE_ROWS) v[u] = spre[q * Dc + cl];      // wave-uniform choice
-                else v[u] = A.wsn[(int64_t)(surv_base + q) * A.ld_ws + c_base + cl];
+                jj[u] = (int)ssurv[q];
+                v[u] = A.wsn[(int64_t)(surv_base + q) * A.ld_ws + c_base + cl];
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u)
@@ -492,7 +600,22 @@ __global__ __launch_bounds__(512, (sizeof(T) == 4 ? 6 : 4)) void tile_kernel(con
     __syncthreads();                                                       // sync #4
 
     // prefetch the next tile's plan metadata: the loads stay in flight during the butterflies
-    if (tile_id + gridDim.x < n_tiles) load_tile_meta<T, IDENT, QM, SLOTS>(A, tile_id + gridDim.x, tid, nthreads, M);
+    if constexpr (PF_GATH) {
+        // Tell hipcc's wait-count bookkeeping that nothing older is outstanding (true here: every
+        // load of this tile has been consumed). Otherwise the first later reuse of a register that
+        // an OPTIONAL load of this tile may have written (weighted leaves, survivors beyond the
+        // prefetched ones) gets an s_waitcnt vmcnt(0), which would drain the prefetch as well.
+        __builtin_amdgcn_s_waitcnt(0x0F70);               // vmcnt(0)
+    }
+    if constexpr (PF_GATH) {
+        const int64_t t2 = tile_id + 2 * (int64_t)gridDim.x;
+        if (t2 < n_tiles) pf_pos = (int32_t)A.inv_order[min(t2 * R + tid, A.n_entries - 1)];
+    }
+    if (tile_id + gridDim.x < n_tiles) load_tile_meta<T, IDENT, QM, SLOTS, PF_GATH>(A, tile_id + gridDim.x, tid, nthreads, M);
+    if constexpr (PF_GATH) {
+        // the next tile's Q rows: issued last, after every optional global load of this tile
+        if (tile_id + gridDim.x < n_tiles) pf_issue_gather(tile_id + gridDim.x, tid);
+    }
 
     // ---- P4. butterflies, one round per level present ----
     {
@@ -669,6 +792,13 @@ static bool persist_enabled()
     return v == 1;
 }
 
+static bool pipe_enabled()
+{
+    static int v = -1;
+    if (v < 0) { const char *e = getenv("RAHT_TILE_PIPE"); v = (e && atoi(e) == 0) ? 0 : 1; }     // tuning knob, default on
+    return v == 1;
+}
+
 static int lp_shift_for(int Dc)
 {
     int s = 0;
@@ -685,12 +815,12 @@ struct XformIO {
     const float *steps = nullptr; int n_steps = 0;
 };
 
-template <typename T, bool INV, bool IDENT, bool QM, int SLOTS>
+template <typename T, bool INV, bool IDENT, bool QM, int SLOTS, bool PIPE = false>
 static int launch_tile_one(const TileArgs<T> &A, const XformIO<T> &io, dim3 grid, int threads, size_t lds, hipStream_t s)
 {
     static bool attr_set = false;
     if (!attr_set) {
-        RAHT_HIP_CHECK(hipFuncSetAttribute((const void *)tile_kernel<T, INV, IDENT, QM, SLOTS>,
+        RAHT_HIP_CHECK(hipFuncSetAttribute((const void *)tile_kernel<T, INV, IDENT, QM, SLOTS, PIPE>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
@@ -698,10 +828,10 @@ static int launch_tile_one(const TileArgs<T> &A, const XformIO<T> &io, dim3 grid
         StepTable st;
         st.n = io.n_steps;
         for (int c = 0; c < io.n_steps; ++c) st.v[c] = io.steps[c];
-        hipLaunchKernelGGL((tile_kernel<T, INV, IDENT, true, SLOTS>), grid, dim3(threads), lds, s, A, st);
+        hipLaunchKernelGGL((tile_kernel<T, INV, IDENT, true, SLOTS, PIPE>), grid, dim3(threads), lds, s, A, st);
     } else {
         NoSteps ns{0};
-        hipLaunchKernelGGL((tile_kernel<T, INV, IDENT, false, SLOTS>), grid, dim3(threads), lds, s, A, ns);
+        hipLaunchKernelGGL((tile_kernel<T, INV, IDENT, false, SLOTS, PIPE>), grid, dim3(threads), lds, s, A, ns);
     }
     RAHT_HIP_CHECK(hipGetLastError());
     return RAHT_OK;
@@ -757,9 +887,21 @@ static int launch_tile_stage(const raht_plan *p, const Schedule &sc, int k, cons
     // per CU), each walking tiles blockIdx.x, blockIdx.x + gridDim.x, ...
     const int per_cu = std::max(1, std::min((int)(128 / ((lds + 1279) / 1280)), 32 / (threads / 64)));
     const int64_t resident = (int64_t)per_cu * device_cus();
-    const int64_t gx = persist_enabled() ? std::min<int64_t>(st.n_tiles, std::max<int64_t>(1, resident / nchunks)) : st.n_tiles;
+    // stage 0 with more tiles than the chip holds: pipelined persistent workgroups (see tile_kernel)
+    const int64_t pgrid = p->pipe_grid > 0 ? p->pipe_grid : std::max<int64_t>(1, resident);
+    bool pipe = pipe_enabled() && p->pipe_mode != 0 && st.rows == nullptr && one_chunk && st.tile_rows <= threads &&
+                p->pipe_mode == 1 &&      // opt-in for now: measured slower than one tile per workgroup (VALU-bound kernel)
+                (size_t)st.tile_rows * Dc * sizeof(T) <= (size_t)TILE_PF_VEC * 16 * threads;
+    if (pipe) {
+        if (!INV) pipe = A.vec_io != 0;
+        else if (!QM) pipe = A.vec_fin != 0;
+        else pipe = st.tile_rows <= TILE_PF_ROWS * (threads / 64);
+    }
+    const int64_t gx = pipe ? std::min<int64_t>(st.n_tiles, pgrid)
+                            : (persist_enabled() ? std::min<int64_t>(st.n_tiles, std::max<int64_t>(1, resident / nchunks)) : st.n_tiles);
     const dim3 grid((unsigned)gx, (unsigned)nchunks);
     const bool one = st.tile_rows <= threads;
+    if (pipe) return launch_tile_one<T, INV, true, QM, 1, true>(A, io, grid, threads, lds, s);
     if (st.rows == nullptr)
         return one ? launch_tile_one<T, INV, true, QM, 1>(A, io, grid, threads, lds, s)
                    : launch_tile_one<T, INV, true, QM, 2>(A, io, grid, threads, lds, s);
