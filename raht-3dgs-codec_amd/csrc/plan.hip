@@ -178,12 +178,25 @@ __global__ void stage_survivor_kernel(const uint32_t *__restrict__ rows, int64_t
     survivor[j] = merged ? 0u : 1u;
 }
 
-int pick_chunk_channels(int elem_size, int D)
+// Channels per chunk (<= max_dc) such that every chunk, the last one included, holds at least one
+// whole 16-byte lane chunk (the tile kernel fetches a row's tail as the 16 bytes that end with it).
+static int fit_chunk_channels(int elem_size, int D, int max_dc)
 {
-    (void)elem_size;
-    const int nchunks = (D + 63) / 64;
-    return (D + nchunks - 1) / nchunks;
+    const int vn = 16 / elem_size;
+    const int hi = std::max(std::min(max_dc, 64), vn);
+    if (D <= hi) return D;
+    for (int Dc = hi; Dc >= vn; --Dc) {
+        const int r = D % Dc;
+        if (r == 0 || r >= vn) return Dc;
+    }
+    for (int Dc = hi + 1; Dc <= 64; ++Dc) {               // nothing that narrow fits: widen
+        const int r = D % Dc;
+        if (r == 0 || r >= vn) return Dc;
+    }
+    return std::min(D, 64);                               // not reached (61..64 cover every remainder for D > 64)
 }
+
+int pick_chunk_channels(int elem_size, int D) { return fit_chunk_channels(elem_size, D, 64); }
 
 size_t tile_lds_bytes(int R, int elem_size, int Dc, bool ident, bool qm)
 {
@@ -191,10 +204,12 @@ size_t tile_lds_bytes(int R, int elem_size, int Dc, bool ident, bool qm)
     // Q position (fused quantization only), flag + histograms (1 KiB) + survivor slot list
     // (R x uint16) + the inverse's survivor prefetch area (12 rows)
     // (must match the carve-up in transform.hip: tile_kernel)
-    size_t data = ((size_t)R * Dc * elem_size + 15) & ~(size_t)15;
+    const int vn = 16 / elem_size;
+    const size_t Dp = (size_t)((Dc + vn - 1) / vn) * vn;                 // rows padded to whole 16-byte chunks
+    size_t data = (size_t)R * Dp * elem_size;
     size_t meta = (size_t)R * ((elem_size == 4 ? 16 : 24) + (ident ? 0 : 4) + (qm ? 4 : 0) + 1);
     size_t surv = ((size_t)R * 2 + 15) & ~(size_t)15;
-    return data + ((meta + 15) & ~(size_t)15) + 1024 + surv + (size_t)12 * Dc * elem_size;
+    return data + ((meta + 15) & ~(size_t)15) + 1024 + surv + (size_t)12 * Dp * elem_size;
 }
 
 int pick_tile_rows(const raht_plan *plan, int elem_size, int Dc)
@@ -204,7 +219,7 @@ int pick_tile_rows(const raht_plan *plan, int elem_size, int Dc)
     // 1280 bytes, so each workgroup may use 42 granules. Measured best on MI355X for the
     // 59-channel float32 case (R = 192); see DESIGN.md for the sweep.
     const size_t budget = (size_t)42 * 1280;
-    for (int R = 512; R >= 64; R -= 32)
+    for (int R = 512; R >= 64; R -= 8)
         if (tile_lds_bytes(R, elem_size, Dc, true, elem_size == 4) <= budget) return R;
     return 0;
 }
@@ -218,7 +233,7 @@ void pick_tail_geometry(const raht_plan *plan, int elem_size, int D, int stage0_
     // (one workgroup per CU, no overlap): 1.02 vs 0.955 ms per fused step.
     int Dc = std::min(D, 64), R = stage0_rows;
     if (D > 64) Dc = pick_chunk_channels(elem_size, D);
-    if (plan->tail_chunk_override > 0) Dc = std::min(plan->tail_chunk_override, std::min(D, 64));
+    if (plan->tail_chunk_override > 0) Dc = fit_chunk_channels(elem_size, D, std::min(plan->tail_chunk_override, std::min(D, 64)));
     if (plan->tail_rows_override > 0) {
         R = plan->tail_rows_override;
         while (R > 64 && tile_lds_bytes(R, elem_size, Dc, false, elem_size == 4) > (size_t)128 * 1280) R -= 64;

@@ -155,10 +155,9 @@ struct TileArgs {
     int R;
     int D;
     int Dc;              // channels per chunk (blockIdx.y selects the chunk)
-    int lp_shift;        // log2 of the lane-group size (>= Dc, power of two, <= 64)
+    int Dp;              // LDS row stride: Dc rounded up to a whole 16-byte chunk
+    int lg;              // log2 of the lanes per row (2^lg >= chunks per row)
     int last_stage;      // this is the top stage of the schedule
-    int vec_io;          // the entry-ordered side (in / out) is contiguous and 16-byte aligned
-    int vec_fin;         // stage 0 only: T rows [e0, e0+R) are contiguous and aligned (bulk path)
     int dbg;             // profiling ablations (raht_debug_run_stage only): 1 = skip butterflies,
                          // 2 = skip merge resolution too (pure staged copy). Always 0 in transforms.
     const uint8_t *lvl;
@@ -177,36 +176,79 @@ template <> struct __align__(16) MRec<float> { uint32_t po; uint32_t jo; float a
 template <> struct __align__(8) MRec<double> { uint32_t po; uint32_t jo; double a; double b; };
 
 constexpr int TILE_MAX_SLOTS = 2;      // slots per thread (template SLOTS = 1 or 2): R <= SLOTS * blockDim
-constexpr int TILE_GATHER_U = 16;      // rows in flight per wave in the inverse's row-granular gathers
-constexpr int TILE_FWD_U = 8;          // same for the forward's strided-row loads
-constexpr int TILE_ROUND_U = 4;        // butterflies in flight per lane group in a round
+constexpr int TILE_IO_U = 6;           // row chunks in flight per lane in the load / gather phases
+constexpr int TILE_ROUND_U = 2;        // butterflies in flight per lane group in a round
 constexpr int TILE_PRE_ROWS = 12;      // survivor rows prefetched by the inverse before flags are known
-constexpr int TILE_PF_VEC = 6;         // PIPE: 16-byte vectors per lane holding the next tile's contiguous span
-constexpr int TILE_PF_ROWS = 24;       // PIPE, fused inverse: rows per wave of the next tile gathered ahead
+constexpr int TILE_PF_VEC = 6;         // PIPE: 16-byte chunks per lane holding the next tile's rows
 
-template <typename T, typename V>
-__device__ __forceinline__ void bulk_copy16(const V *__restrict__ g4, V *__restrict__ l4, int nvec, int tid, int nthreads)
+// ---- row chunks: one lane moves 16 bytes (VN = 16 / sizeof(T) consecutive channels) of one row --------
+// Registers / LDS (16-byte aligned: ds_read_b128 / ds_write_b128) ...
+template <typename E> struct alignas(16) RegChunk { E v[16 / sizeof(E)]; };
+// ... and global memory, where a row starts on an element boundary only (59 channels: 236-byte rows).
+// gfx950 global loads / stores of 8..16 bytes need element alignment only.
+template <typename E> struct __attribute__((packed, aligned(sizeof(E)))) MemChunk { E v[16 / sizeof(E)]; };
+
+// Loading the nv <= VN valid elements at p is split in two so that several loads can be in flight:
+// ld_chunk_raw issues the load and returns the register image as it arrived, fix_chunk (called where
+// the chunk is consumed) turns it into "valid elements first, zero padded". Both are branch-free: a
+// load inside a divergent branch costs an exec-mask region with its own s_waitcnt, i.e. one serialised
+// HBM round trip per chunk. A partial chunk (the last one of a row whose length is not a multiple of
+// VN) is fetched as the 16 bytes that END with it -- VN - nv elements earlier, always inside the row,
+// because the host only runs this kernel on channel chunks of at least VN channels -- and shifted
+// down in registers.
+template <typename E>
+__device__ __forceinline__ RegChunk<E> ld_chunk_raw(const E *__restrict__ p, int nv)
 {
-    for (int v0 = tid; v0 < nvec; v0 += 8 * nthreads) {           // 8 x 16 B in flight per lane
-        V x0, x1, x2, x3, x4, x5, x6, x7;
-        const int i1 = v0 + nthreads, i2 = v0 + 2 * nthreads, i3 = v0 + 3 * nthreads, i4 = v0 + 4 * nthreads,
-                  i5 = v0 + 5 * nthreads, i6 = v0 + 6 * nthreads, i7 = v0 + 7 * nthreads;
-        x0 = g4[v0];
-        if (i1 < nvec) x1 = g4[i1];
-        if (i2 < nvec) x2 = g4[i2];
-        if (i3 < nvec) x3 = g4[i3];
-        if (i4 < nvec) x4 = g4[i4];
-        if (i5 < nvec) x5 = g4[i5];
-        if (i6 < nvec) x6 = g4[i6];
-        if (i7 < nvec) x7 = g4[i7];
-        l4[v0] = x0;
-        if (i1 < nvec) l4[i1] = x1;
-        if (i2 < nvec) l4[i2] = x2;
-        if (i3 < nvec) l4[i3] = x3;
-        if (i4 < nvec) l4[i4] = x4;
-        if (i5 < nvec) l4[i5] = x5;
-        if (i6 < nvec) l4[i6] = x6;
-        if (i7 < nvec) l4[i7] = x7;
+    constexpr int VN = 16 / sizeof(E);
+    const MemChunk<E> t = *(const MemChunk<E> *)(p - (VN - nv));
+    RegChunk<E> x;
+#pragma unroll
+    for (int i = 0; i < VN; ++i) x.v[i] = t.v[i];
+    return x;
+}
+
+template <typename E>
+__device__ __forceinline__ RegChunk<E> fix_chunk(const RegChunk<E> &raw, int nv)
+{
+    constexpr int VN = 16 / sizeof(E);
+    E v[VN];
+#pragma unroll
+    for (int i = 0; i < VN; ++i) v[i] = raw.v[i];
+    const int back = VN - nv;
+#pragma unroll
+    for (int sh = 1; sh < VN; sh <<= 1) {                // barrel shift down by `back` elements, zero fill
+        const bool on = (back & sh) != 0;
+#pragma unroll
+        for (int i = 0; i < VN; ++i) {
+            const E moved = (i + sh < VN) ? v[i + sh] : (E)0;
+            v[i] = on ? moved : v[i];
+        }
+    }
+    RegChunk<E> x;
+#pragma unroll
+    for (int i = 0; i < VN; ++i) x.v[i] = v[i];
+    return x;
+}
+
+template <typename E>
+__device__ __forceinline__ RegChunk<E> ld_chunk(const E *__restrict__ p, int nv)
+{
+    return fix_chunk<E>(ld_chunk_raw<E>(p, nv), nv);
+}
+
+template <typename E>
+__device__ __forceinline__ void st_chunk(E *__restrict__ p, const RegChunk<E> &x, int nv)
+{
+    constexpr int VN = 16 / sizeof(E);
+    if (nv == VN) {
+        MemChunk<E> t;
+#pragma unroll
+        for (int i = 0; i < VN; ++i) t.v[i] = x.v[i];
+        *(MemChunk<E> *)p = t;
+    } else {
+#pragma unroll
+        for (int i = 0; i < VN; ++i)
+            if (i < nv) p[i] = x.v[i];
     }
 }
 
@@ -251,33 +293,46 @@ __device__ __forceinline__ void load_tile_meta(const TileArgs<T> &A, int64_t t, 
     }
 }
 
+// The six prefetch registers of the pipelined mode, as named variables (an array ends up in scratch).
+#define RAHT_PF_EACH(OP) OP(0, pf0) OP(1, pf1) OP(2, pf2) OP(3, pf3) OP(4, pf4) OP(5, pf5)
+
 // IDENT = true is stage 0 (entries are the rows themselves: the HBM-heavy launch); IDENT = false
 // are the later, much smaller stages. QM = true fuses quantize+reorder (forward) / un-reorder+
 // dequantize (inverse). Separate instantiations keep them apart in rocprof kernel statistics.
 // launch bounds: three 512-thread workgroups per CU = 6 waves per SIMD for float32 (<= 80 VGPRs)
 //
-// PIPE = true (stage 0 only, persistent workgroups): software pipeline across a workgroup's tiles.
-// A tile's life is load -> LDS -> ~20 barrier-separated butterfly rounds -> store, a latency chain of
-// ~18 us of which only the ends touch HBM, and LDS capacity fixes how many tiles a CU holds -- so
-// without overlap INSIDE a workgroup the chip idles at ~3.8 TB/s. With PIPE the NEXT tile's input is
-// fetched into registers (24 VGPRs: the contiguous span as 6 x 16 B per lane, or, for the fused
-// inverse, 24 row-granular Q rows per wave) before the current tile's rounds start, and lands in
-// LDS at the top of the next iteration.
+// Lane mapping. The kernel is bound by instruction issue, not by HBM (rocprofv3 SQ_INSTS_VALU: the
+// one-channel-per-lane version spent ~9.4k vector instructions per 192 x 59 tile and kept the VALUs
+// ~70 % busy at 3.8 TB/s), so every data-touching phase works on 16-byte chunks: a lane owns VN
+// consecutive channels of a row, G = 2^lg >= ceil(Dc / VN) lanes cover a row, and one wave
+// instruction moves 64 / G rows (59 float channels: 15 chunks, G = 16, 4 rows). LDS rows are padded
+// to Dp = Dc rounded up to VN so that every chunk is a 16-byte-aligned ds_read/write_b128; global
+// rows need element alignment only. A butterfly is one ds_read_b128 per operand and lane.
+//
+// PIPE = true (stage 0 only, persistent workgroups): software pipeline across a workgroup's tiles:
+// the NEXT tile's input (6 chunks per lane = 24 VGPRs) is fetched into registers while the current
+// tile's rounds run, and lands in LDS at the top of the next iteration.
 template <typename T, bool INV, bool IDENT, bool QM, int SLOTS, bool PIPE>
 __global__ __launch_bounds__(512, (sizeof(T) == 4 ? 6 : 4)) void tile_kernel(const TileArgs<T> A,
                                                    const typename std::conditional<QM, StepTable, NoSteps>::type ST)
 {
     extern __shared__ __align__(16) unsigned char smem[];
-    typedef typename Vec16<T>::type V16;
-    constexpr int VN = Vec16<T>::n;
+    typedef RegChunk<T> V16;
+    typedef typename std::conditional<QM, int32_t, T>::type RawT;       // what the prefetch registers hold
+    typedef RegChunk<RawT> RawChunk;
+    constexpr int VN = 16 / sizeof(T);
+    static_assert(sizeof(RawT) == sizeof(T), "fused quantization is a float32 mode");
     const int R = A.R;
     const int tid0 = threadIdx.x;
     const int nthreads = blockDim.x, nw = nthreads >> 6;
     const int c_base = blockIdx.y * A.Dc;
     const int Dc = min(A.Dc, A.D - c_base);
+    const int Dp = A.Dp;                                  // LDS row stride in elements
+    const int lg = A.lg, lr = 6 - A.lg;                   // log2(lanes per row), log2(rows per wave instruction)
+    const int NC = (Dc + VN - 1) / VN;                    // chunks per row
 
     // ---- LDS carve-up (must match tile_lds_bytes) ----
-    size_t off = ((size_t)R * A.Dc * sizeof(T) + 15) & ~(size_t)15;
+    size_t off = (size_t)R * Dp * sizeof(T);
     T *tile = (T *)smem;
     MRec<T> *mrec = (MRec<T> *)(smem + off); off += (size_t)R * sizeof(MRec<T>);
     int32_t *srow = (int32_t *)(smem + off); if (!IDENT) off += (size_t)R * 4;   // stage 0: row = e0 + slot
@@ -292,64 +347,65 @@ __global__ __launch_bounds__(512, (sizeof(T) == 4 ? 6 : 4)) void tile_kernel(con
     off += 1024;
     uint16_t *ssurv = (uint16_t *)(smem + off);           // [R] slots of this tile's survivors, by rank
     off += ((size_t)R * 2 + 15) & ~(size_t)15;
-    T *spre = (T *)(smem + off);                          // inverse: [TILE_PRE_ROWS * Dc] survivor prefetch
-
-    // quantization step of this lane's channel (row-granular paths map lane -> channel): one
-    // kernarg read at kernel start instead of one inside every gather / scatter iteration
-    float my_step = 1.0f;
-    if constexpr (QM) my_step = ST.v[ST.n == 1 ? 0 : c_base + min(tid0 & 63, Dc - 1)];
+    T *spre = (T *)(smem + off);                          // inverse: [TILE_PRE_ROWS * Dp] survivor prefetch
 
     // ---- persistent loop over this workgroup's tiles; metadata of the next tile is prefetched ----
     const int64_t n_tiles = (A.n_entries + R - 1) / R;
     TileMeta<SLOTS> M;
-    constexpr bool PF_BULK = PIPE && (!INV || !QM);       // next tile = one contiguous span (C, or T rows)
-    constexpr bool PF_GATH = PIPE && INV && QM;           // next tile = rows of Q at inv_order[row]
+    constexpr bool PF_BULK = PIPE && (!INV || !QM);       // next tile's rows: C (forward) or T (plain inverse)
+    constexpr bool PF_GATH = PIPE && INV && QM;           // next tile's rows: Q at inv_order[row]
     static_assert(!PIPE || (IDENT && SLOTS == 1), "PIPE is a stage-0 mode");
-    V16 pfv0, pfv1, pfv2, pfv3, pfv4, pfv5;               // TILE_PF_VEC named registers (an array ends up in scratch)
-    static_assert(TILE_PF_VEC == 6, "pfv0..pfv5");
-    int32_t pfg[PF_GATH ? TILE_PF_ROWS : 1];
+    RawChunk pf0, pf1, pf2, pf3, pf4, pf5;
+    static_assert(TILE_PF_VEC == 6, "pf0..pf5");
     int32_t pf_pos = 0;                                   // PF_GATH: Q position of this lane's row, two tiles ahead
-    const T *pf_src = INV ? (const T *)A.fin : A.in;
-    const int64_t pf_ld = INV ? A.ld_fin : A.ld_in;
-    // issue the loads of tile t's contiguous span; unconditional from clamped indices (see P0b)
-    auto pf_issue_bulk = [&](int64_t t, int tid) {
-        const int64_t e0n = t * R;
-        const int ntn = (int)min((int64_t)R, A.n_entries - e0n);
-        const int nvec = (ntn * Dc) / VN;
-        if (nvec > 0) {
-            const V16 *g4 = (const V16 *)(pf_src + e0n * pf_ld);
-            pfv0 = g4[min(tid, nvec - 1)];
-            pfv1 = g4[min(tid + nthreads, nvec - 1)];
-            pfv2 = g4[min(tid + 2 * nthreads, nvec - 1)];
-            pfv3 = g4[min(tid + 3 * nthreads, nvec - 1)];
-            pfv4 = g4[min(tid + 4 * nthreads, nvec - 1)];
-            pfv5 = g4[min(tid + 5 * nthreads, nvec - 1)];
-        }
+
+    // lane -> (row within the wave instruction, chunk); the same for every tile
+    auto lane_geom = [&](int tid, int &lane, int &wid, int &g, int &coff, int &nv, bool &active) {
+        lane = tid & 63;
+        wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+        g = lane >> lg;
+        const int c4 = lane & ((1 << lg) - 1);
+        active = c4 < NC;
+        const int c4c = min(c4, NC - 1);                  // idle lanes shadow the last chunk (loads stay valid)
+        coff = c4c * VN;
+        nv = min(VN, Dc - coff);
     };
-    // issue the row gathers of tile t; sdst[] holds its Q positions (written before the last barrier)
-    auto pf_issue_gather = [&](int64_t t, int tid) {
-        const int lane = tid & 63;
-        const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // issue the loads of tile t's rows into pf0..pf5; every load is unconditional from a clamped row
+    // (a predicated load compiles to an exec-mask region with its own s_waitcnt)
+    auto pf_issue = [&](int64_t t, int tid) {
+        int lane, wid, g, coff, nv; bool active;
+        lane_geom(tid, lane, wid, g, coff, nv, active);
         const int64_t e0n = t * R;
         const int ntn = (int)min((int64_t)R, A.n_entries - e0n);
-        const int RWc = (R + nw - 1) / nw;
-        const int d_v = sdst[min(wid * RWc + min(lane, RWc - 1), ntn - 1)];
-        const int cl = min(lane, Dc - 1);
+#define RAHT_PF_LOAD(U, REG)                                                                          \
+        {                                                                                             \
+            const int j = min(((wid + U * nw) << lr) + g, ntn - 1);                                    \
+            if constexpr (PF_GATH) REG = ld_chunk_raw<RawT>((const RawT *)A.Q + (int64_t)sdst[j] * A.ldq + c_base + coff, nv); \
+            else REG = ld_chunk_raw<RawT>((const RawT *)(INV ? (const T *)A.fin : A.in) + (e0n + j) * (INV ? A.ld_fin : A.ld_in) + c_base + coff, nv); \
+        }
+        RAHT_PF_EACH(RAHT_PF_LOAD)
+#undef RAHT_PF_LOAD
+    };
+
+    // quantization steps of this lane's channels: kernarg reads at kernel start, not per row
+    float my_step[VN];
 #pragma unroll
-        for (int u = 0; u < TILE_PF_ROWS; ++u) {
-            const int64_t d = (int64_t)__builtin_amdgcn_readlane(d_v, u);
-            pfg[u] = A.Q[d * A.ldq + c_base + cl];
-        }
-    };
+    for (int i = 0; i < VN; ++i) my_step[i] = 1.0f;
+    if constexpr (QM) {
+        const int c4c = min((tid0 & 63) & ((1 << lg) - 1), NC - 1);
+#pragma unroll
+        for (int i = 0; i < VN; ++i) my_step[i] = ST.v[ST.n == 1 ? 0 : min(c_base + c4c * VN + i, A.D - 1)];
+    }
+
     if ((int64_t)blockIdx.x < n_tiles) {
         load_tile_meta<T, IDENT, QM, SLOTS, PF_GATH>(A, blockIdx.x, tid0, nthreads, M);
-        if constexpr (PF_BULK) pf_issue_bulk(blockIdx.x, tid0);
+        if constexpr (PF_BULK) pf_issue(blockIdx.x, tid0);
         if constexpr (PF_GATH) {
             const int64_t e00 = (int64_t)blockIdx.x * R;
             const int nt0 = (int)min((int64_t)R, A.n_entries - e00);
             if (tid0 < nt0) sdst[tid0] = (int32_t)A.inv_order[e00 + tid0];
             __syncthreads();
-            pf_issue_gather(blockIdx.x, tid0);
+            pf_issue(blockIdx.x, tid0);
             __syncthreads();                              // sdst is rewritten at the top of the loop
             const int64_t t1 = (int64_t)blockIdx.x + gridDim.x;
             if (t1 < n_tiles) pf_pos = (int32_t)A.inv_order[min(t1 * R + tid0, A.n_entries - 1)];
@@ -361,8 +417,8 @@ __global__ __launch_bounds__(512, (sizeof(T) == 4 ? 6 : 4)) void tile_kernel(con
     // and spills them (register budget: 80 VGPRs for three workgroups per CU).
     int tid = tid0;
     asm volatile("" : "+v"(tid));
-    const int lane = tid & 63;
-    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int lane, wid, g, coff, nv; bool active;
+    lane_geom(tid, lane, wid, g, coff, nv, active);
     const int64_t e0 = tile_id * R;
     const int nt = (int)min((int64_t)R, A.n_entries - e0);
     const int64_t start_row = M.start_row, end_row = M.end_row;
@@ -376,65 +432,62 @@ __global__ __launch_bounds__(512, (sizeof(T) == 4 ? 6 : 4)) void tile_kernel(con
     }
     if (tid < 64) hist[tid] = 0;
 
-    // ---- P0b. bulk transfers whose addresses do not depend on the plan metadata ----
-    bool bulk_done = false;                   // tile already holds every slot's input
-    if constexpr (PF_BULK) {
-        // this tile's span was fetched during the previous tile's rounds; fetch the next one now
-        const int nvec = (nt * Dc) / VN;
-        V16 *l4 = (V16 *)tile;
-        if (tid < nvec) l4[tid] = pfv0;
-        if (tid + nthreads < nvec) l4[tid + nthreads] = pfv1;
-        if (tid + 2 * nthreads < nvec) l4[tid + 2 * nthreads] = pfv2;
-        if (tid + 3 * nthreads < nvec) l4[tid + 3 * nthreads] = pfv3;
-        if (tid + 4 * nthreads < nvec) l4[tid + 4 * nthreads] = pfv4;
-        if (tid + 5 * nthreads < nvec) l4[tid + 5 * nthreads] = pfv5;
-        for (int e = nvec * VN + tid; e < nt * Dc; e += nthreads) tile[e] = pf_src[e0 * pf_ld + e];
-        // every register of this tile's metadata is "used" here, so that its wait sits BEFORE the
-        // prefetch is issued (loads return in order: a later wait would also drain the prefetch)
-        asm volatile("" :: "v"(m_row[0]), "v"(m_wl[0]), "v"(m_wr[0]), "v"(m_pos[0]), "v"(m_lv[0]), "s"(surv_cnt));
-        __builtin_amdgcn_s_waitcnt(0x0F70);               // vmcnt(0): see the metadata prefetch below
-        if (tile_id + gridDim.x < n_tiles) pf_issue_bulk(tile_id + gridDim.x, tid);
-        bulk_done = true;
-    } else if constexpr (PF_GATH) {
-        const int RWc = (R + nw - 1) / nw;
+    // dequantize (fused inverse) / pass through a raw chunk and drop it into its LDS row
+    auto put_row = [&](int j, const RawChunk &raw0) {
+        const RawChunk raw = fix_chunk<RawT>(raw0, nv);
+        V16 x;
 #pragma unroll
-        for (int u = 0; u < TILE_PF_ROWS; ++u) {
-            const int j = wid * RWc + u;
-            if (u < RWc && j < nt && lane < Dc) tile[j * Dc + lane] = (T)pfg[u] * (T)my_step;   // encode_3dgs.py:261
+        for (int i = 0; i < VN; ++i) {
+            x.v[i] = (T)raw.v[i];
+            if constexpr (QM && INV) x.v[i] = x.v[i] * (T)my_step[i];                     // encode_3dgs.py:261
         }
-        if (tile_id + gridDim.x < n_tiles && tid < R) sdst[tid] = pf_pos;                     // next tile's Q positions
-        bulk_done = true;
-    }
-    if (PIPE && !INV) {
-    } else if (!INV) {
-        if (A.vec_io) {                       // the stage's entries are one contiguous span
-            bulk_copy16<T, V16>((const V16 *)(A.in + e0 * A.ld_in), (V16 *)tile, (nt * Dc) / VN, tid, nthreads);
-            for (int e = ((nt * Dc) / VN) * VN + tid; e < nt * Dc; e += nthreads) tile[e] = A.in[e0 * A.ld_in + e];
-        } else {                              // strided rows / channel chunk
-            const int cl = min(lane, Dc - 1);                // clamped: loads are unconditional
-            for (int j0 = wid * TILE_FWD_U; j0 < nt; j0 += nw * TILE_FWD_U) {
-                T v[TILE_FWD_U];
+        if (j < nt && active) *(V16 *)&tile[j * Dp + coff] = x;
+    };
+
+    // ---- P0b. row transfers whose addresses do not depend on the plan metadata ----
+    bool input_done = false;                  // tile already holds every slot's input
+    if constexpr (PIPE) {
+        // this tile's rows were fetched during the previous tile's rounds
+#define RAHT_PF_PUT(U, REG) put_row(((wid + U * nw) << lr) + g, REG);
+        RAHT_PF_EACH(RAHT_PF_PUT)
+#undef RAHT_PF_PUT
+        if constexpr (PF_GATH) {
+            if (tile_id + gridDim.x < n_tiles && tid < R) sdst[tid] = pf_pos;             // next tile's Q positions
+        } else {
+            // every register of this tile's metadata is "used" here, so that its wait sits BEFORE the
+            // prefetch is issued (loads return in order: a later wait would also drain the prefetch)
+            asm volatile("" :: "v"(m_row[0]), "v"(m_wl[0]), "v"(m_wr[0]), "v"(m_pos[0]), "v"(m_lv[0]), "s"(surv_cnt));
+            __builtin_amdgcn_s_waitcnt(0x0F70);           // vmcnt(0): see the metadata prefetch below
+            if (tile_id + gridDim.x < n_tiles) pf_issue(tile_id + gridDim.x, tid);
+        }
+        input_done = true;
+    } else if (!INV || (IDENT && !QM)) {
+        // forward: this stage's entries, entry order (C or ws_k); plain inverse of stage 0: T rows [e0, e0+nt)
+        const T *src = INV ? (const T *)A.fin : A.in;
+        const int64_t lds = INV ? A.ld_fin : A.ld_in;
+        for (int it0 = wid; (it0 << lr) < nt; it0 += nw * TILE_IO_U) {
+            V16 x[TILE_IO_U];
 #pragma unroll
-                for (int u = 0; u < TILE_FWD_U; ++u)
-                    v[u] = A.in[(e0 + min(j0 + u, nt - 1)) * A.ld_in + c_base + cl];
+            for (int u = 0; u < TILE_IO_U; ++u) {
+                const int j = min(((it0 + u * nw) << lr) + g, nt - 1);
+                x[u] = ld_chunk_raw<T>(src + (e0 + j) * lds + c_base + coff, nv);
+            }
 #pragma unroll
-                for (int u = 0; u < TILE_FWD_U; ++u)
-                    if (j0 + u < nt && lane < Dc) tile[(j0 + u) * Dc + lane] = v[u];
+            for (int u = 0; u < TILE_IO_U; ++u) {
+                const int j = ((it0 + u * nw) << lr) + g;
+                if (j < nt && active) *(V16 *)&tile[j * Dp + coff] = fix_chunk<T>(x[u], nv);
             }
         }
-        bulk_done = true;
-    } else {
-        if (!PIPE && IDENT && !QM && A.vec_fin) {      // stage 0: coefficient rows [e0, e0+nt) of T are contiguous
-            bulk_copy16<T, V16>((const V16 *)(A.fin + e0 * A.ld_fin), (V16 *)tile, (nt * Dc) / VN, tid, nthreads);
-            for (int e = ((nt * Dc) / VN) * VN + tid; e < nt * Dc; e += nthreads) tile[e] = A.fin[e0 * A.ld_fin + e];
-            bulk_done = true;
-        }
+        input_done = true;
+    }
+    if (INV) {
         // survivors of this tile were produced by the stage above: one contiguous chunk of ws_{k+1}
         // (the top stage has no stage above it: its survivors are the roots, handled in P3b)
-        const int npre = A.last_stage ? 0 : (int)min(surv_cnt, (uint32_t)TILE_PRE_ROWS) * Dc;
-        for (int e = tid; e < npre; e += nthreads) {
-            const int rr = e / Dc, cc = e - rr * Dc;
-            spre[e] = A.wsn[(int64_t)(surv_base + rr) * A.ld_ws + c_base + cc];
+        const int npre = A.last_stage ? 0 : (int)min(surv_cnt, (uint32_t)TILE_PRE_ROWS);
+        for (int it = wid; (it << lr) < npre; it += nw) {
+            const int q = (it << lr) + g;
+            const V16 x = ld_chunk<T>(A.wsn + (int64_t)(surv_base + min(q, npre - 1)) * A.ld_ws + c_base + coff, nv);
+            if (q < npre && active) *(V16 *)&spre[q * Dp + coff] = x;
         }
     }
 #pragma unroll
@@ -444,35 +497,19 @@ __global__ __launch_bounds__(512, (sizeof(T) == 4 ? 6 : 4)) void tile_kernel(con
     }
     __syncthreads();                                                       // sync #1
 
-    // inverse without a bulk path: gather every slot's coefficient row now (survivor slots get
-    // overwritten in P3b) -- the addresses only need sdst
-    if (INV && !bulk_done) {
-        const int cl = min(lane, Dc - 1);
-        for (int j0 = wid * TILE_GATHER_U; j0 < nt; j0 += nw * TILE_GATHER_U) {
-            // Branch-free: every load is unconditional from a clamped (valid) address, raw values
-            // stay in registers until all TILE_GATHER_U loads of the wave are in flight; only the
-            // LDS stores are predicated. (Predicated loads compile to one exec-mask region each
-            // with its own s_waitcnt, i.e. TILE_GATHER_U serialised HBM round trips.)
-            typedef typename std::conditional<QM, int32_t, T>::type RawT;
-            int64_t src_row[TILE_GATHER_U];
+    // inverse of the later stages / fused inverse: gather every slot's coefficient row now (survivor
+    // slots get overwritten in P3b) -- the addresses need srow / sdst
+    if (INV && !input_done) {
+        for (int it0 = wid; (it0 << lr) < nt; it0 += nw * TILE_IO_U) {
+            RawChunk x[TILE_IO_U];
 #pragma unroll
-            for (int u = 0; u < TILE_GATHER_U; ++u) {
-                const int j = min(j0 + u, nt - 1);
-                if constexpr (QM) src_row[u] = (int64_t)sdst[j];
-                else src_row[u] = IDENT ? e0 + j : (int64_t)srow[j];
-            }
-            RawT v[TILE_GATHER_U];
-#pragma unroll
-            for (int u = 0; u < TILE_GATHER_U; ++u) {
-                if constexpr (QM) v[u] = A.Q[src_row[u] * A.ldq + c_base + cl];
-                else v[u] = A.fin[src_row[u] * A.ld_fin + c_base + cl];
+            for (int u = 0; u < TILE_IO_U; ++u) {
+                const int j = min(((it0 + u * nw) << lr) + g, nt - 1);
+                if constexpr (QM) x[u] = ld_chunk_raw<RawT>((const RawT *)A.Q + (int64_t)sdst[j] * A.ldq + c_base + coff, nv);
+                else x[u] = ld_chunk_raw<RawT>((const RawT *)A.fin + (int64_t)srow[j] * A.ld_fin + c_base + coff, nv);
             }
 #pragma unroll
-            for (int u = 0; u < TILE_GATHER_U; ++u) {
-                T x = (T)v[u];
-                if constexpr (QM) x = x * (T)my_step;                                     // encode_3dgs.py:261
-                if (j0 + u < nt && lane < Dc) tile[(j0 + u) * Dc + lane] = x;
-            }
+            for (int u = 0; u < TILE_IO_U; ++u) put_row(((it0 + u * nw) << lr) + g, x[u]);
         }
     }
 
@@ -492,6 +529,7 @@ __global__ __launch_bounds__(512, (sizeof(T) == 4 ? 6 : 4)) void tile_kernel(con
             sflag[j] = m_merged[s] ? 1 : (A.last_stage ? 2 : 0);
             if (m_merged[s]) atomicAdd(&hist[m_lv[s]], 1u);
         }
+        if (j < nt && (A.dbg & 2)) sflag[j] = 1;
         const uint64_t bal = __ballot(surv);
         m_rank[s] = __popcll(bal & lt);
         if (lane == 0 && s * nw + wid < 32) scnt[s * nw + wid] = (uint32_t)__popcll(bal);
@@ -549,8 +587,8 @@ __global__ __launch_bounds__(512, (sizeof(T) == 4 ? 6 : 4)) void tile_kernel(con
             pair_weights(r, l, m_wr[s], A.wsum, w0, w1);
             const double den = w0 + w1;
             MRec<T> rec;
-            rec.po = (uint32_t)(p * Dc);
-            rec.jo = (uint32_t)(j * Dc);
+            rec.po = (uint32_t)(p * Dp);
+            rec.jo = (uint32_t)(j * Dp);
             rec.a = (T)sqrt(w0 / den);                    // RAHT.py:321-322
             rec.b = (T)sqrt(w1 / den);
             const uint32_t pos = atomicAdd(&cursor[m_lv[s]], 1u);
@@ -559,42 +597,31 @@ __global__ __launch_bounds__(512, (sizeof(T) == 4 ? 6 : 4)) void tile_kernel(con
     }
     // ---- P3b. inverse: drop the survivors' low-pass rows (from the stage above) into their slots
     if (INV && !A.last_stage && !(A.dbg & 2)) {
-        const int cl = min(lane, Dc - 1);
         // (a) the first TILE_PRE_ROWS survivors were prefetched into spre: LDS -> LDS, no wait on HBM
         //     (kept apart from (b): a value that may come from either source makes hipcc wait for
         //     every outstanding global load, including the next tile's prefetch)
         const uint32_t n_pre = min(surv_cnt, (uint32_t)TILE_PRE_ROWS);
-        for (uint32_t q0 = wid * 4; q0 < n_pre; q0 += nw * 4) {
-            T v[4]; int jj[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const uint32_t q = min(q0 + u, n_pre - 1);
-                jj[u] = (int)ssurv[q];
-                v[u] = spre[q * Dc + cl];
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-                if (q0 + u < n_pre && lane < Dc) tile[jj[u] * Dc + lane] = v[u];
+        for (uint32_t it = wid; (it << lr) < n_pre; it += nw) {
+            const uint32_t q = (it << lr) + g;
+            const uint32_t qc = min(q, n_pre - 1);
+            const V16 x = *(const V16 *)&spre[qc * Dp + coff];
+            if (q < n_pre && active) *(V16 *)&tile[(int)ssurv[qc] * Dp + coff] = x;
         }
         // (b) the rest (tiles with many survivors) straight from the workspace
-        for (uint32_t q0 = TILE_PRE_ROWS + wid * 4; q0 < surv_cnt; q0 += nw * 4) {
-            T v[4]; int jj[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const uint32_t q = min(q0 + u, surv_cnt - 1);
-                jj[u] = (int)ssurv[q];
-                v[u] = A.wsn[(int64_t)(surv_base + q) * A.ld_ws + c_base + cl];
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-                if (q0 + u < surv_cnt && lane < Dc) tile[jj[u] * Dc + lane] = v[u];
+        for (uint32_t it = wid; TILE_PRE_ROWS + (it << lr) < surv_cnt; it += nw) {
+            const uint32_t q = TILE_PRE_ROWS + (it << lr) + g;
+            const uint32_t qc = min(q, surv_cnt - 1);
+            const V16 x = ld_chunk<T>(A.wsn + (int64_t)(surv_base + qc) * A.ld_ws + c_base + coff, nv);
+            if (q < surv_cnt && active) *(V16 *)&tile[(int)ssurv[qc] * Dp + coff] = x;
         }
     }
     // top stage of the inverse: the roots' low-pass values may come from a compact caller buffer
     if (INV && A.last_stage && A.root_buf && !(A.dbg & 2)) {
-        for (uint32_t q = wid; q < surv_cnt; q += nw) {
-            const int j = ssurv[q];
-            if (lane < Dc) tile[j * Dc + lane] = A.root_buf[(int64_t)(surv_base + q) * A.D + c_base + lane];
+        for (uint32_t it = wid; (it << lr) < surv_cnt; it += nw) {
+            const uint32_t q = (it << lr) + g;
+            const uint32_t qc = min(q, surv_cnt - 1);
+            const V16 x = ld_chunk<T>(A.root_buf + (int64_t)(surv_base + qc) * A.D + c_base + coff, nv);
+            if (q < surv_cnt && active) *(V16 *)&tile[(int)ssurv[qc] * Dp + coff] = x;
         }
     }
     __syncthreads();                                                       // sync #4
@@ -606,56 +633,54 @@ __global__ __launch_bounds__(512, (sizeof(T) == 4 ? 6 : 4)) void tile_kernel(con
         // an OPTIONAL load of this tile may have written (weighted leaves, survivors beyond the
         // prefetched ones) gets an s_waitcnt vmcnt(0), which would drain the prefetch as well.
         __builtin_amdgcn_s_waitcnt(0x0F70);               // vmcnt(0)
-    }
-    if constexpr (PF_GATH) {
         const int64_t t2 = tile_id + 2 * (int64_t)gridDim.x;
         if (t2 < n_tiles) pf_pos = (int32_t)A.inv_order[min(t2 * R + tid, A.n_entries - 1)];
     }
     if (tile_id + gridDim.x < n_tiles) load_tile_meta<T, IDENT, QM, SLOTS, PF_GATH>(A, tile_id + gridDim.x, tid, nthreads, M);
     if constexpr (PF_GATH) {
         // the next tile's Q rows: issued last, after every optional global load of this tile
-        if (tile_id + gridDim.x < n_tiles) pf_issue_gather(tile_id + gridDim.x, tid);
+        if (tile_id + gridDim.x < n_tiles) pf_issue(tile_id + gridDim.x, tid);
     }
 
-    // ---- P4. butterflies, one round per level present ----
+    // ---- P4. butterflies, one round per level present; a lane group handles one butterfly ----
     {
-        const int Lp = 1 << A.lp_shift;
-        const int gpw = 64 >> A.lp_shift;
-        const int g = lane >> A.lp_shift, c = lane & (Lp - 1);
-        const uint32_t stride = (uint32_t)(nw * gpw);
+        const uint32_t stride = (uint32_t)(nw << lr);
         uint64_t mask = ((uint64_t)lmask[1] << 32) | lmask[0];
         if (A.dbg & 1) mask = 0;
         while (mask) {
             const int l = INV ? (63 - __clzll((long long)mask)) : (__ffsll((long long)mask) - 1);
             mask &= ~(1ull << l);
             const uint32_t base = loff[l], cnt = hist[l];
-            const uint32_t cc = (uint32_t)min(c, Dc - 1);         // idle lanes read a valid column
             // branch-free body: reads are clamped to valid records (redundant, harmless), only
             // the writes are predicated -> TILE_ROUND_U independent LDS chains in flight per lane
-            for (uint32_t mb = wid * gpw + g; mb < cnt + g; mb += stride * TILE_ROUND_U) {
+            for (uint32_t mb = (uint32_t)(wid << lr) + g; mb < cnt + g; mb += stride * TILE_ROUND_U) {
                 uint32_t ip[TILE_ROUND_U], ij[TILE_ROUND_U];
-                T ca[TILE_ROUND_U], cb[TILE_ROUND_U], x0[TILE_ROUND_U], x1[TILE_ROUND_U];
+                T ca[TILE_ROUND_U], cb[TILE_ROUND_U];
+                V16 x0[TILE_ROUND_U], x1[TILE_ROUND_U];
 #pragma unroll
                 for (int u = 0; u < TILE_ROUND_U; ++u) {
                     const uint32_t m = min(mb + u * stride, cnt - 1);
                     const MRec<T> rec = mrec[base + m];
-                    ip[u] = rec.po + cc;
-                    ij[u] = rec.jo + cc;
+                    ip[u] = rec.po + coff;
+                    ij[u] = rec.jo + coff;
                     ca[u] = rec.a; cb[u] = rec.b;
                 }
 #pragma unroll
-                for (int u = 0; u < TILE_ROUND_U; ++u) { x0[u] = tile[ip[u]]; x1[u] = tile[ij[u]]; }
+                for (int u = 0; u < TILE_ROUND_U; ++u) { x0[u] = *(const V16 *)&tile[ip[u]]; x1[u] = *(const V16 *)&tile[ij[u]]; }
 #pragma unroll
                 for (int u = 0; u < TILE_ROUND_U; ++u) {
-                    T lo, hi;
-                    if (!INV) {                           // RAHT.py:331-332
-                        lo = ca[u] * x0[u] + cb[u] * x1[u];
-                        hi = ca[u] * x1[u] - cb[u] * x0[u];
-                    } else {                              // iRAHT.py:108-109
-                        lo = ca[u] * x0[u] - cb[u] * x1[u];
-                        hi = cb[u] * x0[u] + ca[u] * x1[u];
+                    V16 lo, hi;
+#pragma unroll
+                    for (int i = 0; i < VN; ++i) {
+                        if (!INV) {                       // RAHT.py:331-332
+                            lo.v[i] = ca[u] * x0[u].v[i] + cb[u] * x1[u].v[i];
+                            hi.v[i] = ca[u] * x1[u].v[i] - cb[u] * x0[u].v[i];
+                        } else {                          // iRAHT.py:108-109
+                            lo.v[i] = ca[u] * x0[u].v[i] - cb[u] * x1[u].v[i];
+                            hi.v[i] = cb[u] * x0[u].v[i] + ca[u] * x1[u].v[i];
+                        }
                     }
-                    if ((mb + u * stride < cnt) && (c < Dc)) { tile[ip[u]] = lo; tile[ij[u]] = hi; }
+                    if ((mb + u * stride < cnt) && active) { *(V16 *)&tile[ip[u]] = lo; *(V16 *)&tile[ij[u]] = hi; }
                 }
             }
             __syncthreads();
@@ -665,79 +690,38 @@ __global__ __launch_bounds__(512, (sizeof(T) == 4 ? 6 : 4)) void tile_kernel(con
     // ---- P5. write back ----
     if (INV) {
         // the whole tile, entry order: stage 0 -> C rows [e0, e0+nt); stage k -> ws_k
-        if (A.vec_io) {
-            V16 *g4 = (V16 *)(A.out + e0 * A.ld_out);
-            const V16 *l4 = (const V16 *)tile;
-            const int nvec = (nt * Dc) / VN;
-            for (int v = tid; v < nvec; v += nthreads) g4[v] = l4[v];
-            for (int e = nvec * VN + tid; e < nt * Dc; e += nthreads) A.out[e0 * A.ld_out + e] = tile[e];
-        } else {
-            for (int j = wid; j < nt; j += nw)
-                if (lane < Dc) A.out[(e0 + j) * A.ld_out + c_base + lane] = tile[j * Dc + lane];
+        for (int it = wid; (it << lr) < nt; it += nw) {
+            const int j = (it << lr) + g;
+            const V16 x = *(const V16 *)&tile[min(j, nt - 1) * Dp + coff];
+            if (j < nt && active) st_chunk<T>(A.out + (e0 + j) * A.ld_out + c_base + coff, x, nv);
         }
     } else {
-        const bool bulk_fin = IDENT && !QM && A.vec_fin;
-        if (bulk_fin) {
-            // stage 0: T rows [e0, e0+nt) in one span (survivor rows are rewritten by later stages)
-            V16 *g4 = (V16 *)(A.fin + e0 * A.ld_fin);
-            const V16 *l4 = (const V16 *)tile;
-            const int nvec = (nt * Dc) / VN;
-            for (int v = tid; v < nvec; v += nthreads) g4[v] = l4[v];
-            for (int e = nvec * VN + tid; e < nt * Dc; e += nthreads) A.fin[e0 * A.ld_fin + e] = tile[e];
-        }
-        // survivors (a few per tile): compacted into ws_{k+1} in rank order; at the top stage the
-        // survivors are the roots, optionally exported to the caller's compact root buffer
+        // survivors, compacted, to the next stage's workspace (top stage: the caller's root buffer)
         if (!(A.dbg & 2) && (!A.last_stage || A.root_buf)) {
             T *dstb = A.last_stage ? A.root_buf : A.wsn;
             const int64_t ldb = A.last_stage ? (int64_t)A.D : A.ld_ws;
-            for (uint32_t q = wid; q < surv_cnt; q += nw) {
-                const int j = ssurv[q];
-                if (lane < Dc) dstb[(int64_t)(surv_base + q) * ldb + c_base + lane] = tile[j * Dc + lane];
+            for (uint32_t it = wid; (it << lr) < surv_cnt; it += nw) {
+                const uint32_t q = (it << lr) + g;
+                const V16 x = *(const V16 *)&tile[(int)ssurv[min(q, surv_cnt - 1)] * Dp + coff];
+                if (q < surv_cnt && active) st_chunk<T>(dstb + (int64_t)(surv_base + q) * ldb + c_base + coff, x, nv);
             }
         }
-        // rows finalised here, row-granular (later stages, strided T, or fused quantization).
-        // Each wave owns a contiguous run of rows; lane l fetches the flag / destination of the
-        // run's l-th row ONCE (vector LDS read), rows are then walked with readlane broadcasts and
-        // batched data reads. (Reading the wave-uniform flag / destination per row from LDS makes
-        // hipcc emit a serialised ds_read -> s_waitcnt -> v_readfirstlane -> branch chain per row.)
-        if (!bulk_fin) {
-            const int RW = (nt + nw - 1) / nw;                    // rows per wave
-            const int cl = min(lane, Dc - 1);
-            if (RW <= 64) {
-                const int jb = wid * RW;
-                int fl_v = 0, d_v = 0;
-                if (lane < RW && jb + lane < nt) {
-                    const int j = jb + lane;
-                    fl_v = (A.dbg & 2) ? 1 : (int)sflag[j];
-                    d_v = QM ? sdst[j] : (IDENT ? (int)(e0 + j) : srow[j]);
-                    if (QM && A.root_buf && fl_v == 2) fl_v = 0;  // roots are quantized by the caller's top stage
-                }
-                for (int u0 = 0; u0 < RW; u0 += 8) {
-                    T x[8];
+        // rows finalised here: T[row], or, fused, quantized to Q[inv_order[row]] (encode_3dgs.py:204,210,215)
+        for (int it = wid; (it << lr) < nt; it += nw) {
+            const int j = (it << lr) + g;
+            const int jc = min(j, nt - 1);
+            int fl = (int)sflag[jc];
+            if (QM && A.root_buf && fl == 2) fl = 0;      // roots are quantized by the caller's top stage
+            const V16 x = *(const V16 *)&tile[jc * Dp + coff];
+            if (j < nt && active && fl != 0) {
+                if constexpr (QM) {
+                    RegChunk<int32_t> qv;
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) x[u] = tile[min(jb + u0 + u, nt - 1) * Dc + cl];
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) {
-                        const int fl = __builtin_amdgcn_readlane(fl_v, (u0 + u) & 63);
-                        const int64_t d = (int64_t)__builtin_amdgcn_readlane(d_v, (u0 + u) & 63);
-                        if (u0 + u < RW && jb + u0 + u < nt && fl != 0 && lane < Dc) {
-                            if constexpr (QM)       // encode_3dgs.py:204,210,215
-                                A.Q[d * A.ldq + c_base + lane] = (int32_t)floorf((float)x[u] / my_step + 0.5f);
-                            else
-                                A.fin[d * A.ld_fin + c_base + lane] = x[u];
-                        }
-                    }
-                }
-            } else {                                              // very large tiles: plain loop
-                for (int j = wid; j < nt; j += nw) {
-                    int fl = (A.dbg & 2) ? 1 : (int)sflag[j];
-                    if (QM && A.root_buf && fl == 2) fl = 0;
-                    const int64_t d = QM ? (int64_t)sdst[j] : (IDENT ? e0 + j : (int64_t)srow[j]);
-                    if (fl != 0 && lane < Dc) {
-                        const T xx = tile[j * Dc + lane];
-                        if constexpr (QM) A.Q[d * A.ldq + c_base + lane] = (int32_t)floorf((float)xx / my_step + 0.5f);
-                        else A.fin[d * A.ld_fin + c_base + lane] = xx;
-                    }
+                    for (int i = 0; i < VN; ++i) qv.v[i] = (int32_t)floorf((float)x.v[i] / my_step[i] + 0.5f);
+                    st_chunk<int32_t>(A.Q + (int64_t)sdst[jc] * A.ldq + c_base + coff, qv, nv);
+                } else {
+                    const int64_t d = IDENT ? e0 + j : (int64_t)srow[jc];
+                    st_chunk<T>(A.fin + d * A.ld_fin + c_base + coff, x, nv);
                 }
             }
         }
@@ -745,6 +729,7 @@ __global__ __launch_bounds__(512, (sizeof(T) == 4 ? 6 : 4)) void tile_kernel(con
     __syncthreads();              // LDS is reused by the next tile
     }                             // persistent tile loop
 }
+#undef RAHT_PF_EACH
 
 // node weights of RAHT.py:325-328: after its own butterfly a right sibling carries w0 + w1 and is
 // never touched again; row 0 ends with the total weight.
@@ -850,7 +835,11 @@ static int launch_tile_stage(const raht_plan *p, const Schedule &sc, int k, cons
     const int K = (int)sc.stages.size();
     TileArgs<T> A;
     A.rows = st.rows; A.surv_off = st.surv_off; A.n_entries = st.n_entries; A.N = p->N; A.R = st.tile_rows;
-    A.D = D; A.Dc = Dc; A.lp_shift = lp_shift_for(Dc);
+    A.D = D; A.Dc = Dc;
+    constexpr int VN = 16 / (int)sizeof(T);
+    A.Dp = (Dc + VN - 1) / VN * VN;
+    A.lg = 0;
+    while ((1 << A.lg) < A.Dp / VN) ++A.lg;               // lanes per row: power of two >= chunks per row (Dc <= 64)
     A.last_stage = (k == K - 1) ? 1 : 0;
     A.wsum = p->wsum;
     if (st.rows) { A.lvl = st.e_lvl; A.wl = st.e_wl; A.wr = st.e_wr; A.inv_order = st.e_pos; }
@@ -862,19 +851,14 @@ static int launch_tile_stage(const raht_plan *p, const Schedule &sc, int k, cons
     A.wsn = (k + 1 < K) ? (T *)sc.stages[(size_t)k + 1].ws : nullptr;
     T *ws_k = (k >= 1) ? (T *)st.ws : nullptr;
     const bool one_chunk = (Dc == D);
-    auto aligned = [](const void *q) { return ((uintptr_t)q % 16) == 0; };
     if (!INV) {
         A.in = (k == 0) ? io.src : ws_k; A.ld_in = (k == 0) ? io.ld_src : D;
         A.fin = io.dst; A.ld_fin = io.ld_dst;
         A.out = nullptr; A.ld_out = 0;
-        A.vec_io = (one_chunk && A.ld_in == D && aligned(A.in)) ? 1 : 0;
-        A.vec_fin = (k == 0 && one_chunk && io.dst && io.ld_dst == D && aligned(io.dst)) ? 1 : 0;
     } else {
         A.in = nullptr; A.ld_in = 0;
         A.fin = const_cast<T *>(io.src); A.ld_fin = io.ld_src;
         A.out = (k == 0) ? io.dst : ws_k; A.ld_out = (k == 0) ? io.ld_dst : D;
-        A.vec_io = (one_chunk && A.ld_out == D && aligned(A.out)) ? 1 : 0;
-        A.vec_fin = (k == 0 && one_chunk && io.src && io.ld_src == D && aligned(io.src)) ? 1 : 0;
     }
     const int nchunks = (D + Dc - 1) / Dc;
     const size_t lds = tile_lds_bytes(st.tile_rows, (int)sizeof(T), Dc, st.rows == nullptr, QM);
@@ -891,12 +875,7 @@ static int launch_tile_stage(const raht_plan *p, const Schedule &sc, int k, cons
     const int64_t pgrid = p->pipe_grid > 0 ? p->pipe_grid : std::max<int64_t>(1, resident);
     bool pipe = pipe_enabled() && p->pipe_mode != 0 && st.rows == nullptr && one_chunk && st.tile_rows <= threads &&
                 p->pipe_mode == 1 &&      // opt-in for now: measured slower than one tile per workgroup (VALU-bound kernel)
-                (size_t)st.tile_rows * Dc * sizeof(T) <= (size_t)TILE_PF_VEC * 16 * threads;
-    if (pipe) {
-        if (!INV) pipe = A.vec_io != 0;
-        else if (!QM) pipe = A.vec_fin != 0;
-        else pipe = st.tile_rows <= TILE_PF_ROWS * (threads / 64);
-    }
+                ((st.tile_rows + (64 >> A.lg) - 1) >> (6 - A.lg)) <= TILE_PF_VEC * (threads / 64);   // 6 chunks per lane hold a tile
     const int64_t gx = pipe ? std::min<int64_t>(st.n_tiles, pgrid)
                             : (persist_enabled() ? std::min<int64_t>(st.n_tiles, std::max<int64_t>(1, resident / nchunks)) : st.n_tiles);
     const dim3 grid((unsigned)gx, (unsigned)nchunks);
@@ -959,6 +938,7 @@ static int tile_setup(raht_plan *p, int D, hipStream_t s, Schedule **sc_out, int
 {
     *sc_out = nullptr;
     if (p->engine == RAHT_ENGINE_LEVEL) return RAHT_OK;
+    if (D < 16 / (int)sizeof(T)) return RAHT_OK;      // rows shorter than one 16-byte chunk: level engine
     const int Dc = pick_chunk_channels((int)sizeof(T), D);
     const int R = pick_tile_rows(p, (int)sizeof(T), Dc);
     if (R == 0) return RAHT_OK;
