@@ -131,9 +131,10 @@ __global__ __launch_bounds__(256) void level_pass_kernel(T *__restrict__ data, i
 constexpr int MAX_STEP_CH = 256;
 struct StepTable {
     int n;                         // 0 = no quantization, 1 = one step, D = per channel
+    int fast_div;                  // every step within [2^-100, 2^100]: the forward may divide without range scaling
     float v[MAX_STEP_CH];
 };
-struct NoSteps { int n; };
+struct NoSteps { int n; int fast_div; };
 
 template <typename T>
 struct TileArgs {
@@ -188,19 +189,19 @@ template <typename E> struct alignas(16) RegChunk { E v[16 / sizeof(E)]; };
 // gfx950 global loads / stores of 8..16 bytes need element alignment only.
 template <typename E> struct __attribute__((packed, aligned(sizeof(E)))) MemChunk { E v[16 / sizeof(E)]; };
 
-// Loading the nv <= VN valid elements at p is split in two so that several loads can be in flight:
-// ld_chunk_raw issues the load and returns the register image as it arrived, fix_chunk (called where
-// the chunk is consumed) turns it into "valid elements first, zero padded". Both are branch-free: a
-// load inside a divergent branch costs an exec-mask region with its own s_waitcnt, i.e. one serialised
-// HBM round trip per chunk. A partial chunk (the last one of a row whose length is not a multiple of
-// VN) is fetched as the 16 bytes that END with it -- VN - nv elements earlier, always inside the row,
-// because the host only runs this kernel on channel chunks of at least VN channels -- and shifted
-// down in registers.
+// A chunk is always a whole 16 bytes, in global memory too: when a row's length is not a multiple of
+// VN, its LAST chunk is the 16 bytes that END the row (channels [Dc - VN, Dc)), i.e. it overlaps its
+// neighbour by VN - Dc % VN channels. The overlapped channels live twice in LDS, go through the same
+// butterflies with the same operands in both copies, and are written back twice with identical
+// values. That keeps every load and store a plain, unpredicated 16-byte access (a load inside a
+// divergent branch costs an exec-mask region with its own s_waitcnt, i.e. one serialised HBM round
+// trip per chunk; masks and shifts cost VALU issue slots, which is what bounds this kernel). The host
+// only runs the tile kernel on channel chunks of at least VN channels (plan.hip: fit_chunk_channels).
 template <typename E>
-__device__ __forceinline__ RegChunk<E> ld_chunk_raw(const E *__restrict__ p, int nv)
+__device__ __forceinline__ RegChunk<E> ld_chunk(const E *__restrict__ p)
 {
     constexpr int VN = 16 / sizeof(E);
-    const MemChunk<E> t = *(const MemChunk<E> *)(p - (VN - nv));
+    const MemChunk<E> t = *(const MemChunk<E> *)p;
     RegChunk<E> x;
 #pragma unroll
     for (int i = 0; i < VN; ++i) x.v[i] = t.v[i];
@@ -208,48 +209,13 @@ __device__ __forceinline__ RegChunk<E> ld_chunk_raw(const E *__restrict__ p, int
 }
 
 template <typename E>
-__device__ __forceinline__ RegChunk<E> fix_chunk(const RegChunk<E> &raw, int nv)
+__device__ __forceinline__ void st_chunk(E *__restrict__ p, const RegChunk<E> &x)
 {
     constexpr int VN = 16 / sizeof(E);
-    E v[VN];
+    MemChunk<E> t;
 #pragma unroll
-    for (int i = 0; i < VN; ++i) v[i] = raw.v[i];
-    const int back = VN - nv;
-#pragma unroll
-    for (int sh = 1; sh < VN; sh <<= 1) {                // barrel shift down by `back` elements, zero fill
-        const bool on = (back & sh) != 0;
-#pragma unroll
-        for (int i = 0; i < VN; ++i) {
-            const E moved = (i + sh < VN) ? v[i + sh] : (E)0;
-            v[i] = on ? moved : v[i];
-        }
-    }
-    RegChunk<E> x;
-#pragma unroll
-    for (int i = 0; i < VN; ++i) x.v[i] = v[i];
-    return x;
-}
-
-template <typename E>
-__device__ __forceinline__ RegChunk<E> ld_chunk(const E *__restrict__ p, int nv)
-{
-    return fix_chunk<E>(ld_chunk_raw<E>(p, nv), nv);
-}
-
-template <typename E>
-__device__ __forceinline__ void st_chunk(E *__restrict__ p, const RegChunk<E> &x, int nv)
-{
-    constexpr int VN = 16 / sizeof(E);
-    if (nv == VN) {
-        MemChunk<E> t;
-#pragma unroll
-        for (int i = 0; i < VN; ++i) t.v[i] = x.v[i];
-        *(MemChunk<E> *)p = t;
-    } else {
-#pragma unroll
-        for (int i = 0; i < VN; ++i)
-            if (i < nv) p[i] = x.v[i];
-    }
+    for (int i = 0; i < VN; ++i) t.v[i] = x.v[i];
+    *(MemChunk<E> *)p = t;
 }
 
 // Plan metadata of one tile, held in registers (slot j = tid + s * blockDim). The persistent tile
@@ -360,7 +326,8 @@ __global__ __launch_bounds__(512, (sizeof(T) == 4 ? 6 : 4)) void tile_kernel(con
     int32_t pf_pos = 0;                                   // PF_GATH: Q position of this lane's row, two tiles ahead
 
     // lane -> (row within the wave instruction, chunk); the same for every tile
-    auto lane_geom = [&](int tid, int &lane, int &wid, int &g, int &coff, int &nv, bool &active) {
+    // coff: the chunk's place in the LDS row; goff: its first channel in global rows (last chunk: see ld_chunk)
+    auto lane_geom = [&](int tid, int &lane, int &wid, int &g, int &coff, int &goff, bool &active) {
         lane = tid & 63;
         wid = __builtin_amdgcn_readfirstlane(tid >> 6);
         g = lane >> lg;
@@ -368,33 +335,40 @@ __global__ __launch_bounds__(512, (sizeof(T) == 4 ? 6 : 4)) void tile_kernel(con
         active = c4 < NC;
         const int c4c = min(c4, NC - 1);                  // idle lanes shadow the last chunk (loads stay valid)
         coff = c4c * VN;
-        nv = min(VN, Dc - coff);
+        goff = c_base + min(coff, Dc - VN);
     };
     // issue the loads of tile t's rows into pf0..pf5; every load is unconditional from a clamped row
     // (a predicated load compiles to an exec-mask region with its own s_waitcnt)
     auto pf_issue = [&](int64_t t, int tid) {
-        int lane, wid, g, coff, nv; bool active;
-        lane_geom(tid, lane, wid, g, coff, nv, active);
+        int lane, wid, g, coff, goff; bool active;
+        lane_geom(tid, lane, wid, g, coff, goff, active);
         const int64_t e0n = t * R;
         const int ntn = (int)min((int64_t)R, A.n_entries - e0n);
 #define RAHT_PF_LOAD(U, REG)                                                                          \
         {                                                                                             \
             const int j = min(((wid + U * nw) << lr) + g, ntn - 1);                                    \
-            if constexpr (PF_GATH) REG = ld_chunk_raw<RawT>((const RawT *)A.Q + (int64_t)sdst[j] * A.ldq + c_base + coff, nv); \
-            else REG = ld_chunk_raw<RawT>((const RawT *)(INV ? (const T *)A.fin : A.in) + (e0n + j) * (INV ? A.ld_fin : A.ld_in) + c_base + coff, nv); \
+            if constexpr (PF_GATH) REG = ld_chunk<RawT>((const RawT *)A.Q + (int64_t)sdst[j] * A.ldq + goff); \
+            else REG = ld_chunk<RawT>((const RawT *)(INV ? (const T *)A.fin : A.in) + (e0n + j) * (INV ? A.ld_fin : A.ld_in) + goff); \
         }
         RAHT_PF_EACH(RAHT_PF_LOAD)
 #undef RAHT_PF_LOAD
     };
 
     // quantization steps of this lane's channels: kernarg reads at kernel start, not per row
-    float my_step[VN];
+    float my_step[VN], my_rcp[VN];
 #pragma unroll
-    for (int i = 0; i < VN; ++i) my_step[i] = 1.0f;
+    for (int i = 0; i < VN; ++i) { my_step[i] = 1.0f; my_rcp[i] = 1.0f; }
     if constexpr (QM) {
         const int c4c = min((tid0 & 63) & ((1 << lg) - 1), NC - 1);
+        const int g0 = c_base + min(c4c * VN, Dc - VN);
 #pragma unroll
-        for (int i = 0; i < VN; ++i) my_step[i] = ST.v[ST.n == 1 ? 0 : min(c_base + c4c * VN + i, A.D - 1)];
+        for (int i = 0; i < VN; ++i) {
+            my_step[i] = ST.v[ST.n == 1 ? 0 : g0 + i];
+            // refined reciprocal, exactly as hipcc's own float division computes it per quotient
+            // (v_rcp_f32 + one Newton step); here once per channel instead of once per coefficient
+            const float r0 = __builtin_amdgcn_rcpf(my_step[i]);
+            my_rcp[i] = __builtin_fmaf(__builtin_fmaf(-my_step[i], r0, 1.0f), r0, r0);
+        }
     }
 
     if ((int64_t)blockIdx.x < n_tiles) {
@@ -417,8 +391,8 @@ __global__ __launch_bounds__(512, (sizeof(T) == 4 ? 6 : 4)) void tile_kernel(con
     // and spills them (register budget: 80 VGPRs for three workgroups per CU).
     int tid = tid0;
     asm volatile("" : "+v"(tid));
-    int lane, wid, g, coff, nv; bool active;
-    lane_geom(tid, lane, wid, g, coff, nv, active);
+    int lane, wid, g, coff, goff; bool active;
+    lane_geom(tid, lane, wid, g, coff, goff, active);
     const int64_t e0 = tile_id * R;
     const int nt = (int)min((int64_t)R, A.n_entries - e0);
     const int64_t start_row = M.start_row, end_row = M.end_row;
@@ -433,8 +407,7 @@ __global__ __launch_bounds__(512, (sizeof(T) == 4 ? 6 : 4)) void tile_kernel(con
     if (tid < 64) hist[tid] = 0;
 
     // dequantize (fused inverse) / pass through a raw chunk and drop it into its LDS row
-    auto put_row = [&](int j, const RawChunk &raw0) {
-        const RawChunk raw = fix_chunk<RawT>(raw0, nv);
+    auto put_row = [&](int j, const RawChunk &raw) {
         V16 x;
 #pragma unroll
         for (int i = 0; i < VN; ++i) {
@@ -470,12 +443,12 @@ __global__ __launch_bounds__(512, (sizeof(T) == 4 ? 6 : 4)) void tile_kernel(con
 #pragma unroll
             for (int u = 0; u < TILE_IO_U; ++u) {
                 const int j = min(((it0 + u * nw) << lr) + g, nt - 1);
-                x[u] = ld_chunk_raw<T>(src + (e0 + j) * lds + c_base + coff, nv);
+                x[u] = ld_chunk<T>(src + (e0 + j) * lds + goff);
             }
 #pragma unroll
             for (int u = 0; u < TILE_IO_U; ++u) {
                 const int j = ((it0 + u * nw) << lr) + g;
-                if (j < nt && active) *(V16 *)&tile[j * Dp + coff] = fix_chunk<T>(x[u], nv);
+                if (j < nt && active) *(V16 *)&tile[j * Dp + coff] = x[u];
             }
         }
         input_done = true;
@@ -486,7 +459,7 @@ __global__ __launch_bounds__(512, (sizeof(T) == 4 ? 6 : 4)) void tile_kernel(con
         const int npre = A.last_stage ? 0 : (int)min(surv_cnt, (uint32_t)TILE_PRE_ROWS);
         for (int it = wid; (it << lr) < npre; it += nw) {
             const int q = (it << lr) + g;
-            const V16 x = ld_chunk<T>(A.wsn + (int64_t)(surv_base + min(q, npre - 1)) * A.ld_ws + c_base + coff, nv);
+            const V16 x = ld_chunk<T>(A.wsn + (int64_t)(surv_base + min(q, npre - 1)) * A.ld_ws + goff);
             if (q < npre && active) *(V16 *)&spre[q * Dp + coff] = x;
         }
     }
@@ -505,8 +478,8 @@ __global__ __launch_bounds__(512, (sizeof(T) == 4 ? 6 : 4)) void tile_kernel(con
 #pragma unroll
             for (int u = 0; u < TILE_IO_U; ++u) {
                 const int j = min(((it0 + u * nw) << lr) + g, nt - 1);
-                if constexpr (QM) x[u] = ld_chunk_raw<RawT>((const RawT *)A.Q + (int64_t)sdst[j] * A.ldq + c_base + coff, nv);
-                else x[u] = ld_chunk_raw<RawT>((const RawT *)A.fin + (int64_t)srow[j] * A.ld_fin + c_base + coff, nv);
+                if constexpr (QM) x[u] = ld_chunk<RawT>((const RawT *)A.Q + (int64_t)sdst[j] * A.ldq + goff);
+                else x[u] = ld_chunk<RawT>((const RawT *)A.fin + (int64_t)srow[j] * A.ld_fin + goff);
             }
 #pragma unroll
             for (int u = 0; u < TILE_IO_U; ++u) put_row(((it0 + u * nw) << lr) + g, x[u]);
@@ -611,7 +584,7 @@ __global__ __launch_bounds__(512, (sizeof(T) == 4 ? 6 : 4)) void tile_kernel(con
         for (uint32_t it = wid; TILE_PRE_ROWS + (it << lr) < surv_cnt; it += nw) {
             const uint32_t q = TILE_PRE_ROWS + (it << lr) + g;
             const uint32_t qc = min(q, surv_cnt - 1);
-            const V16 x = ld_chunk<T>(A.wsn + (int64_t)(surv_base + qc) * A.ld_ws + c_base + coff, nv);
+            const V16 x = ld_chunk<T>(A.wsn + (int64_t)(surv_base + qc) * A.ld_ws + goff);
             if (q < surv_cnt && active) *(V16 *)&tile[(int)ssurv[qc] * Dp + coff] = x;
         }
     }
@@ -620,7 +593,7 @@ __global__ __launch_bounds__(512, (sizeof(T) == 4 ? 6 : 4)) void tile_kernel(con
         for (uint32_t it = wid; (it << lr) < surv_cnt; it += nw) {
             const uint32_t q = (it << lr) + g;
             const uint32_t qc = min(q, surv_cnt - 1);
-            const V16 x = ld_chunk<T>(A.root_buf + (int64_t)(surv_base + qc) * A.D + c_base + coff, nv);
+            const V16 x = ld_chunk<T>(A.root_buf + (int64_t)(surv_base + qc) * A.D + goff);
             if (q < surv_cnt && active) *(V16 *)&tile[(int)ssurv[qc] * Dp + coff] = x;
         }
     }
@@ -651,38 +624,44 @@ __global__ __launch_bounds__(512, (sizeof(T) == 4 ? 6 : 4)) void tile_kernel(con
             const int l = INV ? (63 - __clzll((long long)mask)) : (__ffsll((long long)mask) - 1);
             mask &= ~(1ull << l);
             const uint32_t base = loff[l], cnt = hist[l];
-            // branch-free body: reads are clamped to valid records (redundant, harmless), only
-            // the writes are predicated -> TILE_ROUND_U independent LDS chains in flight per lane
-            for (uint32_t mb = (uint32_t)(wid << lr) + g; mb < cnt + g; mb += stride * TILE_ROUND_U) {
-                uint32_t ip[TILE_ROUND_U], ij[TILE_ROUND_U];
-                T ca[TILE_ROUND_U], cb[TILE_ROUND_U];
-                V16 x0[TILE_ROUND_U], x1[TILE_ROUND_U];
+            // branch-free body: reads are clamped to valid records (redundant, harmless), only the
+            // writes are predicated -> U independent LDS chains in flight per lane. Most levels of a
+            // tile hold fewer butterflies than one pass of the workgroup covers: those take U = 1.
+            auto pass = [&](auto UC) {
+                constexpr int U = decltype(UC)::value;
+                for (uint32_t mb = (uint32_t)(wid << lr) + g; mb < cnt + g; mb += stride * U) {
+                    uint32_t ip[U], ij[U];
+                    T ca[U], cb[U];
+                    V16 x0[U], x1[U];
 #pragma unroll
-                for (int u = 0; u < TILE_ROUND_U; ++u) {
-                    const uint32_t m = min(mb + u * stride, cnt - 1);
-                    const MRec<T> rec = mrec[base + m];
-                    ip[u] = rec.po + coff;
-                    ij[u] = rec.jo + coff;
-                    ca[u] = rec.a; cb[u] = rec.b;
-                }
-#pragma unroll
-                for (int u = 0; u < TILE_ROUND_U; ++u) { x0[u] = *(const V16 *)&tile[ip[u]]; x1[u] = *(const V16 *)&tile[ij[u]]; }
-#pragma unroll
-                for (int u = 0; u < TILE_ROUND_U; ++u) {
-                    V16 lo, hi;
-#pragma unroll
-                    for (int i = 0; i < VN; ++i) {
-                        if (!INV) {                       // RAHT.py:331-332
-                            lo.v[i] = ca[u] * x0[u].v[i] + cb[u] * x1[u].v[i];
-                            hi.v[i] = ca[u] * x1[u].v[i] - cb[u] * x0[u].v[i];
-                        } else {                          // iRAHT.py:108-109
-                            lo.v[i] = ca[u] * x0[u].v[i] - cb[u] * x1[u].v[i];
-                            hi.v[i] = cb[u] * x0[u].v[i] + ca[u] * x1[u].v[i];
-                        }
+                    for (int u = 0; u < U; ++u) {
+                        const uint32_t m = min(mb + u * stride, cnt - 1);
+                        const MRec<T> rec = mrec[base + m];
+                        ip[u] = rec.po + coff;
+                        ij[u] = rec.jo + coff;
+                        ca[u] = rec.a; cb[u] = rec.b;
                     }
-                    if ((mb + u * stride < cnt) && active) { *(V16 *)&tile[ip[u]] = lo; *(V16 *)&tile[ij[u]] = hi; }
+#pragma unroll
+                    for (int u = 0; u < U; ++u) { x0[u] = *(const V16 *)&tile[ip[u]]; x1[u] = *(const V16 *)&tile[ij[u]]; }
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        V16 lo, hi;
+#pragma unroll
+                        for (int i = 0; i < VN; ++i) {
+                            if (!INV) {                       // RAHT.py:331-332
+                                lo.v[i] = ca[u] * x0[u].v[i] + cb[u] * x1[u].v[i];
+                                hi.v[i] = ca[u] * x1[u].v[i] - cb[u] * x0[u].v[i];
+                            } else {                          // iRAHT.py:108-109
+                                lo.v[i] = ca[u] * x0[u].v[i] - cb[u] * x1[u].v[i];
+                                hi.v[i] = cb[u] * x0[u].v[i] + ca[u] * x1[u].v[i];
+                            }
+                        }
+                        if ((mb + u * stride < cnt) && active) { *(V16 *)&tile[ip[u]] = lo; *(V16 *)&tile[ij[u]] = hi; }
+                    }
                 }
-            }
+            };
+            if (cnt <= stride) pass(std::integral_constant<int, 1>());
+            else pass(std::integral_constant<int, TILE_ROUND_U>());
             __syncthreads();
         }
     }
@@ -693,7 +672,7 @@ __global__ __launch_bounds__(512, (sizeof(T) == 4 ? 6 : 4)) void tile_kernel(con
         for (int it = wid; (it << lr) < nt; it += nw) {
             const int j = (it << lr) + g;
             const V16 x = *(const V16 *)&tile[min(j, nt - 1) * Dp + coff];
-            if (j < nt && active) st_chunk<T>(A.out + (e0 + j) * A.ld_out + c_base + coff, x, nv);
+            if (j < nt && active) st_chunk<T>(A.out + (e0 + j) * A.ld_out + goff, x);
         }
     } else {
         // survivors, compacted, to the next stage's workspace (top stage: the caller's root buffer)
@@ -703,7 +682,7 @@ __global__ __launch_bounds__(512, (sizeof(T) == 4 ? 6 : 4)) void tile_kernel(con
             for (uint32_t it = wid; (it << lr) < surv_cnt; it += nw) {
                 const uint32_t q = (it << lr) + g;
                 const V16 x = *(const V16 *)&tile[(int)ssurv[min(q, surv_cnt - 1)] * Dp + coff];
-                if (q < surv_cnt && active) st_chunk<T>(dstb + (int64_t)(surv_base + q) * ldb + c_base + coff, x, nv);
+                if (q < surv_cnt && active) st_chunk<T>(dstb + (int64_t)(surv_base + q) * ldb + goff, x);
             }
         }
         // rows finalised here: T[row], or, fused, quantized to Q[inv_order[row]] (encode_3dgs.py:204,210,215)
@@ -717,11 +696,25 @@ __global__ __launch_bounds__(512, (sizeof(T) == 4 ? 6 : 4)) void tile_kernel(con
                 if constexpr (QM) {
                     RegChunk<int32_t> qv;
 #pragma unroll
-                    for (int i = 0; i < VN; ++i) qv.v[i] = (int32_t)floorf((float)x.v[i] / my_step[i] + 0.5f);
-                    st_chunk<int32_t>(A.Q + (int64_t)sdst[jc] * A.ldq + c_base + coff, qv, nv);
+                    for (int i = 0; i < VN; ++i) {
+                        float q;
+                        if (ST.fast_div) {
+                            // x / step, correctly rounded: the quotient refinement of hipcc's float
+                            // division (mul, 4 fma) without its range scaling and special-case fixup,
+                            // which the host has ruled out (steps within [2^-100, 2^100]; see check_steps)
+                            const float xf = (float)x.v[i], sp = my_step[i], r = my_rcp[i];
+                            const float q0 = xf * r;
+                            const float q1 = __builtin_fmaf(__builtin_fmaf(-sp, q0, xf), r, q0);
+                            q = __builtin_fmaf(__builtin_fmaf(-sp, q1, xf), r, q1);
+                        } else {
+                            q = (float)x.v[i] / my_step[i];
+                        }
+                        qv.v[i] = (int32_t)floorf(q + 0.5f);
+                    }
+                    st_chunk<int32_t>(A.Q + (int64_t)sdst[jc] * A.ldq + goff, qv);
                 } else {
                     const int64_t d = IDENT ? e0 + j : (int64_t)srow[jc];
-                    st_chunk<T>(A.fin + d * A.ld_fin + c_base + coff, x, nv);
+                    st_chunk<T>(A.fin + d * A.ld_fin + goff, x);
                 }
             }
         }
@@ -812,10 +805,14 @@ static int launch_tile_one(const TileArgs<T> &A, const XformIO<T> &io, dim3 grid
     if constexpr (QM) {
         StepTable st;
         st.n = io.n_steps;
-        for (int c = 0; c < io.n_steps; ++c) st.v[c] = io.steps[c];
+        st.fast_div = 1;
+        for (int c = 0; c < io.n_steps; ++c) {
+            st.v[c] = io.steps[c];
+            if (!(io.steps[c] >= 0x1p-100f && io.steps[c] <= 0x1p100f)) st.fast_div = 0;
+        }
         hipLaunchKernelGGL((tile_kernel<T, INV, IDENT, true, SLOTS, PIPE>), grid, dim3(threads), lds, s, A, st);
     } else {
-        NoSteps ns{0};
+        NoSteps ns{0, 0};
         hipLaunchKernelGGL((tile_kernel<T, INV, IDENT, false, SLOTS, PIPE>), grid, dim3(threads), lds, s, A, ns);
     }
     RAHT_HIP_CHECK(hipGetLastError());

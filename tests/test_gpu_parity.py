@@ -580,3 +580,46 @@ def test_pipelined_stage0_is_bit_identical(rt, N, D, tile_rows, grid):
         for a, b in zip(out[0], out[1]):
             assert torch.equal(a, b), (N, D, tile_rows, grid, f64)
         assert (out[1][1] - C).abs().max().item() <= (1e-11 if f64 else 2e-5) * C.abs().max().item()
+
+
+def test_fused_quantization_divides_exactly(rt):
+    """The fused forward replaces x / step by a hoisted-reciprocal refinement (transform.hip, P5); it
+    must round like the IEEE division of encode_3dgs.py:204 for every coefficient. Keys that are all
+    even with top_level = 1 leave no butterfly below the truncation level, so T == C and the quantizer
+    sees exactly the adversarial values placed in C (ties, neighbours of ties, tiny, huge, signed zero)."""
+    import torch
+    N, D = 40000, 59
+    rng = np.random.default_rng(77)
+    keys = torch.arange(N, dtype=torch.int64, device="cuda") * 2
+    p = rt.RahtPlan.from_keys(keys, 24, top_level=1)
+    assert p.n_roots == N
+    steps = torch.from_numpy(np.exp(rng.uniform(np.log(1e-6), np.log(1e3), size=D)).astype(np.float32)).cuda()
+    steps[0], steps[1], steps[2], steps[3] = 0.01, 1.0, 3.0, 2.0 ** -20
+    k = torch.from_numpy(rng.integers(-2 ** 20, 2 ** 20, size=(N, D))).to(torch.float32).cuda()
+    base = (k + 0.5) * steps                                  # at / next to rounding ties
+    C = base.clone()
+    sel = torch.from_numpy(rng.integers(0, 6, size=(N, D))).cuda()
+    C = torch.where(sel == 1, torch.nextafter(base, torch.full_like(base, float("inf"))), C)
+    C = torch.where(sel == 2, torch.nextafter(base, torch.full_like(base, float("-inf"))), C)
+    C = torch.where(sel == 3, torch.from_numpy(rng.normal(size=(N, D)).astype(np.float32)).cuda() * steps * 1000, C)
+    C = torch.where(sel == 4, torch.from_numpy((rng.normal(size=(N, D)) * 1e-38).astype(np.float32)).cuda(), C)
+    C = torch.where(sel == 5, k * steps, C)
+    C[0, :] = 0.0
+    C[1, :] = -0.0
+    C[2, :] = 1e-45
+    C = C.contiguous()
+    want = torch.floor(C / steps + 0.5).clamp(-2.0 ** 31, 2.0 ** 31 - 1).to(torch.int32)[p.order_RAGFT]
+    for st in (steps, 0.01, 0.3, 2.0 ** -7):
+        if not torch.is_tensor(st):
+            # a TENSOR divisor: torch turns division by a Python scalar into a multiplication by 1 / st
+            sv = torch.full((D,), st, dtype=torch.float32, device="cuda")
+            want_s = torch.floor(C / sv + 0.5).clamp(-2.0 ** 31, 2.0 ** 31 - 1).to(torch.int32)[p.order_RAGFT]
+        else:
+            want_s = want
+        Q = p.forward_quant(C, st)
+        assert torch.equal(Q, p.quant_reorder(C, st))
+        assert torch.equal(Q, want_s)
+    # steps outside the fast divider's range take the plain division path
+    tiny = torch.full((D,), 1e-38, dtype=torch.float32, device="cuda")
+    Cs = (C * 1e-36).contiguous()
+    assert torch.equal(p.forward_quant(Cs, tiny), p.quant_reorder(Cs, tiny))

@@ -1,5 +1,6 @@
 #!/bin/bash
 # Instruction-mix / stall counters of the tile kernels (separate rocprofv3 --pmc passes, kernel trace only).
+# (TA_* counters are left out: a pass with them hung rocprofv3 on this pool)
 # usage (GPU box): bash tools/pmc_sq.sh <out-tag> [bench.py args...]   -> gpurun_out/<tag>_pmc/<pass>/
 tag=$1; shift
 export TMPDIR=/tmp
@@ -7,7 +8,6 @@ i=0
 for set in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM" \
            "SQ_BUSY_CU_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM" \
            "SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY" \
-           "TA_BUSY TA_TOTAL_WAVEFRONTS TA_ADDR_STALLED_BY_TC_CYCLES TA_DATA_STALLED_BY_TC_CYCLES" \
            "SQ_LDS_BANK_CONFLICT SQ_LDS_UNALIGNED_STALL SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT" \
            "SQ_INSTS_LDS_LOAD SQ_INSTS_LDS_STORE SQ_INST_CYCLES_VMEM_RD SQ_INST_CYCLES_VMEM_WR"; do
   i=$((i+1))
