@@ -112,23 +112,6 @@ int raht_plan_nbits(const raht_plan *plan);             /* 3 * depth */
 int raht_plan_set_engine(raht_plan *plan, int engine, int tile_rows);
 int raht_plan_set_tail_tile(raht_plan *plan, int tail_rows, int tail_channels, int final_rows);
 
-/* Stage-0 software pipeline of the tile engine: persistent workgroups fetch their NEXT tile into
- * registers while the current tile's butterfly rounds run (transform.hip, tile_kernel PIPE). mode:
- * -1 automatic (when stage 0 has more tiles than the chip keeps resident; default), 0 off, 1 on.
- * grid: number of persistent workgroups, 0 = as many as the chip keeps resident (tests use small
- * grids so that small inputs walk several tiles per workgroup). Results do not depend on either. */
-int raht_plan_set_pipeline(raht_plan *plan, int mode, int grid);
-
-/* Two-way split. The root butterfly of the tree joins rows [0, r) and [r, N); the two row ranges are
- * independent trees. A split plan runs them as two chains -- one on the caller's stream, one on an
- * internal stream (event fork / join, hipGraph-capturable) -- so that the latency-bound small stages
- * of one chain overlap the HBM-bound big kernel of the other, and performs the root butterfly with
- * one tiny kernel. Results are identical to the unsplit transform. mode: -1 automatic (>= 400k
- * rows and a reasonably balanced root split; default), 0 never, 1 whenever the tree allows.
- * raht_plan_split_row returns r (0 = not split). */
-int raht_plan_set_split(raht_plan *plan, int mode);
-int64_t raht_plan_split_row(raht_plan *plan, raht_stream_t stream);
-
 /* Reference-shaped views, for parity tests and the drivers' DEBUG save_lists
  * (reference python/encode_3dgs.py:165). HOST output buffers.
  *   raht_plan_levels       = len(Flags) of the reference

@@ -393,59 +393,6 @@ static int compute_roots(raht_plan *p, hipStream_t s)
     return RAHT_OK;
 }
 
-// ---- two-way split -----------------------------------------------------------------------------------
-static raht_plan *make_view(raht_plan *p, int64_t row0, int64_t n, hipStream_t s)
-{
-    raht_plan *v = new raht_plan();
-    v->is_view = true;
-    v->N = n;
-    v->nbits = p->nbits;
-    v->max_level = p->max_level;
-    v->keys = p->keys + row0; v->lvl = p->lvl + row0; v->wl = p->wl + row0; v->wr = p->wr + row0;
-    v->inv_order = p->inv_order + row0;          // GLOBAL positions in order_RAGFT order
-    v->engine = RAHT_ENGINE_TILE;
-    v->tile_rows_override = p->tile_rows_override;
-    v->tail_rows_override = p->tail_rows_override;
-    v->tail_chunk_override = p->tail_chunk_override;
-    v->final_rows_override = p->final_rows_override;
-    v->pipe_mode = p->pipe_mode; v->pipe_grid = p->pipe_grid;
-    v->split_mode = 0;
-    v->split_state = 2;
-    if (compute_roots(v, s) != RAHT_OK || v->n_roots != 1) { raht_plan_destroy(v); return nullptr; }
-    return v;
-}
-
-bool ensure_split(raht_plan *p, hipStream_t s)
-{
-    if (p->split_state == 1) return true;
-    if (p->split_state == 2) return false;
-    p->split_state = 2;
-    const int64_t min_rows = 400000;             // below this the stage-0 kernels are themselves short
-    if (p->is_view || p->split_mode == 0 || p->wsum || p->top_level != 64 || p->max_level < 0 || p->N < 2) return false;
-    if (p->split_mode < 0 && p->N < min_rows) return false;
-    const uint32_t cnt = p->level_off[p->max_level + 1] - p->level_off[p->max_level];
-    if (cnt != 1) return false;                  // the root butterfly is unique for valid keys
-    uint32_t row = 0;
-    if (hipMemcpyAsync(&row, p->level_rows + p->level_off[p->max_level], sizeof(uint32_t), hipMemcpyDeviceToHost, s) != hipSuccess ||
-        hipStreamSynchronize(s) != hipSuccess) return false;
-    const int64_t i = row, N = p->N;
-    if (i < 1 || i >= N) return false;
-    if (p->split_mode < 0 && std::min(i, N - i) * 8 < N) return false;          // too unbalanced to pay off
-    raht_plan *a = make_view(p, 0, i, s), *b = make_view(p, i, N - i, s);
-    bool ok = a && b;
-    if (ok && !p->aux) ok = hipStreamCreateWithFlags(&p->aux, hipStreamNonBlocking) == hipSuccess;
-    if (ok && !p->ev_fork) ok = hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming) == hipSuccess;
-    if (ok && !p->ev_join) ok = hipEventCreateWithFlags(&p->ev_join, hipEventDisableTiming) == hipSuccess;
-    if (!ok) {
-        if (a) raht_plan_destroy(a);
-        if (b) raht_plan_destroy(b);
-        return false;
-    }
-    p->part[0] = a; p->part[1] = b; p->split_row = i;
-    p->split_state = 1;
-    return true;
-}
-
 // ---- plan construction ---------------------------------------------------------------------------
 static int finish_plan(raht_plan *p, const int64_t *leaf_weights, hipStream_t s)
 {
@@ -591,23 +538,15 @@ int raht_plan_create_from_keys(const uint64_t *keys_sorted, int64_t N, int nbits
 int raht_plan_destroy(raht_plan *p)
 {
     if (!p) return RAHT_OK;
-    for (int k = 0; k < 2; ++k)
-        if (p->part[k]) { raht_plan_destroy(p->part[k]); p->part[k] = nullptr; }
-    if (p->aux) (void)hipStreamDestroy(p->aux);
-    if (p->ev_fork) (void)hipEventDestroy(p->ev_fork);
-    if (p->ev_join) (void)hipEventDestroy(p->ev_join);
-    if (p->pair_buf) (void)hipFree(p->pair_buf);
     for (auto &sc : p->schedules) free_schedule(sc);
-    if (!p->is_view) {
-        if (p->keys) (void)hipFree(p->keys);
-        if (p->lvl) (void)hipFree(p->lvl);
-        if (p->wl) (void)hipFree(p->wl);
-        if (p->wr) (void)hipFree(p->wr);
-        if (p->wsum) (void)hipFree(p->wsum);
-        if (p->order) (void)hipFree(p->order);
-        if (p->inv_order) (void)hipFree(p->inv_order);
-        if (p->level_rows) (void)hipFree(p->level_rows);
-    }
+    if (p->keys) (void)hipFree(p->keys);
+    if (p->lvl) (void)hipFree(p->lvl);
+    if (p->wl) (void)hipFree(p->wl);
+    if (p->wr) (void)hipFree(p->wr);
+    if (p->wsum) (void)hipFree(p->wsum);
+    if (p->order) (void)hipFree(p->order);
+    if (p->inv_order) (void)hipFree(p->inv_order);
+    if (p->level_rows) (void)hipFree(p->level_rows);
     if (p->root_rows) (void)hipFree(p->root_rows);
     delete p;
     return RAHT_OK;
@@ -615,13 +554,6 @@ int raht_plan_destroy(raht_plan *p)
 
 int64_t raht_plan_size(const raht_plan *p) { return p ? p->N : -1; }
 int raht_plan_nbits(const raht_plan *p) { return p ? p->nbits : -1; }
-
-static void reset_split(raht_plan *p)
-{
-    for (int k = 0; k < 2; ++k)
-        if (p->part[k]) { raht_plan_destroy(p->part[k]); p->part[k] = nullptr; }
-    p->split_state = 0;
-}
 
 int raht_plan_set_tail_tile(raht_plan *p, int tail_rows, int tail_channels, int final_rows)
 {
@@ -633,31 +565,7 @@ int raht_plan_set_tail_tile(raht_plan *p, int tail_rows, int tail_channels, int 
     p->tail_rows_override = tail_rows;
     p->tail_chunk_override = tail_channels;
     p->final_rows_override = final_rows;
-    reset_split(p);
     return RAHT_OK;
-}
-
-int raht_plan_set_pipeline(raht_plan *p, int mode, int grid)
-{
-    if (!p || mode < -1 || mode > 1 || grid < 0) { set_error("raht_plan_set_pipeline: mode must be -1 (auto), 0 (off) or 1 (on), grid >= 0"); return RAHT_ERR_INVALID; }
-    p->pipe_mode = mode;
-    p->pipe_grid = grid;
-    reset_split(p);
-    return RAHT_OK;
-}
-
-int raht_plan_set_split(raht_plan *p, int mode)
-{
-    if (!p || mode < -1 || mode > 1) { set_error("raht_plan_set_split: mode must be -1 (auto), 0 (off) or 1 (on)"); return RAHT_ERR_INVALID; }
-    p->split_mode = mode;
-    reset_split(p);
-    return RAHT_OK;
-}
-
-int64_t raht_plan_split_row(raht_plan *p, raht_stream_t stream)
-{
-    if (!p) return -1;
-    return ensure_split(p, (hipStream_t)stream) ? p->split_row : 0;
 }
 
 int raht_plan_set_engine(raht_plan *p, int engine, int tile_rows)
@@ -666,7 +574,6 @@ int raht_plan_set_engine(raht_plan *p, int engine, int tile_rows)
     if (tile_rows != 0 && (tile_rows < 64 || tile_rows > 1024 || (tile_rows & 3))) { set_error("tile_rows must be a multiple of 4 in [64, 1024]"); return RAHT_ERR_INVALID; }
     p->engine = engine;
     p->tile_rows_override = tile_rows;
-    reset_split(p);
     return RAHT_OK;
 }
 
@@ -745,7 +652,6 @@ int raht_plan_set_top_level(raht_plan *p, int top_level, raht_stream_t stream)
     for (auto &sc : p->schedules) free_schedule(sc);
     p->schedules.clear();
     p->top_level = top_level;
-    reset_split(p);
     return compute_roots(p, (hipStream_t)stream);
 }
 

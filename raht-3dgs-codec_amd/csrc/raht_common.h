@@ -126,21 +126,6 @@ struct raht_plan {
     int final_rows_override = 0; // single-tile finishing stage up to this many entries (0 = automatic)
     std::vector<raht::Schedule> schedules;   // cache keyed by tile_rows
     std::vector<uint8_t> lvl_host;           // lazily downloaded for export_level
-    // ---- two-way split (transform.hip: run_split) -------------------------------------------------
-    // The tree's root butterfly joins rows [0, split_row) and [split_row, N). The two row ranges are
-    // independent trees: they run as two chains on two streams so that the latency-bound tail stages
-    // of one overlap the HBM-bound stage 0 of the other; one tiny kernel performs the root butterfly.
-    int pipe_mode = -1;          // stage-0 software pipeline (transform.hip, PIPE): -1 auto, 0 off, 1 on
-    int pipe_grid = 0;           // persistent workgroups for it; 0 = as many as the chip keeps resident
-    bool is_view = false;        // part of a split plan: borrows keys / lvl / wl / wr / inv_order
-    int split_mode = -1;         // -1 automatic (large, balanced scenes), 0 never, 1 whenever possible
-    int split_state = 0;         // 0 undecided, 1 split, 2 not splittable
-    int64_t split_row = 0;
-    raht_plan *part[2] = {nullptr, nullptr};
-    hipStream_t aux = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    void *pair_buf = nullptr;    // 2 x D root rows handed between the parts and the root butterfly
-    size_t pair_bytes = 0;
 };
 
 namespace raht {
@@ -156,7 +141,6 @@ int ensure_workspace(Schedule *sc, size_t row_bytes);
 // Rows per LDS tile for an element size / channel count (0 = does not fit).
 int pick_tile_rows(const raht_plan *plan, int elem_size, int chunk_channels);
 int pick_chunk_channels(int elem_size, int D);
-// Decide / build the two-way split of a plan (see raht_plan::part). Returns true when split.
-bool ensure_split(raht_plan *plan, hipStream_t s);
+
 size_t tile_lds_bytes(int R, int elem_size, int Dc, bool ident, bool qm);
 }  // namespace raht

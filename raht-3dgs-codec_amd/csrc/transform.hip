@@ -180,7 +180,6 @@ constexpr int TILE_MAX_SLOTS = 2;      // slots per thread (template SLOTS = 1 o
 constexpr int TILE_IO_U = 6;           // row chunks in flight per lane in the load / gather phases
 constexpr int TILE_ROUND_U = 2;        // butterflies in flight per lane group in a round
 constexpr int TILE_PRE_ROWS = 12;      // survivor rows prefetched by the inverse before flags are known
-constexpr int TILE_PF_VEC = 6;         // PIPE: 16-byte chunks per lane holding the next tile's rows
 
 // ---- row chunks: one lane moves 16 bytes (VN = 16 / sizeof(T) consecutive channels) of one row --------
 // Registers / LDS (16-byte aligned: ds_read_b128 / ds_write_b128) ...
@@ -231,7 +230,7 @@ struct TileMeta {
                                        // after the load would also drain every older load, i.e. the prefetch)
 };
 
-template <typename T, bool IDENT, bool QM, int SLOTS, bool NOPOS = false>
+template <typename T, bool IDENT, bool QM, int SLOTS>
 __device__ __forceinline__ void load_tile_meta(const TileArgs<T> &A, int64_t t, int tid, int nthreads, TileMeta<SLOTS> &M)
 {
     const int R = A.R;
@@ -254,13 +253,10 @@ __device__ __forceinline__ void load_tile_meta(const TileArgs<T> &A, int64_t t, 
             M.wl[s] = A.wl[e0 + j];
             M.wr[s] = A.wr[e0 + j];
             M.lv[s] = A.lvl[e0 + j];
-            if (!NOPOS) M.pos[s] = QM ? (int32_t)A.inv_order[e0 + j] : (int32_t)r;    // where the final coefficient lives
+            M.pos[s] = QM ? (int32_t)A.inv_order[e0 + j] : (int32_t)r;    // where the final coefficient lives
         }
     }
 }
-
-// The six prefetch registers of the pipelined mode, as named variables (an array ends up in scratch).
-#define RAHT_PF_EACH(OP) OP(0, pf0) OP(1, pf1) OP(2, pf2) OP(3, pf3) OP(4, pf4) OP(5, pf5)
 
 // IDENT = true is stage 0 (entries are the rows themselves: the HBM-heavy launch); IDENT = false
 // are the later, much smaller stages. QM = true fuses quantize+reorder (forward) / un-reorder+
@@ -274,17 +270,13 @@ __device__ __forceinline__ void load_tile_meta(const TileArgs<T> &A, int64_t t, 
 // instruction moves 64 / G rows (59 float channels: 15 chunks, G = 16, 4 rows). LDS rows are padded
 // to Dp = Dc rounded up to VN so that every chunk is a 16-byte-aligned ds_read/write_b128; global
 // rows need element alignment only. A butterfly is one ds_read_b128 per operand and lane.
-//
-// PIPE = true (stage 0 only, persistent workgroups): software pipeline across a workgroup's tiles:
-// the NEXT tile's input (6 chunks per lane = 24 VGPRs) is fetched into registers while the current
-// tile's rounds run, and lands in LDS at the top of the next iteration.
-template <typename T, bool INV, bool IDENT, bool QM, int SLOTS, bool PIPE>
+template <typename T, bool INV, bool IDENT, bool QM, int SLOTS>
 __global__ __launch_bounds__(512, (sizeof(T) == 4 ? 6 : 4)) void tile_kernel(const TileArgs<T> A,
                                                    const typename std::conditional<QM, StepTable, NoSteps>::type ST)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     typedef RegChunk<T> V16;
-    typedef typename std::conditional<QM, int32_t, T>::type RawT;       // what the prefetch registers hold
+    typedef typename std::conditional<QM, int32_t, T>::type RawT;       // element type of the inverse's input rows
     typedef RegChunk<RawT> RawChunk;
     constexpr int VN = 16 / sizeof(T);
     static_assert(sizeof(RawT) == sizeof(T), "fused quantization is a float32 mode");
@@ -318,14 +310,6 @@ __global__ __launch_bounds__(512, (sizeof(T) == 4 ? 6 : 4)) void tile_kernel(con
     // ---- persistent loop over this workgroup's tiles; metadata of the next tile is prefetched ----
     const int64_t n_tiles = (A.n_entries + R - 1) / R;
     TileMeta<SLOTS> M;
-    constexpr bool PF_BULK = PIPE && (!INV || !QM);       // next tile's rows: C (forward) or T (plain inverse)
-    constexpr bool PF_GATH = PIPE && INV && QM;           // next tile's rows: Q at inv_order[row]
-    static_assert(!PIPE || (IDENT && SLOTS == 1), "PIPE is a stage-0 mode");
-    RawChunk pf0, pf1, pf2, pf3, pf4, pf5;
-    static_assert(TILE_PF_VEC == 6, "pf0..pf5");
-    int32_t pf_pos = 0;                                   // PF_GATH: Q position of this lane's row, two tiles ahead
-
-    // lane -> (row within the wave instruction, chunk); the same for every tile
     // coff: the chunk's place in the LDS row; goff: its first channel in global rows (last chunk: see ld_chunk)
     auto lane_geom = [&](int tid, int &lane, int &wid, int &g, int &coff, int &goff, bool &active) {
         lane = tid & 63;
@@ -337,23 +321,6 @@ __global__ __launch_bounds__(512, (sizeof(T) == 4 ? 6 : 4)) void tile_kernel(con
         coff = c4c * VN;
         goff = c_base + min(coff, Dc - VN);
     };
-    // issue the loads of tile t's rows into pf0..pf5; every load is unconditional from a clamped row
-    // (a predicated load compiles to an exec-mask region with its own s_waitcnt)
-    auto pf_issue = [&](int64_t t, int tid) {
-        int lane, wid, g, coff, goff; bool active;
-        lane_geom(tid, lane, wid, g, coff, goff, active);
-        const int64_t e0n = t * R;
-        const int ntn = (int)min((int64_t)R, A.n_entries - e0n);
-#define RAHT_PF_LOAD(U, REG)                                                                          \
-        {                                                                                             \
-            const int j = min(((wid + U * nw) << lr) + g, ntn - 1);                                    \
-            if constexpr (PF_GATH) REG = ld_chunk<RawT>((const RawT *)A.Q + (int64_t)sdst[j] * A.ldq + goff); \
-            else REG = ld_chunk<RawT>((const RawT *)(INV ? (const T *)A.fin : A.in) + (e0n + j) * (INV ? A.ld_fin : A.ld_in) + goff); \
-        }
-        RAHT_PF_EACH(RAHT_PF_LOAD)
-#undef RAHT_PF_LOAD
-    };
-
     // quantization steps of this lane's channels: kernarg reads at kernel start, not per row
     float my_step[VN], my_rcp[VN];
 #pragma unroll
@@ -371,20 +338,7 @@ __global__ __launch_bounds__(512, (sizeof(T) == 4 ? 6 : 4)) void tile_kernel(con
         }
     }
 
-    if ((int64_t)blockIdx.x < n_tiles) {
-        load_tile_meta<T, IDENT, QM, SLOTS, PF_GATH>(A, blockIdx.x, tid0, nthreads, M);
-        if constexpr (PF_BULK) pf_issue(blockIdx.x, tid0);
-        if constexpr (PF_GATH) {
-            const int64_t e00 = (int64_t)blockIdx.x * R;
-            const int nt0 = (int)min((int64_t)R, A.n_entries - e00);
-            if (tid0 < nt0) sdst[tid0] = (int32_t)A.inv_order[e00 + tid0];
-            __syncthreads();
-            pf_issue(blockIdx.x, tid0);
-            __syncthreads();                              // sdst is rewritten at the top of the loop
-            const int64_t t1 = (int64_t)blockIdx.x + gridDim.x;
-            if (t1 < n_tiles) pf_pos = (int32_t)A.inv_order[min(t1 * R + tid0, A.n_entries - 1)];
-        }
-    }
+    if ((int64_t)blockIdx.x < n_tiles) load_tile_meta<T, IDENT, QM, SLOTS>(A, blockIdx.x, tid0, nthreads, M);
     for (int64_t tile_id = blockIdx.x; tile_id < n_tiles; tile_id += gridDim.x) {
     // Re-derive the lane-dependent indices every iteration from an opaque copy of the thread id:
     // otherwise the compiler hoists dozens of lane-dependent addresses out of this long loop body
@@ -419,22 +373,7 @@ __global__ __launch_bounds__(512, (sizeof(T) == 4 ? 6 : 4)) void tile_kernel(con
 
     // ---- P0b. row transfers whose addresses do not depend on the plan metadata ----
     bool input_done = false;                  // tile already holds every slot's input
-    if constexpr (PIPE) {
-        // this tile's rows were fetched during the previous tile's rounds
-#define RAHT_PF_PUT(U, REG) put_row(((wid + U * nw) << lr) + g, REG);
-        RAHT_PF_EACH(RAHT_PF_PUT)
-#undef RAHT_PF_PUT
-        if constexpr (PF_GATH) {
-            if (tile_id + gridDim.x < n_tiles && tid < R) sdst[tid] = pf_pos;             // next tile's Q positions
-        } else {
-            // every register of this tile's metadata is "used" here, so that its wait sits BEFORE the
-            // prefetch is issued (loads return in order: a later wait would also drain the prefetch)
-            asm volatile("" :: "v"(m_row[0]), "v"(m_wl[0]), "v"(m_wr[0]), "v"(m_pos[0]), "v"(m_lv[0]), "s"(surv_cnt));
-            __builtin_amdgcn_s_waitcnt(0x0F70);           // vmcnt(0): see the metadata prefetch below
-            if (tile_id + gridDim.x < n_tiles) pf_issue(tile_id + gridDim.x, tid);
-        }
-        input_done = true;
-    } else if (!INV || (IDENT && !QM)) {
+    if (!INV || (IDENT && !QM)) {
         // forward: this stage's entries, entry order (C or ws_k); plain inverse of stage 0: T rows [e0, e0+nt)
         const T *src = INV ? (const T *)A.fin : A.in;
         const int64_t lds = INV ? A.ld_fin : A.ld_in;
@@ -466,7 +405,7 @@ __global__ __launch_bounds__(512, (sizeof(T) == 4 ? 6 : 4)) void tile_kernel(con
 #pragma unroll
     for (int s = 0; s < SLOTS; ++s) {
         const int j = tid + s * nthreads;
-        if (j < nt) { if (!IDENT) srow[j] = m_row[s]; if (QM && !PF_GATH) sdst[j] = m_pos[s]; }
+        if (j < nt) { if (!IDENT) srow[j] = m_row[s]; if (QM) sdst[j] = m_pos[s]; }
     }
     __syncthreads();                                                       // sync #1
 
@@ -600,20 +539,7 @@ __global__ __launch_bounds__(512, (sizeof(T) == 4 ? 6 : 4)) void tile_kernel(con
     __syncthreads();                                                       // sync #4
 
     // prefetch the next tile's plan metadata: the loads stay in flight during the butterflies
-    if constexpr (PF_GATH) {
-        // Tell hipcc's wait-count bookkeeping that nothing older is outstanding (true here: every
-        // load of this tile has been consumed). Otherwise the first later reuse of a register that
-        // an OPTIONAL load of this tile may have written (weighted leaves, survivors beyond the
-        // prefetched ones) gets an s_waitcnt vmcnt(0), which would drain the prefetch as well.
-        __builtin_amdgcn_s_waitcnt(0x0F70);               // vmcnt(0)
-        const int64_t t2 = tile_id + 2 * (int64_t)gridDim.x;
-        if (t2 < n_tiles) pf_pos = (int32_t)A.inv_order[min(t2 * R + tid, A.n_entries - 1)];
-    }
-    if (tile_id + gridDim.x < n_tiles) load_tile_meta<T, IDENT, QM, SLOTS, PF_GATH>(A, tile_id + gridDim.x, tid, nthreads, M);
-    if constexpr (PF_GATH) {
-        // the next tile's Q rows: issued last, after every optional global load of this tile
-        if (tile_id + gridDim.x < n_tiles) pf_issue(tile_id + gridDim.x, tid);
-    }
+    if (tile_id + gridDim.x < n_tiles) load_tile_meta<T, IDENT, QM, SLOTS>(A, tile_id + gridDim.x, tid, nthreads, M);
 
     // ---- P4. butterflies, one round per level present; a lane group handles one butterfly ----
     {
@@ -722,7 +648,6 @@ __global__ __launch_bounds__(512, (sizeof(T) == 4 ? 6 : 4)) void tile_kernel(con
     __syncthreads();              // LDS is reused by the next tile
     }                             // persistent tile loop
 }
-#undef RAHT_PF_EACH
 
 // node weights of RAHT.py:325-328: after its own butterfly a right sibling carries w0 + w1 and is
 // never touched again; row 0 ends with the total weight.
@@ -770,13 +695,6 @@ static bool persist_enabled()
     return v == 1;
 }
 
-static bool pipe_enabled()
-{
-    static int v = -1;
-    if (v < 0) { const char *e = getenv("RAHT_TILE_PIPE"); v = (e && atoi(e) == 0) ? 0 : 1; }     // tuning knob, default on
-    return v == 1;
-}
-
 static int lp_shift_for(int Dc)
 {
     int s = 0;
@@ -793,12 +711,12 @@ struct XformIO {
     const float *steps = nullptr; int n_steps = 0;
 };
 
-template <typename T, bool INV, bool IDENT, bool QM, int SLOTS, bool PIPE = false>
+template <typename T, bool INV, bool IDENT, bool QM, int SLOTS>
 static int launch_tile_one(const TileArgs<T> &A, const XformIO<T> &io, dim3 grid, int threads, size_t lds, hipStream_t s)
 {
     static bool attr_set = false;
     if (!attr_set) {
-        RAHT_HIP_CHECK(hipFuncSetAttribute((const void *)tile_kernel<T, INV, IDENT, QM, SLOTS, PIPE>,
+        RAHT_HIP_CHECK(hipFuncSetAttribute((const void *)tile_kernel<T, INV, IDENT, QM, SLOTS>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
@@ -810,10 +728,10 @@ static int launch_tile_one(const TileArgs<T> &A, const XformIO<T> &io, dim3 grid
             st.v[c] = io.steps[c];
             if (!(io.steps[c] >= 0x1p-100f && io.steps[c] <= 0x1p100f)) st.fast_div = 0;
         }
-        hipLaunchKernelGGL((tile_kernel<T, INV, IDENT, true, SLOTS, PIPE>), grid, dim3(threads), lds, s, A, st);
+        hipLaunchKernelGGL((tile_kernel<T, INV, IDENT, true, SLOTS>), grid, dim3(threads), lds, s, A, st);
     } else {
         NoSteps ns{0, 0};
-        hipLaunchKernelGGL((tile_kernel<T, INV, IDENT, false, SLOTS, PIPE>), grid, dim3(threads), lds, s, A, ns);
+        hipLaunchKernelGGL((tile_kernel<T, INV, IDENT, false, SLOTS>), grid, dim3(threads), lds, s, A, ns);
     }
     RAHT_HIP_CHECK(hipGetLastError());
     return RAHT_OK;
@@ -847,7 +765,6 @@ static int launch_tile_stage(const raht_plan *p, const Schedule &sc, int k, cons
     A.ld_ws = D;
     A.wsn = (k + 1 < K) ? (T *)sc.stages[(size_t)k + 1].ws : nullptr;
     T *ws_k = (k >= 1) ? (T *)st.ws : nullptr;
-    const bool one_chunk = (Dc == D);
     if (!INV) {
         A.in = (k == 0) ? io.src : ws_k; A.ld_in = (k == 0) ? io.ld_src : D;
         A.fin = io.dst; A.ld_fin = io.ld_dst;
@@ -868,16 +785,9 @@ static int launch_tile_stage(const raht_plan *p, const Schedule &sc, int k, cons
     // per CU), each walking tiles blockIdx.x, blockIdx.x + gridDim.x, ...
     const int per_cu = std::max(1, std::min((int)(128 / ((lds + 1279) / 1280)), 32 / (threads / 64)));
     const int64_t resident = (int64_t)per_cu * device_cus();
-    // stage 0 with more tiles than the chip holds: pipelined persistent workgroups (see tile_kernel)
-    const int64_t pgrid = p->pipe_grid > 0 ? p->pipe_grid : std::max<int64_t>(1, resident);
-    bool pipe = pipe_enabled() && p->pipe_mode != 0 && st.rows == nullptr && one_chunk && st.tile_rows <= threads &&
-                p->pipe_mode == 1 &&      // opt-in for now: measured slower than one tile per workgroup (VALU-bound kernel)
-                ((st.tile_rows + (64 >> A.lg) - 1) >> (6 - A.lg)) <= TILE_PF_VEC * (threads / 64);   // 6 chunks per lane hold a tile
-    const int64_t gx = pipe ? std::min<int64_t>(st.n_tiles, pgrid)
-                            : (persist_enabled() ? std::min<int64_t>(st.n_tiles, std::max<int64_t>(1, resident / nchunks)) : st.n_tiles);
+    const int64_t gx = persist_enabled() ? std::min<int64_t>(st.n_tiles, std::max<int64_t>(1, resident / nchunks)) : st.n_tiles;
     const dim3 grid((unsigned)gx, (unsigned)nchunks);
     const bool one = st.tile_rows <= threads;
-    if (pipe) return launch_tile_one<T, INV, true, QM, 1, true>(A, io, grid, threads, lds, s);
     if (st.rows == nullptr)
         return one ? launch_tile_one<T, INV, true, QM, 1>(A, io, grid, threads, lds, s)
                    : launch_tile_one<T, INV, true, QM, 2>(A, io, grid, threads, lds, s);

@@ -172,19 +172,6 @@ class RahtPlan:
         check(_lib.lib().raht_plan_set_engine(self._h, e, int(tile_rows)))
         check(_lib.lib().raht_plan_set_tail_tile(self._h, int(tail_rows), int(tail_channels), int(final_rows)))
 
-    def set_pipeline(self, mode=-1, grid=0):
-        """Stage-0 software pipeline (see raht_plan_set_pipeline): -1 automatic, 0 off, 1 on."""
-        check(_lib.lib().raht_plan_set_pipeline(self._h, int(mode), int(grid)))
-
-    def set_split(self, mode=-1):
-        """Two-chain execution (see raht_plan_set_split): -1 automatic, 0 off, 1 whenever possible."""
-        check(_lib.lib().raht_plan_set_split(self._h, int(mode)))
-
-    @property
-    def split_row(self):
-        with torch.cuda.device(self.device):
-            return int(_lib.lib().raht_plan_split_row(self._h, _stream()))
-
     def export_lists(self):
         """Reference-shaped (List, Flags, weights) as CPU tensors (RAHT_param.py:190-279 outputs)."""
         import numpy as np

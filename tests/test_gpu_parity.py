@@ -549,39 +549,6 @@ def test_randomised_configurations(rt, seed):
         assert torch.equal(p.dequant_inverse(Q1, steps), p.inverse(p.dequant_unreorder(Q1, steps)))
 
 
-# -------------------------------------------------------------------- stage-0 software pipeline (PIPE)
-@pytest.mark.parametrize("N,D,tile_rows,grid", [(20000, 59, 0, 7), (20001, 59, 192, 3), (5003, 59, 64, 5), (777, 59, 64, 1),
-                                                (30011, 56, 0, 16), (40000, 14, 0, 4), (9999, 3, 128, 2), (12345, 64, 96, 9),
-                                                (193, 59, 192, 1), (50000, 59, 0, 1000)])
-def test_pipelined_stage0_is_bit_identical(rt, N, D, tile_rows, grid):
-    """Persistent workgroups that prefetch their next tile (raht_plan_set_pipeline) against one tile
-    per workgroup: same arithmetic in the same order, so every output must match bit for bit."""
-    import torch
-    rng = np.random.default_rng(N + D)
-    J = 8
-    keys = np.sort(rng.choice(1 << (3 * J), size=N, replace=False)).astype(np.int64)
-    kd = torch.from_numpy(keys).cuda()
-    for f64 in (False, True):
-        C = torch.from_numpy(rng.normal(size=(N, D))).to(torch.float64 if f64 else torch.float32).cuda()
-        out = {}
-        for mode in (0, 1):
-            p = rt.RahtPlan.from_keys(kd, 3 * J)
-            p.set_engine("tile", tile_rows)
-            p.set_pipeline(mode, grid)
-            T = p.forward(C, want_w=False)
-            res = [T, p.inverse(T)]
-            if not f64:
-                Q = p.forward_quant(C, 0.02)
-                res += [Q, p.dequant_inverse(Q, 0.02)]
-                steps = torch.linspace(0.01, 0.05, D)
-                Qc = p.forward_quant(C, steps)
-                res += [Qc, p.dequant_inverse(Qc, steps)]
-            out[mode] = res
-        for a, b in zip(out[0], out[1]):
-            assert torch.equal(a, b), (N, D, tile_rows, grid, f64)
-        assert (out[1][1] - C).abs().max().item() <= (1e-11 if f64 else 2e-5) * C.abs().max().item()
-
-
 def test_fused_quantization_divides_exactly(rt):
     """The fused forward replaces x / step by a hoisted-reciprocal refinement (transform.hip, P5); it
     must round like the IEEE division of encode_3dgs.py:204 for every coefficient. Keys that are all
