@@ -41,6 +41,7 @@ def parse():
     ap.add_argument("--no-quant", action="store_true", help="time forward + inverse only")
     ap.add_argument("--engine", default="tile", choices=["tile", "level"])
     ap.add_argument("--tile-rows", type=int, default=0)
+    ap.add_argument("--top-rows", type=int, default=0, help="entries at which the single-launch top stage takes over (0 = automatic)")
     ap.add_argument("--quant-step", type=float, default=0.01)
     ap.add_argument("--skip-cpu-baseline", action="store_true")
     ap.add_argument("--skip-prelude", action="store_true", help="do not time plan build / sort / voxelizer")
@@ -125,7 +126,7 @@ def main():
 
     if world == 1:
         plan = R.RahtPlan.from_keys(kd, 3 * J)
-        plan.set_engine(a.engine, a.tile_rows)
+        plan.set_engine(a.engine, a.tile_rows, 0, 0, a.top_rows)
         T = torch.empty_like(Cd)
         Q = torch.empty((N, D), dtype=torch.int32, device=dev)
         Td = torch.empty_like(Cd)

@@ -242,12 +242,15 @@ void pick_tail_geometry(const raht_plan *plan, int elem_size, int D, int stage0_
     }
     *tail_rows = R;
     *tail_chunk = Dc;
-    // The finishing stage is latency-bound: once few enough entries are left, ONE workgroup with all
-    // 128 LDS granules takes them as a single tile and completes the tree in one launch.
-    int Rf = 512;
-    if (plan->final_rows_override > 0) Rf = plan->final_rows_override;
-    while (Rf > 64 && tile_lds_bytes(Rf, elem_size, Dc, false, elem_size == 4) > (size_t)128 * 1280) Rf -= 64;
-    *final_rows = std::max(Rf, 64);
+    // The top of the tree is latency-bound: once at most this many entries are left, ONE launch
+    // (top_kernel: a workgroup per 16-byte channel chunk, all entries in LDS, 16 bytes per entry)
+    // finishes the tree. 8192 entries = 128 KiB of the CU's 160 KiB.
+    // Default 4096: above that, one workgroup per chunk touching EVERY entry's row (one 128-byte line per
+    // 16 useful bytes, on ceil(D / 4) CUs only) costs more than a tile stage spread over the chip
+    // (cfg3: 7013 entries in the top stage 41 us, as a tile stage + a 439-entry top stage 15 + 10 us).
+    int Rf = 4096;
+    if (plan->final_rows_override > 0) Rf = std::min(plan->final_rows_override, RAHT_TOP_MAX_ROWS);
+    *final_rows = Rf;
 }
 
 static void free_schedule(Schedule &sc)
@@ -259,6 +262,11 @@ static void free_schedule(Schedule &sc)
         if (st.e_wr) (void)hipFree(st.e_wr);
         if (st.e_lvl) (void)hipFree(st.e_lvl);
         if (st.e_pos) (void)hipFree(st.e_pos);
+        if (st.t_pj) (void)hipFree(st.t_pj);
+        if (st.t_ab32) (void)hipFree(st.t_ab32);
+        if (st.t_ab64) (void)hipFree(st.t_ab64);
+        if (st.t_root) (void)hipFree(st.t_root);
+        if (st.t_lev) (void)hipFree(st.t_lev);
         if (st.ws) (void)hipFree(st.ws);
     }
     sc.stages.clear();
@@ -300,6 +308,123 @@ __global__ void gather_meta_kernel(const uint32_t *__restrict__ rows, int64_t n,
     e_wl[j] = wl[r]; e_wr[j] = wr[r]; e_lvl[j] = lvl[r]; e_pos[j] = inv_order[r];
 }
 
+// ---- TOP stage: every butterfly still to do, resolved against the stage's entry list ----------------
+__global__ void top_resolve_kernel(const uint32_t *__restrict__ rows, int64_t n, const int32_t *__restrict__ wl,
+                                   const int32_t *__restrict__ wr, const uint8_t *__restrict__ lvl,
+                                   const int64_t *__restrict__ wsum, int top_level, uint32_t *__restrict__ pj,
+                                   double *__restrict__ ab, uint8_t *__restrict__ bucket, uint32_t *__restrict__ is_root)
+{
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    const int64_t r = rows ? (int64_t)rows[e] : e;
+    const int l = (int)lvl[r];
+    const bool merged = (r > 0) && (l < top_level);
+    is_root[e] = merged ? 0u : 1u;
+    bucket[e] = merged ? (uint8_t)l : (uint8_t)63;       // roots sort behind every butterfly (levels are <= 62)
+    uint32_t rec = 0;
+    double a = 0.0, b = 0.0;
+    if (merged) {
+        const int64_t want = r - wl[r];                  // the partner row is an entry of this stage as well
+        int64_t p = want;
+        if (rows) {
+            int64_t lo = 0, hi = e - 1;
+            while (lo < hi) {
+                const int64_t mid = (lo + hi) >> 1;
+                if ((int64_t)rows[mid] < want) lo = mid + 1; else hi = mid;
+            }
+            p = lo;
+        }
+        double w0, w1;
+        pair_weights(r, wl[r], wr[r], wsum, w0, w1);
+        const double den = w0 + w1;
+        a = sqrt(w0 / den);                              // RAHT.py:321-322
+        b = sqrt(w1 / den);
+        rec = (uint32_t)p | ((uint32_t)e << 16);
+    }
+    pj[e] = rec; ab[2 * e] = a; ab[2 * e + 1] = b;
+}
+
+__global__ void top_gather_kernel(const uint32_t *__restrict__ perm, uint32_t n_merges, const uint32_t *__restrict__ pj,
+                                  const double *__restrict__ ab, uint32_t *__restrict__ t_pj,
+                                  float *__restrict__ t_ab32, double *__restrict__ t_ab64)
+{
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n_merges) return;
+    const uint32_t e = perm[k];
+    t_pj[k] = pj[e];
+    const double a = ab[2 * e], b = ab[2 * e + 1];
+    t_ab64[2 * k] = a; t_ab64[2 * k + 1] = b;
+    t_ab32[2 * k] = (float)a; t_ab32[2 * k + 1] = (float)b;
+}
+
+__global__ void top_root_rank_kernel(const uint32_t *__restrict__ is_root, const uint32_t *__restrict__ pos, int64_t n,
+                                     uint32_t *__restrict__ t_root)
+{
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < n) t_root[e] = is_root[e] ? pos[e] : 0xffffffffu;
+}
+
+static int build_top_stage(raht_plan *plan, uint32_t *rows, int64_t n, hipStream_t s, Stage &st)
+{
+    st.is_top = true;
+    st.n_entries = n;
+    st.n_tiles = 1;
+    st.rows = rows;
+    st.tile_rows = (int)n;
+    const unsigned gb = (unsigned)ceil_div(n, 256);
+    if (rows) {
+        RAHT_HIP_CHECK(hipMalloc(&st.e_wl, sizeof(int32_t) * (size_t)n));
+        RAHT_HIP_CHECK(hipMalloc(&st.e_wr, sizeof(int32_t) * (size_t)n));
+        RAHT_HIP_CHECK(hipMalloc(&st.e_lvl, (size_t)n));
+        RAHT_HIP_CHECK(hipMalloc(&st.e_pos, sizeof(uint32_t) * (size_t)n));
+        hipLaunchKernelGGL(gather_meta_kernel, dim3(gb), dim3(256), 0, s, rows, n, plan->wl, plan->wr, plan->lvl,
+                           plan->inv_order, st.e_wl, st.e_wr, st.e_lvl, st.e_pos);
+    }
+    // scratch: pj | is_root | pos | perm | boff[65] | total | ab (double, 8-byte aligned first) | bucket
+    Scratch buf(sizeof(double) * 2 * (size_t)n + sizeof(uint32_t) * (4 * (size_t)n + 66) + (size_t)n);
+    if (!buf.ok()) return RAHT_ERR_NOMEM;
+    double *ab = buf.as<double>();
+    uint32_t *pj = (uint32_t *)(ab + 2 * n), *is_root = pj + n, *pos = is_root + n, *perm = pos + n, *boff = perm + n,
+             *total = boff + 65;
+    uint8_t *bucket = (uint8_t *)(total + 1);
+    hipLaunchKernelGGL(top_resolve_kernel, dim3(gb), dim3(256), 0, s, rows, n, plan->wl, plan->wr, plan->lvl, plan->wsum,
+                       plan->top_level, pj, ab, bucket, is_root);
+    RAHT_RET(exclusive_scan_u32(is_root, pos, n, total, s));
+    RAHT_HIP_CHECK(hipMalloc(&st.t_root, sizeof(uint32_t) * (size_t)n));
+    hipLaunchKernelGGL(top_root_rank_kernel, dim3(gb), dim3(256), 0, s, is_root, pos, n, st.t_root);
+    RAHT_RET(bucket_sort_u8(bucket, perm, n, 6, boff, s));
+    RAHT_HIP_CHECK(hipMemcpyAsync(st.t_loff, boff, sizeof(uint32_t) * 65, hipMemcpyDeviceToHost, s));
+    RAHT_HIP_CHECK(hipStreamSynchronize(s));
+    st.n_merges = st.t_loff[63];
+    {
+        // the level program: non-empty levels, ascending; the trailing run of levels with at most 64
+        // butterflies each (the top of the tree) is chained by one wave
+        uint32_t lev[2 * 63];
+        int nlev = 0;
+        for (int l = 0; l < 63; ++l)
+            if (st.t_loff[l + 1] > st.t_loff[l]) { lev[2 * nlev] = st.t_loff[l]; lev[2 * nlev + 1] = st.t_loff[l + 1]; ++nlev; }
+        int nbig = nlev;
+        while (nbig > 0 && lev[2 * (nbig - 1) + 1] - lev[2 * (nbig - 1)] <= 64) --nbig;
+        // the chained records live in LDS next to the entries (16 B each + 12 / 20 B per record)
+        const size_t lds_budget = 160 * 1024 - 1024;
+        while (nbig < nlev && (size_t)n * 16 + (size_t)(st.n_merges - lev[2 * nbig]) * 20 > lds_budget) ++nbig;
+        st.t_nlev = nlev; st.t_nbig = nbig;
+        st.t_small_start = (nbig < nlev) ? lev[2 * nbig] : st.n_merges;
+        RAHT_HIP_CHECK(hipMalloc(&st.t_lev, sizeof(uint32_t) * 2 * 64));
+        RAHT_HIP_CHECK(hipMemcpyAsync(st.t_lev, lev, sizeof(uint32_t) * 2 * (size_t)std::max(nlev, 1), hipMemcpyHostToDevice, s));
+        RAHT_HIP_CHECK(hipStreamSynchronize(s));       // lev[] is a stack array
+    }
+    const size_t nm = std::max<size_t>(st.n_merges, 1);
+    RAHT_HIP_CHECK(hipMalloc(&st.t_pj, sizeof(uint32_t) * nm));
+    RAHT_HIP_CHECK(hipMalloc(&st.t_ab32, sizeof(float) * 2 * nm));
+    RAHT_HIP_CHECK(hipMalloc(&st.t_ab64, sizeof(double) * 2 * nm));
+    if (st.n_merges)
+        hipLaunchKernelGGL(top_gather_kernel, dim3((unsigned)ceil_div(st.n_merges, 256)), dim3(256), 0, s, perm, st.n_merges,
+                           pj, ab, st.t_pj, st.t_ab32, st.t_ab64);
+    RAHT_HIP_CHECK(hipStreamSynchronize(s));         // the scratch goes back to the pool
+    return RAHT_OK;
+}
+
 int get_schedule(raht_plan *plan, int R0, int R1, int Rf, hipStream_t s, Schedule **out)
 {
     for (auto &sc : plan->schedules)
@@ -317,8 +442,13 @@ int get_schedule(raht_plan *plan, int R0, int R1, int Rf, hipStream_t s, Schedul
     int64_t n = N;
     int rc = RAHT_OK;
     for (int k = 0; k < 24; ++k) {
-        int R = (k == 0) ? R0 : R1;
-        if (n <= Rf && n > R) R = (int)(ceil_div(n, 64) * 64);   // few entries left: one big tile finishes the tree
+        const int R = (k == 0) ? R0 : R1;
+        if (n <= Rf) {                                       // few entries left: the TOP stage finishes the tree
+            Stage st;
+            rc = build_top_stage(plan, rows, n, s, st);
+            sc.stages.push_back(st);
+            break;
+        }
         Stage st;
         st.n_entries = n;
         st.n_tiles = ceil_div(n, R);
@@ -558,8 +688,8 @@ int raht_plan_nbits(const raht_plan *p) { return p ? p->nbits : -1; }
 int raht_plan_set_tail_tile(raht_plan *p, int tail_rows, int tail_channels, int final_rows)
 {
     if (!p || tail_rows < 0 || tail_rows > 1024 || (tail_rows & 3) || tail_channels < 0 || tail_channels > 64 ||
-        final_rows < 0 || final_rows > 1024 || (final_rows & 63)) {
-        set_error("raht_plan_set_tail_tile: rows multiple of 4 in [0, 1024], channels in [0, 64], final rows multiple of 64 in [0, 1024]");
+        final_rows < 0 || final_rows > RAHT_TOP_MAX_ROWS) {
+        set_error("raht_plan_set_tail_tile: rows multiple of 4 in [0, 1024], channels in [0, 64], top-stage rows in [0, %d]", RAHT_TOP_MAX_ROWS);
         return RAHT_ERR_INVALID;
     }
     p->tail_rows_override = tail_rows;

@@ -76,6 +76,8 @@ int compact_u32(const uint32_t *in, const uint32_t *flag, uint32_t *out, int64_t
                 int64_t *count_host, hipStream_t s);
 
 // ---- plan (plan.hip) ---------------------------------------------------------------------------
+constexpr int RAHT_TOP_MAX_ROWS = 8192;   // entries the TOP stage can hold (16 bytes each in LDS)
+
 struct Stage {
     int64_t n_entries = 0;   // active rows entering this stage
     int64_t n_tiles = 0;
@@ -89,12 +91,27 @@ struct Stage {
     int32_t *e_wl = nullptr, *e_wr = nullptr;
     uint8_t *e_lvl = nullptr;
     uint32_t *e_pos = nullptr;
+    // TOP stage (the last one, when at most `top_rows` entries are left): ONE launch of top_kernel
+    // finishes the tree. A workgroup per 16-byte channel chunk keeps all entries in LDS and walks
+    // the butterflies level by level from this precomputed list, sorted by level:
+    bool is_top = false;
+    uint32_t n_merges = 0;
+    uint32_t *t_pj = nullptr;      // device [n_merges]: partner entry | own entry << 16
+    float *t_ab32 = nullptr;       // device [2 * n_merges]: a, b as the float32 transform uses them
+    double *t_ab64 = nullptr;      // device [2 * n_merges]: a, b in float64
+    uint32_t *t_root = nullptr;    // device [n_entries]: rank among the roots (root buffer row), ~0u = not a root
+    uint32_t t_loff[65] = {0};     // host: first merge of every binary level (t_loff[63] = n_merges)
+    uint32_t *t_lev = nullptr;     // device [2 * t_nlev]: (first, end) butterfly of every NON-EMPTY level, ascending
+    int t_nlev = 0;
+    int t_nbig = 0;                // the first t_nbig of them run on the whole workgroup (a barrier each); the rest
+                                   // hold <= 64 butterflies each and are chained by ONE wave without barriers
+    uint32_t t_small_start = 0;    // first butterfly of the chained part (its records are staged in LDS)
 };
 
 struct Schedule {
     int tile_rows = 0;         // rows per tile of stage 0 (cache key, with tail_rows)
     int tail_rows = 0;         // rows per tile of the stages >= 1
-    int final_rows = 0;        // a stage with at most this many entries runs as ONE tile and finishes the tree
+    int final_rows = 0;        // a stage with at most this many entries becomes the TOP stage (one launch finishes the tree)
     bool valid = false;        // false: tile stages cannot finish the tree -> use the level engine
     std::vector<Stage> stages;
     size_t ws_row_bytes = 0;   // bytes per workspace row currently allocated (D * elem_size)
@@ -129,6 +146,19 @@ struct raht_plan {
 };
 
 namespace raht {
+// Weights of the two children of the butterfly at row i (left extent l, right extent r): row counts,
+// or sums of leaf weights (weighted plans: prefix populations of a sharded scene).
+__device__ __forceinline__ void pair_weights(int64_t i, int l, int r, const int64_t *wsum, double &w0, double &w1)
+{
+    if (wsum) {
+        w0 = (double)(wsum[i] - wsum[i - l]);
+        w1 = (double)(wsum[i + r] - wsum[i]);
+    } else {
+        w0 = (double)l;
+        w1 = (double)r;
+    }
+}
+
 // Tile schedule for `tile_rows` rows per tile (built on first use, cached in the plan).
 int get_schedule(raht_plan *plan, int tile_rows, int tail_rows, int final_rows, hipStream_t s, Schedule **out);
 // Tile geometry of the later (small, latency-bound) stages: as many rows as one workgroup per CU can

@@ -31,17 +31,6 @@ template <typename T> struct Vec16;
 template <> struct Vec16<float> { typedef float4 type; static constexpr int n = 4; };
 template <> struct Vec16<double> { typedef double2 type; static constexpr int n = 2; };
 
-__device__ __forceinline__ void pair_weights(int64_t i, int l, int r, const int64_t *wsum, double &w0, double &w1)
-{
-    if (wsum) {
-        w0 = (double)(wsum[i] - wsum[i - l]);
-        w1 = (double)(wsum[i + r] - wsum[i]);
-    } else {
-        w0 = (double)l;
-        w1 = (double)r;
-    }
-}
-
 // ------------------------------------------------------------------------------------------------
 // strided row copy (only used when the level engine needs dst = src first)
 // ------------------------------------------------------------------------------------------------
@@ -217,6 +206,29 @@ __device__ __forceinline__ void st_chunk(E *__restrict__ p, const RegChunk<E> &x
     *(MemChunk<E> *)p = t;
 }
 
+__device__ __forceinline__ int32_t quantize_one(float x, float sp, float r, int fast_div)
+{
+    float q;
+    if (fast_div) {
+        // x / step, correctly rounded: the quotient refinement of hipcc's float division (mul, 4 fma)
+        // without its range scaling and special-case fixup, which the host has ruled out (steps
+        // within [2^-100, 2^100]); r is the refined reciprocal of the step (refined_rcp)
+        const float q0 = x * r;
+        const float q1 = __builtin_fmaf(__builtin_fmaf(-sp, q0, x), r, q0);
+        q = __builtin_fmaf(__builtin_fmaf(-sp, q1, x), r, q1);
+    } else {
+        q = x / sp;
+    }
+    return (int32_t)floorf(q + 0.5f);                     // encode_3dgs.py:204
+}
+
+// v_rcp_f32 + one Newton step: exactly how hipcc's own float division refines 1 / step per quotient
+__device__ __forceinline__ float refined_rcp(float sp)
+{
+    const float r0 = __builtin_amdgcn_rcpf(sp);
+    return __builtin_fmaf(__builtin_fmaf(-sp, r0, 1.0f), r0, r0);
+}
+
 // Plan metadata of one tile, held in registers (slot j = tid + s * blockDim). The persistent tile
 // loop loads the NEXT tile's metadata while the current tile's butterflies run, so no tile waits on
 // an HBM round trip before it can issue its own data loads.
@@ -331,10 +343,7 @@ __global__ __launch_bounds__(512, (sizeof(T) == 4 ? 6 : 4)) void tile_kernel(con
 #pragma unroll
         for (int i = 0; i < VN; ++i) {
             my_step[i] = ST.v[ST.n == 1 ? 0 : g0 + i];
-            // refined reciprocal, exactly as hipcc's own float division computes it per quotient
-            // (v_rcp_f32 + one Newton step); here once per channel instead of once per coefficient
-            const float r0 = __builtin_amdgcn_rcpf(my_step[i]);
-            my_rcp[i] = __builtin_fmaf(__builtin_fmaf(-my_step[i], r0, 1.0f), r0, r0);
+            my_rcp[i] = refined_rcp(my_step[i]);          // once per channel instead of once per coefficient
         }
     }
 
@@ -622,21 +631,7 @@ __global__ __launch_bounds__(512, (sizeof(T) == 4 ? 6 : 4)) void tile_kernel(con
                 if constexpr (QM) {
                     RegChunk<int32_t> qv;
 #pragma unroll
-                    for (int i = 0; i < VN; ++i) {
-                        float q;
-                        if (ST.fast_div) {
-                            // x / step, correctly rounded: the quotient refinement of hipcc's float
-                            // division (mul, 4 fma) without its range scaling and special-case fixup,
-                            // which the host has ruled out (steps within [2^-100, 2^100]; see check_steps)
-                            const float xf = (float)x.v[i], sp = my_step[i], r = my_rcp[i];
-                            const float q0 = xf * r;
-                            const float q1 = __builtin_fmaf(__builtin_fmaf(-sp, q0, xf), r, q0);
-                            q = __builtin_fmaf(__builtin_fmaf(-sp, q1, xf), r, q1);
-                        } else {
-                            q = (float)x.v[i] / my_step[i];
-                        }
-                        qv.v[i] = (int32_t)floorf(q + 0.5f);
-                    }
+                    for (int i = 0; i < VN; ++i) qv.v[i] = quantize_one((float)x.v[i], my_step[i], my_rcp[i], ST.fast_div);
                     st_chunk<int32_t>(A.Q + (int64_t)sdst[jc] * A.ldq + goff, qv);
                 } else {
                     const int64_t d = IDENT ? e0 + j : (int64_t)srow[jc];
@@ -647,6 +642,206 @@ __global__ __launch_bounds__(512, (sizeof(T) == 4 ? 6 : 4)) void tile_kernel(con
     }
     __syncthreads();              // LDS is reused by the next tile
     }                             // persistent tile loop
+}
+
+// ------------------------------------------------------------------------------------------------
+// TOP stage: the last <= RAHT_TOP_MAX_ROWS entries of the tree in ONE launch.
+//
+// The top of the tree is a handful of butterflies per level over a few thousand rows: as tile
+// stages it was two or three launches of ~15-20 us each, all of it latency (launch, metadata round
+// trip, merge resolution, ~20 barrier-separated rounds per tile). Here the butterflies are resolved
+// once per schedule (plan.hip: build_top_stage; partner entry, a, b, sorted by level), a workgroup
+// owns ONE 16-byte channel chunk of ALL entries (LDS: 16 bytes per entry), every thread keeps its
+// <= 8 butterfly records in registers, and the levels are walked with one barrier each.
+// ------------------------------------------------------------------------------------------------
+constexpr int TOP_THREADS = 1024;
+constexpr int TOP_SLOTS = RAHT_TOP_MAX_ROWS / TOP_THREADS;       // entries / butterflies per thread
+
+template <typename T>
+struct TopArgs {
+    const T *in;  int64_t ld_in;       // fwd: the stage's entries, entry order (C when it is the only stage, else ws)
+    T *fin;       int64_t ld_fin;      // T rows (fwd out / inv in)
+    T *out;       int64_t ld_out;      // inv: the stage's entries, entry order (C or ws)
+    int32_t *Q;   int64_t ldq;         // fused quantization
+    const uint32_t *rows;              // entry -> row (nullptr: identity)
+    const uint32_t *e_pos;             // entry -> position in Q
+    const uint32_t *pj;                // butterflies sorted by level: partner entry | own entry << 16
+    const T *ab;                       // a, b per butterfly
+    const uint32_t *root_rank;         // entry -> row of the caller's root buffer (~0u: not a root)
+    T *root_buf;
+    int n, n_merges, D;
+    const uint32_t *lev;               // device [2 * nlev]: (first, end) butterfly of every non-empty level, ascending
+    int nlev, nbig;                    // levels [0, nbig): whole workgroup, a barrier each; [nbig, nlev): chained by wave 0
+    uint32_t small_start;              // first butterfly of the chained part
+};
+
+template <typename T, bool INV, bool QM>
+__global__ __launch_bounds__(TOP_THREADS) void top_kernel(const TopArgs<T> A,
+                                                          const typename std::conditional<QM, StepTable, NoSteps>::type ST)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    typedef RegChunk<T> V16;
+    constexpr int VN = 16 / sizeof(T);
+    V16 *tile = (V16 *)smem;
+    __shared__ uint32_t s_lev[2 * 64];
+    const int tid = threadIdx.x;
+    const int goff = min((int)blockIdx.x * VN, A.D - VN);          // last chunk: the 16 bytes that end the row
+    const int n = A.n, nm = A.n_merges;
+    if (tid < 2 * A.nlev) s_lev[tid] = A.lev[tid];
+    // records of the chained levels, staged in LDS behind the entries
+    const int n_small = nm - (int)A.small_start;
+    uint32_t *s_pj = (uint32_t *)(smem + (size_t)n * 16);
+    T *s_ab = (T *)(s_pj + ((n_small + 3) & ~3));
+    for (int i = tid; i < n_small; i += TOP_THREADS) {
+        s_pj[i] = A.pj[A.small_start + i];
+        s_ab[2 * i] = A.ab[2 * (A.small_start + i)];
+        s_ab[2 * i + 1] = A.ab[2 * (A.small_start + i) + 1];
+    }
+
+    float my_step[VN], my_rcp[VN];
+#pragma unroll
+    for (int i = 0; i < VN; ++i) { my_step[i] = 1.0f; my_rcp[i] = 1.0f; }
+    if constexpr (QM) {
+#pragma unroll
+        for (int i = 0; i < VN; ++i) {
+            my_step[i] = ST.v[ST.n == 1 ? 0 : goff + i];
+            my_rcp[i] = refined_rcp(my_step[i]);
+        }
+    }
+
+    // this thread's butterflies (clamped, unconditional loads) ...
+    uint32_t pj[TOP_SLOTS];
+    T ra[TOP_SLOTS], rb[TOP_SLOTS];
+#pragma unroll
+    for (int k = 0; k < TOP_SLOTS; ++k) {
+        const int idx = min(k * TOP_THREADS + tid, max(nm - 1, 0));
+        pj[k] = A.pj[idx]; ra[k] = A.ab[2 * idx]; rb[k] = A.ab[2 * idx + 1];
+    }
+    // ... where its entries' coefficients live (T row or Q position; root buffer row), fetched up front
+    // so that neither the loads nor the stores below wait on a dependent metadata load per entry ...
+    uint32_t m_dst[TOP_SLOTS], m_rr[TOP_SLOTS];
+#pragma unroll
+    for (int k = 0; k < TOP_SLOTS; ++k) {
+        const int e = min(k * TOP_THREADS + tid, n - 1);
+        m_rr[k] = A.root_rank[e];
+        m_dst[k] = QM ? A.e_pos[e] : (A.rows ? A.rows[e] : (uint32_t)e);
+    }
+    // ... and the entries themselves
+    {
+        typedef typename std::conditional<QM && INV, int32_t, T>::type RawT;
+        RegChunk<RawT> x[TOP_SLOTS];
+#pragma unroll
+        for (int k = 0; k < TOP_SLOTS; ++k) {
+            const int e = min(k * TOP_THREADS + tid, n - 1);
+            if constexpr (!INV) {
+                x[k] = ld_chunk<RawT>((const RawT *)A.in + (int64_t)e * A.ld_in + goff);
+            } else if constexpr (QM) {
+                x[k] = ld_chunk<RawT>((const RawT *)A.Q + (int64_t)m_dst[k] * A.ldq + goff);
+            } else {
+                const T *src = (A.root_buf && m_rr[k] != 0xffffffffu) ? A.root_buf + (int64_t)m_rr[k] * A.D
+                                                                      : A.fin + (int64_t)m_dst[k] * A.ld_fin;
+                x[k] = ld_chunk<RawT>((const RawT *)src + goff);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < TOP_SLOTS; ++k) {
+            const int e = k * TOP_THREADS + tid;
+            if (e < n) {
+                V16 v;
+#pragma unroll
+                for (int i = 0; i < VN; ++i) {
+                    v.v[i] = (T)x[k].v[i];
+                    if constexpr (QM && INV) v.v[i] = v.v[i] * (T)my_step[i];            // encode_3dgs.py:261
+                }
+                tile[e] = v;
+            }
+        }
+        if constexpr (QM && INV) {
+            // the roots' low-pass values come from the caller's compact buffer (already dequantized)
+            if (A.root_buf) {
+#pragma unroll
+                for (int k = 0; k < TOP_SLOTS; ++k) {
+                    const int e = k * TOP_THREADS + tid;
+                    if (e < n && m_rr[k] != 0xffffffffu) tile[e] = ld_chunk<T>(A.root_buf + (int64_t)m_rr[k] * A.D + goff);
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    auto butterfly = [&](uint32_t rec, T a, T b) {
+        const uint32_t ip = rec & 0xffffu, ij = rec >> 16;
+        const V16 x0 = tile[ip], x1 = tile[ij];
+        V16 vlo, vhi;
+#pragma unroll
+        for (int i = 0; i < VN; ++i) {
+            if (!INV) {                                   // RAHT.py:331-332
+                vlo.v[i] = a * x0.v[i] + b * x1.v[i];
+                vhi.v[i] = a * x1.v[i] - b * x0.v[i];
+            } else {                                      // iRAHT.py:108-109
+                vlo.v[i] = a * x0.v[i] - b * x1.v[i];
+                vhi.v[i] = b * x0.v[i] + a * x1.v[i];
+            }
+        }
+        tile[ip] = vlo; tile[ij] = vhi;
+    };
+    // levels with more than 64 butterflies: the whole workgroup, one barrier per level (loops not
+    // unrolled: 63 copies of the body thrash the instruction cache)
+    auto big_levels = [&]() {
+#pragma unroll 1
+        for (int q = 0; q < A.nbig; ++q) {
+            const int li = INV ? A.nbig - 1 - q : q;
+            const uint32_t lo = s_lev[2 * li], hi = s_lev[2 * li + 1];
+#pragma unroll
+            for (int k = 0; k < TOP_SLOTS; ++k) {
+                const uint32_t idx = (uint32_t)(k * TOP_THREADS + tid);
+                if ((uint32_t)(k * TOP_THREADS) < hi && (uint32_t)((k + 1) * TOP_THREADS) > lo && idx >= lo && idx < hi)
+                    butterfly(pj[k], ra[k], rb[k]);
+            }
+            __syncthreads();
+        }
+    };
+    // the top of the tree, <= 64 butterflies per level: ONE wave walks it without barriers (a wave's
+    // LDS operations execute in order, so a level sees the previous level's stores)
+    auto small_levels = [&]() {
+        if (tid < 64) {
+#pragma unroll 1
+            for (int q = A.nbig; q < A.nlev; ++q) {
+                const int li = INV ? A.nlev - 1 - (q - A.nbig) : q;
+                const uint32_t lo = s_lev[2 * li], hi = s_lev[2 * li + 1];
+                const uint32_t i = lo - A.small_start + (uint32_t)tid;
+                if (lo + (uint32_t)tid < hi) butterfly(s_pj[i], s_ab[2 * i], s_ab[2 * i + 1]);
+            }
+        }
+        __syncthreads();
+    };
+    if (!INV) { big_levels(); small_levels(); }
+    else { small_levels(); big_levels(); }
+
+    // write back
+#pragma unroll
+    for (int k = 0; k < TOP_SLOTS; ++k) {
+        const int e = k * TOP_THREADS + tid;
+        if (e >= n) continue;
+        const V16 v = tile[e];
+        if constexpr (INV) {
+            st_chunk<T>(A.out + (int64_t)e * A.ld_out + goff, v);
+        } else {
+            const uint32_t rr = m_rr[k];
+            const bool to_buf = A.root_buf && rr != 0xffffffffu;   // still a low-pass value: the caller's top stage takes it
+            if (to_buf) st_chunk<T>(A.root_buf + (int64_t)rr * A.D + goff, v);
+            if (QM && to_buf) {
+                // roots are quantized by the caller's top stage
+            } else if constexpr (QM) {
+                RegChunk<int32_t> qv;
+#pragma unroll
+                for (int i = 0; i < VN; ++i) qv.v[i] = quantize_one((float)v.v[i], my_step[i], my_rcp[i], ST.fast_div);
+                st_chunk<int32_t>(A.Q + (int64_t)m_dst[k] * A.ldq + goff, qv);
+            } else {
+                st_chunk<T>(A.fin + (int64_t)m_dst[k] * A.ld_fin + goff, v);
+            }
+        }
+    }
 }
 
 // node weights of RAHT.py:325-328: after its own butterfly a right sibling carries w0 + w1 and is
@@ -738,10 +933,56 @@ static int launch_tile_one(const TileArgs<T> &A, const XformIO<T> &io, dim3 grid
 }
 
 template <typename T, bool INV, bool QM>
+static int launch_top_stage(const raht_plan *p, const Schedule &sc, int k, const XformIO<T> &io, int D, hipStream_t s)
+{
+    const Stage &st = sc.stages[(size_t)k];
+    constexpr int VN = 16 / (int)sizeof(T);
+    TopArgs<T> A;
+    T *ws_k = (k >= 1) ? (T *)st.ws : nullptr;
+    A.in = nullptr; A.ld_in = 0; A.out = nullptr; A.ld_out = 0;
+    if (!INV) { A.in = (k == 0) ? io.src : ws_k; A.ld_in = (k == 0) ? io.ld_src : D; A.fin = io.dst; A.ld_fin = io.ld_dst; }
+    else { A.fin = const_cast<T *>(io.src); A.ld_fin = io.ld_src; A.out = (k == 0) ? io.dst : ws_k; A.ld_out = (k == 0) ? io.ld_dst : D; }
+    A.Q = io.Q; A.ldq = io.ldq;
+    A.rows = st.rows;
+    A.e_pos = st.rows ? st.e_pos : p->inv_order;
+    A.pj = st.t_pj;
+    if constexpr (sizeof(T) == 4) A.ab = (const T *)st.t_ab32; else A.ab = (const T *)st.t_ab64;
+    A.root_rank = st.t_root;
+    A.root_buf = (T *)p->root_buf;
+    A.n = (int)st.n_entries; A.n_merges = (int)st.n_merges; A.D = D;
+    A.lev = st.t_lev; A.nlev = st.t_nlev; A.nbig = st.t_nbig; A.small_start = st.t_small_start;
+    const dim3 grid((unsigned)((D + VN - 1) / VN));
+    const size_t n_small = st.n_merges - st.t_small_start;
+    const size_t lds = (size_t)st.n_entries * 16 + ((n_small + 3) & ~(size_t)3) * 4 + n_small * 2 * sizeof(T);   // + 512 B static
+    static bool attr_set = false;
+    if (!attr_set) {
+        RAHT_HIP_CHECK(hipFuncSetAttribute((const void *)top_kernel<T, INV, QM>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           160 * 1024 - 1024));
+        attr_set = true;
+    }
+    if constexpr (QM) {
+        StepTable stp;
+        stp.n = io.n_steps;
+        stp.fast_div = 1;
+        for (int c = 0; c < io.n_steps; ++c) {
+            stp.v[c] = io.steps[c];
+            if (!(io.steps[c] >= 0x1p-100f && io.steps[c] <= 0x1p100f)) stp.fast_div = 0;
+        }
+        hipLaunchKernelGGL((top_kernel<T, INV, true>), grid, dim3(TOP_THREADS), lds, s, A, stp);
+    } else {
+        NoSteps ns{0, 0};
+        hipLaunchKernelGGL((top_kernel<T, INV, false>), grid, dim3(TOP_THREADS), lds, s, A, ns);
+    }
+    RAHT_HIP_CHECK(hipGetLastError());
+    return RAHT_OK;
+}
+
+template <typename T, bool INV, bool QM>
 static int launch_tile_stage(const raht_plan *p, const Schedule &sc, int k, const XformIO<T> &io, int D, int Dc0,
                              hipStream_t s, int dbg = 0)
 {
     const Stage &st = sc.stages[(size_t)k];
+    if (st.is_top) return launch_top_stage<T, INV, QM>(p, sc, k, io, D, s);
     int Dc = Dc0;
     if (k >= 1) {                                    // later stages: large tiles, channel chunks
         int r1 = 0, rf = 0;
