@@ -296,6 +296,8 @@ def main():
                 return best * 1e3
             pre = {}
             pre["plan_from_sorted_keys_ms"] = wall(lambda: R.RahtPlan.from_keys(kd, 3 * J))
+            # + the tile schedule and workspaces, normally built by the first transform of a plan
+            pre["plan_and_schedule_ms"] = wall(lambda: R.RahtPlan.from_keys(kd, 3 * J).prepare(D))
             g = torch.Generator(device=dev); g.manual_seed(1)
             perm = torch.randperm(N, device=dev, generator=g)
             ku = kd[perm].contiguous()

@@ -112,6 +112,11 @@ int raht_plan_nbits(const raht_plan *plan);             /* 3 * depth */
 int raht_plan_set_engine(raht_plan *plan, int engine, int tile_rows);
 int raht_plan_set_tail_tile(raht_plan *plan, int tail_rows, int tail_channels, int final_rows);
 
+/* Plans, schedules and workspaces take their device memory from a process-wide cache of freed blocks
+ * (a codec that builds one plan per frame stops paying hipMalloc / hipFree once the cache is warm;
+ * at most RAHT_POOL_MAX_BYTES, default 8 GiB, stay cached). This returns the cached blocks to HIP. */
+int raht_release_cached_memory(void);
+
 /* Reference-shaped views, for parity tests and the drivers' DEBUG save_lists
  * (reference python/encode_3dgs.py:165). HOST output buffers.
  *   raht_plan_levels       = len(Flags) of the reference

@@ -256,18 +256,18 @@ void pick_tail_geometry(const raht_plan *plan, int elem_size, int D, int stage0_
 static void free_schedule(Schedule &sc)
 {
     for (auto &st : sc.stages) {
-        if (st.rows) (void)hipFree(st.rows);
-        if (st.surv_off) (void)hipFree(st.surv_off);
-        if (st.e_wl) (void)hipFree(st.e_wl);
-        if (st.e_wr) (void)hipFree(st.e_wr);
-        if (st.e_lvl) (void)hipFree(st.e_lvl);
-        if (st.e_pos) (void)hipFree(st.e_pos);
-        if (st.t_pj) (void)hipFree(st.t_pj);
-        if (st.t_ab32) (void)hipFree(st.t_ab32);
-        if (st.t_ab64) (void)hipFree(st.t_ab64);
-        if (st.t_root) (void)hipFree(st.t_root);
-        if (st.t_lev) (void)hipFree(st.t_lev);
-        if (st.ws) (void)hipFree(st.ws);
+        if (st.rows) dev_free(st.rows);
+        if (st.surv_off) dev_free(st.surv_off);
+        if (st.e_wl) dev_free(st.e_wl);
+        if (st.e_wr) dev_free(st.e_wr);
+        if (st.e_lvl) dev_free(st.e_lvl);
+        if (st.e_pos) dev_free(st.e_pos);
+        if (st.t_pj) dev_free(st.t_pj);
+        if (st.t_ab32) dev_free(st.t_ab32);
+        if (st.t_ab64) dev_free(st.t_ab64);
+        if (st.t_root) dev_free(st.t_root);
+        if (st.t_lev) dev_free(st.t_lev);
+        if (st.ws) dev_free(st.ws);
     }
     sc.stages.clear();
 }
@@ -277,8 +277,8 @@ int ensure_workspace(Schedule *sc, size_t row_bytes)
     if (row_bytes <= sc->ws_row_bytes) return RAHT_OK;
     for (size_t k = 1; k < sc->stages.size(); ++k) {
         Stage &st = sc->stages[k];
-        if (st.ws) { (void)hipFree(st.ws); st.ws = nullptr; }
-        if (hipMalloc(&st.ws, row_bytes * (size_t)st.n_entries) != hipSuccess) {
+        if (st.ws) { dev_free(st.ws); st.ws = nullptr; }
+        if (dev_malloc(&st.ws, row_bytes * (size_t)st.n_entries) != hipSuccess) {
             set_error("workspace allocation failed (%zu bytes)", row_bytes * (size_t)st.n_entries);
             sc->ws_row_bytes = 0;
             return RAHT_ERR_NOMEM;
@@ -373,10 +373,10 @@ static int build_top_stage(raht_plan *plan, uint32_t *rows, int64_t n, hipStream
     st.tile_rows = (int)n;
     const unsigned gb = (unsigned)ceil_div(n, 256);
     if (rows) {
-        RAHT_HIP_CHECK(hipMalloc(&st.e_wl, sizeof(int32_t) * (size_t)n));
-        RAHT_HIP_CHECK(hipMalloc(&st.e_wr, sizeof(int32_t) * (size_t)n));
-        RAHT_HIP_CHECK(hipMalloc(&st.e_lvl, (size_t)n));
-        RAHT_HIP_CHECK(hipMalloc(&st.e_pos, sizeof(uint32_t) * (size_t)n));
+        RAHT_HIP_CHECK(dev_malloc(&st.e_wl, sizeof(int32_t) * (size_t)n));
+        RAHT_HIP_CHECK(dev_malloc(&st.e_wr, sizeof(int32_t) * (size_t)n));
+        RAHT_HIP_CHECK(dev_malloc(&st.e_lvl, (size_t)n));
+        RAHT_HIP_CHECK(dev_malloc(&st.e_pos, sizeof(uint32_t) * (size_t)n));
         hipLaunchKernelGGL(gather_meta_kernel, dim3(gb), dim3(256), 0, s, rows, n, plan->wl, plan->wr, plan->lvl,
                            plan->inv_order, st.e_wl, st.e_wr, st.e_lvl, st.e_pos);
     }
@@ -390,7 +390,7 @@ static int build_top_stage(raht_plan *plan, uint32_t *rows, int64_t n, hipStream
     hipLaunchKernelGGL(top_resolve_kernel, dim3(gb), dim3(256), 0, s, rows, n, plan->wl, plan->wr, plan->lvl, plan->wsum,
                        plan->top_level, pj, ab, bucket, is_root);
     RAHT_RET(exclusive_scan_u32(is_root, pos, n, total, s));
-    RAHT_HIP_CHECK(hipMalloc(&st.t_root, sizeof(uint32_t) * (size_t)n));
+    RAHT_HIP_CHECK(dev_malloc(&st.t_root, sizeof(uint32_t) * (size_t)n));
     hipLaunchKernelGGL(top_root_rank_kernel, dim3(gb), dim3(256), 0, s, is_root, pos, n, st.t_root);
     RAHT_RET(bucket_sort_u8(bucket, perm, n, 6, boff, s));
     RAHT_HIP_CHECK(hipMemcpyAsync(st.t_loff, boff, sizeof(uint32_t) * 65, hipMemcpyDeviceToHost, s));
@@ -410,14 +410,14 @@ static int build_top_stage(raht_plan *plan, uint32_t *rows, int64_t n, hipStream
         while (nbig < nlev && (size_t)n * 16 + (size_t)(st.n_merges - lev[2 * nbig]) * 20 > lds_budget) ++nbig;
         st.t_nlev = nlev; st.t_nbig = nbig;
         st.t_small_start = (nbig < nlev) ? lev[2 * nbig] : st.n_merges;
-        RAHT_HIP_CHECK(hipMalloc(&st.t_lev, sizeof(uint32_t) * 2 * 64));
+        RAHT_HIP_CHECK(dev_malloc(&st.t_lev, sizeof(uint32_t) * 2 * 64));
         RAHT_HIP_CHECK(hipMemcpyAsync(st.t_lev, lev, sizeof(uint32_t) * 2 * (size_t)std::max(nlev, 1), hipMemcpyHostToDevice, s));
         RAHT_HIP_CHECK(hipStreamSynchronize(s));       // lev[] is a stack array
     }
     const size_t nm = std::max<size_t>(st.n_merges, 1);
-    RAHT_HIP_CHECK(hipMalloc(&st.t_pj, sizeof(uint32_t) * nm));
-    RAHT_HIP_CHECK(hipMalloc(&st.t_ab32, sizeof(float) * 2 * nm));
-    RAHT_HIP_CHECK(hipMalloc(&st.t_ab64, sizeof(double) * 2 * nm));
+    RAHT_HIP_CHECK(dev_malloc(&st.t_pj, sizeof(uint32_t) * nm));
+    RAHT_HIP_CHECK(dev_malloc(&st.t_ab32, sizeof(float) * 2 * nm));
+    RAHT_HIP_CHECK(dev_malloc(&st.t_ab64, sizeof(double) * 2 * nm));
     if (st.n_merges)
         hipLaunchKernelGGL(top_gather_kernel, dim3((unsigned)ceil_div(st.n_merges, 256)), dim3(256), 0, s, perm, st.n_merges,
                            pj, ab, st.t_pj, st.t_ab32, st.t_ab64);
@@ -455,8 +455,8 @@ int get_schedule(raht_plan *plan, int R0, int R1, int Rf, hipStream_t s, Schedul
         st.rows = rows;
         st.tile_rows = R;
         if (rows) {
-            if (hipMalloc(&st.e_wl, sizeof(int32_t) * (size_t)n) != hipSuccess || hipMalloc(&st.e_wr, sizeof(int32_t) * (size_t)n) != hipSuccess ||
-                hipMalloc(&st.e_lvl, (size_t)n) != hipSuccess || hipMalloc(&st.e_pos, sizeof(uint32_t) * (size_t)n) != hipSuccess) { rc = RAHT_ERR_NOMEM; sc.stages.push_back(st); break; }
+            if (dev_malloc(&st.e_wl, sizeof(int32_t) * (size_t)n) != hipSuccess || dev_malloc(&st.e_wr, sizeof(int32_t) * (size_t)n) != hipSuccess ||
+                dev_malloc(&st.e_lvl, (size_t)n) != hipSuccess || dev_malloc(&st.e_pos, sizeof(uint32_t) * (size_t)n) != hipSuccess) { rc = RAHT_ERR_NOMEM; sc.stages.push_back(st); break; }
             hipLaunchKernelGGL(gather_meta_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, s, rows, n, plan->wl,
                                plan->wr, plan->lvl, plan->inv_order, st.e_wl, st.e_wr, st.e_lvl, st.e_pos);
         }
@@ -474,12 +474,12 @@ int get_schedule(raht_plan *plan, int R0, int R1, int Rf, hipStream_t s, Schedul
             sc.valid = false;
             break;
         }
-        if (hipMalloc(&st.surv_off, sizeof(uint32_t) * (size_t)(st.n_tiles + 1)) != hipSuccess) { rc = RAHT_ERR_NOMEM; break; }
+        if (dev_malloc(&st.surv_off, sizeof(uint32_t) * (size_t)(st.n_tiles + 1)) != hipSuccess) { rc = RAHT_ERR_NOMEM; break; }
         hipLaunchKernelGGL(tile_start_kernel, dim3((unsigned)ceil_div(st.n_tiles + 1, 256)), dim3(256), 0, s,
                            pos, n, R, st.n_tiles, cnt32, st.surv_off);
         if (last) { sc.stages.push_back(st); break; }
         uint32_t *next = nullptr;
-        if (hipMalloc(&next, sizeof(uint32_t) * (size_t)cnt) != hipSuccess) { rc = RAHT_ERR_NOMEM; break; }
+        if (dev_malloc(&next, sizeof(uint32_t) * (size_t)cnt) != hipSuccess) { rc = RAHT_ERR_NOMEM; break; }
         hipLaunchKernelGGL(compact_scatter_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, s, rows,
                            flag, pos, next, n);
         sc.stages.push_back(st);
@@ -489,7 +489,7 @@ int get_schedule(raht_plan *plan, int R0, int R1, int Rf, hipStream_t s, Schedul
     hipError_t e = hipStreamSynchronize(s);
     if (rc == RAHT_OK && e != hipSuccess) rc = RAHT_ERR_HIP;
     if (rc != RAHT_OK) {
-        if (!sc.stages.empty() && sc.stages.back().rows != rows && rows) (void)hipFree(rows);
+        if (!sc.stages.empty() && sc.stages.back().rows != rows && rows) dev_free(rows);
         free_schedule(sc);
         set_error("schedule build failed");
         return rc;
@@ -508,7 +508,7 @@ __global__ void root_flag_kernel(const uint8_t *__restrict__ lvl, int64_t N, int
 
 static int compute_roots(raht_plan *p, hipStream_t s)
 {
-    if (p->root_rows) { (void)hipFree(p->root_rows); p->root_rows = nullptr; }
+    if (p->root_rows) { dev_free(p->root_rows); p->root_rows = nullptr; }
     Scratch buf(sizeof(uint32_t) * 2 * (size_t)p->N);
     if (!buf.ok()) return RAHT_ERR_NOMEM;
     uint32_t *flag = buf.as<uint32_t>(), *tmp = flag + p->N;
@@ -517,7 +517,7 @@ static int compute_roots(raht_plan *p, hipStream_t s)
     int64_t cnt = 0;
     RAHT_RET(compact_u32(nullptr, flag, tmp, p->N, &cnt, s));
     p->n_roots = cnt;
-    RAHT_HIP_CHECK(hipMalloc(&p->root_rows, sizeof(uint32_t) * (size_t)cnt));
+    RAHT_HIP_CHECK(dev_malloc(&p->root_rows, sizeof(uint32_t) * (size_t)cnt));
     RAHT_HIP_CHECK(hipMemcpyAsync(p->root_rows, tmp, sizeof(uint32_t) * (size_t)cnt, hipMemcpyDeviceToDevice, s));
     RAHT_HIP_CHECK(hipStreamSynchronize(s));
     return RAHT_OK;
@@ -535,12 +535,12 @@ static int finish_plan(raht_plan *p, const int64_t *leaf_weights, hipStream_t s)
     uint8_t *bucket = (uint8_t *)(boff + 65);
     PlanErr h0 = {0, 0xffffffffu};
     RAHT_HIP_CHECK(hipMemcpyAsync(derr, &h0, sizeof(h0), hipMemcpyHostToDevice, s));
-    RAHT_HIP_CHECK(hipMalloc(&p->lvl, (size_t)N));
-    RAHT_HIP_CHECK(hipMalloc(&p->wl, sizeof(int32_t) * (size_t)N));
-    RAHT_HIP_CHECK(hipMalloc(&p->wr, sizeof(int32_t) * (size_t)N));
-    RAHT_HIP_CHECK(hipMalloc(&p->order, sizeof(uint32_t) * (size_t)N));
-    RAHT_HIP_CHECK(hipMalloc(&p->inv_order, sizeof(uint32_t) * (size_t)N));
-    RAHT_HIP_CHECK(hipMalloc(&p->level_rows, sizeof(uint32_t) * (size_t)N));
+    RAHT_HIP_CHECK(dev_malloc(&p->lvl, (size_t)N));
+    RAHT_HIP_CHECK(dev_malloc(&p->wl, sizeof(int32_t) * (size_t)N));
+    RAHT_HIP_CHECK(dev_malloc(&p->wr, sizeof(int32_t) * (size_t)N));
+    RAHT_HIP_CHECK(dev_malloc(&p->order, sizeof(uint32_t) * (size_t)N));
+    RAHT_HIP_CHECK(dev_malloc(&p->inv_order, sizeof(uint32_t) * (size_t)N));
+    RAHT_HIP_CHECK(dev_malloc(&p->level_rows, sizeof(uint32_t) * (size_t)N));
     hipLaunchKernelGGL(level_kernel, dim3(gb), dim3(256), 0, s, p->keys, N, p->nbits, p->lvl, derr);
     // everything below is enqueued speculatively; the error word is checked at the single sync
     hipLaunchKernelGGL(extent_kernel, dim3(gb), dim3(256), 0, s, p->keys, N, p->lvl, p->wl, p->wr);
@@ -578,7 +578,7 @@ static int finish_plan(raht_plan *p, const int64_t *leaf_weights, hipStream_t s)
             if (w[(size_t)i] < 1) { set_error("leaf weight < 1 at row %lld", (long long)i); return RAHT_ERR_INVALID; }
             ps[(size_t)i + 1] = ps[(size_t)i] + w[(size_t)i];
         }
-        RAHT_HIP_CHECK(hipMalloc(&p->wsum, sizeof(int64_t) * ((size_t)N + 1)));
+        RAHT_HIP_CHECK(dev_malloc(&p->wsum, sizeof(int64_t) * ((size_t)N + 1)));
         RAHT_HIP_CHECK(hipMemcpy(p->wsum, ps.data(), sizeof(int64_t) * ((size_t)N + 1), hipMemcpyHostToDevice));
     }
     RAHT_HIP_CHECK(hipGetLastError());
@@ -614,9 +614,9 @@ int raht_plan_create(const void *V, int v_dtype, int64_t N, const double minV[3]
     p->nbits = 3 * depth;
     int rc = RAHT_OK;
     do {
-        if (hipMalloc(&p->keys, sizeof(uint64_t) * (size_t)N) != hipSuccess) { rc = RAHT_ERR_NOMEM; set_error("hipMalloc keys"); break; }
+        if (dev_malloc(&p->keys, sizeof(uint64_t) * (size_t)N) != hipSuccess) { rc = RAHT_ERR_NOMEM; set_error("hipMalloc keys"); break; }
         PlanErr *derr = nullptr;
-        if (hipMalloc(&derr, sizeof(PlanErr)) != hipSuccess) { rc = RAHT_ERR_NOMEM; break; }
+        if (dev_malloc(&derr, sizeof(PlanErr)) != hipSuccess) { rc = RAHT_ERR_NOMEM; break; }
         PlanErr h0 = {0, 0xffffffffu};
         (void)hipMemcpyAsync(derr, &h0, sizeof(h0), hipMemcpyHostToDevice, s);
         const double Q = width / (double)((uint64_t)1 << depth);
@@ -628,11 +628,11 @@ int raht_plan_create(const void *V, int v_dtype, int64_t N, const double minV[3]
         case RAHT_I64: hipLaunchKernelGGL(keys_from_coords_kernel<int64_t>, dim3(gb), dim3(256), 0, s, (const int64_t *)V, N, minV[0], minV[1], minV[2], Q, depth, p->keys, derr); break;
         default: rc = RAHT_ERR_INVALID; set_error("raht_plan_create: bad v_dtype %d", v_dtype); break;
         }
-        if (rc != RAHT_OK) { (void)hipFree(derr); break; }
+        if (rc != RAHT_OK) { dev_free(derr); break; }
         PlanErr he;
         hipError_t e = hipMemcpyAsync(&he, derr, sizeof(he), hipMemcpyDeviceToHost, s);
         if (e == hipSuccess) e = hipStreamSynchronize(s);
-        (void)hipFree(derr);
+        dev_free(derr);
         if (e != hipSuccess) { rc = RAHT_ERR_HIP; set_error("plan keys: %s", hipGetErrorString(e)); break; }
         if (he.code != 0) {
             rc = he.code;
@@ -657,7 +657,7 @@ int raht_plan_create_from_keys(const uint64_t *keys_sorted, int64_t N, int nbits
     p->N = N;
     p->nbits = nbits;
     int rc = RAHT_OK;
-    if (hipMalloc(&p->keys, sizeof(uint64_t) * (size_t)N) != hipSuccess) { rc = RAHT_ERR_NOMEM; set_error("hipMalloc keys"); }
+    if (dev_malloc(&p->keys, sizeof(uint64_t) * (size_t)N) != hipSuccess) { rc = RAHT_ERR_NOMEM; set_error("hipMalloc keys"); }
     if (rc == RAHT_OK && hipMemcpyAsync(p->keys, keys_sorted, sizeof(uint64_t) * (size_t)N, hipMemcpyDeviceToDevice, s) != hipSuccess) { rc = RAHT_ERR_HIP; set_error("copy keys"); }
     if (rc == RAHT_OK) rc = finish_plan(p, leaf_weights, s);
     if (rc != RAHT_OK) { raht_plan_destroy(p); return rc; }
@@ -668,16 +668,19 @@ int raht_plan_create_from_keys(const uint64_t *keys_sorted, int64_t N, int nbits
 int raht_plan_destroy(raht_plan *p)
 {
     if (!p) return RAHT_OK;
+    // the plan's blocks go back to the cache and may be handed to another plan at once: nothing
+    // enqueued on any stream may still be using them (hipFree used to imply the same wait)
+    (void)hipDeviceSynchronize();
     for (auto &sc : p->schedules) free_schedule(sc);
-    if (p->keys) (void)hipFree(p->keys);
-    if (p->lvl) (void)hipFree(p->lvl);
-    if (p->wl) (void)hipFree(p->wl);
-    if (p->wr) (void)hipFree(p->wr);
-    if (p->wsum) (void)hipFree(p->wsum);
-    if (p->order) (void)hipFree(p->order);
-    if (p->inv_order) (void)hipFree(p->inv_order);
-    if (p->level_rows) (void)hipFree(p->level_rows);
-    if (p->root_rows) (void)hipFree(p->root_rows);
+    if (p->keys) dev_free(p->keys);
+    if (p->lvl) dev_free(p->lvl);
+    if (p->wl) dev_free(p->wl);
+    if (p->wr) dev_free(p->wr);
+    if (p->wsum) dev_free(p->wsum);
+    if (p->order) dev_free(p->order);
+    if (p->inv_order) dev_free(p->inv_order);
+    if (p->level_rows) dev_free(p->level_rows);
+    if (p->root_rows) dev_free(p->root_rows);
     delete p;
     return RAHT_OK;
 }

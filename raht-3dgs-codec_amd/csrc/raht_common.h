@@ -54,6 +54,14 @@ private:
     int slot_ = -1;
 };
 
+// Long-lived device blocks (plan arrays, schedules, workspaces) come from a process-wide cache of freed
+// blocks in ~12 % size classes: a codec that builds one plan per frame pays hipMalloc / hipFree (each a
+// device synchronisation, ~0.1-0.3 ms for the six N-sized plan arrays) only until the cache is warm.
+// dev_free keeps at most RAHT_POOL_MAX_BYTES (default 8 GiB) cached; raht_release_cached_memory() empties it.
+hipError_t dev_malloc(void **p, size_t bytes);
+template <typename T> inline hipError_t dev_malloc(T **p, size_t bytes) { return dev_malloc((void **)p, bytes); }
+void dev_free(void *p);
+
 // ---- device primitives (scan_sort.hip) ---------------------------------------------------------
 // Exclusive prefix sum of n uint32 values, in place allowed (out may equal in). `total` (device
 // uint32*, may be NULL) receives the sum. Allocates its own small workspace (plan/voxelize time

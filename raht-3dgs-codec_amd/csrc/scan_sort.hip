@@ -5,6 +5,9 @@
 // These are integer/HBM-bound kernels (no MFMA). They run at plan / voxelize time, not inside the
 // transform entry points.
 #include "raht_common.h"
+#include <map>
+#include <mutex>
+#include <unordered_map>
 
 namespace raht {
 
@@ -47,6 +50,80 @@ Scratch::Scratch(size_t bytes)
 Scratch::~Scratch()
 {
     if (slot_ >= 0 && slot_ < (int)g_pool.size()) g_pool[(size_t)slot_].used = false;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Cache of long-lived device blocks (see raht_common.h).
+// ------------------------------------------------------------------------------------------------
+namespace {
+struct DevCache {
+    std::mutex mu;
+    std::unordered_map<void *, size_t> live;             // block -> class size
+    std::multimap<size_t, void *> free_blocks;           // class size -> block
+    size_t cached = 0, limit = 0;
+};
+DevCache &dev_cache()
+{
+    static DevCache c;
+    if (c.limit == 0) {
+        const char *e = getenv("RAHT_POOL_MAX_BYTES");
+        c.limit = e ? (size_t)strtoull(e, nullptr, 10) : ((size_t)8 << 30);
+        if (c.limit == 0) c.limit = 1;                    // "0" = cache nothing
+    }
+    return c;
+}
+size_t size_class(size_t bytes)
+{
+    if (bytes < 4096) return 4096;
+    int hb = 63 - __builtin_clzll((unsigned long long)bytes);
+    const size_t step = (size_t)1 << (hb - 3);           // eight classes per power of two
+    return (bytes + step - 1) / step * step;
+}
+}  // namespace
+
+hipError_t dev_malloc(void **p, size_t bytes)
+{
+    DevCache &c = dev_cache();
+    const size_t cls = size_class(bytes);
+    {
+        std::lock_guard<std::mutex> g(c.mu);
+        auto it = c.free_blocks.find(cls);
+        if (it != c.free_blocks.end()) {
+            *p = it->second;
+            c.free_blocks.erase(it);
+            c.cached -= cls;
+            c.live[*p] = cls;
+            return hipSuccess;
+        }
+    }
+    hipError_t e = hipMalloc(p, cls);
+    if (e != hipSuccess) {                               // under memory pressure: drop the cache and retry
+        raht_release_cached_memory();
+        e = hipMalloc(p, cls);
+    }
+    if (e == hipSuccess) {
+        std::lock_guard<std::mutex> g(c.mu);
+        c.live[*p] = cls;
+    }
+    return e;
+}
+
+void dev_free(void *p)
+{
+    if (!p) return;
+    DevCache &c = dev_cache();
+    size_t cls = 0;
+    {
+        std::lock_guard<std::mutex> g(c.mu);
+        auto it = c.live.find(p);
+        if (it != c.live.end()) { cls = it->second; c.live.erase(it); }
+        if (cls && c.cached + cls <= c.limit) {
+            c.free_blocks.emplace(cls, p);
+            c.cached += cls;
+            return;
+        }
+    }
+    (void)hipFree(p);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -357,3 +434,17 @@ int compact_u32(const uint32_t *in, const uint32_t *flag, uint32_t *out, int64_t
 }
 
 }  // namespace raht
+
+extern "C" int raht_release_cached_memory(void)
+{
+    auto &c = raht::dev_cache();
+    std::vector<void *> blocks;
+    {
+        std::lock_guard<std::mutex> g(c.mu);
+        for (auto &kv : c.free_blocks) blocks.push_back(kv.second);
+        c.free_blocks.clear();
+        c.cached = 0;
+    }
+    for (void *q : blocks) (void)hipFree(q);
+    return RAHT_OK;
+}
