@@ -295,9 +295,8 @@ def main():
                     best = dtt if best is None else min(best, dtt)
                 return best * 1e3
             pre = {}
+            # plan arrays + the default tile schedule (built speculatively at creation) + destroy
             pre["plan_from_sorted_keys_ms"] = wall(lambda: R.RahtPlan.from_keys(kd, 3 * J))
-            # + the tile schedule and workspaces, normally built by the first transform of a plan
-            pre["plan_and_schedule_ms"] = wall(lambda: R.RahtPlan.from_keys(kd, 3 * J).prepare(D))
             g = torch.Generator(device=dev); g.manual_seed(1)
             perm = torch.randperm(N, device=dev, generator=g)
             ku = kd[perm].contiguous()

@@ -106,9 +106,9 @@ int raht_plan_nbits(const raht_plan *plan);             /* 3 * depth */
 
 /* Engine / tile-size selection (tile_rows = 0 keeps the automatic choice). tile_rows applies to
  * stage 0 (the HBM-heavy launch); raht_plan_set_tail_tile sets the geometry of the later, small
- * stages: rows per tile, channels per chunk, and `final_rows`: a stage with at most that many
- * entries runs as ONE single-workgroup tile and finishes the tree (0 = automatic: stage-0 geometry,
- * finishing tile of up to 512 rows). */
+ * stages: rows per tile, channels per chunk (rounded so that every chunk holds at least 16 bytes of
+ * channels), and `final_rows`: once at most that many entries are left, ONE launch (the top stage)
+ * finishes the tree (0 = automatic: 4096; at most 8192). */
 int raht_plan_set_engine(raht_plan *plan, int engine, int tile_rows);
 int raht_plan_set_tail_tile(raht_plan *plan, int tail_rows, int tail_channels, int final_rows);
 
