@@ -121,7 +121,10 @@ class ShardedRaht:
         roots = torch.empty((self.n_roots, C.shape[1]), dtype=self.qdt, device=C.device)
         Q = self.plan.forward_quant(C, step, roots=roots)
         top = self._mine(self.top.forward(self._gather_var(roots), want_w=False))
-        Q[self._root_positions()] = torch.floor(top / step + 0.5).to(torch.int32)
+        # a tensor divisor: torch turns division by a Python scalar into a multiplication by 1 / step on the
+        # GPU, which rounds differently from the kernels' IEEE division next to a tie
+        st = torch.as_tensor(step, dtype=top.dtype, device=top.device)
+        Q[self._root_positions()] = torch.floor(top / st + 0.5).to(torch.int32)
         return Q
 
     def _root_positions(self):

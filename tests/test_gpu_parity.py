@@ -590,3 +590,57 @@ def test_fused_quantization_divides_exactly(rt):
     tiny = torch.full((D,), 1e-38, dtype=torch.float32, device="cuda")
     Cs = (C * 1e-36).contiguous()
     assert torch.equal(p.forward_quant(Cs, tiny), p.quant_reorder(Cs, tiny))
+
+
+@pytest.mark.parametrize("N,D,top_rows", [(6000, 59, 8192), (6000, 59, 4096), (6000, 14, 1), (8192, 7, 8192), (8193, 64, 8192),
+                                          (30000, 59, 8192), (30000, 59, 300), (1, 5, 0), (2, 4, 0), (65, 100, 0)])
+def test_top_stage_thresholds(rt, N, D, top_rows):
+    """The single-launch top stage (top_kernel) at every take-over point, against the level engine:
+    whole tree in one launch (N <= top_rows), behind one / several tile stages, and switched off in
+    favour of tile stages down to the roots (top_rows = 1)."""
+    import torch
+    rng = np.random.default_rng(N * 7 + D)
+    nbits = 27
+    keys = np.sort(rng.choice(1 << nbits, size=N, replace=False)).astype(np.int64) if N > 2 else np.arange(N, dtype=np.int64) * 5
+    kd = torch.from_numpy(keys).cuda()
+    ref = rt.RahtPlan.from_keys(kd, nbits)
+    ref.set_engine("level")
+    p = rt.RahtPlan.from_keys(kd, nbits)
+    p.set_engine("tile", 0, 0, 0, top_rows)
+    st = p.stage_stats(4, D)
+    assert st["valid"]
+    for dt, tol in ((torch.float32, 3e-6), (torch.float64, 1e-12)):
+        C = torch.from_numpy(rng.normal(size=(N, D))).to(dt).cuda()
+        T, w = p.forward(C)
+        Tr, wr = ref.forward(C)
+        scale = Tr.abs().amax(dim=0).clamp_min(1e-30)
+        assert ((T - Tr).abs().amax(dim=0) / scale).max().item() <= tol
+        assert torch.equal(w, wr)
+        R = p.inverse(T)
+        assert (R - C).abs().max().item() <= (2e-5 if dt == torch.float32 else 1e-11) * C.abs().max().item()
+        if dt == torch.float32:
+            Q = p.forward_quant(C, 0.05)
+            assert torch.equal(Q, p.quant_reorder(T, 0.05))
+            assert torch.equal(p.dequant_inverse(Q, 0.05), p.inverse(p.dequant_unreorder(Q, 0.05)))
+
+
+def test_plan_memory_cache_survives_churn(rt):
+    """Plans are built and dropped per frame: their device blocks are recycled through the library's
+    cache (raht_release_cached_memory empties it) and every new plan still computes the same thing."""
+    import torch
+    from raht_3dgs_codec_amd import _lib
+    rng = np.random.default_rng(5)
+    first = None
+    for it in range(6):
+        N = 50000 + 37 * (it % 3)
+        keys = torch.from_numpy(np.sort(rng.choice(1 << 30, size=N, replace=False)).astype(np.int64)).cuda()
+        C = torch.from_numpy(rng.normal(size=(N, 16)).astype(np.float32)).cuda()
+        p = rt.RahtPlan.from_keys(keys, 30)
+        T, _ = p.forward(C)
+        assert (p.inverse(T) - C).abs().max().item() <= 2e-5 * C.abs().max().item()
+        p.set_engine("level")
+        Tl, _ = p.forward(C)
+        assert (T - Tl).abs().max().item() <= 3e-6 * Tl.abs().max().item()
+        del p
+        if it == 2:
+            _lib.check(_lib.lib().raht_release_cached_memory())
