@@ -235,6 +235,15 @@ int raht_merge_clusters(const int32_t *cluster_indices, const int32_t *cluster_o
                         float *merged_quats, float *merged_scales, float *merged_opacities,
                         float *merged_colors, raht_stream_t stream);
 
+/* A few rows at explicit positions: Q[pos[i], :] = floor(X[i, :] / step + 0.5) and X[i, :] =
+ * Q[pos[i], :] * step (pos: DEVICE int64[n], NULL = identity). Used for the <= 512 top coefficients of
+ * a Morton-prefix sharded scene, which the shard-local fused kernels leave to the caller (no
+ * counterpart in the reference; same arithmetic as python/encode_3dgs.py:204,215,261). */
+int raht_quant_rows(const float *X, int64_t ldx, int64_t n, int D, const float *steps, int n_steps,
+                    const int64_t *pos, int32_t *Q, int64_t ldq, raht_stream_t stream);
+int raht_dequant_rows(const int32_t *Q, int64_t ldq, const int64_t *pos, int64_t n, int D, const float *steps,
+                      int n_steps, float *X, int64_t ldx, raht_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * RLGR entropy stage: adaptive Run-Length / Golomb-Rice coder, byte-exact with the
  * reference's vendored PyRLGR (python/PyRLGR/src/libs/rlgr/membuf.cpp:258-423, call sites

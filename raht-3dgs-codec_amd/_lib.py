@@ -19,7 +19,7 @@ ENGINE_TILE, ENGINE_LEVEL = 0, 1
 # every symbol include/raht.h declares (checked by tests/test_abi.py)
 EXPORTS = [
     "raht_last_error", "raht_version", "raht_plan_create", "raht_plan_create_from_keys",
-    "raht_plan_destroy", "raht_plan_set_top_level", "raht_plan_roots", "raht_plan_set_root_buffer", "raht_plan_size", "raht_plan_nbits", "raht_plan_set_engine", "raht_plan_set_tail_tile", "raht_release_cached_memory",
+    "raht_plan_destroy", "raht_plan_set_top_level", "raht_plan_roots", "raht_plan_set_root_buffer", "raht_plan_size", "raht_plan_nbits", "raht_plan_set_engine", "raht_plan_set_tail_tile", "raht_release_cached_memory", "raht_quant_rows", "raht_dequant_rows",
     "raht_plan_levels", "raht_plan_export_level", "raht_plan_order", "raht_plan_arrays",
     "raht_plan_copy_array", "raht_plan_stage_stats", "raht_fwd", "raht_fwd_f64", "raht_inv", "raht_inv_f64", "raht_debug_run_stage", "raht_fwd_quant", "raht_dequant_inv", "raht_plan_prepare",
     "raht_quant_reorder", "raht_dequant_unreorder", "raht_voxelize", "raht_morton", "raht_sort_keys",
@@ -91,6 +91,8 @@ def lib():
     L.raht_plan_prepare.argtypes = [vp, i32, i32, vp]
     L.raht_quant_reorder.argtypes = [vp, vp, i64, i32, C.POINTER(C.c_float), i32, vp, i64, vp]
     L.raht_dequant_unreorder.argtypes = [vp, vp, i64, i32, C.POINTER(C.c_float), i32, vp, i64, vp]
+    L.raht_quant_rows.argtypes = [vp, i64, i64, i32, C.POINTER(C.c_float), i32, vp, vp, i64, vp]
+    L.raht_dequant_rows.argtypes = [vp, i64, vp, i64, i32, C.POINTER(C.c_float), i32, vp, i64, vp]
     L.raht_voxelize.argtypes = [vp, i64, i64, i32, C.POINTER(C.c_float), dbl, i32, vp, vp, vp, vp, vp,
                                 C.POINTER(i64), C.POINTER(C.c_float), C.POINTER(dbl), C.POINTER(dbl), vp]
     L.raht_morton.argtypes = [vp, i64, i32, vp, vp]

@@ -53,6 +53,36 @@ __global__ __launch_bounds__(256) void dequant_unreorder_kernel(const int32_t *_
     }
 }
 
+// A few rows at explicit positions (the <= 512 top coefficients of a Morton-prefix sharded scene, which
+// the shard-local fused kernels leave to the caller): Q[pos[i], :] = quantize(X[i, :]) and back.
+__global__ __launch_bounds__(256) void quant_rows_kernel(const float *__restrict__ X, int64_t ldx, int64_t n, int D,
+                                                         const int64_t *__restrict__ pos, const StepTable steps,
+                                                         int32_t *__restrict__ Q, int64_t ldq)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (int64_t i = wave; i < n; i += nwaves) {
+        const float *src = X + i * ldx;
+        int32_t *dst = Q + (pos ? pos[i] : i) * ldq;
+        for (int c = lane; c < D; c += 64) dst[c] = (int32_t)floorf(src[c] / steps.v[steps.n == 1 ? 0 : c] + 0.5f);
+    }
+}
+
+__global__ __launch_bounds__(256) void dequant_rows_kernel(const int32_t *__restrict__ Q, int64_t ldq,
+                                                           const int64_t *__restrict__ pos, int64_t n, int D,
+                                                           const StepTable steps, float *__restrict__ X, int64_t ldx)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (int64_t i = wave; i < n; i += nwaves) {
+        const int32_t *src = Q + (pos ? pos[i] : i) * ldq;
+        float *dst = X + i * ldx;
+        for (int c = lane; c < D; c += 64) dst[c] = (float)src[c] * steps.v[steps.n == 1 ? 0 : c];
+    }
+}
+
 // int32 matrix transpose through an LDS tile (64 rows x 64 columns, padded): row-major N x D  <->
 // channel-major D x N, so that the entropy stage reads / writes contiguous channels. Both global
 // sides are coalesced (lanes along the contiguous dimension).
@@ -113,6 +143,32 @@ int raht_dequant_unreorder(const raht_plan *p, const int32_t *Q, int64_t ldq, in
     const unsigned gb = (unsigned)std::min<int64_t>(ceil_div(p->N, 4), 4096);
     hipLaunchKernelGGL(dequant_unreorder_kernel, dim3(gb), dim3(256), 0, (hipStream_t)stream, Q, ldq, D,
                        p->order, p->N, st, T, ldt);
+    RAHT_HIP_CHECK(hipGetLastError());
+    return RAHT_OK;
+}
+
+int raht_quant_rows(const float *X, int64_t ldx, int64_t n, int D, const float *steps, int n_steps,
+                    const int64_t *pos, int32_t *Q, int64_t ldq, raht_stream_t stream)
+{
+    if (!X || !Q || n < 0 || D < 1 || ldx < D || ldq < D) { set_error("raht_quant_rows: bad argument"); return RAHT_ERR_INVALID; }
+    StepTable st;
+    RAHT_RET(fill_steps(st, steps, n_steps, D));
+    if (n == 0) return RAHT_OK;
+    const unsigned gb = (unsigned)std::min<int64_t>(ceil_div(n, 4), 4096);
+    hipLaunchKernelGGL(quant_rows_kernel, dim3(gb), dim3(256), 0, (hipStream_t)stream, X, ldx, n, D, pos, st, Q, ldq);
+    RAHT_HIP_CHECK(hipGetLastError());
+    return RAHT_OK;
+}
+
+int raht_dequant_rows(const int32_t *Q, int64_t ldq, const int64_t *pos, int64_t n, int D, const float *steps,
+                      int n_steps, float *X, int64_t ldx, raht_stream_t stream)
+{
+    if (!X || !Q || n < 0 || D < 1 || ldx < D || ldq < D) { set_error("raht_dequant_rows: bad argument"); return RAHT_ERR_INVALID; }
+    StepTable st;
+    RAHT_RET(fill_steps(st, steps, n_steps, D));
+    if (n == 0) return RAHT_OK;
+    const unsigned gb = (unsigned)std::min<int64_t>(ceil_div(n, 4), 4096);
+    hipLaunchKernelGGL(dequant_rows_kernel, dim3(gb), dim3(256), 0, (hipStream_t)stream, Q, ldq, pos, n, D, st, X, ldx);
     RAHT_HIP_CHECK(hipGetLastError());
     return RAHT_OK;
 }

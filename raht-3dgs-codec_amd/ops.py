@@ -327,6 +327,36 @@ def _steps(steps, D):
     return (C.c_float * len(steps))(*steps)
 
 
+def quant_rows(X, steps, pos, Q):
+    """Q[pos[i], :] = floor(X[i, :] / step + 0.5) in place (X float32 (n, D), pos int64 (n,), Q int32)."""
+    _need_cuda(X, "X")
+    X = X.to(torch.float32).contiguous()
+    n, D = X.shape
+    st = _steps(steps, D)
+    pos = pos.to(torch.int64).contiguous()
+    if Q.dtype != torch.int32 or Q.stride(1) != 1:
+        raise ValueError("Q must be an int32 matrix with contiguous rows")
+    with torch.cuda.device(X.device):
+        check(_lib.lib().raht_quant_rows(C.c_void_p(X.data_ptr()), D, n, D, st, len(st), C.c_void_p(pos.data_ptr()),
+                                         C.c_void_p(Q.data_ptr()), Q.stride(0), _stream()))
+    return Q
+
+
+def dequant_rows(Q, steps, pos):
+    """-> float32 (n, D): Q[pos[i], :] * step."""
+    _need_cuda(Q, "Q")
+    if Q.dtype != torch.int32 or Q.stride(1) != 1:
+        raise ValueError("Q must be an int32 matrix with contiguous rows")
+    D = Q.shape[1]
+    st = _steps(steps, D)
+    pos = pos.to(torch.int64).contiguous()
+    X = torch.empty((pos.shape[0], D), dtype=torch.float32, device=Q.device)
+    with torch.cuda.device(Q.device):
+        check(_lib.lib().raht_dequant_rows(C.c_void_p(Q.data_ptr()), Q.stride(0), C.c_void_p(pos.data_ptr()), pos.shape[0], D,
+                                           st, len(st), C.c_void_p(X.data_ptr()), D, _stream()))
+    return X
+
+
 # ---------------------------------------------------------------------------------------------------
 # plan tokens: what RAHT_param hands back in place of the reference's List / Flags / weights
 # ---------------------------------------------------------------------------------------------------

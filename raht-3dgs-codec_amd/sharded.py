@@ -29,6 +29,17 @@ class HipLocalOps:
         from .ops import RahtPlan
         return RahtPlan.from_keys(keys, nbits, leaf_weights=leaf_weights, top_level=top_level)
 
+    # the few top coefficients, quantized into / dequantized out of their places in Q: one launch each
+    @staticmethod
+    def quant_rows(X, step, pos, Q):
+        from .ops import quant_rows
+        return quant_rows(X, step, pos, Q)
+
+    @staticmethod
+    def dequant_rows(Q, step, pos):
+        from .ops import dequant_rows
+        return dequant_rows(Q, step, pos)
+
 
 class ShardedRaht:
     def __init__(self, keys_sorted, nbits, prefix_bits=9, group=None, local_ops=None):
@@ -121,10 +132,13 @@ class ShardedRaht:
         roots = torch.empty((self.n_roots, C.shape[1]), dtype=self.qdt, device=C.device)
         Q = self.plan.forward_quant(C, step, roots=roots)
         top = self._mine(self.top.forward(self._gather_var(roots), want_w=False))
-        # a tensor divisor: torch turns division by a Python scalar into a multiplication by 1 / step on the
-        # GPU, which rounds differently from the kernels' IEEE division next to a tie
-        st = torch.as_tensor(step, dtype=top.dtype, device=top.device)
-        Q[self._root_positions()] = torch.floor(top / st + 0.5).to(torch.int32)
+        if hasattr(self.ops, "quant_rows"):
+            self.ops.quant_rows(top, step, self._root_positions(), Q)
+        else:
+            # a tensor divisor: torch turns division by a Python scalar into a multiplication by 1 / step
+            # on the GPU, which rounds differently from the kernels' IEEE division next to a tie
+            st = torch.as_tensor(step, dtype=top.dtype, device=top.device)
+            Q[self._root_positions()] = torch.floor(top / st + 0.5).to(torch.int32)
         return Q
 
     def _root_positions(self):
@@ -133,8 +147,11 @@ class ShardedRaht:
         return self._root_pos
 
     def dequant_inverse(self, Q, step):
-        roots_c = Q[self._root_positions()].to(self.qdt) * step
-        low = self.top.inverse(self._gather_var(roots_c.contiguous()))
+        if hasattr(self.ops, "dequant_rows"):
+            roots_c = self.ops.dequant_rows(Q, step, self._root_positions())
+        else:
+            roots_c = (Q[self._root_positions()].to(self.qdt) * step).contiguous()
+        low = self.top.inverse(self._gather_var(roots_c))
         return self.plan.dequant_inverse(Q, step, roots=self._mine(low))
 
     # ---- bench helpers -----------------------------------------------------------------------------
