@@ -261,3 +261,39 @@ def encode_3dgs(ply_list, J=10, colorStep=(1, 4, 8, 12, 16, 20, 24, 32, 64), csv
     with open(csv_path, "w") as f:
         f.write("\n".join(lines) + "\n")
     return lines
+
+
+# ---- per-attribute quantization policy ------------------------------------------------
+ATTRIBUTE_IMPORTANCE = {"quats": 1.0 / 21.93, "scales": 1.0 / 26.36, "opacity": 1.0 / 42.22, "colors": 1.0 / 38.67}
+
+
+def per_attribute_steps(Coeff, total_levels_budget=1024, importance=None):
+    """Per-channel quantization steps from the visual-importance policy of the reference's debug driver
+    (reference python/encode_3dgs_debug.py:326-369): channels are grouped quats(4) / scales(3) /
+    opacity(1) / colors(rest); each group gets `budget * importance / sum(importance)` quantization
+    levels (at least 2, truncated to int) and the step range / (levels - 1), floored at 1e-6, where
+    range = max - min of the group's RAHT coefficients. Returns a float32 tensor with one step per
+    channel, usable with every quantize entry point (`forward_quant`, `quant_reorder`, ...), and the
+    per-group table {name: dict(step, levels, range, channels)}.
+
+    Coeff: (N, n_channels) RAHT coefficients (any device). The ranges need the coefficients, so the
+    policy costs one un-fused forward transform per frame; the quantization itself is
+    `plan.quant_reorder(Coeff, steps)` (or `plan.forward_quant(C, steps)` on the next, similar frame)."""
+    imp = dict(ATTRIBUTE_IMPORTANCE if importance is None else importance)
+    n_channels = int(Coeff.shape[1])
+    ranges = {"quats": (0, 4), "scales": (4, 7), "opacity": (7, 8), "colors": (8, n_channels)}
+    total = sum(imp.values())
+    steps = torch.ones(n_channels, dtype=torch.float32)
+    table = {}
+    for name, (c0, c1) in ranges.items():
+        if c0 >= n_channels:
+            continue                                       # :353-354
+        c1 = min(c1, n_channels)
+        blk = Coeff[:, c0:c1]
+        rng = blk.max() - blk.min()                        # :357-358
+        levels = max(int(total_levels_budget * imp[name] / total), 2)       # :361-362
+        step = rng / max(levels - 1, 1)                    # :365
+        step = float(max(step.item(), 1e-6))               # :366 (a zero range must not divide by zero)
+        steps[c0:c1] = step
+        table[name] = dict(step=step, levels=levels, range=float(rng.item()), channels=(c0, c1))
+    return steps, table
