@@ -1,0 +1,101 @@
+// raht_device.h -- device-side helpers shared by the HIP sources: 16-byte row chunks and the
+// quantizer's arithmetic.
+#pragma once
+#include "raht_common.h"
+
+namespace raht {
+
+constexpr int MAX_STEP_CH = 256;
+struct StepTable {
+    int n;                         // 0 = no quantization, 1 = one step, D = per channel
+    int fast_div;                  // every step within [2^-100, 2^100]: the forward may divide without range scaling
+    float v[MAX_STEP_CH];
+};
+struct NoSteps { int n; int fast_div; };
+
+
+// ---- row chunks: one lane moves 16 bytes (VN = 16 / sizeof(T) consecutive channels) of one row --------
+// Registers / LDS (16-byte aligned: ds_read_b128 / ds_write_b128) ...
+template <typename E> struct alignas(16) RegChunk { E v[16 / sizeof(E)]; };
+// ... and global memory, where a row starts on an element boundary only (59 channels: 236-byte rows).
+// gfx950 global loads / stores of 8..16 bytes need element alignment only.
+template <typename E> struct __attribute__((packed, aligned(sizeof(E)))) MemChunk { E v[16 / sizeof(E)]; };
+
+// A chunk is always a whole 16 bytes, in global memory too: when a row's length is not a multiple of
+// VN, its LAST chunk is the 16 bytes that END the row (channels [Dc - VN, Dc)), i.e. it overlaps its
+// neighbour by VN - Dc % VN channels. The overlapped channels live twice in LDS, go through the same
+// butterflies with the same operands in both copies, and are written back twice with identical
+// values. That keeps every load and store a plain, unpredicated 16-byte access (a load inside a
+// divergent branch costs an exec-mask region with its own s_waitcnt, i.e. one serialised HBM round
+// trip per chunk; masks and shifts cost VALU issue slots, which is what bounds this kernel). The host
+// only runs the tile kernel on channel chunks of at least VN channels (plan.hip: fit_chunk_channels).
+// STREAM = true marks the once-touched matrices (C, T, Q): nontemporal loads / stores (`nt`), measured
+// +1.5 % on the fused cfg3 step when applied to both directions of the big streams (loads alone: -3 %).
+// Workspace rows, which the next stage re-reads from L2, keep the default policy.
+template <typename E, bool STREAM = false>
+__device__ __forceinline__ RegChunk<E> ld_chunk(const E *__restrict__ p)
+{
+    constexpr int VN = 16 / sizeof(E);
+    RegChunk<E> x;
+    if constexpr (STREAM) {
+#pragma unroll
+        for (int i = 0; i < VN; ++i) x.v[i] = __builtin_nontemporal_load(p + i);      // one global_load_dwordx4 ... nt
+    } else {
+        const MemChunk<E> t = *(const MemChunk<E> *)p;
+#pragma unroll
+        for (int i = 0; i < VN; ++i) x.v[i] = t.v[i];
+    }
+    return x;
+}
+
+template <typename E, bool STREAM = false>
+__device__ __forceinline__ void st_chunk(E *__restrict__ p, const RegChunk<E> &x)
+{
+    constexpr int VN = 16 / sizeof(E);
+    if constexpr (STREAM) {
+#pragma unroll
+        for (int i = 0; i < VN; ++i) __builtin_nontemporal_store(x.v[i], p + i);
+    } else {
+        MemChunk<E> t;
+#pragma unroll
+        for (int i = 0; i < VN; ++i) t.v[i] = x.v[i];
+        *(MemChunk<E> *)p = t;
+    }
+}
+
+__device__ __forceinline__ int32_t quantize_one(float x, float sp, float r, int fast_div)
+{
+    float q;
+    if (fast_div) {
+        // x / step, correctly rounded: the quotient refinement of hipcc's float division (mul, 4 fma)
+        // without its range scaling and special-case fixup, which the host has ruled out (steps
+        // within [2^-100, 2^100]); r is the refined reciprocal of the step (refined_rcp)
+        const float q0 = x * r;
+        const float q1 = __builtin_fmaf(__builtin_fmaf(-sp, q0, x), r, q0);
+        q = __builtin_fmaf(__builtin_fmaf(-sp, q1, x), r, q1);
+    } else {
+        q = x / sp;
+    }
+    return (int32_t)floorf(q + 0.5f);                     // encode_3dgs.py:204
+}
+
+// v_rcp_f32 + one Newton step: exactly how hipcc's own float division refines 1 / step per quotient
+__device__ __forceinline__ float refined_rcp(float sp)
+{
+    const float r0 = __builtin_amdgcn_rcpf(sp);
+    return __builtin_fmaf(__builtin_fmaf(-sp, r0, 1.0f), r0, r0);
+}
+
+
+// StepTable from the caller's steps (host)
+inline void fill_step_table(StepTable &t, const float *steps, int n_steps)
+{
+    t.n = n_steps;
+    t.fast_div = 1;
+    for (int c = 0; c < n_steps; ++c) {
+        t.v[c] = steps[c];
+        if (!(steps[c] >= 0x1p-100f && steps[c] <= 0x1p100f)) t.fast_div = 0;
+    }
+}
+
+}  // namespace raht

@@ -18,6 +18,7 @@
 //
 // Bandwidth-bound integer/fp32 work: no MFMA by design (3 flops per 4 bytes).
 #include "raht_common.h"
+#include "raht_device.h"
 
 #include <algorithm>
 #include <cstdlib>
@@ -117,14 +118,6 @@ __global__ __launch_bounds__(256) void level_pass_kernel(T *__restrict__ data, i
 // So every large transfer is a coalesced contiguous span; only finalised rows of stages >= 1 (a
 // few % of N) and the fused Q rows are row-granular (236-byte segments at D = 59).
 // ------------------------------------------------------------------------------------------------
-constexpr int MAX_STEP_CH = 256;
-struct StepTable {
-    int n;                         // 0 = no quantization, 1 = one step, D = per channel
-    int fast_div;                  // every step within [2^-100, 2^100]: the forward may divide without range scaling
-    float v[MAX_STEP_CH];
-};
-struct NoSteps { int n; int fast_div; };
-
 template <typename T>
 struct TileArgs {
     const T *in;         // fwd: this stage's entries, entry order (stage 0: C; k >= 1: ws_k)
@@ -169,78 +162,6 @@ constexpr int TILE_MAX_SLOTS = 2;      // slots per thread (template SLOTS = 1 o
 constexpr int TILE_IO_U = 6;           // row chunks in flight per lane in the load / gather phases
 constexpr int TILE_ROUND_U = 2;        // butterflies in flight per lane group in a round
 constexpr int TILE_PRE_ROWS = 12;      // survivor rows prefetched by the inverse before flags are known
-
-// ---- row chunks: one lane moves 16 bytes (VN = 16 / sizeof(T) consecutive channels) of one row --------
-// Registers / LDS (16-byte aligned: ds_read_b128 / ds_write_b128) ...
-template <typename E> struct alignas(16) RegChunk { E v[16 / sizeof(E)]; };
-// ... and global memory, where a row starts on an element boundary only (59 channels: 236-byte rows).
-// gfx950 global loads / stores of 8..16 bytes need element alignment only.
-template <typename E> struct __attribute__((packed, aligned(sizeof(E)))) MemChunk { E v[16 / sizeof(E)]; };
-
-// A chunk is always a whole 16 bytes, in global memory too: when a row's length is not a multiple of
-// VN, its LAST chunk is the 16 bytes that END the row (channels [Dc - VN, Dc)), i.e. it overlaps its
-// neighbour by VN - Dc % VN channels. The overlapped channels live twice in LDS, go through the same
-// butterflies with the same operands in both copies, and are written back twice with identical
-// values. That keeps every load and store a plain, unpredicated 16-byte access (a load inside a
-// divergent branch costs an exec-mask region with its own s_waitcnt, i.e. one serialised HBM round
-// trip per chunk; masks and shifts cost VALU issue slots, which is what bounds this kernel). The host
-// only runs the tile kernel on channel chunks of at least VN channels (plan.hip: fit_chunk_channels).
-// STREAM = true marks the once-touched matrices (C, T, Q): nontemporal loads / stores (`nt`), measured
-// +1.5 % on the fused cfg3 step when applied to both directions of the big streams (loads alone: -3 %).
-// Workspace rows, which the next stage re-reads from L2, keep the default policy.
-template <typename E, bool STREAM = false>
-__device__ __forceinline__ RegChunk<E> ld_chunk(const E *__restrict__ p)
-{
-    constexpr int VN = 16 / sizeof(E);
-    RegChunk<E> x;
-    if constexpr (STREAM) {
-#pragma unroll
-        for (int i = 0; i < VN; ++i) x.v[i] = __builtin_nontemporal_load(p + i);      // one global_load_dwordx4 ... nt
-    } else {
-        const MemChunk<E> t = *(const MemChunk<E> *)p;
-#pragma unroll
-        for (int i = 0; i < VN; ++i) x.v[i] = t.v[i];
-    }
-    return x;
-}
-
-template <typename E, bool STREAM = false>
-__device__ __forceinline__ void st_chunk(E *__restrict__ p, const RegChunk<E> &x)
-{
-    constexpr int VN = 16 / sizeof(E);
-    if constexpr (STREAM) {
-#pragma unroll
-        for (int i = 0; i < VN; ++i) __builtin_nontemporal_store(x.v[i], p + i);
-    } else {
-        MemChunk<E> t;
-#pragma unroll
-        for (int i = 0; i < VN; ++i) t.v[i] = x.v[i];
-        *(MemChunk<E> *)p = t;
-    }
-}
-
-__device__ __forceinline__ int32_t quantize_one(float x, float sp, float r, int fast_div)
-{
-    float q;
-    if (fast_div) {
-        // x / step, correctly rounded: the quotient refinement of hipcc's float division (mul, 4 fma)
-        // without its range scaling and special-case fixup, which the host has ruled out (steps
-        // within [2^-100, 2^100]); r is the refined reciprocal of the step (refined_rcp)
-        const float q0 = x * r;
-        const float q1 = __builtin_fmaf(__builtin_fmaf(-sp, q0, x), r, q0);
-        q = __builtin_fmaf(__builtin_fmaf(-sp, q1, x), r, q1);
-    } else {
-        q = x / sp;
-    }
-    return (int32_t)floorf(q + 0.5f);                     // encode_3dgs.py:204
-}
-
-// v_rcp_f32 + one Newton step: exactly how hipcc's own float division refines 1 / step per quotient
-__device__ __forceinline__ float refined_rcp(float sp)
-{
-    const float r0 = __builtin_amdgcn_rcpf(sp);
-    return __builtin_fmaf(__builtin_fmaf(-sp, r0, 1.0f), r0, r0);
-}
 
 // Plan metadata of one tile, held in registers (slot j = tid + s * blockDim). The persistent tile
 // loop loads the NEXT tile's metadata while the current tile's butterflies run, so no tile waits on
@@ -942,12 +863,7 @@ static int launch_tile_one(const TileArgs<T> &A, const XformIO<T> &io, dim3 grid
     }
     if constexpr (QM) {
         StepTable st;
-        st.n = io.n_steps;
-        st.fast_div = 1;
-        for (int c = 0; c < io.n_steps; ++c) {
-            st.v[c] = io.steps[c];
-            if (!(io.steps[c] >= 0x1p-100f && io.steps[c] <= 0x1p100f)) st.fast_div = 0;
-        }
+        fill_step_table(st, io.steps, io.n_steps);
         hipLaunchKernelGGL((tile_kernel<T, INV, IDENT, true, SLOTS>), grid, dim3(threads), lds, s, A, st);
     } else {
         NoSteps ns{0, 0};
@@ -987,12 +903,7 @@ static int launch_top_stage(const raht_plan *p, const Schedule &sc, int k, const
     }
     if constexpr (QM) {
         StepTable stp;
-        stp.n = io.n_steps;
-        stp.fast_div = 1;
-        for (int c = 0; c < io.n_steps; ++c) {
-            stp.v[c] = io.steps[c];
-            if (!(io.steps[c] >= 0x1p-100f && io.steps[c] <= 0x1p100f)) stp.fast_div = 0;
-        }
+        fill_step_table(stp, io.steps, io.n_steps);
         hipLaunchKernelGGL((top_kernel<T, INV, true>), grid, dim3(TOP_THREADS), lds, s, A, stp);
     } else {
         NoSteps ns{0, 0};
