@@ -307,7 +307,7 @@ def main():
             # voxelizer on the unsorted cloud: xyz (voxel centres) + the D-3 (or D) attribute columns
             xyz = torch.from_numpy(V.astype(np.float32)).to(dev)[perm] + 0.5
             PC = torch.cat([xyz, Cd[perm][:, : min(D, 56)]], dim=1).contiguous()
-            pre["voxelize_ms"] = wall(lambda: R.voxelize_pc_batched(PC, [0.0, 0.0, 0.0], float(2 ** J), J, device=dev, residuals=False))
+            pre["voxelize_ms"] = wall(lambda: R.voxelize_pc_batched(PC, [0.0, 0.0, 0.0], float(2 ** J), J, device=dev, residuals=False, sorted_points=False))
             pre["voxelize_points"] = N
             pre["voxelize_columns"] = int(PC.shape[1])
             out["prelude_ms"] = {k: (round(v, 3) if isinstance(v, float) else v) for k, v in pre.items()}

@@ -3,6 +3,7 @@
 // Replaces voxelize_pc_batched (reference python/voxelize_pc.py:62-172). Float32 arithmetic, as
 // torch performs it on a float32 point cloud; integer outputs are bit-exact.
 #include "raht_common.h"
+#include "raht_device.h"
 
 #include <algorithm>
 #include <cmath>
@@ -147,6 +148,76 @@ __global__ __launch_bounds__(256) void voxel_mean_kernel(const float *__restrict
     }
 }
 
+// The same on 16-byte row chunks (raht_device.h) for d >= 8 attribute columns: a lane owns 4 columns of
+// a voxel, G lanes cover the row, a wave instruction moves 64 / G voxels and four such groups are in
+// flight; the last chunk of a row whose length is not a multiple of 4 is the 16 bytes that END it.
+// Duplicate points are still added in sorted order, and the division is the same correctly rounded
+// one, so results are bit-identical to the kernel above.
+__global__ __launch_bounds__(256) void voxel_mean_chunk_kernel(const float *__restrict__ PC, int64_t ld, int64_t N, int d, int lg,
+                                                               const uint64_t *__restrict__ keys_sorted,
+                                                               const uint32_t *__restrict__ sort_idx,
+                                                               const uint32_t *__restrict__ vstart, int64_t nvox,
+                                                               float *__restrict__ PCvox, int64_t *__restrict__ Vvox)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    const int ldo = 3 + d;
+    const int G = 1 << lg, rpi = 64 >> lg;                    // lg >= 1: rpi <= 32
+    const int U = min(4, 32 / rpi);                           // voxel groups in flight; U * rpi <= 32 voxels per iteration
+    const int vpi = U * rpi;
+    const int g = lane >> lg, c4 = lane & (G - 1);
+    const int NC = (d + 3) >> 2;
+    for (int64_t v0 = wave * vpi; v0 < nvox; v0 += nwaves * vpi) {
+        const int64_t vi = v0 + lane;
+        const uint32_t vs = (lane <= vpi && vi < nvox) ? vstart[vi] : (uint32_t)N;
+        uint32_t first = 0, klo = 0, khi = 0;
+        if (lane < vpi && vi < nvox) {
+            first = sort_idx[vs];
+            const uint64_t k = keys_sorted[vs];
+            klo = (uint32_t)k; khi = (uint32_t)(k >> 32);
+            // integer voxel coordinates from the key (:152,:155)
+            const uint64_t key = ((uint64_t)khi << 32) | klo;
+            const uint32_t x = vx_compact3(key >> 2), y = vx_compact3(key >> 1), z = vx_compact3(key);
+            if (PCvox) { PCvox[vi * ldo + 0] = (float)x; PCvox[vi * ldo + 1] = (float)y; PCvox[vi * ldo + 2] = (float)z; }
+            if (Vvox) { Vvox[vi * 3 + 0] = x; Vvox[vi * 3 + 1] = y; Vvox[vi * 3 + 2] = z; }
+        }
+        if (!PCvox) continue;
+        // this lane's voxels: extents and first member. Shuffled here, with every lane active -- inside
+        // the chunk loop the idle lanes of a row group are masked off and a shuffle would read garbage
+        // from them (an extent of garbage is a multi-million-iteration member loop)
+        uint32_t s0[4], e0[4], i0[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int sel = min(u, U - 1) * rpi + g;
+            s0[u] = (uint32_t)__shfl((int)vs, sel, 64);
+            e0[u] = (uint32_t)__shfl((int)vs, sel + 1, 64);
+            i0[u] = (uint32_t)__shfl((int)first, sel, 64);
+        }
+        for (int cc = c4; cc < NC; cc += G) {
+            const int goff = 3 + min(cc * 4, d - 4);
+            RegChunk<float> acc[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc[u] = ld_chunk<float, true>(PC + (int64_t)i0[u] * ld + goff);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int64_t v = v0 + u * rpi + g;
+                if (u >= U || v >= nvox) continue;
+                RegChunk<float> a = acc[u];
+                for (uint32_t i = s0[u] + 1; i < e0[u]; ++i) {       // further members (rare), sorted order (:140-144)
+                    const RegChunk<float> b = ld_chunk<float, true>(PC + (int64_t)sort_idx[i] * ld + goff);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) a.v[q] += b.v[q];
+                }
+                const float cnt = (float)(e0[u] - s0[u]);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) a.v[q] = __fdiv_rn(a.v[q], cnt);                  // :137,:144
+                st_chunk<float, true>(PCvox + v * ldo + goff, a);
+            }
+        }
+    }
+}
+
 static int sort_keys_u32idx(const uint64_t *keys_in, int64_t N, int nbits, uint64_t *keys_out,
                             uint32_t *idx_out, hipStream_t s)
 {
@@ -249,7 +320,13 @@ int raht_voxelize(const float *PC, int64_t ldpc, int64_t N, int d, const float *
         RAHT_RET(compact_u32(nullptr, flag, vstart, N, &nv, s));
         if (PCvox || Vvox) {
             const unsigned gv = (unsigned)std::min<int64_t>(ceil_div(nv, 64), 8192);
-            hipLaunchKernelGGL(voxel_mean_kernel, dim3(gv), dim3(256), 0, s, PC, ldpc, N, d, ks, idx, vstart, nv, PCvox, Vvox);
+            if (PCvox && d >= 8) {
+                int lg = 1;
+                while ((1 << lg) < (d + 3) / 4 && lg < 6) ++lg;
+                hipLaunchKernelGGL(voxel_mean_chunk_kernel, dim3(gv), dim3(256), 0, s, PC, ldpc, N, d, lg, ks, idx, vstart, nv, PCvox, Vvox);
+            } else {
+                hipLaunchKernelGGL(voxel_mean_kernel, dim3(gv), dim3(256), 0, s, PC, ldpc, N, d, ks, idx, vstart, nv, PCvox, Vvox);
+            }
         }
         if (sort_idx) hipLaunchKernelGGL(u32_to_i64_kernel, dim3(gb), dim3(256), 0, s, idx, N, sort_idx);
         if (voxel_indices) hipLaunchKernelGGL(u32_to_i64_kernel, dim3((unsigned)ceil_div(nv, 256)), dim3(256), 0, s, vstart, nv, voxel_indices);

@@ -449,13 +449,15 @@ def sort_keys(keys, nbits=64):
 
 
 @torch.no_grad()
-def voxelize_pc_batched(PC, vmin=None, width=None, J=10, device="cuda", residuals=True):
+def voxelize_pc_batched(PC, vmin=None, width=None, J=10, device="cuda", residuals=True, sorted_points=True):
     """Drop-in for reference python/voxelize_pc.py:62-172.
 
     Returns (PCvox, PCsorted, voxel_indices, DeltaPC, info) like the reference. PCvox,
     voxel_indices, info['sort_idx'] and the sorted Morton keys (info['keys_sorted'], extra) come
     from the HIP voxelizer; PCsorted / DeltaPC are secondary outputs derived from them with two
-    torch gathers (``residuals=False`` skips DeltaPC).
+    torch gathers (``residuals=False`` skips DeltaPC; ``sorted_points=False`` also skips PCsorted -- a
+    full gather of the cloud, 0.47 ms on 3 M x 59 -- and returns None in its place; the codec path only
+    consumes PCvox).
     """
     PC = PC.to(device)
     _need_cuda(PC, "PC")
@@ -481,7 +483,7 @@ def voxelize_pc_batched(PC, vmin=None, width=None, J=10, device="cuda", residual
     nv = nvox.value
     voxel_indices = vidx[:nv]
     PCvox = pcv[:nv]
-    PCsorted = PC[idx]
+    PCsorted = PC[idx] if (sorted_points or residuals) else None
     vmin_t = torch.tensor(list(vmin_out), dtype=torch.float32, device=dev)
     DeltaPC = None
     if residuals:

@@ -216,7 +216,7 @@ def compress_to_nvox(means, quats, scales, opacities, colors, J=10, device="cuda
     from .ply_io import save_ply
     means = means.to(device).float().contiguous()
     N = means.shape[0]
-    PCvox, _, voxel_indices, _, info = voxelize_pc_batched(means, J=J, device=device, residuals=False)
+    PCvox, _, voxel_indices, _, info = voxelize_pc_batched(means, J=J, device=device, residuals=False, sorted_points=False)
     cluster_indices = info["sort_idx"].int()                                       # :225-226
     cluster_offsets = torch.cat([voxel_indices, torch.tensor([N], dtype=torch.int64, device=means.device)]).int()   # :230-233
     mm, mq, ms, mo, mc = merge_gaussian_clusters_with_indices(means, quats.to(device), scales.to(device),
