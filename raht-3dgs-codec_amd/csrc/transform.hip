@@ -10,11 +10,15 @@
 //    is one coalesced segment. 2 row reads + 2 row writes per pair: HBM traffic ~2x the ideal.
 //
 //  * TILE engine (default): a workgroup stages a run of R Morton-contiguous rows (all channels) in
-//    LDS with 16-byte coalesced loads, performs EVERY butterfly whose subtree lies inside the run
-//    (levels ascending, one barrier per level present), and writes the run back once. Rows whose
-//    subtree crosses the run boundary (~3-4 % at R = 256) are the active rows of the next, much
-//    smaller stage, which gathers them by index. HBM traffic ~1.04x the ideal (read C once, write T
-//    once). Stage membership is a pure function of the plan, so it is precomputed (plan.hip).
+//    LDS, performs EVERY butterfly whose subtree lies inside the run (levels ascending; a barrier
+//    per level that needs the whole workgroup, none between levels one wave instruction can take),
+//    and writes the run back once. Rows whose subtree crosses the run boundary (4.3 % at R = 184)
+//    are the entries of the next, ~20x smaller stage. HBM traffic ~1.05x the ideal (read C once,
+//    write T once). Stage membership is a pure function of the plan, so it is precomputed
+//    (plan.hip). Every data-touching phase works on 16-byte row chunks (raht_device.h).
+//
+//  * TOP stage: once <= 4096 entries are left, one launch of top_kernel finishes the tree from
+//    butterflies resolved at schedule time.
 //
 // Bandwidth-bound integer/fp32 work: no MFMA by design (3 flops per 4 bytes).
 #include "raht_common.h"
