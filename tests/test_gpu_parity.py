@@ -644,3 +644,27 @@ def test_plan_memory_cache_survives_churn(rt):
         del p
         if it == 2:
             _lib.check(_lib.lib().raht_release_cached_memory())
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_fused_quantization_wide_step_range(rt, seed):
+    """The hoisted-reciprocal divider over most of its admitted step range ([2^-100, 2^100]; here 2^+-80) and
+    quotients from denormal to far beyond int32: every integer must equal floor(IEEE x / step + 0.5)
+    (saturated like v_cvt_i32_f32)."""
+    import torch
+    N, D = 30000, 64
+    rng = np.random.default_rng(900 + seed)
+    keys = torch.arange(N, dtype=torch.int64, device="cuda") * 2
+    p = rt.RahtPlan.from_keys(keys, 24, top_level=1)            # no butterflies: T == C
+    steps = torch.from_numpy(np.exp2(rng.uniform(-80, 80, size=D)).astype(np.float32)).cuda()
+    mant = torch.from_numpy(rng.uniform(0.5, 1.0, size=(N, D)).astype(np.float32)).cuda()
+    expo = torch.from_numpy(rng.integers(-40, 36, size=(N, D)).astype(np.float32)).cuda()
+    sign = torch.from_numpy(rng.choice([-1.0, 1.0], size=(N, D)).astype(np.float32)).cuda()
+    C = (sign * mant * torch.exp2(expo) * steps).contiguous()      # quotients 2^-41 .. 2^36, finite everywhere
+    half = (torch.floor(mant * 64) + 0.5) * steps                   # exact-looking ties k + 0.5
+    C = torch.where(torch.from_numpy(rng.random((N, D)) < 0.2).cuda(), sign * half, C).contiguous()
+    assert torch.isfinite(C).all()
+    want = torch.floor(C / steps + 0.5).clamp(-2.0 ** 31, 2.0 ** 31 - 1).to(torch.int32)[p.order_RAGFT]
+    Q = p.forward_quant(C, steps)
+    assert torch.equal(Q, want)
+    assert torch.equal(Q, p.quant_reorder(C, steps))
