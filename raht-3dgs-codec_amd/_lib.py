@@ -8,7 +8,7 @@ import subprocess
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_PKG, "csrc")
-SO_PATH = os.environ.get("RAHT_HIP_LIB_EXPERIMENT") or os.path.join(_PKG, "libraht_hip.so")
+SO_PATH = os.path.join(_PKG, "libraht_hip.so")
 
 RAHT_OK = 0
 ERRORS = {-1: "RAHT_ERR_INVALID", -2: "RAHT_ERR_UNSORTED", -3: "RAHT_ERR_BOUNDS", -4: "RAHT_ERR_HIP",
