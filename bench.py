@@ -41,6 +41,7 @@ def parse():
     ap.add_argument("--no-quant", action="store_true", help="time forward + inverse only")
     ap.add_argument("--engine", default="tile", choices=["tile", "level"])
     ap.add_argument("--tile-rows", type=int, default=0)
+    ap.add_argument("--pooled-buffers", type=int, default=0, help="1: carve C/T/Q buffers from one allocation, 64 MiB apart")
     ap.add_argument("--top-rows", type=int, default=0, help="entries at which the single-launch top stage takes over (0 = automatic)")
     ap.add_argument("--quant-step", type=float, default=0.01)
     ap.add_argument("--skip-cpu-baseline", action="store_true")
@@ -127,10 +128,24 @@ def main():
     if world == 1:
         plan = R.RahtPlan.from_keys(kd, 3 * J)
         plan.set_engine(a.engine, a.tile_rows, 0, 0, a.top_rows)
-        T = torch.empty_like(Cd)
-        Q = torch.empty((N, D), dtype=torch.int32, device=dev)
-        Td = torch.empty_like(Cd)
-        Crec = torch.empty_like(Cd)
+        if a.pooled_buffers:
+            # one allocation, buffers 64 MiB apart (buffer placement: the duration of a
+            # streaming kernel has a bump over a window of input->output distances that moves with the
+            # physical mapping; inside ONE allocation gaps >= 32 MiB were outside it on every box tried)
+            nb = N * D * 4
+            stride = ((nb + (1 << 21) - 1) >> 21 << 21) + (64 << 20)
+            pool = torch.empty(5 * stride, dtype=torch.uint8, device=dev)
+            al = (-pool.data_ptr()) % (1 << 21)
+            def carve(i, dt):
+                return pool[al + i * stride: al + i * stride + nb].view(dt).view(N, D)
+            C0 = Cd
+            Cd = carve(0, torch.float32); Cd.copy_(C0); del C0
+            T, Q, Td, Crec = carve(1, torch.float32), carve(2, torch.int32), carve(3, torch.float32), carve(4, torch.float32)
+        else:
+            T = torch.empty_like(Cd)
+            Q = torch.empty((N, D), dtype=torch.int32, device=dev)
+            Td = torch.empty_like(Cd)
+            Crec = torch.empty_like(Cd)
         h = plan._h
         vp = C.c_void_p
 
