@@ -55,7 +55,10 @@ def parse():
 
 
 def cpu_baseline(V, C32, J, repeats):
-    """The C oracle (scalar restatement of the reference, float64 like the reference) on this host."""
+    """The C oracle (scalar restatement of the reference, float64 like the reference) on this host:
+    one core, and all cores (the transform is independent per channel: one thread per channel block,
+    ctypes releases the GIL). -> (single-core M-G/s, s per pass, all-cores M-G/s, s per pass, threads, err)"""
+    import threading
     from oracle import oracle as orc
     orc.lib()
     p = orc.raht_param(V.astype(np.float64), np.zeros(3), 2 ** J, J)
@@ -68,7 +71,27 @@ def cpu_baseline(V, C32, J, repeats):
         dt = time.perf_counter() - t0
         best = dt if best is None else min(best, dt)
     err = float(np.abs(R - C64).max())
-    return V.shape[0] / best / 1e6, best, err
+    del T, R
+    D = C64.shape[1]
+    nthr = max(1, min(os.cpu_count() or 1, D, 64))
+    cuts = [round(i * D / nthr) for i in range(nthr + 1)]
+    blocks = [np.ascontiguousarray(C64[:, cuts[i]:cuts[i + 1]]) for i in range(nthr)]
+
+    def work(b):
+        Tb, _ = orc.raht_fwd(b, p)
+        orc.raht_inv(Tb, p)
+    best_all = None
+    for _ in range(max(1, repeats)):
+        th = [threading.Thread(target=work, args=(b,)) for b in blocks]
+        t0 = time.perf_counter()
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        dt = time.perf_counter() - t0
+        best_all = dt if best_all is None else min(best_all, dt)
+    n = V.shape[0]
+    return n / best / 1e6, best, n / best_all / 1e6, best_all, nthr, err
 
 
 def main():
@@ -329,11 +352,12 @@ def main():
             del PC, xyz, ku, k60, perm
 
         if not a.skip_cpu_baseline:
-            v, secs, err = cpu_baseline(V, Ch, J, a.cpu_repeats)
-            out["cpu_baseline"] = {"value": round(v, 4), "unit": "M-Gaussians/s", "cores": 1, "kind": "port",
+            v1, s1, va, sa, nthr, err = cpu_baseline(V, Ch, J, a.cpu_repeats)
+            out["cpu_baseline"] = {"value": round(va, 4), "unit": "M-Gaussians/s", "cores": nthr, "kind": "port",
                                    "sample": (f"the full {a.workload} scene ({N} rows x {D} ch), fwd+inv RAHT only, float64, "
-                                              f"best of {a.cpu_repeats}, {secs:.2f} s per pass; scalar C oracle (oracle/raht_oracle.c)"),
-                                   "roundtrip_abs_err": err}
+                                              f"best of {a.cpu_repeats}; scalar C oracle (oracle/raht_oracle.c), one thread per "
+                                              f"channel block on {nthr} threads: {sa:.2f} s per pass; on one core {s1:.2f} s"),
+                                   "single_core_value": round(v1, 4), "roundtrip_abs_err": err}
     if rank == 0:
         print(json.dumps(out))
     if world > 1:

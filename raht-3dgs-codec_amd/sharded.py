@@ -20,6 +20,33 @@ def _dist():
     return dist if dist.is_available() and dist.is_initialized() else None
 
 
+def balanced_prefix_cuts(keys_sorted, nbits, world, prefix_bits=9):
+    """Where to cut a Morton-sorted scene into `world` shards: row boundaries
+    [0 = b_0 <= b_1 <= ... <= b_world = N] such that every cut falls between two different values of
+    the top ``prefix_bits`` key bits, balanced by the 2^prefix_bits-bin population histogram. Shard r =
+    rows [b_r, b_{r+1}); hand each to one rank's ``ShardedRaht``. Works on CPU or GPU tensors."""
+    N = int(keys_sorted.shape[0])
+    nb = 1 << prefix_bits
+    pref = (keys_sorted.to(torch.int64) >> (nbits - prefix_bits)).clamp_(0, nb - 1)
+    cum = torch.cumsum(torch.bincount(pref, minlength=nb), 0).cpu().tolist()     # rows with prefix <= p
+    cuts, lo = [0], 0
+    for r in range(1, world):
+        target = N * r / world
+        # the prefix boundary whose row count is closest to the target, never moving backwards
+        best, best_err = lo, None
+        for p in range(lo, nb):
+            rows_below = cum[p - 1] if p > 0 else 0
+            err = abs(rows_below - target)
+            if best_err is None or err < best_err:
+                best, best_err = p, err
+            if rows_below > target:
+                break
+        lo = best
+        cuts.append(cum[best - 1] if best > 0 else 0)
+    cuts.append(N)
+    return cuts
+
+
 class HipLocalOps:
     """Shard-local operations on the MI355X through libraht_hip.so."""
     quant_dtype = torch.float32          # arithmetic type of the fused quantize / dequantize kernels

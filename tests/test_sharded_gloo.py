@@ -27,7 +27,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, J, n, D, q):
+def _worker(rank, world, port, J, n, D, q, balanced=False):
     try:
         sys.path.insert(0, ROOT)
         os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -39,10 +39,15 @@ def _worker(rank, world, port, J, n, D, q):
 
         V, keys, C = synth.scene(n, J, D, seed=77)            # the whole scene, same on every rank
         nbits, pb = 3 * J, 9
-        pref = (keys >> np.uint64(nbits - pb)).astype(np.int64)
-        per = (1 << pb) // world
-        lo, hi = rank * per, ((rank + 1) * per if rank < world - 1 else 1 << pb)
-        mine = np.nonzero((pref >= lo) & (pref < hi))[0]
+        if balanced:
+            # shards cut by the population-balanced helper (512-bin prefix histogram)
+            cuts = sharded.balanced_prefix_cuts(torch.from_numpy(keys.view(np.int64).copy()), nbits, world, pb)
+            mine = np.arange(cuts[rank], cuts[rank + 1])
+        else:
+            pref = (keys >> np.uint64(nbits - pb)).astype(np.int64)
+            per = (1 << pb) // world
+            lo, hi = rank * per, ((rank + 1) * per if rank < world - 1 else 1 << pb)
+            mine = np.nonzero((pref >= lo) & (pref < hi))[0]
         assert mine.size > 0 and np.all(np.diff(mine) == 1)
         k_loc = torch.from_numpy(keys[mine].view(np.int64).copy())
         C_loc = torch.from_numpy(C[mine].astype(np.float64))
@@ -80,12 +85,13 @@ def _worker(rank, world, port, J, n, D, q):
         q.put((rank, traceback.format_exc()))
 
 
-@pytest.mark.parametrize("world,J,n,D", [(2, 6, 6000, 5), (2, 10, 4000, 14), (3, 5, 3000, 3)])
-def test_sharded_matches_unsharded_oracle(world, J, n, D):
+@pytest.mark.parametrize("world,J,n,D,balanced", [(2, 6, 6000, 5, False), (2, 10, 4000, 14, False), (3, 5, 3000, 3, False),
+                                                  (3, 8, 5000, 7, True)])
+def test_sharded_matches_unsharded_oracle(world, J, n, D, balanced):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, J, n, D, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, J, n, D, q, balanced)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=240) for _ in range(world)]
@@ -107,3 +113,25 @@ def test_single_process_degenerates_to_plain_transform():
     full = NumpyPlan(k, 21)
     np.testing.assert_allclose(sh.forward(Cd).numpy(), full.forward(Cd).numpy(), rtol=1e-12, atol=1e-12)
     assert sh.roundtrip_error(Cd) < 1e-12
+
+
+def test_balanced_prefix_cuts_fall_on_prefix_boundaries_and_balance():
+    import numpy as np
+    import torch
+    from raht_3dgs_codec_amd import sharded, synth
+    for seed, world in ((1, 2), (2, 3), (3, 8)):
+        keys = torch.from_numpy(synth.sorted_unique_keys(60000, 10, seed).view(np.int64))
+        N, nbits = keys.shape[0], 30
+        cuts = sharded.balanced_prefix_cuts(keys, nbits, world)
+        assert cuts[0] == 0 and cuts[-1] == N and len(cuts) == world + 1
+        assert all(a <= b for a, b in zip(cuts, cuts[1:]))
+        pref = keys >> (nbits - 9)
+        for b in cuts[1:-1]:
+            assert 0 < b < N and pref[b - 1] != pref[b]          # never inside a prefix node
+        biggest_bin = int(torch.bincount(pref, minlength=512).max())
+        sizes = [b - a for a, b in zip(cuts, cuts[1:])]
+        assert max(abs(sz - N / world) for sz in sizes) <= biggest_bin
+    # degenerate: everything in one prefix node -> one shard gets it all, the others are empty
+    one = torch.arange(100, dtype=torch.int64)
+    c = sharded.balanced_prefix_cuts(one, 30, 4)
+    assert c[0] == 0 and c[-1] == 100 and sorted(c) == c
