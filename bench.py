@@ -73,7 +73,11 @@ def cpu_baseline(V, C32, J, repeats):
     err = float(np.abs(R - C64).max())
     del T, R
     D = C64.shape[1]
-    nthr = max(1, min(os.cpu_count() or 1, D, 64))
+    try:
+        ncpu = len(os.sched_getaffinity(0))
+    except Exception:
+        ncpu = os.cpu_count() or 1
+    nthr = max(1, min(ncpu, D, 16))        # every thread re-walks the plan's lists: more, narrower blocks stop paying
     cuts = [round(i * D / nthr) for i in range(nthr + 1)]
     blocks = [np.ascontiguousarray(C64[:, cuts[i]:cuts[i + 1]]) for i in range(nthr)]
 
