@@ -494,10 +494,14 @@ __global__ __launch_bounds__(512, (sizeof(T) == 4 ? 6 : 4)) void tile_kernel(con
         uint64_t mask = ((uint64_t)lmask[1] << 32) | lmask[0];
         if (A.dbg & 1) mask = 0;
         bool chained = false;                 // wave 0 has run levels the other waves have not synchronised with yet
+        // lane l keeps level l's offset and count: a v_readlane per level instead of a dependent LDS
+        // round trip in front of every round (the rounds are a latency chain; +1.5 % on the step).
+        // Fetching the next chained level's record one link ahead as well measured no further gain.
+        const int loff_v = (int)loff[lane], hist_v = (int)hist[lane];
         while (mask) {
             const int l = INV ? (63 - __clzll((long long)mask)) : (__ffsll((long long)mask) - 1);
             mask &= ~(1ull << l);
-            const uint32_t base = loff[l], cnt = hist[l];
+            const uint32_t base = (uint32_t)__builtin_amdgcn_readlane(loff_v, l), cnt = (uint32_t)__builtin_amdgcn_readlane(hist_v, l);
             // branch-free body: reads are clamped to valid records (redundant, harmless), only the
             // writes are predicated -> U independent LDS chains in flight per lane. Most levels of a
             // tile hold fewer butterflies than one pass of the workgroup covers: those take U = 1.
