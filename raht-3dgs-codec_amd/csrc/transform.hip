@@ -250,7 +250,6 @@ __global__ __launch_bounds__(512, (sizeof(T) == 4 ? 6 : 4)) void tile_kernel(con
     uint32_t *hist = (uint32_t *)(smem + off);            // [64]
     uint32_t *loff = hist + 64;                           // [64]
     uint32_t *cursor = hist + 128;                        // [64]
-    uint32_t *lmask = hist + 192;                         // [2]
     uint32_t *scnt = hist + 196;                          // [32] survivors per (slot chunk, wave)
     off += 1024;
     uint16_t *ssurv = (uint16_t *)(smem + off);           // [R] slots of this tile's survivors, by rank
@@ -406,8 +405,6 @@ __global__ __launch_bounds__(512, (sizeof(T) == 4 ? 6 : 4)) void tile_kernel(con
         }
         loff[lane] = inc - c;
         cursor[lane] = inc - c;
-        const uint64_t m = __ballot(c > 0);
-        if (lane == 0) { lmask[0] = (uint32_t)m; lmask[1] = (uint32_t)(m >> 32); }
     }
     {
 #pragma unroll
@@ -491,13 +488,13 @@ __global__ __launch_bounds__(512, (sizeof(T) == 4 ? 6 : 4)) void tile_kernel(con
     // ---- P4. butterflies, one round per level present; a lane group handles one butterfly ----
     {
         const uint32_t stride = (uint32_t)(nw << lr);
-        uint64_t mask = ((uint64_t)lmask[1] << 32) | lmask[0];
-        if (A.dbg & 1) mask = 0;
         bool chained = false;                 // wave 0 has run levels the other waves have not synchronised with yet
         // lane l keeps level l's offset and count: a v_readlane per level instead of a dependent LDS
         // round trip in front of every round (the rounds are a latency chain; +1.5 % on the step).
         // Fetching the next chained level's record one link ahead as well measured no further gain.
         const int loff_v = (int)loff[lane], hist_v = (int)hist[lane];
+        uint64_t mask = __ballot(hist_v > 0);            // levels present in this tile
+        if (A.dbg & 1) mask = 0;
         while (mask) {
             const int l = INV ? (63 - __clzll((long long)mask)) : (__ffsll((long long)mask) - 1);
             mask &= ~(1ull << l);
