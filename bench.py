@@ -42,6 +42,8 @@ def parse():
     ap.add_argument("--engine", default="tile", choices=["tile", "level"])
     ap.add_argument("--tile-rows", type=int, default=0)
     ap.add_argument("--pooled-buffers", type=int, default=0, help="1: carve C/T/Q buffers from one allocation, 64 MiB apart")
+    ap.add_argument("--tail-rows", type=int, default=0, help="rows per tile of the stages >= 1 (0 = automatic)")
+    ap.add_argument("--tail-ch", type=int, default=0, help="channels per chunk of the stages >= 1 (0 = automatic)")
     ap.add_argument("--top-rows", type=int, default=0, help="entries at which the single-launch top stage takes over (0 = automatic)")
     ap.add_argument("--quant-step", type=float, default=0.01)
     ap.add_argument("--skip-cpu-baseline", action="store_true")
@@ -154,7 +156,7 @@ def main():
 
     if world == 1:
         plan = R.RahtPlan.from_keys(kd, 3 * J)
-        plan.set_engine(a.engine, a.tile_rows, 0, 0, a.top_rows)
+        plan.set_engine(a.engine, a.tile_rows, a.tail_rows, a.tail_ch, a.top_rows)
         if a.pooled_buffers:
             # one allocation, buffers 64 MiB apart (buffer placement: the duration of a
             # streaming kernel has a bump over a window of input->output distances that moves with the
