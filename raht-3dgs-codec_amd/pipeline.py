@@ -83,7 +83,7 @@ def encode_frame(V_int, attributes, J, steps, frame=1, device="cuda:0", dtype=to
             r["RAHT_transform_time"] = t_transform
         # device -> host, channel-major so that the entropy coder reads contiguous channels
         q_dev = rlgr_mod.transpose_on_device(coeff_reordered) if channel_major else coeff_reordered
-        q_cpu = q_dev.cpu().numpy()                                                 # :215-217
+        q_cpu = rlgr_mod.to_host(q_dev)                                             # :215-217 (pinned staging)
         streams, t_enc = rlgr_mod.encode_channels(q_cpu, 1, nthreads=nthreads, channel_major=channel_major)   # :229-234
         size_bytes = sum(int(s.shape[0]) for s in streams)                          # :247
         r["Entropy_enc_time"] = t_enc
@@ -177,7 +177,7 @@ def encode_ply_frame(V_int, Crgb, J, steps=(1, 2, 4, 6, 8, 12, 16, 20, 24, 32, 6
         mse = (torch.linalg.norm(Coeff[:, 0].double() - Y_hat.double()) ** 2) / (N * 255 ** 2)     # :150-151
         r["psnr"] = float(-10 * torch.log10(mse))
         q_dev = Coeff_enc.index_select(0, order_RAGFT).to(torch.int32)              # :156-157
-        q_cpu = rlgr_mod.transpose_on_device(q_dev).cpu().numpy()
+        q_cpu = rlgr_mod.to_host(rlgr_mod.transpose_on_device(q_dev))
         streams, r["Entropy_enc_time"] = rlgr_mod.encode_channels(q_cpu, 1, nthreads=nthreads, channel_major=True)   # :164-176
         q_back, r["Entropy_dec_time"] = rlgr_mod.decode_channels(streams, N, 1, nthreads=nthreads, channel_major=True)
         assert np.array_equal(q_back, q_cpu), "RLGR roundtrip failed"               # :184-187

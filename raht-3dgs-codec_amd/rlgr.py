@@ -122,3 +122,26 @@ def transpose_on_device(Q):
         check(_lib.lib().raht_transpose_i32(C.c_void_p(Q.data_ptr()), Q.stride(0), rows, cols, C.c_void_p(out.data_ptr()),
                                             rows, C.c_void_p(torch.cuda.current_stream().cuda_stream)))
     return out
+
+
+_STAGING = {}
+
+
+def to_host(t):
+    """Device tensor -> numpy array through a cached page-locked staging buffer: 57 GB/s instead of the
+    6.7 GB/s of a pageable ``.cpu()`` on the MI355X box (708 MB of quantized coefficients: 12 ms
+    instead of 106 ms; tools/probe_d2h.py). The array aliases the staging buffer of its dtype and stays
+    valid until the next ``to_host`` call with that dtype."""
+    import torch
+    if not t.is_cuda:
+        return t.contiguous().numpy()
+    t = t.contiguous()
+    n = t.numel()
+    buf = _STAGING.get(t.dtype)
+    if buf is None or buf.numel() < n:
+        buf = torch.empty(max(n, 1), dtype=t.dtype, pin_memory=True)
+        _STAGING[t.dtype] = buf
+    out = buf[:n].view(t.shape)
+    out.copy_(t, non_blocking=True)
+    torch.cuda.current_stream(t.device).synchronize()
+    return out.numpy()

@@ -116,3 +116,15 @@ def test_compress_to_nvox_then_encode(oracle, tmp_path):
     assert abs(vs - vx["voxel_size"]) <= 1e-12 * vs and np.allclose(vmin.numpy(), vx["vmin"], rtol=0, atol=1e-6)
     rows = pipeline.encode_frame(V2, A2, J, [0.05], dtype=torch.float32)
     assert rows[0]["size_bytes"] > 0 and rows[0]["PSNR_all"] > 20
+
+
+@pytest.mark.gpu
+def test_to_host_through_pinned_staging():
+    import torch
+    from raht_3dgs_codec_amd import rlgr
+    a = torch.randint(-1000, 1000, (7, 12345), dtype=torch.int32, device="cuda")
+    h = rlgr.to_host(a)
+    assert h.dtype == np.int32 and np.array_equal(h, a.cpu().numpy())
+    b = torch.randint(-5, 5, (3, 100), dtype=torch.int32, device="cuda")[:, ::2]        # non-contiguous, smaller: buffer reuse
+    assert np.array_equal(rlgr.to_host(b), b.cpu().numpy())
+    assert np.array_equal(rlgr.to_host(torch.arange(5)), np.arange(5))                     # CPU tensors pass through
