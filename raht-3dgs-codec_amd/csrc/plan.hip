@@ -399,7 +399,7 @@ static int build_top_stage(raht_plan *plan, uint32_t *rows, int64_t n, hipStream
     {
         // the level program: non-empty levels, ascending; the trailing run of levels with at most 64
         // butterflies each (the top of the tree) is chained by one wave
-        uint32_t lev[2 * 63];
+        uint32_t *lev = st.t_lev_host;                    // lives in the stage: the upload below stays asynchronous
         int nlev = 0;
         for (int l = 0; l < 63; ++l)
             if (st.t_loff[l + 1] > st.t_loff[l]) { lev[2 * nlev] = st.t_loff[l]; lev[2 * nlev + 1] = st.t_loff[l + 1]; ++nlev; }
@@ -411,8 +411,9 @@ static int build_top_stage(raht_plan *plan, uint32_t *rows, int64_t n, hipStream
         st.t_nlev = nlev; st.t_nbig = nbig;
         st.t_small_start = (nbig < nlev) ? lev[2 * nbig] : st.n_merges;
         RAHT_HIP_CHECK(dev_malloc(&st.t_lev, sizeof(uint32_t) * 2 * 64));
+        // staged through a scratch-independent pageable copy: hipMemcpyAsync from pageable memory copies the
+        // source before it returns, so `st` may be moved afterwards
         RAHT_HIP_CHECK(hipMemcpyAsync(st.t_lev, lev, sizeof(uint32_t) * 2 * (size_t)std::max(nlev, 1), hipMemcpyHostToDevice, s));
-        RAHT_HIP_CHECK(hipStreamSynchronize(s));       // lev[] is a stack array
     }
     const size_t nm = std::max<size_t>(st.n_merges, 1);
     RAHT_HIP_CHECK(dev_malloc(&st.t_pj, sizeof(uint32_t) * nm));
@@ -421,8 +422,7 @@ static int build_top_stage(raht_plan *plan, uint32_t *rows, int64_t n, hipStream
     if (st.n_merges)
         hipLaunchKernelGGL(top_gather_kernel, dim3((unsigned)ceil_div(st.n_merges, 256)), dim3(256), 0, s, perm, st.n_merges,
                            pj, ab, st.t_pj, st.t_ab32, st.t_ab64);
-    RAHT_HIP_CHECK(hipStreamSynchronize(s));         // the scratch goes back to the pool
-    return RAHT_OK;
+    return RAHT_OK;                                  // (the scratch goes back to the pool: stream-ordered reuse)
 }
 
 int get_schedule(raht_plan *plan, int R0, int R1, int Rf, hipStream_t s, Schedule **out)
@@ -509,6 +509,13 @@ __global__ void root_flag_kernel(const uint8_t *__restrict__ lvl, int64_t N, int
 static int compute_roots(raht_plan *p, hipStream_t s)
 {
     if (p->root_rows) { dev_free(p->root_rows); p->root_rows = nullptr; }
+    if (p->top_level > p->max_level) {
+        // untruncated tree (the usual case): row 0 is the only row left carrying a low-pass value
+        p->n_roots = 1;
+        RAHT_HIP_CHECK(dev_malloc(&p->root_rows, sizeof(uint32_t)));
+        RAHT_HIP_CHECK(hipMemsetAsync(p->root_rows, 0, sizeof(uint32_t), s));
+        return RAHT_OK;
+    }
     Scratch buf(sizeof(uint32_t) * 2 * (size_t)p->N);
     if (!buf.ok()) return RAHT_ERR_NOMEM;
     uint32_t *flag = buf.as<uint32_t>(), *tmp = flag + p->N;

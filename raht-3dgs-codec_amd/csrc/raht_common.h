@@ -109,6 +109,7 @@ struct Stage {
     double *t_ab64 = nullptr;      // device [2 * n_merges]: a, b in float64
     uint32_t *t_root = nullptr;    // device [n_entries]: rank among the roots (root buffer row), ~0u = not a root
     uint32_t t_loff[65] = {0};     // host: first merge of every binary level (t_loff[63] = n_merges)
+    uint32_t t_lev_host[2 * 64] = {0};
     uint32_t *t_lev = nullptr;     // device [2 * t_nlev]: (first, end) butterfly of every NON-EMPTY level, ascending
     int t_nlev = 0;
     int t_nbig = 0;                // the first t_nbig of them run on the whole workgroup (a barrier each); the rest
