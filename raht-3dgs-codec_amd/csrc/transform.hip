@@ -832,13 +832,14 @@ static int device_cus()
     return n;
 }
 
-static bool persist_enabled()
+// RAHT_TILE_PERSIST (tuning knob): 0 / unset = one tile per workgroup (default, measured fastest);
+// 1 = as many workgroups as the chip keeps resident, each walking tiles b, b + grid, ...;
+// k >= 2 = k tiles per workgroup.
+static int persist_mode()
 {
     static int v = -1;
-    // default off: one tile per workgroup measured faster (3155 vs 2857 M-Gaussians/s on the fused
-    // cfg3 step); persistent workgroups start in lock-step and pay a tail
-    if (v < 0) { const char *e = getenv("RAHT_TILE_PERSIST"); v = (e && atoi(e) == 1) ? 1 : 0; }
-    return v == 1;
+    if (v < 0) { const char *e = getenv("RAHT_TILE_PERSIST"); v = e ? std::max(0, atoi(e)) : 0; }
+    return v;
 }
 
 static int lp_shift_for(int Dc)
@@ -967,7 +968,9 @@ static int launch_tile_stage(const raht_plan *p, const Schedule &sc, int k, cons
     // per CU), each walking tiles blockIdx.x, blockIdx.x + gridDim.x, ...
     const int per_cu = std::max(1, std::min((int)(128 / ((lds + 1279) / 1280)), 32 / (threads / 64)));
     const int64_t resident = (int64_t)per_cu * device_cus();
-    const int64_t gx = persist_enabled() ? std::min<int64_t>(st.n_tiles, std::max<int64_t>(1, resident / nchunks)) : st.n_tiles;
+    const int pm = persist_mode();
+    const int64_t gx = pm == 1 ? std::min<int64_t>(st.n_tiles, std::max<int64_t>(1, resident / nchunks))
+                     : pm >= 2 ? ceil_div(st.n_tiles, (int64_t)pm) : st.n_tiles;
     const dim3 grid((unsigned)gx, (unsigned)nchunks);
     const bool one = st.tile_rows <= threads;
     if (st.rows == nullptr)
