@@ -255,6 +255,9 @@ void pick_tail_geometry(const raht_plan *plan, int elem_size, int D, int stage0_
 
 static void free_schedule(Schedule &sc)
 {
+    // blocks go back to the cache and may be handed out again at once: nothing enqueued may still use
+    // them (hipFree used to imply this wait; schedules are only dropped on rare, synchronous paths)
+    if (!sc.stages.empty()) (void)hipDeviceSynchronize();
     for (auto &st : sc.stages) {
         if (st.rows) dev_free(st.rows);
         if (st.surv_off) dev_free(st.surv_off);
@@ -277,7 +280,7 @@ int ensure_workspace(Schedule *sc, size_t row_bytes)
     if (row_bytes <= sc->ws_row_bytes) return RAHT_OK;
     for (size_t k = 1; k < sc->stages.size(); ++k) {
         Stage &st = sc->stages[k];
-        if (st.ws) { dev_free(st.ws); st.ws = nullptr; }
+        if (st.ws) { (void)hipDeviceSynchronize(); dev_free(st.ws); st.ws = nullptr; }
         if (dev_malloc(&st.ws, row_bytes * (size_t)st.n_entries) != hipSuccess) {
             set_error("workspace allocation failed (%zu bytes)", row_bytes * (size_t)st.n_entries);
             sc->ws_row_bytes = 0;
