@@ -303,7 +303,40 @@ def main():
                 _lib.check(L.raht_debug_run_stage(h, 1, 0, vp(T.data_ptr()), D, D, vp(Crec.data_ptr()), D, qp, D, qs,
                                                   a.ablate, s_()))
             k_fwd(); k_inv()
-            tf, ti = timed(k_fwd, reps), timed(k_inv, reps)
+            tf_iso, ti_iso = timed(k_fwd, reps), timed(k_inv, reps)
+            tf, ti = tf_iso, ti_iso
+            if a.ablate == 0:
+                # The same two kernels timed INSIDE real steps: the library records a HIP event pair on the
+                # launch stream around the stage-0 launch of each direction (raht_plan_set_stage0_events).
+                hip = C.CDLL("libamdhip64.so")
+                hip.hipEventCreate.argtypes = [C.POINTER(vp)]
+                hip.hipEventElapsedTime.argtypes = [C.POINTER(C.c_float), vp, vp]
+                hip.hipEventDestroy.argtypes = [vp]
+
+                def new_event():
+                    e = vp()
+                    assert hip.hipEventCreate(C.byref(e)) == 0
+                    return e
+                nrep = max(5, a.steps)
+                evs = [[new_event() for _ in range(4)] for _ in range(nrep)]
+                one_fwd, one_inv = ((fwd, lambda: inv(T)) if a.no_quant else
+                                    (fwd, lambda: inv(Td)) if a.unfused else (fwd_quant, dequant_inv))
+                for e4 in evs:
+                    _lib.check(L.raht_plan_set_stage0_events(h, e4[0], e4[1])); one_fwd()
+                    if a.unfused and not a.no_quant:
+                        _lib.check(L.raht_plan_set_stage0_events(h, None, None)); quant(); dequant()
+                    _lib.check(L.raht_plan_set_stage0_events(h, e4[2], e4[3])); one_inv()
+                _lib.check(L.raht_plan_set_stage0_events(h, None, None))
+                torch.cuda.synchronize()
+                ms = C.c_float()
+                acc = [0.0, 0.0]
+                for e4 in evs:
+                    for d_ in (0, 1):
+                        assert hip.hipEventElapsedTime(C.byref(ms), e4[2 * d_], e4[2 * d_ + 1]) == 0
+                        acc[d_] += ms.value
+                    for e in e4:
+                        hip.hipEventDestroy(e)
+                tf, ti = acc[0] / nrep, acc[1] / nrep
             traffic = None
             tp = os.path.join(ROOT, "profiles", "traffic.json")
             if os.path.exists(tp):
@@ -316,12 +349,15 @@ def main():
                                          + (", fused quantize+reorder)" if fused else ")"), "bound": "hbm",
                                "achieved": round(alg / (tf * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": round(alg / (tf * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": traffic,
-                               "alg_bytes_per_launch": alg, "avg_launch_ms": round(tf, 4)}
+                               "alg_bytes_per_launch": alg, "avg_launch_ms": round(tf, 4),
+                               "timed": "HIP events around the stage-0 launch inside real steps" if a.ablate == 0 else "isolated launches",
+                               "isolated_launch_ms": round(tf_iso, 4)}
             out["roofline_inv"] = {"kernel": f"raht::tile_kernel<float, true, true, {tq}, 1> (inverse, stage 0"
                                              + (", fused un-reorder+dequantize)" if fused else ")"), "bound": "hbm",
                                    "achieved": round(alg / (ti * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                    "frac": round(alg / (ti * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                                   "alg_bytes_per_launch": alg, "avg_launch_ms": round(ti, 4)}
+                                   "alg_bytes_per_launch": alg, "avg_launch_ms": round(ti, 4),
+                                   "isolated_launch_ms": round(ti_iso, 4)}
         # whole fwd+inv against the whole-path algorithmic bytes (16 N D + 16 N)
         tot = br["fwd_ms"] + br["inv_ms"]
         out["path_hbm"] = {"alg_bytes_fwd_inv": 2 * alg, "fwd_inv_ms": round(tot, 4),

@@ -174,6 +174,12 @@ int raht_dequant_inv(const raht_plan *plan, const int32_t *Q, int64_t ldq, int D
  * A plan owns its workspaces: do not run transforms of one plan concurrently on several streams. */
 int raht_plan_prepare(raht_plan *plan, int elem_size, int D, raht_stream_t stream);
 
+/* Profiling aid: HIP events (hipEvent_t, created by the caller with timing enabled) recorded on the
+ * launch stream immediately before and after the STAGE-0 kernel of every following transform of this
+ * plan, so that the dominant kernel can be timed inside a real step (hipEventElapsedTime after the
+ * stream has been synchronised). NULL, NULL switches it off. */
+int raht_plan_set_stage0_events(raht_plan *plan, void *ev_before, void *ev_after);
+
 /* Profiling aid: enqueue ONE stage of the float32 tile schedule (stage 0 is the HBM-heavy launch).
  * Not a transform by itself; bench.py uses it to time the dominant kernel with HIP events.
  *   Q == NULL : plain kernels   (forward: mat = C in, mat2 = T out;  inverse: mat = T in, mat2 = C out)

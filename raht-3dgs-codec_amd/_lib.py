@@ -21,7 +21,7 @@ EXPORTS = [
     "raht_last_error", "raht_version", "raht_plan_create", "raht_plan_create_from_keys",
     "raht_plan_destroy", "raht_plan_set_top_level", "raht_plan_roots", "raht_plan_set_root_buffer", "raht_plan_size", "raht_plan_nbits", "raht_plan_set_engine", "raht_plan_set_tail_tile", "raht_release_cached_memory", "raht_quant_rows", "raht_dequant_rows",
     "raht_plan_levels", "raht_plan_export_level", "raht_plan_order", "raht_plan_arrays",
-    "raht_plan_copy_array", "raht_plan_stage_stats", "raht_fwd", "raht_fwd_f64", "raht_inv", "raht_inv_f64", "raht_debug_run_stage", "raht_fwd_quant", "raht_dequant_inv", "raht_plan_prepare",
+    "raht_plan_copy_array", "raht_plan_stage_stats", "raht_fwd", "raht_fwd_f64", "raht_inv", "raht_inv_f64", "raht_debug_run_stage", "raht_plan_set_stage0_events", "raht_fwd_quant", "raht_dequant_inv", "raht_plan_prepare",
     "raht_quant_reorder", "raht_dequant_unreorder", "raht_voxelize", "raht_morton", "raht_sort_keys",
     "raht_rlgr_bound", "raht_rlgr_encode", "raht_rlgr_decode", "raht_rlgr_encode_channels", "raht_rlgr_decode_channels", "raht_transpose_i32", "raht_merge_clusters",
 ]
@@ -85,6 +85,7 @@ def lib():
         f.argtypes = [vp, vp, i64, i32, vp, i64, vp, vp]
     for f in (L.raht_inv, L.raht_inv_f64):
         f.argtypes = [vp, vp, i64, i32, vp, i64, vp]
+    L.raht_plan_set_stage0_events.argtypes = [vp, vp, vp]
     L.raht_debug_run_stage.argtypes = [vp, i32, i32, vp, i64, i32, vp, i64, vp, i64, C.c_float, i32, vp]
     L.raht_fwd_quant.argtypes = [vp, vp, i64, i32, C.POINTER(C.c_float), i32, vp, i64, vp]
     L.raht_dequant_inv.argtypes = [vp, vp, i64, i32, C.POINTER(C.c_float), i32, vp, i64, vp]

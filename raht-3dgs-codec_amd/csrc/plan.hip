@@ -711,6 +711,14 @@ int raht_plan_set_tail_tile(raht_plan *p, int tail_rows, int tail_channels, int 
     return RAHT_OK;
 }
 
+int raht_plan_set_stage0_events(raht_plan *p, void *ev_before, void *ev_after)
+{
+    if (!p || ((ev_before == nullptr) != (ev_after == nullptr))) { set_error("raht_plan_set_stage0_events: need both events or none"); return RAHT_ERR_INVALID; }
+    p->ev_before = (hipEvent_t)ev_before;
+    p->ev_after = (hipEvent_t)ev_after;
+    return RAHT_OK;
+}
+
 int raht_plan_set_engine(raht_plan *p, int engine, int tile_rows)
 {
     if (!p || (engine != RAHT_ENGINE_TILE && engine != RAHT_ENGINE_LEVEL)) { set_error("raht_plan_set_engine: bad argument"); return RAHT_ERR_INVALID; }

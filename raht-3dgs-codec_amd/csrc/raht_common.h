@@ -150,6 +150,7 @@ struct raht_plan {
     int tail_rows_override = 0;  // rows per tile of the later stages (0 = automatic)
     int tail_chunk_override = 0; // channels per chunk of the later stages (0 = automatic)
     int final_rows_override = 0; // single-tile finishing stage up to this many entries (0 = automatic)
+    hipEvent_t ev_before = nullptr, ev_after = nullptr;   // profiling: recorded around the stage-0 launch
     std::vector<raht::Schedule> schedules;   // cache keyed by tile_rows
     std::vector<uint8_t> lvl_host;           // lazily downloaded for export_level
 };

@@ -668,3 +668,34 @@ def test_fused_quantization_wide_step_range(rt, seed):
     Q = p.forward_quant(C, steps)
     assert torch.equal(Q, want)
     assert torch.equal(Q, p.quant_reorder(C, steps))
+
+
+def test_stage0_events_bracket_the_dominant_kernel(rt):
+    """raht_plan_set_stage0_events: the caller's HIP events are recorded around the stage-0 launch of a
+    real transform (bench.py times the dominant kernel inside its steps with them)."""
+    import ctypes as C
+    import torch
+    from raht_3dgs_codec_amd import _lib
+    hip = C.CDLL("libamdhip64.so")
+    vp = C.c_void_p
+    hip.hipEventCreate.argtypes = [C.POINTER(vp)]
+    hip.hipEventElapsedTime.argtypes = [C.POINTER(C.c_float), vp, vp]
+    hip.hipEventDestroy.argtypes = [vp]
+    a, b = vp(), vp()
+    assert hip.hipEventCreate(C.byref(a)) == 0 and hip.hipEventCreate(C.byref(b)) == 0
+    N, D = 300000, 59
+    keys = torch.arange(N, dtype=torch.int64, device="cuda") * 3 + 1
+    p = rt.RahtPlan.from_keys(keys, 24)
+    Cm = torch.randn(N, D, device="cuda")
+    ref = p.forward_quant(Cm, 0.1)
+    L = _lib.lib()
+    _lib.check(L.raht_plan_set_stage0_events(p._h, a, b))
+    Q = p.forward_quant(Cm, 0.1)
+    _lib.check(L.raht_plan_set_stage0_events(p._h, None, None))
+    torch.cuda.synchronize()
+    ms = C.c_float()
+    assert hip.hipEventElapsedTime(C.byref(ms), a, b) == 0
+    assert 0.0 < ms.value < 5.0                       # a 71 MB launch: tens of microseconds
+    assert torch.equal(Q, ref)
+    assert L.raht_plan_set_stage0_events(p._h, a, None) != 0        # both or none
+    hip.hipEventDestroy(a); hip.hipEventDestroy(b)
