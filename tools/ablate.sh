@@ -1,3 +1,4 @@
+# bench.py --ablate 0/1/2/3 on fused and plain stage-0 kernels (1 = no butterflies, 2 = no merge resolution either)
 for i in 1 2; do for a in 0 1 2 3; do timeout -k 10 200 python bench.py --skip-cpu-baseline --skip-prelude --ablate $a 2>/dev/null | python -c "
 import json,sys
 d=json.loads(sys.stdin.read())

@@ -1,3 +1,4 @@
+# GPU check: RCCL initialises and all-gathers at world size 1; the sharded driver round-trips on it
 import os, sys, torch, torch.distributed as dist
 sys.path.insert(0, '.')
 os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29555")

@@ -1,3 +1,4 @@
+# GPU timing: plan creation (arrays + default schedule), prepare and destroy on cfg3
 import sys, time
 import numpy as np, torch
 sys.path.insert(0, '.')
