@@ -24,65 +24,94 @@ namespace rlgr {
 
 constexpr uint64_t L = 4, U0 = 3, D0 = 1, U1 = 2, D1 = 1;
 
-// MSB-first bit writer with a 64-bit accumulator (same byte stream as membuf::write/flush).
+// MSB-first bit writer with a 64-bit accumulator (same byte stream as membuf::write/flush). Fewer than
+// 32 bits stay pending after every put; whole 32-bit words leave as one big-endian store.
 struct BitWriter {
     uint8_t *out;
     int64_t cap, size = 0;
-    uint64_t acc = 0;        // pending bits, right-aligned
-    int nbits = 0;           // < 8 after every put
+    uint64_t acc = 0;        // pending bits, right-aligned (bits above nbits are stale)
+    int nbits = 0;           // < 32 after every put
     bool overflow = false;
 
-    inline void put(uint64_t v, int bits)                 // bits <= 56, v < 2^bits
+    inline void put(uint64_t v, int bits)                 // bits <= 32, v < 2^bits
     {
         acc = (acc << bits) | v;
         nbits += bits;
-        while (nbits >= 8) {
-            nbits -= 8;
-            if (size < cap) out[size] = (uint8_t)(acc >> nbits);
-            else overflow = true;
-            ++size;
+        if (nbits >= 32) {
+            nbits -= 32;
+            const uint32_t word = (uint32_t)(acc >> nbits);
+            if (size + 4 <= cap) {
+                const uint32_t be = __builtin_bswap32(word);
+                memcpy(out + size, &be, 4);
+            } else {
+                for (int b = 0; b < 4; ++b) {
+                    if (size + b < cap) out[size + b] = (uint8_t)(word >> (24 - 8 * b));
+                    else overflow = true;
+                }
+            }
+            size += 4;
         }
-        acc &= (nbits ? ((1ull << nbits) - 1) : 0);
     }
-    inline void put_wide(uint64_t v, int bits)            // membuf.cpp:172-184 (split above 56 bits)
+    inline void put_wide(uint64_t v, int bits)            // membuf.cpp:172-184; any width up to 64
     {
-        if (bits > 56) { put(v >> 32, bits - 32); put(v & 0xffffffffull, 32); }
-        else put(bits ? (v & ((bits == 64) ? ~0ull : ((1ull << bits) - 1))) : 0, bits);
+        if (bits > 32) { put((bits == 64) ? (v >> 32) : ((v >> 32) & ((1ull << (bits - 32)) - 1)), bits - 32); put(v & 0xffffffffull, 32); }
+        else put(bits ? (v & ((1ull << bits) - 1)) : 0, bits);
     }
-    inline void golomb_rice(uint64_t u, int k)            // membuf.cpp:242-256
+    inline void golomb_rice(uint64_t u, int k)            // membuf.cpp:242-256 (k <= 32)
     {
         const uint64_t p = u >> k;
         if (p < 32) {
-            put((1ull << (p + 1)) - 2, (int)p + 1);       // p ones, one zero
-            put(k ? (u & ((1ull << k) - 1)) : 0, k);
+            if (p + 1 + (uint64_t)k <= 32) {              // prefix (p ones, one zero) and remainder in one go
+                put((((1ull << (p + 1)) - 2) << k) | (k ? (u & ((1ull << k) - 1)) : 0), (int)p + 1 + k);
+            } else {
+                put((1ull << (p + 1)) - 2, (int)p + 1);
+                put(k ? (u & ((1ull << k) - 1)) : 0, k);
+            }
         } else {
             put(0xffffffffull, 32);                       // escape: 32 ones, then 32 raw bits
             put(u & 0xffffffffull, 32);
         }
     }
-    inline void close() { if (nbits) put(0, 8 - nbits); } // membuf.cpp:47-58
+    inline void close()                                   // membuf.cpp:47-58: pad the last byte with zeros
+    {
+        if (nbits & 7) put(0, 8 - (nbits & 7));
+        while (nbits > 0) {
+            nbits -= 8;
+            if (size < cap) out[size] = (uint8_t)(acc >> nbits);
+            else overflow = true;
+            ++size;
+        }
+    }
 };
 
+// MSB-first bit reader: the valid bits sit right-aligned in acc; bits past the end of the stream read
+// as zeros (the reference underflows there).
 struct BitReader {
     const uint8_t *in;
     int64_t size, pos = 0;
     uint64_t acc = 0;
     int nbits = 0;
 
-    inline void fill()
+    inline void fill()                                    // afterwards nbits > 56 unless the stream ended
     {
+        if (nbits <= 32 && pos + 4 <= size) {
+            uint32_t be;
+            memcpy(&be, in + pos, 4);
+            acc = (acc << 32) | __builtin_bswap32(be);
+            pos += 4; nbits += 32;
+        }
         while (nbits <= 56 && pos < size) { acc = (acc << 8) | in[pos++]; nbits += 8; }
     }
     inline uint32_t bit()
     {
-        if (!nbits) { fill(); if (!nbits) return 0; }     // past the end: zeros (the reference underflows)
+        if (!nbits) { fill(); if (!nbits) return 0; }
         --nbits;
         return (uint32_t)((acc >> nbits) & 1u);
     }
     inline uint64_t get(int bits)                         // bits <= 56
     {
         if (!bits) return 0;
-        fill();
+        if (nbits < bits) fill();
         if (nbits < bits) { const int miss = bits - nbits; acc <<= miss; nbits += miss; }   // zero padding
         nbits -= bits;
         return (acc >> nbits) & ((1ull << bits) - 1);
@@ -94,8 +123,18 @@ struct BitReader {
     }
     inline uint64_t golomb_rice(int k)                    // membuf.cpp:228-240
     {
-        uint64_t p = 0;
-        while (bit()) { if (++p >= 32) return get(32); }
+        // unary prefix by counting leading ones of the pending bits (at most 32 count)
+        if (nbits < 33) fill();
+        uint64_t p;
+        if (nbits >= 33) {
+            const uint64_t top = acc << (64 - nbits);     // pending bits, left-aligned
+            p = (uint64_t)__builtin_clzll(~top | (1ull << 30));              // leading ones, at most 33 counted
+            if (p >= 32) { nbits -= 32; return get(32); }
+            nbits -= (int)p + 1;                          // the ones and the terminating zero
+        } else {                                          // tail of the stream: bit by bit, zeros past the end
+            p = 0;
+            while (bit()) { if (++p >= 32) return get(32); }
+        }
         return (p << k) + get(k);
     }
 };
