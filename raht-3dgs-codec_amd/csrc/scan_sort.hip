@@ -290,6 +290,10 @@ __device__ __forceinline__ uint64_t match_digit(uint32_t digit, int bits, uint64
     return m;
 }
 
+// The block's items are first sorted by digit INSIDE LDS (stable: ranks in (wave, round, lane) order) and
+// then written out slot by slot, so that every digit leaves the block as one contiguous run
+// (4096 items over 256 digits: 16 items = 128-192 bytes per run) instead of one scattered 8 + 4 byte
+// store per item.
 template <typename KeyT, bool HAS_VALS_IN, bool WRITE_KEYS>
 __global__ __launch_bounds__(RP_THREADS) void radix_scatter_kernel(
     const KeyT *__restrict__ keys_in, const uint32_t *__restrict__ vals_in,
@@ -297,33 +301,44 @@ __global__ __launch_bounds__(RP_THREADS) void radix_scatter_kernel(
     const uint32_t *__restrict__ goffs, uint32_t nblocks)
 {
     __shared__ uint32_t wcnt[RP_WAVES][256];
+    __shared__ uint32_t gdelta[256];                   // global position - block-local slot, per digit
+    __shared__ KeyT skey[RP_BLOCK];
+    __shared__ uint32_t sval[RP_BLOCK];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const uint32_t mask = (1u << bits) - 1u;
     for (int k = threadIdx.x; k < RP_WAVES * 256; k += RP_THREADS) (&wcnt[0][0])[k] = 0;
     __syncthreads();
 
-    const int64_t wbase = (int64_t)blockIdx.x * RP_BLOCK + (int64_t)wid * RP_WAVE_ITEMS;
+    const int64_t bbase = (int64_t)blockIdx.x * RP_BLOCK;
+    const int64_t wbase = bbase + (int64_t)wid * RP_WAVE_ITEMS;
+    const int nblk = (int)min((int64_t)RP_BLOCK, n - bbase);
     KeyT key[RP_ROUNDS];
-    // phase 1: per-wave digit histogram (keys stay in registers)
+    uint32_t val[RP_ROUNDS];
+    // phase 1: per-wave digit histogram (keys and payloads stay in registers)
 #pragma unroll
     for (int r = 0; r < RP_ROUNDS; ++r) {
         const int64_t i = wbase + r * 64 + lane;
         key[r] = (i < n) ? keys_in[i] : (KeyT)0;
+        val[r] = HAS_VALS_IN ? ((i < n) ? vals_in[i] : 0u) : (uint32_t)i;
         if (i < n) atomicAdd(&wcnt[wid][digit_of(key[r], shift, mask)], 1u);
     }
     __syncthreads();
-    // phase 2: turn counts into start offsets: global digit offset of this block + earlier waves
-    if (threadIdx.x <= mask) {
-        uint32_t run = goffs[(size_t)threadIdx.x * nblocks + blockIdx.x];
+    // phase 2: counts -> block-local start slots (digit-major, then wave); remember where the digit's
+    // run of this block starts globally
+    {
+        const uint32_t d = threadIdx.x;                 // RP_THREADS == 256 digits
+        uint32_t c[RP_WAVES], tot = 0;
 #pragma unroll
-        for (int w = 0; w < RP_WAVES; ++w) {
-            const uint32_t c = wcnt[w][threadIdx.x];
-            wcnt[w][threadIdx.x] = run;
-            run += c;
-        }
+        for (int w = 0; w < RP_WAVES; ++w) { c[w] = wcnt[w][d]; tot += c[w]; }
+        uint32_t btot;
+        uint32_t run = block_excl_scan_256(tot, &btot); // (contains the barriers that order the reads above)
+#pragma unroll
+        for (int w = 0; w < RP_WAVES; ++w) { wcnt[w][d] = run; run += c[w]; }
+        const uint32_t lbase = run - tot;
+        gdelta[d] = (d <= mask ? goffs[(size_t)d * nblocks + blockIdx.x] : 0u) - lbase;
     }
     __syncthreads();
-    // phase 3: rank inside the round by ballots, bump the wave's running offset, scatter
+    // phase 3: rank inside the round by ballots, bump the wave's running slot, place into LDS
     volatile uint32_t *myc = wcnt[wid];
     const uint64_t lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
 #pragma unroll
@@ -335,15 +350,20 @@ __global__ __launch_bounds__(RP_THREADS) void radix_scatter_kernel(
         const uint32_t d = digit_of(key[r], shift, mask);
         const uint64_t same = match_digit(d, bits, vmask);
         const uint32_t rank = (uint32_t)__popcll(same & lt);
-        uint32_t pos = 0;
-        if (valid) pos = myc[d] + rank;
+        uint32_t slot = 0;
+        if (valid) slot = myc[d] + rank;
         __builtin_amdgcn_wave_barrier();
-        if (valid && rank == 0) myc[d] = pos + (uint32_t)__popcll(same);
+        if (valid && rank == 0) myc[d] = slot + (uint32_t)__popcll(same);
         __builtin_amdgcn_wave_barrier();
-        if (valid) {
-            if (WRITE_KEYS) keys_out[pos] = key[r];
-            vals_out[pos] = HAS_VALS_IN ? vals_in[i] : (uint32_t)i;
-        }
+        if (valid) { skey[slot] = key[r]; sval[slot] = val[r]; }
+    }
+    __syncthreads();
+    // phase 4: slots in order -> global memory; consecutive slots of one digit are consecutive there
+    for (int q = threadIdx.x; q < nblk; q += RP_THREADS) {
+        const KeyT k = skey[q];
+        const uint32_t pos = (uint32_t)q + gdelta[digit_of(k, shift, mask)];
+        if (WRITE_KEYS) keys_out[pos] = k;
+        vals_out[pos] = sval[q];
     }
 }
 
