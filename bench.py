@@ -10,6 +10,8 @@ forward RAHT -> quantize + reorder -> dequantize + un-reorder -> inverse RAHT (B
 configs[2]: "~3M Gaussians, SH deg 3 (59 ch), fwd+inv + quantize").  `--no-quant` times fwd+inv
 only.  N > 1: every rank owns one Morton-prefix shard of an N-times larger scene (weak scaling);
 the top three octree levels are stitched with one small all-gather over RCCL per direction.
+`--workload cfg4` (BASELINE.json configs[3]): every rank codes its own scene of 1-6 M Gaussians,
+no collective on the data path (replicas only).
 
 Prints ONE JSON line (rank 0) with the driver's contract fields plus `roofline` (dominant kernel,
 HIP-event timed, algorithmic bytes) and `cpu_baseline` (the C oracle on the host cores).
@@ -36,8 +38,9 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="cfg3", choices=["cfg3", "cfg2", "cfg5"],
-                    help="cfg3 = headline (3M x 59); cfg2 = 1M x 14; cfg5 = 50M x 59 single-GPU equivalent, generated on device")
+    ap.add_argument("--workload", default="cfg3", choices=["cfg3", "cfg2", "cfg4", "cfg5"],
+                    help="cfg3 = headline (3M x 59); cfg2 = 1M x 14; cfg4 = one independent 1-6M x 59 scene per rank; "
+                         "cfg5 = 50M x 59 single-GPU equivalent, generated on device")
     ap.add_argument("--no-quant", action="store_true", help="time forward + inverse only")
     ap.add_argument("--engine", default="tile", choices=["tile", "level"])
     ap.add_argument("--tile-rows", type=int, default=0)
@@ -126,6 +129,9 @@ def main():
     L = _lib.lib()                                     # fails loudly if the HIP library is missing
 
     n_draws, J, D, seed = synth.CONFIGS[a.workload]
+    solo = world == 1 or a.workload == "cfg4"          # this rank runs the whole transform of its own scene
+    if a.workload == "cfg4":
+        n_draws, seed = synth.CFG4_DRAWS[rank % len(synth.CFG4_DRAWS)], seed + rank
     # ---- synthetic scene (host, seeded), one Morton-prefix shard per rank ----
     if a.workload == "cfg5":
         # 50 M rows: generated on the device (host generation would take minutes); no CPU baseline
@@ -137,7 +143,7 @@ def main():
         keys = None; V = None
         Ch = None
         a.skip_cpu_baseline = True; a.skip_prelude = True
-    elif world == 1:
+    elif solo:
         V, keys, Ch = synth.scene(n_draws, J, D, seed)
     else:
         per = 512 // world
@@ -154,7 +160,7 @@ def main():
         kd = torch.from_numpy(keys.view(np.int64)).to(dev)
     steps_arr = (C.c_float * 1)(a.quant_step)
 
-    if world == 1:
+    if solo:
         plan = R.RahtPlan.from_keys(kd, 3 * J)
         plan.set_engine(a.engine, a.tile_rows, a.tail_rows, a.tail_ch, a.top_rows)
         if a.pooled_buffers:
@@ -219,7 +225,7 @@ def main():
         total_rows = None
 
     # ---- correctness gate: never report a number for a wrong transform ----
-    if world == 1:
+    if solo:
         fwd(); inv(T)
         torch.cuda.synchronize()
         rt_err = (Crec - Cd).abs().max().item() / Cd.abs().max().item()
@@ -252,16 +258,16 @@ def main():
     value = total_rows / (dt / a.steps) / 1e6
 
     out = {
-        "metric": "M-Gaussians/s fwd+inv RAHT, 59-ch SH3 3DGS" if a.workload == "cfg3" else "M-Gaussians/s fwd+inv RAHT, 14-ch SH0 3DGS",
+        "metric": "M-Gaussians/s fwd+inv RAHT, 59-ch SH3 3DGS" if D == 59 else "M-Gaussians/s fwd+inv RAHT, 14-ch SH0 3DGS",
         "value": round(value, 2), "unit": "M-Gaussians/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {
-            "workload": (f"{a.workload}: {total_rows} Gaussians ({n_draws} draws/GPU, J={J}, {D} channels), "
+            "workload": (f"{a.workload}: {total_rows} Gaussians ({'1-6 M' if a.workload == 'cfg4' and world > 1 else n_draws} draws/GPU, J={J}, {D} channels), "
                          + ("fwd + inv RAHT" if a.no_quant else "fwd RAHT + quantize/reorder + dequantize/un-reorder + inv RAHT"
                             + (" (separate passes)" if a.unfused else " (quantization fused into the transform kernels)"))),
             "rows_per_gpu": N, "channels": D, "depth_J": J, "engine": a.engine, "quantize": not a.no_quant,
-            "parallelism": "1 GPU" if world == 1 else f"morton-prefix sharded x{world}, top-3-octree-level all-gather ({'RCCL' if a.backend == 'nccl' else 'gloo, TEST ONLY'})",
+            "parallelism": "1 GPU" if world == 1 else f"{world} independent scenes, one per GPU, no collective" if solo else f"morton-prefix sharded x{world}, top-3-octree-level all-gather ({'RCCL' if a.backend == 'nccl' else 'gloo, TEST ONLY'})",
             "roundtrip_rel_err": rt_err,
         },
     }

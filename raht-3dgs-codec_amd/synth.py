@@ -89,5 +89,8 @@ CONFIGS = {
     # name: (n_draws, J, D, seed)         BASELINE.json configs / SURVEY 8d
     "cfg2": (1_000_000, 10, 14, 1),       # ~1M Gaussians, SH deg 0 (~14 attribute channels)
     "cfg3": (3_000_000, 12, 59, 2),       # ~3M Gaussians, SH deg 3 (59 channels) -- headline
+    "cfg4": (3_000_000, 12, 59, 10),      # BASELINE configs[3]: one scene per GPU, sizes CFG4_DRAWS[rank], seed 10 + rank
     "cfg5": (50_000_000, 14, 59, 3),      # ~50M Gaussians (BASELINE configs[4] on ONE GPU; bench.py builds it on device)
 }
+# cfg4: 8 scenes of Mip-NeRF360-like sizes, one per GPU
+CFG4_DRAWS = (1_000_000, 6_000_000, 2_000_000, 5_000_000, 3_000_000, 4_000_000, 1_500_000, 3_500_000)
