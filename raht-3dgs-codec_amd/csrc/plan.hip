@@ -396,8 +396,7 @@ static int build_top_stage(raht_plan *plan, uint32_t *rows, int64_t n, hipStream
     RAHT_HIP_CHECK(dev_malloc(&st.t_root, sizeof(uint32_t) * (size_t)n));
     hipLaunchKernelGGL(top_root_rank_kernel, dim3(gb), dim3(256), 0, s, is_root, pos, n, st.t_root);
     RAHT_RET(bucket_sort_u8(bucket, perm, n, 6, boff, s));
-    RAHT_HIP_CHECK(hipMemcpyAsync(st.t_loff, boff, sizeof(uint32_t) * 65, hipMemcpyDeviceToHost, s));
-    RAHT_HIP_CHECK(hipStreamSynchronize(s));
+    RAHT_RET(read_back_u32(st.t_loff, boff, 65, nullptr, nullptr, 0, s));
     st.n_merges = st.t_loff[63];
     {
         // the level program: non-empty levels, ascending; the trailing run of levels with at most 64
@@ -468,8 +467,8 @@ int get_schedule(raht_plan *plan, int R0, int R1, int Rf, hipStream_t s, Schedul
         rc = exclusive_scan_u32(flag, pos, n, dtotal, s);
         if (rc != RAHT_OK) break;
         uint32_t cnt32 = 0;
-        if (hipMemcpyAsync(&cnt32, dtotal, sizeof(uint32_t), hipMemcpyDeviceToHost, s) != hipSuccess ||
-            hipStreamSynchronize(s) != hipSuccess) { rc = RAHT_ERR_HIP; break; }
+        rc = read_back_u32(&cnt32, dtotal, 1, nullptr, nullptr, 0, s);
+        if (rc != RAHT_OK) break;
         const int64_t cnt = cnt32;
         const bool last = (cnt == plan->n_roots);            // only the roots are left: tree finished
         if (!last && (cnt >= n || k == 23)) {                // no progress: pathological key pattern
@@ -563,9 +562,8 @@ static int finish_plan(raht_plan *p, const int64_t *leaf_weights, hipStream_t s)
     hipLaunchKernelGGL(level_bucket_kernel, dim3(gb), dim3(256), 0, s, p->lvl, N, bucket);
     RAHT_RET(bucket_sort_u8(bucket, p->level_rows, N, 6, boff, s));
     PlanErr he;
-    RAHT_HIP_CHECK(hipMemcpyAsync(&he, derr, sizeof(he), hipMemcpyDeviceToHost, s));
-    RAHT_HIP_CHECK(hipMemcpyAsync(p->level_off, boff, sizeof(uint32_t) * 65, hipMemcpyDeviceToHost, s));
-    RAHT_HIP_CHECK(hipStreamSynchronize(s));
+    static_assert(sizeof(PlanErr) == 2 * sizeof(uint32_t), "PlanErr is read back as two words");
+    RAHT_RET(read_back_u32((uint32_t *)&he, (const uint32_t *)derr, 2, p->level_off, boff, 65, s));
     if (he.code != 0) {
         if (he.code == RAHT_ERR_UNSORTED)
             set_error("Morton keys are not strictly increasing at row %u (input must be Morton-sorted "

@@ -445,12 +445,81 @@ int compact_u32(const uint32_t *in, const uint32_t *flag, uint32_t *out, int64_t
         hipLaunchKernelGGL(compact_scatter_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, s, in,
                            flag, pos.as<uint32_t>(), out, n);
         uint32_t t = 0;
-        hipError_t e = hipMemcpyAsync(&t, total, sizeof(uint32_t), hipMemcpyDeviceToHost, s);
-        if (e == hipSuccess) e = hipStreamSynchronize(s);
-        if (e != hipSuccess) { set_error("compact: %s", hipGetErrorString(e)); rc = RAHT_ERR_HIP; }
+        rc = read_back_u32(&t, total, 1, nullptr, nullptr, 0, s);
         *count_host = t;
     }
     return rc;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Small device -> host read-backs through a polled mailbox in mapped pinned memory.
+// ------------------------------------------------------------------------------------------------
+static constexpr int MAILBOX_WORDS = 192;
+
+__global__ void __launch_bounds__(64) mailbox_publish_kernel(const uint32_t *__restrict__ a, int na,
+                                                             const uint32_t *__restrict__ b, int nb,
+                                                             volatile uint32_t *box, uint32_t seq)
+{
+    // one wave: the data stores are complete (system scope) before lane 0 raises the sequence word
+    for (int t = threadIdx.x; t < na; t += 64) box[1 + t] = a[t];
+    for (int t = threadIdx.x; t < nb; t += 64) box[1 + na + t] = b[t];
+    __threadfence_system();
+    if (threadIdx.x == 0) box[0] = seq;
+}
+
+struct Mailbox {
+    std::mutex mu;
+    uint32_t *box = nullptr;      // [0] = sequence word, [1 ..] = payload
+    uint32_t seq = 0;
+};
+static Mailbox &mailbox() { static Mailbox m; return m; }
+
+int read_back_u32(uint32_t *dst_a, const uint32_t *dev_a, int na, uint32_t *dst_b, const uint32_t *dev_b, int nb,
+                  hipStream_t s)
+{
+    if (na < 0 || nb < 0 || na + nb > MAILBOX_WORDS) { set_error("read_back_u32: too many words"); return RAHT_ERR_INVALID; }
+    Mailbox &m = mailbox();
+    std::lock_guard<std::mutex> g(m.mu);
+    if (!m.box) {
+        // portable + mapped + coherent: the same pointer is valid on the host and on every device
+        if (hipHostMalloc((void **)&m.box, sizeof(uint32_t) * (MAILBOX_WORDS + 1),
+                          hipHostMallocPortable | hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) {
+            m.box = nullptr;
+            (void)hipGetLastError();
+        } else {
+            m.box[0] = 0;
+        }
+    }
+    bool done = false;
+    if (m.box) {
+        const uint32_t seq = ++m.seq ? m.seq : ++m.seq;            // never 0
+        hipLaunchKernelGGL(mailbox_publish_kernel, dim3(1), dim3(64), 0, s, dev_a, na, dev_b, nb, m.box, seq);
+        if (hipGetLastError() == hipSuccess) {
+            volatile uint32_t *flag = m.box;
+            for (uint32_t it = 1;; ++it) {
+                if (*flag == seq) { done = true; break; }
+                if ((it & 0xfffu) == 0) {
+                    // a failed or finished stream ends the wait even if the word never arrives
+                    const hipError_t q = hipStreamQuery(s);
+                    if (q != hipErrorNotReady) { done = (q == hipSuccess && *flag == seq); break; }
+                }
+                __builtin_ia32_pause();
+            }
+            if (done) {
+                __atomic_thread_fence(__ATOMIC_ACQUIRE);
+                for (int t = 0; t < na; ++t) dst_a[t] = flag[1 + t];
+                for (int t = 0; t < nb; ++t) dst_b[t] = flag[1 + na + t];
+            }
+        }
+    }
+    if (!done) {                                                     // no mailbox / stream error: the plain way
+        hipError_t e = hipSuccess;
+        if (na) e = hipMemcpyAsync(dst_a, dev_a, sizeof(uint32_t) * (size_t)na, hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess && nb) e = hipMemcpyAsync(dst_b, dev_b, sizeof(uint32_t) * (size_t)nb, hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+        if (e != hipSuccess) { set_error("read-back: %s", hipGetErrorString(e)); return RAHT_ERR_HIP; }
+    }
+    return RAHT_OK;
 }
 
 }  // namespace raht

@@ -1,7 +1,7 @@
 # GPU timing: plan creation (arrays + default schedule), prepare and destroy on cfg3
-import sys, time
+import os, sys, time
 import numpy as np, torch
-sys.path.insert(0, '.')
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import raht_3dgs_codec_amd as R
 from raht_3dgs_codec_amd import synth
 n, J, D, seed = synth.CONFIGS["cfg3"]
