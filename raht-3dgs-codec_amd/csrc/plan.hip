@@ -80,52 +80,116 @@ __global__ void morton_i64_kernel(const int64_t *__restrict__ V, int64_t N, uint
     keys[i] = morton3((uint64_t)V[3 * i + 0], (uint64_t)V[3 * i + 1], (uint64_t)V[3 * i + 2]);
 }
 
-// ---- lvl[] -------------------------------------------------------------------------------------
-__global__ void level_kernel(const uint64_t *__restrict__ keys, int64_t N, int nbits,
-                             uint8_t *__restrict__ lvl, PlanErr *err)
-{
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= N) return;
-    const uint64_t k = keys[i];
-    if (nbits < 64 && (k >> nbits) != 0) report(err, RAHT_ERR_BOUNDS, i);
-    if (i == 0) { lvl[0] = 255; return; }
-    const uint64_t p = keys[i - 1];
-    if (k <= p) { report(err, RAHT_ERR_UNSORTED, i); lvl[i] = 0; return; }
-    lvl[i] = (uint8_t)(63 - __clzll((long long)(k ^ p)));
-}
+// ---- lvl[], wl[], wr[] ---------------------------------------------------------------------------
+// lvl[i] = highest bit in which key[i] differs from key[i-1] (row i starts a node at every level <= lvl[i]).
+// wr[i]  = rows of the level-lvl[i] node that starts at row i  = (first m > i with lvl[m] >= lvl[i], or N) - i
+// wl[i]  = rows of the level-lvl[i] node that ends at row i-1  = i - (last m < i with lvl[m] >= lvl[i]); lvl[0] = 255
+//
+// Most of these neighbours are a few rows away: the ones inside the row's own wave (64 consecutive rows)
+// come from ballots, with no memory traffic at all. The rows whose node reaches past the wave (about one
+// in six) are queued in LDS and the workgroup then searches for their ends in the keys with every lane
+// busy. (One search per row made each wave pay the instruction stream of its longest search: 76 us on
+// cfg3; one global queue for the whole grid serialised on its counter: 1 ms.)
+static constexpr int EXT_THREADS = 1024;
 
-// ---- wl[], wr[] --------------------------------------------------------------------------------
-__global__ void extent_kernel(const uint64_t *__restrict__ keys, int64_t N,
-                              const uint8_t *__restrict__ lvl, int32_t *__restrict__ wl,
-                              int32_t *__restrict__ wr)
+__global__ void __launch_bounds__(EXT_THREADS) level_extent_kernel(const uint64_t *__restrict__ keys, int64_t N, int nbits,
+                                                                    uint8_t *__restrict__ lvl, int32_t *__restrict__ wl,
+                                                                    int32_t *__restrict__ wr, PlanErr *err)
 {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= N) return;
-    if (i == 0) { wl[0] = 0; wr[0] = 0; return; }
-    const int l = lvl[i];
-    // right end: first m > i with (key[m] >> l) != (key[i] >> l), N if none
-    {
-        const uint64_t pref = keys[i] >> l;
-        int64_t pos = i, step = 1;
-        while (pos + step < N && (keys[pos + step] >> l) == pref) { pos += step; step <<= 1; }
-        int64_t lo = pos + 1, hi = min(pos + step, N);    // answer in [lo, hi]
-        while (lo < hi) {
-            const int64_t mid = (lo + hi) >> 1;
-            if ((keys[mid] >> l) == pref) lo = mid + 1; else hi = mid;
+    __shared__ uint32_t queue[2 * EXT_THREADS];      // row within the block | direction << 31
+    __shared__ uint8_t s_lvl[EXT_THREADS];
+    __shared__ uint32_t n_queued;
+    if (threadIdx.x == 0) n_queued = 0;
+    __syncthreads();
+    const int64_t b0 = (int64_t)blockIdx.x * EXT_THREADS;
+    const int64_t i = b0 + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int64_t w0 = i - lane;                     // first row of this wave
+    const bool valid = i < N;
+    int l = -1;                                      // rows past the end never bound a node
+    if (valid) {
+        const uint64_t k = keys[i];
+        if (nbits < 64 && (k >> nbits) != 0) report(err, RAHT_ERR_BOUNDS, i);
+        if (i == 0) {
+            l = 255;
+        } else {
+            const uint64_t p = keys[i - 1];
+            if (k <= p) { report(err, RAHT_ERR_UNSORTED, i); l = 0; }
+            else l = 63 - __clzll((long long)(k ^ p));
         }
-        wr[i] = (int32_t)(lo - i);
+        lvl[i] = (uint8_t)l;
+        s_lvl[threadIdx.x] = (uint8_t)l;
     }
-    // left end: first row of the level-l node containing row i-1
-    {
-        const uint64_t pref = keys[i - 1] >> l;
-        int64_t pos = i - 1, step = 1;
-        while (pos - step >= 0 && (keys[pos - step] >> l) == pref) { pos -= step; step <<= 1; }
-        int64_t lo = max(pos - step + 1, (int64_t)0), hi = pos;   // node start in [lo, hi]
-        while (lo < hi) {
-            const int64_t mid = (lo + hi) >> 1;
-            if ((keys[mid] >> l) == pref) hi = mid; else lo = mid + 1;
+    const bool searching = valid && i != 0;
+    const uint64_t below = ((uint64_t)1 << lane) - 1, above = ~(below | ((uint64_t)1 << lane));
+    int next_j = -1, prev_j = -1;                    // lane of the neighbour inside the wave, -1 = none
+    uint64_t todo = __ballot(searching);
+    while (todo) {                                   // one pass per distinct level in the wave (uniform)
+        const int t = __builtin_amdgcn_readlane(l, __ffsll((unsigned long long)todo) - 1);
+        const uint64_t ge = __ballot(l >= t);
+        if (l == t) {
+            const uint64_t hi = ge & above, lo = ge & below;
+            next_j = hi ? __ffsll((unsigned long long)hi) - 1 : -1;
+            prev_j = lo ? 63 - __clzll((long long)lo) : -1;
         }
-        wl[i] = (int32_t)(i - lo);
+        todo &= ~__ballot(l == t);
+    }
+    const bool last_wave = w0 + 64 >= N;
+    const bool q_r = searching && next_j < 0 && !last_wave, q_l = searching && prev_j < 0;   // (wave 0 holds row 0: no q_l)
+    const uint64_t m_r = __ballot(q_r), m_l = __ballot(q_l);
+    if (m_r | m_l) {
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(&n_queued, (uint32_t)(__popcll(m_r) + __popcll(m_l)));
+        base = __builtin_amdgcn_readfirstlane(base);
+        if (q_r) queue[base + __popcll(m_r & below)] = threadIdx.x;
+        if (q_l) queue[base + __popcll(m_r) + __popcll(m_l & below)] = threadIdx.x | 0x80000000u;
+    }
+    if (searching) {
+        if (next_j >= 0) wr[i] = (int32_t)(next_j - lane);
+        else if (last_wave) wr[i] = (int32_t)(N - i);
+        if (prev_j >= 0) wl[i] = (int32_t)(lane - prev_j);
+    } else if (valid) {
+        wl[0] = 0; wr[0] = 0;
+    }
+    __syncthreads();
+    // The queued searches, over a monotone predicate on the keys ((key >> l) == prefix holds exactly on the
+    // node): gallop away from the wave by x8, then split the bracket in 8 with 7 independent probes per
+    // step -- the chain of dependent loads is what a search costs. Every probe address is a valid row.
+    const uint32_t nq = n_queued;
+    for (uint32_t t = threadIdx.x; t < nq; t += EXT_THREADS) {
+        const uint32_t q = queue[t];
+        const bool right = (q >> 31) == 0;
+        const int64_t r = b0 + (q & 0x7fffffffu);
+        const int64_t dir = right ? 1 : -1;
+        const int ql = s_lvl[q & 0x7fffffffu];
+        // right: the node starting at row r reaches at least to the end of its wave; left: the node
+        // ending at row r - 1 reaches back at least to the row before the wave (never wave 0)
+        const uint64_t pref = keys[right ? r : r - 1] >> ql;
+        int64_t in = right ? min((r | 63), N - 1) : max((r & ~(int64_t)63) - 1, (int64_t)0);
+        int64_t out = right ? N : -1;
+        for (int64_t step = 1;; step <<= 3) {
+            const int64_t p = in + dir * step;
+            const bool in_range = right ? p < N : p >= 0;
+            const uint64_t k = keys[min(max(p, (int64_t)0), N - 1)];
+            if (in_range && (k >> ql) == pref) in = p;
+            else { out = right ? min(p, N) : max(p, (int64_t)-1); break; }
+        }
+        while ((right ? out - in : in - out) > 1) {
+            const int64_t w = right ? out - in : in - out;
+            uint64_t k[7];
+#pragma unroll
+            for (int j = 0; j < 7; ++j) k[j] = keys[in + dir * ((w * (j + 1)) >> 3)];     // between in and out
+            int64_t nin = in, nout = out;
+            bool hit = false;
+#pragma unroll
+            for (int j = 0; j < 7; ++j) {
+                const int64_t p = in + dir * ((w * (j + 1)) >> 3);
+                if (!hit) { if ((k[j] >> ql) == pref) nin = p; else { nout = p; hit = true; } }
+            }
+            in = nin; out = nout;
+        }
+        if (right) wr[r] = (int32_t)(out - r);
+        else wl[r] = (int32_t)(r - in);
     }
 }
 
@@ -550,9 +614,9 @@ static int finish_plan(raht_plan *p, const int64_t *leaf_weights, hipStream_t s)
     RAHT_HIP_CHECK(dev_malloc(&p->order, sizeof(uint32_t) * (size_t)N));
     RAHT_HIP_CHECK(dev_malloc(&p->inv_order, sizeof(uint32_t) * (size_t)N));
     RAHT_HIP_CHECK(dev_malloc(&p->level_rows, sizeof(uint32_t) * (size_t)N));
-    hipLaunchKernelGGL(level_kernel, dim3(gb), dim3(256), 0, s, p->keys, N, p->nbits, p->lvl, derr);
     // everything below is enqueued speculatively; the error word is checked at the single sync
-    hipLaunchKernelGGL(extent_kernel, dim3(gb), dim3(256), 0, s, p->keys, N, p->lvl, p->wl, p->wr);
+    hipLaunchKernelGGL(level_extent_kernel, dim3((unsigned)ceil_div(N, EXT_THREADS)), dim3(EXT_THREADS), 0, s, p->keys, N,
+                       p->nbits, p->lvl, p->wl, p->wr, derr);
     // order_RAGFT and the per-level row buckets: two stable bucket sorts
     hipLaunchKernelGGL(order_bucket_kernel, dim3(gb), dim3(256), 0, s, p->lvl, N, bucket);
     RAHT_RET(bucket_sort_u8(bucket, p->order, N, 5, nullptr, s));
