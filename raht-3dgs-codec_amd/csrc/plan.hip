@@ -93,8 +93,8 @@ __global__ void morton_i64_kernel(const int64_t *__restrict__ V, int64_t N, uint
 static constexpr int EXT_THREADS = 1024;
 
 __global__ void __launch_bounds__(EXT_THREADS) level_extent_kernel(const uint64_t *__restrict__ keys, int64_t N, int nbits,
-                                                                    uint8_t *__restrict__ lvl, int32_t *__restrict__ wl,
-                                                                    int32_t *__restrict__ wr, PlanErr *err)
+                                                                    uint8_t *__restrict__ lvl, uint8_t *__restrict__ order_bucket,
+                                                                    int32_t *__restrict__ wl, int32_t *__restrict__ wr, PlanErr *err)
 {
     __shared__ uint32_t queue[2 * EXT_THREADS];      // row within the block | direction << 31
     __shared__ uint8_t s_lvl[EXT_THREADS];
@@ -119,6 +119,10 @@ __global__ void __launch_bounds__(EXT_THREADS) level_extent_kernel(const uint64_
         }
         lvl[i] = (uint8_t)l;
         s_lvl[threadIdx.x] = (uint8_t)l;
+        // order_RAGFT (RAHT_param.py:251-274): [root] ++ groups of rows that stop being node starts within
+        // octree level g = lvl / 3, coarse to fine, ascending row index inside a group  ==  a stable bucket
+        // sort by bucket(0) = 0, bucket(i) = 1 + (20 - lvl[i] / 3)
+        order_bucket[i] = (i == 0) ? 0 : (uint8_t)(1 + (20 - l / 3));
     }
     const bool searching = valid && i != 0;
     const uint64_t below = ((uint64_t)1 << lane) - 1, above = ~(below | ((uint64_t)1 << lane));
@@ -194,16 +198,6 @@ __global__ void __launch_bounds__(EXT_THREADS) level_extent_kernel(const uint64_
 }
 
 // ---- order_RAGFT -------------------------------------------------------------------------------
-// RAHT_param.py:251-274: [root] ++ groups of rows that stop being node starts within octree level
-// g = lvl / 3, coarse to fine, ascending row index inside a group  ==  stable bucket sort by
-// bucket(0) = 0, bucket(i) = 1 + (20 - lvl[i] / 3).
-__global__ void order_bucket_kernel(const uint8_t *__restrict__ lvl, int64_t N, uint8_t *__restrict__ bucket)
-{
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= N) return;
-    bucket[i] = (i == 0) ? 0 : (uint8_t)(1 + (20 - (int)lvl[i] / 3));
-}
-
 __global__ void order_to_identity_kernel(uint32_t *order, int64_t N)
 {
     const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -214,13 +208,6 @@ __global__ void invert_perm_kernel(const uint32_t *__restrict__ order, int64_t N
 {
     const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (k < N) inv[order[k]] = (uint32_t)k;
-}
-
-__global__ void level_bucket_kernel(const uint8_t *__restrict__ lvl, int64_t N, uint8_t *__restrict__ bucket)
-{
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= N) return;
-    bucket[i] = lvl[i] & 63;      // row 0 (255) -> 63, the only member of that bucket
 }
 
 // ---- tile schedule -----------------------------------------------------------------------------
@@ -616,15 +603,14 @@ static int finish_plan(raht_plan *p, const int64_t *leaf_weights, hipStream_t s)
     RAHT_HIP_CHECK(dev_malloc(&p->level_rows, sizeof(uint32_t) * (size_t)N));
     // everything below is enqueued speculatively; the error word is checked at the single sync
     hipLaunchKernelGGL(level_extent_kernel, dim3((unsigned)ceil_div(N, EXT_THREADS)), dim3(EXT_THREADS), 0, s, p->keys, N,
-                       p->nbits, p->lvl, p->wl, p->wr, derr);
+                       p->nbits, p->lvl, bucket, p->wl, p->wr, derr);
     // order_RAGFT and the per-level row buckets: two stable bucket sorts
-    hipLaunchKernelGGL(order_bucket_kernel, dim3(gb), dim3(256), 0, s, p->lvl, N, bucket);
     RAHT_RET(bucket_sort_u8(bucket, p->order, N, 5, nullptr, s));
     if (getenv("RAHT_DEBUG_IDENTITY_ORDER"))      // timing experiments only: order_RAGFT := identity
         hipLaunchKernelGGL(order_to_identity_kernel, dim3(gb), dim3(256), 0, s, p->order, N);
     hipLaunchKernelGGL(invert_perm_kernel, dim3(gb), dim3(256), 0, s, p->order, N, p->inv_order);
-    hipLaunchKernelGGL(level_bucket_kernel, dim3(gb), dim3(256), 0, s, p->lvl, N, bucket);
-    RAHT_RET(bucket_sort_u8(bucket, p->level_rows, N, 6, boff, s));
+    // rows bucketed by level: the low 6 bits of lvl are the bucket (row 0, lvl 255, is alone in bucket 63)
+    RAHT_RET(bucket_sort_u8(p->lvl, p->level_rows, N, 6, boff, s));
     PlanErr he;
     static_assert(sizeof(PlanErr) == 2 * sizeof(uint32_t), "PlanErr is read back as two words");
     RAHT_RET(read_back_u32((uint32_t *)&he, (const uint32_t *)derr, 2, p->level_off, boff, 65, s));
