@@ -699,3 +699,55 @@ def test_stage0_events_bracket_the_dominant_kernel(rt):
     assert torch.equal(Q, ref)
     assert L.raht_plan_set_stage0_events(p._h, a, None) != 0        # both or none
     hip.hipEventDestroy(a); hip.hipEventDestroy(b)
+
+
+# ---------------------------------------------------------------- node extents, straight from their definition
+def _extents_by_definition(keys):
+    """lvl / wl / wr of include/raht.h from sorted Python-int keys (bisect on the prefix ranges)."""
+    import bisect
+    n = len(keys)
+    lvl, wl, wr = [255] + [0] * (n - 1), [0] * n, [0] * n
+    for i in range(1, n):
+        l = (keys[i] ^ keys[i - 1]).bit_length() - 1
+        lvl[i] = l
+        end = bisect.bisect_left(keys, ((keys[i] >> l) + 1) << l)              # first row past the node starting at i
+        start = bisect.bisect_left(keys, (keys[i - 1] >> l) << l)              # first row of the node ending at i - 1
+        wr[i], wl[i] = end - i, i - start
+    return lvl, wl, wr
+
+
+@pytest.mark.parametrize("n", [2, 63, 64, 65, 127, 129, 1023, 1024, 1025, 2049, 5000])
+@pytest.mark.parametrize("pattern", ["uniform60", "clustered", "staircase"])
+def test_node_extents_match_their_definition(rt, n, pattern):
+    """Sizes around the wave (64 rows) and workgroup (1024 rows) boundaries of the extent kernel, keys whose
+    nodes span many of them, and level sequences that leave whole waves unresolved (staircase)."""
+    import torch
+    rng = np.random.default_rng(n * 7 + len(pattern))
+    nbits = 60
+    if pattern == "uniform60":
+        ks = set(int(x) for x in rng.integers(0, 1 << 60, size=2 * n, dtype=np.uint64))
+    elif pattern == "clustered":
+        # a few deep clusters: long runs of rows differing only in low bits, joined at very high levels
+        ks = set()
+        centres = [int(x) for x in rng.integers(0, 1 << 60, size=5, dtype=np.uint64)]
+        while len(ks) < n:
+            c = centres[int(rng.integers(0, 5))]
+            ks.add((c & ~((1 << 14) - 1)) | int(rng.integers(0, 1 << 14)))
+    else:
+        # lvl strictly decreasing, then increasing, over long stretches: nodes nested like a staircase
+        ks, k = set(), 0
+        for i in range(n):
+            b = 59 - (i % 60) if (i // 60) % 2 == 0 else (i % 60)
+            k += 1 << b
+            k &= (1 << 60) - 1
+            ks.add(k | (i & 1))
+        ks |= set(int(x) for x in rng.integers(0, 1 << 60, size=n, dtype=np.uint64))
+    keys = sorted(ks)[:n]
+    assert len(keys) == n
+    kd = torch.tensor(np.array(keys, dtype=np.uint64).view(np.int64), device="cuda")
+    p = rt.RahtPlan.from_keys(kd, nbits)
+    _, lvl, wl, wr = p.arrays()
+    rl, rwl, rwr = _extents_by_definition(keys)
+    assert np.array_equal(lvl, np.array(rl, dtype=np.uint8))
+    assert np.array_equal(wr, np.array(rwr, dtype=np.int32))
+    assert np.array_equal(wl, np.array(rwl, dtype=np.int32))
