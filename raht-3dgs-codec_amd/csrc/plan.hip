@@ -688,10 +688,9 @@ int raht_plan_create(const void *V, int v_dtype, int64_t N, const double minV[3]
         }
         if (rc != RAHT_OK) { dev_free(derr); break; }
         PlanErr he;
-        hipError_t e = hipMemcpyAsync(&he, derr, sizeof(he), hipMemcpyDeviceToHost, s);
-        if (e == hipSuccess) e = hipStreamSynchronize(s);
+        rc = read_back_u32((uint32_t *)&he, (const uint32_t *)derr, 2, nullptr, nullptr, 0, s);
         dev_free(derr);
-        if (e != hipSuccess) { rc = RAHT_ERR_HIP; set_error("plan keys: %s", hipGetErrorString(e)); break; }
+        if (rc != RAHT_OK) break;
         if (he.code != 0) {
             rc = he.code;
             set_error("coordinate out of [0, 2^%d) at row %u (reference RAHT_param.py:26-27 raises ValueError)", depth, he.row);
