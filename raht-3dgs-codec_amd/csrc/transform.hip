@@ -208,6 +208,24 @@ __device__ __forceinline__ void load_tile_meta(const TileArgs<T> &A, int64_t t, 
     }
 }
 
+// Row addressing. The kernel is bound by vector-instruction issue, and a 64 x 64-bit row * stride product
+// per 16-byte chunk (3 quarter-rate multiplies + 5 more instructions) was a tenth of it.
+//  row_at:  rows of the tile being processed: a wave-uniform base (scalar registers) plus a 32-bit byte
+//           offset per lane, one v_mad_u32_u24 and a shift (tile_setup guarantees R * ld * 8 < 2^31);
+//  row_far: rows anywhere in a matrix (scatter / gather through the plan's permutations): the 32 x 32 -> 64
+//           bit product is ONE v_mad_u64_u32.
+template <typename P>
+__device__ __forceinline__ P *row_at(P *uniform_base, uint32_t j, uint32_t ld, uint32_t goff)
+{
+    typedef typename std::conditional<std::is_const<P>::value, const char, char>::type Byte;
+    return (P *)((Byte *)uniform_base + (uint32_t)((__umul24(j, ld) + goff) * (uint32_t)sizeof(P)));
+}
+template <typename P>
+__device__ __forceinline__ P *row_far(P *base, uint32_t row, uint32_t ld, uint32_t goff)
+{
+    return base + ((uint64_t)row * ld + goff);
+}
+
 // IDENT = true is stage 0 (entries are the rows themselves: the HBM-heavy launch); IDENT = false
 // are the later, much smaller stages. QM = true fuses quantize+reorder (forward) / un-reorder+
 // dequantize (inverse). Separate instantiations keep them apart in rocprof kernel statistics.
@@ -314,26 +332,26 @@ __global__ __launch_bounds__(512, (sizeof(T) == 4 ? 6 : 4)) void tile_kernel(con
             x.v[i] = (T)raw.v[i];
             if constexpr (QM && INV) x.v[i] = x.v[i] * (T)my_step[i];                     // encode_3dgs.py:261
         }
-        if (j < nt && active) *(V16 *)&tile[j * Dp + coff] = x;
+        if (j < nt && active) *(V16 *)&tile[__mul24(j, Dp) + coff] = x;
     };
 
     // ---- P0b. row transfers whose addresses do not depend on the plan metadata ----
     bool input_done = false;                  // tile already holds every slot's input
     if (!INV || (IDENT && !QM)) {
         // forward: this stage's entries, entry order (C or ws_k); plain inverse of stage 0: T rows [e0, e0+nt)
-        const T *src = INV ? (const T *)A.fin : A.in;
-        const int64_t lds = INV ? A.ld_fin : A.ld_in;
+        const uint32_t lds = (uint32_t)(INV ? A.ld_fin : A.ld_in);
+        const T *src = (INV ? (const T *)A.fin : A.in) + e0 * (int64_t)lds;      // wave-uniform
         for (int it0 = wid; (it0 << lr) < nt; it0 += nw * TILE_IO_U) {
             V16 x[TILE_IO_U];
 #pragma unroll
             for (int u = 0; u < TILE_IO_U; ++u) {
                 const int j = min(((it0 + u * nw) << lr) + g, nt - 1);
-                x[u] = ld_chunk<T, IDENT>(src + (e0 + j) * lds + goff);      // stage 0: C (or T) itself; later stages: workspace
+                x[u] = ld_chunk<T, IDENT>(row_at(src, (uint32_t)j, lds, (uint32_t)goff));   // stage 0: C (or T) itself; later stages: workspace
             }
 #pragma unroll
             for (int u = 0; u < TILE_IO_U; ++u) {
                 const int j = ((it0 + u * nw) << lr) + g;
-                if (j < nt && active) *(V16 *)&tile[j * Dp + coff] = x[u];
+                if (j < nt && active) *(V16 *)&tile[__mul24(j, Dp) + coff] = x[u];
             }
         }
         input_done = true;
@@ -344,8 +362,8 @@ __global__ __launch_bounds__(512, (sizeof(T) == 4 ? 6 : 4)) void tile_kernel(con
         const int npre = A.last_stage ? 0 : (int)min(surv_cnt, (uint32_t)TILE_PRE_ROWS);
         for (int it = wid; (it << lr) < npre; it += nw) {
             const int q = (it << lr) + g;
-            const V16 x = ld_chunk<T>(A.wsn + (int64_t)(surv_base + min(q, npre - 1)) * A.ld_ws + goff);
-            if (q < npre && active) *(V16 *)&spre[q * Dp + coff] = x;
+            const V16 x = ld_chunk<T>(row_at((const T *)A.wsn + (int64_t)surv_base * A.ld_ws, (uint32_t)min(q, npre - 1), (uint32_t)A.ld_ws, (uint32_t)goff));
+            if (q < npre && active) *(V16 *)&spre[__mul24(q, Dp) + coff] = x;
         }
     }
 #pragma unroll
@@ -363,8 +381,8 @@ __global__ __launch_bounds__(512, (sizeof(T) == 4 ? 6 : 4)) void tile_kernel(con
 #pragma unroll
             for (int u = 0; u < TILE_IO_U; ++u) {
                 const int j = min(((it0 + u * nw) << lr) + g, nt - 1);
-                if constexpr (QM) x[u] = ld_chunk<RawT, true>((const RawT *)A.Q + (int64_t)sdst[j] * A.ldq + goff);
-                else x[u] = ld_chunk<RawT, true>((const RawT *)A.fin + (int64_t)srow[j] * A.ld_fin + goff);
+                if constexpr (QM) x[u] = ld_chunk<RawT, true>(row_far((const RawT *)A.Q, (uint32_t)sdst[j], (uint32_t)A.ldq, (uint32_t)goff));
+                else x[u] = ld_chunk<RawT, true>(row_far((const RawT *)A.fin, (uint32_t)srow[j], (uint32_t)A.ld_fin, (uint32_t)goff));
             }
 #pragma unroll
             for (int u = 0; u < TILE_IO_U; ++u) put_row(((it0 + u * nw) << lr) + g, x[u]);
@@ -443,8 +461,8 @@ __global__ __launch_bounds__(512, (sizeof(T) == 4 ? 6 : 4)) void tile_kernel(con
             pair_weights(r, l, m_wr[s], A.wsum, w0, w1);
             const double den = w0 + w1;
             MRec<T> rec;
-            rec.po = (uint32_t)(p * Dp);
-            rec.jo = (uint32_t)(j * Dp);
+            rec.po = (uint32_t)__mul24((int)p, Dp);
+            rec.jo = (uint32_t)__mul24((int)j, Dp);
             rec.a = (T)sqrt(w0 / den);                    // RAHT.py:321-322
             rec.b = (T)sqrt(w1 / den);
             const uint32_t pos = atomicAdd(&cursor[m_lv[s]], 1u);
@@ -460,15 +478,15 @@ __global__ __launch_bounds__(512, (sizeof(T) == 4 ? 6 : 4)) void tile_kernel(con
         for (uint32_t it = wid; (it << lr) < n_pre; it += nw) {
             const uint32_t q = (it << lr) + g;
             const uint32_t qc = min(q, n_pre - 1);
-            const V16 x = *(const V16 *)&spre[qc * Dp + coff];
-            if (q < n_pre && active) *(V16 *)&tile[(int)ssurv[qc] * Dp + coff] = x;
+            const V16 x = *(const V16 *)&spre[__mul24((int)qc, Dp) + coff];
+            if (q < n_pre && active) *(V16 *)&tile[__mul24((int)ssurv[qc], Dp) + coff] = x;
         }
         // (b) the rest (tiles with many survivors) straight from the workspace
         for (uint32_t it = wid; TILE_PRE_ROWS + (it << lr) < surv_cnt; it += nw) {
             const uint32_t q = TILE_PRE_ROWS + (it << lr) + g;
             const uint32_t qc = min(q, surv_cnt - 1);
-            const V16 x = ld_chunk<T>(A.wsn + (int64_t)(surv_base + qc) * A.ld_ws + goff);
-            if (q < surv_cnt && active) *(V16 *)&tile[(int)ssurv[qc] * Dp + coff] = x;
+            const V16 x = ld_chunk<T>(row_at((const T *)A.wsn + (int64_t)surv_base * A.ld_ws, qc, (uint32_t)A.ld_ws, (uint32_t)goff));
+            if (q < surv_cnt && active) *(V16 *)&tile[__mul24((int)ssurv[qc], Dp) + coff] = x;
         }
     }
     // top stage of the inverse: the roots' low-pass values may come from a compact caller buffer
@@ -477,7 +495,7 @@ __global__ __launch_bounds__(512, (sizeof(T) == 4 ? 6 : 4)) void tile_kernel(con
             const uint32_t q = (it << lr) + g;
             const uint32_t qc = min(q, surv_cnt - 1);
             const V16 x = ld_chunk<T>(A.root_buf + (int64_t)(surv_base + qc) * A.D + goff);
-            if (q < surv_cnt && active) *(V16 *)&tile[(int)ssurv[qc] * Dp + coff] = x;
+            if (q < surv_cnt && active) *(V16 *)&tile[__mul24((int)ssurv[qc], Dp) + coff] = x;
         }
     }
     __syncthreads();                                                       // sync #4
@@ -557,8 +575,8 @@ __global__ __launch_bounds__(512, (sizeof(T) == 4 ? 6 : 4)) void tile_kernel(con
         // the whole tile, entry order: stage 0 -> C rows [e0, e0+nt); stage k -> ws_k
         for (int it = wid; (it << lr) < nt; it += nw) {
             const int j = (it << lr) + g;
-            const V16 x = *(const V16 *)&tile[min(j, nt - 1) * Dp + coff];
-            if (j < nt && active) st_chunk<T, IDENT>(A.out + (e0 + j) * A.ld_out + goff, x);     // stage 0: C itself
+            const V16 x = *(const V16 *)&tile[__mul24(min(j, nt - 1), Dp) + coff];
+            if (j < nt && active) st_chunk<T, IDENT>(row_at(A.out + e0 * A.ld_out, (uint32_t)j, (uint32_t)A.ld_out, (uint32_t)goff), x);   // stage 0: C itself
         }
     } else {
         // survivors, compacted, to the next stage's workspace (top stage: the caller's root buffer)
@@ -567,8 +585,8 @@ __global__ __launch_bounds__(512, (sizeof(T) == 4 ? 6 : 4)) void tile_kernel(con
             const int64_t ldb = A.last_stage ? (int64_t)A.D : A.ld_ws;
             for (uint32_t it = wid; (it << lr) < surv_cnt; it += nw) {
                 const uint32_t q = (it << lr) + g;
-                const V16 x = *(const V16 *)&tile[(int)ssurv[min(q, surv_cnt - 1)] * Dp + coff];
-                if (q < surv_cnt && active) st_chunk<T>(dstb + (int64_t)(surv_base + q) * ldb + goff, x);
+                const V16 x = *(const V16 *)&tile[__mul24((int)ssurv[min(q, surv_cnt - 1)], Dp) + coff];
+                if (q < surv_cnt && active) st_chunk<T>(row_at(dstb + (int64_t)surv_base * ldb, q, (uint32_t)ldb, (uint32_t)goff), x);
             }
         }
         // rows finalised here: T[row], or, fused, quantized to Q[inv_order[row]] (encode_3dgs.py:204,210,215)
@@ -577,16 +595,16 @@ __global__ __launch_bounds__(512, (sizeof(T) == 4 ? 6 : 4)) void tile_kernel(con
             const int jc = min(j, nt - 1);
             int fl = (int)sflag[jc];
             if (QM && A.root_buf && fl == 2) fl = 0;      // roots are quantized by the caller's top stage
-            const V16 x = *(const V16 *)&tile[jc * Dp + coff];
+            const V16 x = *(const V16 *)&tile[__mul24(jc, Dp) + coff];
             if (j < nt && active && fl != 0) {
                 if constexpr (QM) {
                     RegChunk<int32_t> qv;
 #pragma unroll
                     for (int i = 0; i < VN; ++i) qv.v[i] = quantize_one((float)x.v[i], my_step[i], my_rcp[i], ST.fast_div);
-                    st_chunk<int32_t, true>(A.Q + (int64_t)sdst[jc] * A.ldq + goff, qv);
+                    st_chunk<int32_t, true>(row_far(A.Q, (uint32_t)sdst[jc], (uint32_t)A.ldq, (uint32_t)goff), qv);
                 } else {
-                    const int64_t d = IDENT ? e0 + j : (int64_t)srow[jc];
-                    st_chunk<T, true>(A.fin + d * A.ld_fin + goff, x);
+                    if constexpr (IDENT) st_chunk<T, true>(row_at(A.fin + e0 * A.ld_fin, (uint32_t)j, (uint32_t)A.ld_fin, (uint32_t)goff), x);
+                    else st_chunk<T, true>(row_far(A.fin, (uint32_t)srow[jc], (uint32_t)A.ld_fin, (uint32_t)goff), x);
                 }
             }
         }
@@ -1043,10 +1061,11 @@ static int run_level_engine(const raht_plan *p, const T *src, int64_t ld_src, T 
 
 // Tile schedule (+ workspaces) for this element type / channel count; nullptr -> use the level engine.
 template <typename T>
-static int tile_setup(raht_plan *p, int D, hipStream_t s, Schedule **sc_out, int *Dc_out)
+static int tile_setup(raht_plan *p, int D, int64_t max_ld, hipStream_t s, Schedule **sc_out, int *Dc_out)
 {
     *sc_out = nullptr;
     if (p->engine == RAHT_ENGINE_LEVEL) return RAHT_OK;
+    if (max_ld > ((int64_t)1 << 18)) return RAHT_OK;  // row_at(): 32-bit byte offsets inside a tile; wider strides: level engine
     if (D < 16 / (int)sizeof(T)) return RAHT_OK;      // rows shorter than one 16-byte chunk: level engine
     const int Dc = pick_chunk_channels((int)sizeof(T), D);
     const int R = pick_tile_rows(p, (int)sizeof(T), Dc);
@@ -1071,7 +1090,7 @@ static int run_transform(const raht_plan *cp, const T *src, int64_t ld_src, int 
     if (D < 1 || ld_src < D || ld_dst < D) { set_error("raht transform: bad D/ld (D=%d ld_src=%lld ld_dst=%lld)", D, (long long)ld_src, (long long)ld_dst); return RAHT_ERR_INVALID; }
     Schedule *sc = nullptr;
     int Dc = 0;
-    RAHT_RET(tile_setup<T>(p, D, s, &sc, &Dc));
+    RAHT_RET(tile_setup<T>(p, D, std::max(ld_src, ld_dst), s, &sc, &Dc));
     int rc = RAHT_OK;
     if (!sc) {
         rc = run_level_engine<T, INV>(p, src, ld_src, dst, ld_dst, D, s);
@@ -1142,7 +1161,7 @@ int raht_fwd_quant(const raht_plan *cp, const float *C, int64_t ldc, int D, cons
     RAHT_RET(check_steps(steps, n_steps, D));
     Schedule *sc = nullptr;
     int Dc = 0;
-    RAHT_RET(tile_setup<float>(p, D, s, &sc, &Dc));
+    RAHT_RET(tile_setup<float>(p, D, std::max(ldc, ldq), s, &sc, &Dc));
     if (!sc) {
         // level engine (selected explicitly, or fallback for pathological key patterns): two passes
         // through a pooled temporary (stream-ordered reuse; see Scratch in raht_common.h)
@@ -1168,7 +1187,7 @@ int raht_dequant_inv(const raht_plan *cp, const int32_t *Q, int64_t ldq, int D, 
     RAHT_RET(check_steps(steps, n_steps, D));
     Schedule *sc = nullptr;
     int Dc = 0;
-    RAHT_RET(tile_setup<float>(p, D, s, &sc, &Dc));
+    RAHT_RET(tile_setup<float>(p, D, std::max(ldc, ldq), s, &sc, &Dc));
     if (!sc) {
         Scratch tmp(sizeof(float) * (size_t)p->N * (size_t)D);
         if (!tmp.ok()) return RAHT_ERR_NOMEM;
@@ -1189,8 +1208,8 @@ int raht_plan_prepare(raht_plan *p, int elem_size, int D, raht_stream_t stream)
     if (!p || (elem_size != 4 && elem_size != 8) || D < 1) { set_error("raht_plan_prepare: bad argument"); return RAHT_ERR_INVALID; }
     Schedule *sc = nullptr;
     int Dc = 0;
-    if (elem_size == 4) return tile_setup<float>(p, D, (hipStream_t)stream, &sc, &Dc);
-    return tile_setup<double>(p, D, (hipStream_t)stream, &sc, &Dc);
+    if (elem_size == 4) return tile_setup<float>(p, D, D, (hipStream_t)stream, &sc, &Dc);
+    return tile_setup<double>(p, D, D, (hipStream_t)stream, &sc, &Dc);
 }
 
 /* Profiling aid: enqueue ONE stage of the float32 tile schedule (stage 0 = the HBM-heavy launch).
@@ -1210,7 +1229,7 @@ int raht_debug_run_stage(const raht_plan *cp, int inverse, int stage, const floa
     }
     Schedule *sc = nullptr;
     int Dc = 0;
-    RAHT_RET(tile_setup<float>(p, D, s, &sc, &Dc));
+    RAHT_RET(tile_setup<float>(p, D, std::max(std::max(ld_mat, ld_mat2), ldq), s, &sc, &Dc));
     if (!sc) { set_error("raht_debug_run_stage: tile engine unavailable"); return RAHT_ERR_UNSUPPORTED; }
     if (stage < 0 || stage >= (int)sc->stages.size()) { set_error("raht_debug_run_stage: stage out of range"); return RAHT_ERR_INVALID; }
     XformIO<float> io;
