@@ -369,7 +369,7 @@ __global__ __launch_bounds__(512, (sizeof(T) == 4 ? 6 : 4)) void tile_kernel(con
 #pragma unroll
     for (int s = 0; s < SLOTS; ++s) {
         const int j = tid + s * nthreads;
-        if (j < nt) { if (!IDENT) srow[j] = m_row[s]; if (QM) sdst[j] = m_pos[s]; }
+        if (j < nt) { if (!IDENT) srow[j] = m_row[s]; if (QM && INV) sdst[j] = m_pos[s]; }
     }
     __syncthreads();                                                       // sync #1
 
@@ -403,9 +403,12 @@ __global__ __launch_bounds__(512, (sizeof(T) == 4 ? 6 : 4)) void tile_kernel(con
             m_merged[s] = (r > 0) && (m_lv[s] < A.top_level) && (r - m_wl[s] >= start_row) && (r + m_wr[s] <= end_row);
             surv = !m_merged[s];
             sflag[j] = m_merged[s] ? 1 : (A.last_stage ? 2 : 0);
+            // fused forward: bit 31 of the row's place in Q says "final here" (roots of a truncated tree are
+            // quantized by the caller's top stage): the write-back needs ONE LDS word per row
+            if (QM && !INV) sdst[j] = m_pos[s] | ((m_merged[s] || (A.last_stage && !A.root_buf)) ? (int32_t)0x80000000 : 0);
             if (m_merged[s]) atomicAdd(&hist[m_lv[s]], 1u);
         }
-        if (j < nt && (A.dbg & 2)) sflag[j] = 1;
+        if (j < nt && (A.dbg & 2)) { sflag[j] = 1; if (QM && !INV) sdst[j] = m_pos[s] | (int32_t)0x80000000; }
         const uint64_t bal = __ballot(surv);
         m_rank[s] = __popcll(bal & lt);
         if (lane == 0 && s * nw + wid < 32) scnt[s * nw + wid] = (uint32_t)__popcll(bal);
@@ -590,23 +593,32 @@ __global__ __launch_bounds__(512, (sizeof(T) == 4 ? 6 : 4)) void tile_kernel(con
             }
         }
         // rows finalised here: T[row], or, fused, quantized to Q[inv_order[row]] (encode_3dgs.py:204,210,215)
-        for (int it = wid; (it << lr) < nt; it += nw) {
-            const int j = (it << lr) + g;
-            const int jc = min(j, nt - 1);
-            int fl = (int)sflag[jc];
-            if (QM && A.root_buf && fl == 2) fl = 0;      // roots are quantized by the caller's top stage
-            const V16 x = *(const V16 *)&tile[__mul24(jc, Dp) + coff];
-            if (j < nt && active && fl != 0) {
+        auto store_final = [&](auto fast_div) {
+            for (int it = wid; (it << lr) < nt; it += nw) {
+                const int j = (it << lr) + g;
+                const int jc = min(j, nt - 1);
+                V16 x = *(const V16 *)&tile[__mul24(jc, Dp) + coff];
                 if constexpr (QM) {
-                    RegChunk<int32_t> qv;
+                    const uint32_t dv = (uint32_t)sdst[jc];
+                    asm volatile("" : "+v"(x.v[0]));          // keep the row read next to the flag read, not behind its branch
+                    if (j < nt && active && (dv >> 31)) {
+                        RegChunk<int32_t> qv;
 #pragma unroll
-                    for (int i = 0; i < VN; ++i) qv.v[i] = quantize_one((float)x.v[i], my_step[i], my_rcp[i], ST.fast_div);
-                    st_chunk<int32_t, true>(row_far(A.Q, (uint32_t)sdst[jc], (uint32_t)A.ldq, (uint32_t)goff), qv);
+                        for (int i = 0; i < VN; ++i) qv.v[i] = quantize_one((float)x.v[i], my_step[i], my_rcp[i], decltype(fast_div)::value);
+                        st_chunk<int32_t, true>(row_far(A.Q, dv & 0x7fffffffu, (uint32_t)A.ldq, (uint32_t)goff), qv);
+                    }
                 } else {
-                    if constexpr (IDENT) st_chunk<T, true>(row_at(A.fin + e0 * A.ld_fin, (uint32_t)j, (uint32_t)A.ld_fin, (uint32_t)goff), x);
-                    else st_chunk<T, true>(row_far(A.fin, (uint32_t)srow[jc], (uint32_t)A.ld_fin, (uint32_t)goff), x);
+                    if (j < nt && active && sflag[jc] != 0) {
+                        if constexpr (IDENT) st_chunk<T, true>(row_at(A.fin + e0 * A.ld_fin, (uint32_t)j, (uint32_t)A.ld_fin, (uint32_t)goff), x);
+                        else st_chunk<T, true>(row_far(A.fin, (uint32_t)srow[jc], (uint32_t)A.ld_fin, (uint32_t)goff), x);
+                    }
                 }
             }
+        };
+        if constexpr (QM) {
+            if (ST.fast_div) store_final(std::true_type()); else store_final(std::false_type());
+        } else {
+            store_final(std::false_type());
         }
     }
     __syncthreads();              // LDS is reused by the next tile
