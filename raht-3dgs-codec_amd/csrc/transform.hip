@@ -324,15 +324,22 @@ __global__ __launch_bounds__(512, (sizeof(T) == 4 ? 6 : 4)) void tile_kernel(con
     }
     if (tid < 64) hist[tid] = 0;
 
-    // dequantize (fused inverse) / pass through a raw chunk and drop it into its LDS row
-    auto put_row = [&](int j, const RawChunk &raw) {
+    // Predication. Every row loop below runs inside ONE `if (active)` region (lanes beyond the row's last
+    // chunk sit the whole loop out) and addresses rows past the end of the tile as its last row: those lanes
+    // move the same bytes to the same place as the lane that owns the row, so no per-chunk exec-mask
+    // juggling is needed (it was 4 scalar instructions and a branch per chunk; the kernel issues nearly
+    // as many scalar as vector instructions). A whole wave instruction past the end (the unrolled loads of
+    // the last step) rewrites the tile's last row with the bytes it already holds.
+    // dequantize (fused inverse) / pass through a raw chunk and drop it into its LDS row (jb: the wave
+    // instruction's first row, uniform)
+    auto put_row = [&](int jb, const RawChunk &raw) {
         V16 x;
 #pragma unroll
         for (int i = 0; i < VN; ++i) {
             x.v[i] = (T)raw.v[i];
             if constexpr (QM && INV) x.v[i] = x.v[i] * (T)my_step[i];                     // encode_3dgs.py:261
         }
-        if (j < nt && active) *(V16 *)&tile[__mul24(j, Dp) + coff] = x;
+        *(V16 *)&tile[__mul24(min(jb + g, nt - 1), Dp) + coff] = x;
     };
 
     // ---- P0b. row transfers whose addresses do not depend on the plan metadata ----
@@ -341,7 +348,7 @@ __global__ __launch_bounds__(512, (sizeof(T) == 4 ? 6 : 4)) void tile_kernel(con
         // forward: this stage's entries, entry order (C or ws_k); plain inverse of stage 0: T rows [e0, e0+nt)
         const uint32_t lds = (uint32_t)(INV ? A.ld_fin : A.ld_in);
         const T *src = (INV ? (const T *)A.fin : A.in) + e0 * (int64_t)lds;      // wave-uniform
-        for (int it0 = wid; (it0 << lr) < nt; it0 += nw * TILE_IO_U) {
+        if (active) for (int it0 = wid; (it0 << lr) < nt; it0 += nw * TILE_IO_U) {
             V16 x[TILE_IO_U];
 #pragma unroll
             for (int u = 0; u < TILE_IO_U; ++u) {
@@ -350,8 +357,8 @@ __global__ __launch_bounds__(512, (sizeof(T) == 4 ? 6 : 4)) void tile_kernel(con
             }
 #pragma unroll
             for (int u = 0; u < TILE_IO_U; ++u) {
-                const int j = ((it0 + u * nw) << lr) + g;
-                if (j < nt && active) *(V16 *)&tile[__mul24(j, Dp) + coff] = x[u];
+                const int j = min(((it0 + u * nw) << lr) + g, nt - 1);
+                *(V16 *)&tile[__mul24(j, Dp) + coff] = x[u];
             }
         }
         input_done = true;
@@ -360,10 +367,10 @@ __global__ __launch_bounds__(512, (sizeof(T) == 4 ? 6 : 4)) void tile_kernel(con
         // survivors of this tile were produced by the stage above: one contiguous chunk of ws_{k+1}
         // (the top stage has no stage above it: its survivors are the roots, handled in P3b)
         const int npre = A.last_stage ? 0 : (int)min(surv_cnt, (uint32_t)TILE_PRE_ROWS);
-        for (int it = wid; (it << lr) < npre; it += nw) {
-            const int q = (it << lr) + g;
-            const V16 x = ld_chunk<T>(row_at((const T *)A.wsn + (int64_t)surv_base * A.ld_ws, (uint32_t)min(q, npre - 1), (uint32_t)A.ld_ws, (uint32_t)goff));
-            if (q < npre && active) *(V16 *)&spre[__mul24(q, Dp) + coff] = x;
+        if (active) for (int it = wid; (it << lr) < npre; it += nw) {
+            const int q = min((it << lr) + g, npre - 1);
+            const V16 x = ld_chunk<T>(row_at((const T *)A.wsn + (int64_t)surv_base * A.ld_ws, (uint32_t)q, (uint32_t)A.ld_ws, (uint32_t)goff));
+            *(V16 *)&spre[__mul24(q, Dp) + coff] = x;
         }
     }
 #pragma unroll
@@ -376,7 +383,7 @@ __global__ __launch_bounds__(512, (sizeof(T) == 4 ? 6 : 4)) void tile_kernel(con
     // inverse of the later stages / fused inverse: gather every slot's coefficient row now (survivor
     // slots get overwritten in P3b) -- the addresses need srow / sdst
     if (INV && !input_done) {
-        for (int it0 = wid; (it0 << lr) < nt; it0 += nw * TILE_IO_U) {
+        if (active) for (int it0 = wid; (it0 << lr) < nt; it0 += nw * TILE_IO_U) {
             RawChunk x[TILE_IO_U];
 #pragma unroll
             for (int u = 0; u < TILE_IO_U; ++u) {
@@ -385,7 +392,7 @@ __global__ __launch_bounds__(512, (sizeof(T) == 4 ? 6 : 4)) void tile_kernel(con
                 else x[u] = ld_chunk<RawT, true>(row_far((const RawT *)A.fin, (uint32_t)srow[j], (uint32_t)A.ld_fin, (uint32_t)goff));
             }
 #pragma unroll
-            for (int u = 0; u < TILE_IO_U; ++u) put_row(((it0 + u * nw) << lr) + g, x[u]);
+            for (int u = 0; u < TILE_IO_U; ++u) put_row((it0 + u * nw) << lr, x[u]);
         }
     }
 
@@ -478,27 +485,24 @@ __global__ __launch_bounds__(512, (sizeof(T) == 4 ? 6 : 4)) void tile_kernel(con
         //     (kept apart from (b): a value that may come from either source makes hipcc wait for
         //     every outstanding global load, including the next tile's prefetch)
         const uint32_t n_pre = min(surv_cnt, (uint32_t)TILE_PRE_ROWS);
-        for (uint32_t it = wid; (it << lr) < n_pre; it += nw) {
-            const uint32_t q = (it << lr) + g;
-            const uint32_t qc = min(q, n_pre - 1);
+        if (active) for (uint32_t it = wid; (it << lr) < n_pre; it += nw) {
+            const uint32_t qc = min((it << lr) + g, n_pre - 1);
             const V16 x = *(const V16 *)&spre[__mul24((int)qc, Dp) + coff];
-            if (q < n_pre && active) *(V16 *)&tile[__mul24((int)ssurv[qc], Dp) + coff] = x;
+            *(V16 *)&tile[__mul24((int)ssurv[qc], Dp) + coff] = x;
         }
         // (b) the rest (tiles with many survivors) straight from the workspace
-        for (uint32_t it = wid; TILE_PRE_ROWS + (it << lr) < surv_cnt; it += nw) {
-            const uint32_t q = TILE_PRE_ROWS + (it << lr) + g;
-            const uint32_t qc = min(q, surv_cnt - 1);
+        if (active) for (uint32_t it = wid; TILE_PRE_ROWS + (it << lr) < surv_cnt; it += nw) {
+            const uint32_t qc = min(TILE_PRE_ROWS + (it << lr) + g, surv_cnt - 1);
             const V16 x = ld_chunk<T>(row_at((const T *)A.wsn + (int64_t)surv_base * A.ld_ws, qc, (uint32_t)A.ld_ws, (uint32_t)goff));
-            if (q < surv_cnt && active) *(V16 *)&tile[__mul24((int)ssurv[qc], Dp) + coff] = x;
+            *(V16 *)&tile[__mul24((int)ssurv[qc], Dp) + coff] = x;
         }
     }
     // top stage of the inverse: the roots' low-pass values may come from a compact caller buffer
     if (INV && A.last_stage && A.root_buf && !(A.dbg & 2)) {
-        for (uint32_t it = wid; (it << lr) < surv_cnt; it += nw) {
-            const uint32_t q = (it << lr) + g;
-            const uint32_t qc = min(q, surv_cnt - 1);
+        if (active) for (uint32_t it = wid; (it << lr) < surv_cnt; it += nw) {
+            const uint32_t qc = min((it << lr) + g, surv_cnt - 1);
             const V16 x = ld_chunk<T>(A.root_buf + (int64_t)(surv_base + qc) * A.D + goff);
-            if (q < surv_cnt && active) *(V16 *)&tile[__mul24((int)ssurv[qc], Dp) + coff] = x;
+            *(V16 *)&tile[__mul24((int)ssurv[qc], Dp) + coff] = x;
         }
     }
     __syncthreads();                                                       // sync #4
@@ -576,40 +580,39 @@ __global__ __launch_bounds__(512, (sizeof(T) == 4 ? 6 : 4)) void tile_kernel(con
     // ---- P5. write back ----
     if (INV) {
         // the whole tile, entry order: stage 0 -> C rows [e0, e0+nt); stage k -> ws_k
-        for (int it = wid; (it << lr) < nt; it += nw) {
-            const int j = (it << lr) + g;
-            const V16 x = *(const V16 *)&tile[__mul24(min(j, nt - 1), Dp) + coff];
-            if (j < nt && active) st_chunk<T, IDENT>(row_at(A.out + e0 * A.ld_out, (uint32_t)j, (uint32_t)A.ld_out, (uint32_t)goff), x);   // stage 0: C itself
+        if (active) for (int it = wid; (it << lr) < nt; it += nw) {
+            const int j = min((it << lr) + g, nt - 1);
+            const V16 x = *(const V16 *)&tile[__mul24(j, Dp) + coff];
+            st_chunk<T, IDENT>(row_at(A.out + e0 * A.ld_out, (uint32_t)j, (uint32_t)A.ld_out, (uint32_t)goff), x);   // stage 0: C itself
         }
     } else {
         // survivors, compacted, to the next stage's workspace (top stage: the caller's root buffer)
         if (!(A.dbg & 2) && (!A.last_stage || A.root_buf)) {
             T *dstb = A.last_stage ? A.root_buf : A.wsn;
             const int64_t ldb = A.last_stage ? (int64_t)A.D : A.ld_ws;
-            for (uint32_t it = wid; (it << lr) < surv_cnt; it += nw) {
-                const uint32_t q = (it << lr) + g;
-                const V16 x = *(const V16 *)&tile[__mul24((int)ssurv[min(q, surv_cnt - 1)], Dp) + coff];
-                if (q < surv_cnt && active) st_chunk<T>(row_at(dstb + (int64_t)surv_base * ldb, q, (uint32_t)ldb, (uint32_t)goff), x);
+            if (active) for (uint32_t it = wid; (it << lr) < surv_cnt; it += nw) {
+                const uint32_t q = min((it << lr) + g, surv_cnt - 1);
+                const V16 x = *(const V16 *)&tile[__mul24((int)ssurv[q], Dp) + coff];
+                st_chunk<T>(row_at(dstb + (int64_t)surv_base * ldb, q, (uint32_t)ldb, (uint32_t)goff), x);
             }
         }
         // rows finalised here: T[row], or, fused, quantized to Q[inv_order[row]] (encode_3dgs.py:204,210,215)
         auto store_final = [&](auto fast_div) {
-            for (int it = wid; (it << lr) < nt; it += nw) {
-                const int j = (it << lr) + g;
-                const int jc = min(j, nt - 1);
+            if (active) for (int it = wid; (it << lr) < nt; it += nw) {
+                const int jc = min((it << lr) + g, nt - 1);
                 V16 x = *(const V16 *)&tile[__mul24(jc, Dp) + coff];
                 if constexpr (QM) {
                     const uint32_t dv = (uint32_t)sdst[jc];
                     asm volatile("" : "+v"(x.v[0]));          // keep the row read next to the flag read, not behind its branch
-                    if (j < nt && active && (dv >> 31)) {
+                    if (dv >> 31) {
                         RegChunk<int32_t> qv;
 #pragma unroll
                         for (int i = 0; i < VN; ++i) qv.v[i] = quantize_one((float)x.v[i], my_step[i], my_rcp[i], decltype(fast_div)::value);
                         st_chunk<int32_t, true>(row_far(A.Q, dv & 0x7fffffffu, (uint32_t)A.ldq, (uint32_t)goff), qv);
                     }
                 } else {
-                    if (j < nt && active && sflag[jc] != 0) {
-                        if constexpr (IDENT) st_chunk<T, true>(row_at(A.fin + e0 * A.ld_fin, (uint32_t)j, (uint32_t)A.ld_fin, (uint32_t)goff), x);
+                    if (sflag[jc] != 0) {
+                        if constexpr (IDENT) st_chunk<T, true>(row_at(A.fin + e0 * A.ld_fin, (uint32_t)jc, (uint32_t)A.ld_fin, (uint32_t)goff), x);
                         else st_chunk<T, true>(row_far(A.fin, (uint32_t)srow[jc], (uint32_t)A.ld_fin, (uint32_t)goff), x);
                     }
                 }
