@@ -524,18 +524,21 @@ __global__ __launch_bounds__(512, (sizeof(T) == 4 ? 6 : 4)) void tile_kernel(con
             const int l = INV ? (63 - __clzll((long long)mask)) : (__ffsll((long long)mask) - 1);
             mask &= ~(1ull << l);
             const uint32_t base = (uint32_t)__builtin_amdgcn_readlane(loff_v, l), cnt = (uint32_t)__builtin_amdgcn_readlane(hist_v, l);
-            // branch-free body: reads are clamped to valid records (redundant, harmless), only the
-            // writes are predicated -> U independent LDS chains in flight per lane. Most levels of a
+            // branch-free body, U independent LDS chains in flight per lane. Lanes past the level's last
+            // butterfly (and the lanes past a row's last chunk) redo the last butterfly (chunk) in lockstep
+            // with the lane that owns it: same reads, same writes, one instruction -- no exec-mask
+            // juggling in the chain. Only a WHOLE wave instruction past the end must be skipped (a second
+            // application by another instruction would not be harmless): a scalar branch. Most levels of a
             // tile hold fewer butterflies than one pass of the workgroup covers: those take U = 1.
             auto pass = [&](auto UC) {
                 constexpr int U = decltype(UC)::value;
-                for (uint32_t mb = (uint32_t)(wid << lr) + g; mb < cnt + g; mb += stride * U) {
+                for (uint32_t mb = (uint32_t)(wid << lr); mb < cnt; mb += stride * U) {
                     uint32_t ip[U], ij[U];
                     T ca[U], cb[U];
                     V16 x0[U], x1[U];
 #pragma unroll
                     for (int u = 0; u < U; ++u) {
-                        const uint32_t m = min(mb + u * stride, cnt - 1);
+                        const uint32_t m = min(mb + u * stride + g, cnt - 1);
                         const MRec<T> rec = mrec[base + m];
                         ip[u] = rec.po + coff;
                         ij[u] = rec.jo + coff;
@@ -556,7 +559,7 @@ __global__ __launch_bounds__(512, (sizeof(T) == 4 ? 6 : 4)) void tile_kernel(con
                                 hi.v[i] = cb[u] * x0[u].v[i] + ca[u] * x1[u].v[i];
                             }
                         }
-                        if ((mb + u * stride < cnt) && active) { *(V16 *)&tile[ip[u]] = lo; *(V16 *)&tile[ij[u]] = hi; }
+                        if (u == 0 || mb + u * stride < cnt) { *(V16 *)&tile[ip[u]] = lo; *(V16 *)&tile[ij[u]] = hi; }
                     }
                 }
             };
