@@ -208,6 +208,16 @@ __device__ __forceinline__ void load_tile_meta(const TileArgs<T> &A, int64_t t, 
     }
 }
 
+// Profiling build only (-DRAHT_PHASE_CLOCKS, tools/phase_clocks.py): thread 0 of the first workgroups stamps
+// the shader clock at the phase boundaries of its first tile.
+#ifdef RAHT_PHASE_CLOCKS
+constexpr int PHASE_CLK_TILES = 4096, PHASE_CLK_SLOTS = 10;
+__device__ unsigned long long g_phase_clk[PHASE_CLK_TILES][PHASE_CLK_SLOTS];
+#define PHASE_STAMP(k) do { if (threadIdx.x == 0 && tile_id < PHASE_CLK_TILES) g_phase_clk[tile_id][k] = __builtin_readcyclecounter(); } while (0)
+#else
+#define PHASE_STAMP(k) do { } while (0)
+#endif
+
 // Row addressing. The kernel is bound by vector-instruction issue, and a 64 x 64-bit row * stride product
 // per 16-byte chunk (3 quarter-rate multiplies + 5 more instructions) was a tenth of it.
 //  row_at:  rows of the tile being processed: a wave-uniform base (scalar registers) plus a 32-bit byte
@@ -342,6 +352,7 @@ __global__ __launch_bounds__(512, (sizeof(T) == 4 ? 6 : 4)) void tile_kernel(con
         *(V16 *)&tile[__mul24(min(jb + g, nt - 1), Dp) + coff] = x;
     };
 
+    PHASE_STAMP(0);
     // ---- P0b. row transfers whose addresses do not depend on the plan metadata ----
     bool input_done = false;                  // tile already holds every slot's input
     if (!INV || (IDENT && !QM)) {
@@ -378,7 +389,9 @@ __global__ __launch_bounds__(512, (sizeof(T) == 4 ? 6 : 4)) void tile_kernel(con
         const int j = tid + s * nthreads;
         if (j < nt) { if (!IDENT) srow[j] = m_row[s]; if (QM && INV) sdst[j] = m_pos[s]; }
     }
+    PHASE_STAMP(1);
     __syncthreads();                                                       // sync #1
+    PHASE_STAMP(2);
 
     // inverse of the later stages / fused inverse: gather every slot's coefficient row now (survivor
     // slots get overwritten in P3b) -- the addresses need srow / sdst
@@ -421,6 +434,7 @@ __global__ __launch_bounds__(512, (sizeof(T) == 4 ? 6 : 4)) void tile_kernel(con
         if (lane == 0 && s * nw + wid < 32) scnt[s * nw + wid] = (uint32_t)__popcll(bal);
     }
     __syncthreads();                                                       // sync #2
+    PHASE_STAMP(3);
 
     // ---- P2. level offsets (wave 0); survivor destinations ----
     if (wid == 0) {
@@ -447,6 +461,7 @@ __global__ __launch_bounds__(512, (sizeof(T) == 4 ? 6 : 4)) void tile_kernel(con
         }
     }
     __syncthreads();                                                       // sync #3
+    PHASE_STAMP(4);
 
     // ---- P3a. resolve every butterfly of this tile into a record, bucketed by level ----
 #pragma unroll
@@ -506,6 +521,7 @@ __global__ __launch_bounds__(512, (sizeof(T) == 4 ? 6 : 4)) void tile_kernel(con
         }
     }
     __syncthreads();                                                       // sync #4
+    PHASE_STAMP(5);
 
     // prefetch the next tile's plan metadata: the loads stay in flight during the butterflies
     if (tile_id + gridDim.x < n_tiles) load_tile_meta<T, IDENT, QM, SLOTS>(A, tile_id + gridDim.x, tid, nthreads, M);
@@ -580,6 +596,7 @@ __global__ __launch_bounds__(512, (sizeof(T) == 4 ? 6 : 4)) void tile_kernel(con
         if (chained) __syncthreads();
     }
 
+    PHASE_STAMP(6);
     // ---- P5. write back ----
     if (INV) {
         // the whole tile, entry order: stage 0 -> C rows [e0, e0+nt); stage k -> ws_k
@@ -627,7 +644,9 @@ __global__ __launch_bounds__(512, (sizeof(T) == 4 ? 6 : 4)) void tile_kernel(con
             store_final(std::false_type());
         }
     }
+    PHASE_STAMP(7);
     __syncthreads();              // LDS is reused by the next tile
+    PHASE_STAMP(8);
     }                             // persistent tile loop
 }
 
@@ -1229,6 +1248,15 @@ int raht_plan_prepare(raht_plan *p, int elem_size, int D, raht_stream_t stream)
     if (elem_size == 4) return tile_setup<float>(p, D, D, (hipStream_t)stream, &sc, &Dc);
     return tile_setup<double>(p, D, D, (hipStream_t)stream, &sc, &Dc);
 }
+
+#ifdef RAHT_PHASE_CLOCKS
+int raht_debug_read_phase_clocks(unsigned long long *dst, int n_tiles)
+{
+    RAHT_HIP_CHECK(hipDeviceSynchronize());
+    RAHT_HIP_CHECK(hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_phase_clk), sizeof(unsigned long long) * PHASE_CLK_SLOTS * (size_t)std::min(n_tiles, PHASE_CLK_TILES)));
+    return PHASE_CLK_SLOTS;
+}
+#endif
 
 /* Profiling aid: enqueue ONE stage of the float32 tile schedule (stage 0 = the HBM-heavy launch).
  * Results are only meaningful as part of a full transform; bench.py uses this to time the dominant
