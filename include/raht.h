@@ -146,6 +146,8 @@ int raht_plan_stage_stats(raht_plan *plan, int elem_size, int D, int *n_stages, 
  * the node weights of RAHT.py:325-328.
  * f32: fp32 arithmetic, tolerance vs the float64 reference is stated in DESIGN.md / tests;
  * f64: float64 arithmetic (the reference's own precision), rtol = atol = 1e-12.
+ * Row strides (ld*, in elements) may be anything >= D; strides above 2^18 elements and rows shorter
+ * than 16 bytes take the one-launch-per-level engine instead of the LDS-tile engine (same results).
  */
 int raht_fwd(const raht_plan *plan, const float *C, int64_t ldc, int D, float *T, int64_t ldt,
              float *w, raht_stream_t stream);

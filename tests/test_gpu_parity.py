@@ -751,3 +751,24 @@ def test_node_extents_match_their_definition(rt, n, pattern):
     assert np.array_equal(lvl, np.array(rl, dtype=np.uint8))
     assert np.array_equal(wr, np.array(rwr, dtype=np.int32))
     assert np.array_equal(wl, np.array(rwl, dtype=np.int32))
+
+
+def test_very_wide_row_stride_takes_the_level_engine(rt):
+    """Row strides above 2^18 elements do not fit the tile kernel's 32-bit in-tile offsets: the entry points
+    fall back to the level engine and return the same coefficients (include/raht.h)."""
+    import torch
+    g = load_golden("n257_j3_d11")
+    p = _plan(rt, g)
+    N, D = g["C"].shape
+    ld = (1 << 18) + 5
+    big = torch.zeros((N, ld), dtype=torch.float32, device="cuda")
+    big[:, :D] = _dev(g["C"])
+    T0, _ = p.forward(_dev(g["C"]))
+    T1, _ = p.forward(big[:, :D])
+    _check_f32(T1.cpu().numpy(), g["T"], "wide stride")
+    assert float((T1 - T0).abs().max()) <= 2e-6 * float(T0.abs().max())
+    Q0 = p.forward_quant(_dev(g["C"]), 0.5)
+    Q1 = p.forward_quant(big[:, :D], 0.5)
+    assert int((Q0 != Q1).sum()) <= 2                      # two engines: a rounding tie may fall either way
+    C1 = p.dequant_inverse(Q1, 0.5)
+    assert float((C1 - _dev(g["C"])).abs().max()) < 40 * 0.5
