@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- M-Gaussians/s for the RAHT hot path on MI355X (BASELINE.json metric).
 
-    python bench.py --gpus 1 --steps 20 --warmup 5
+    python bench.py --gpus 1 --steps 200 --warmup 50
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -36,8 +36,12 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--settle-steps", type=int, default=-1,
+                    help="untimed steps BEFORE the warmup so that the GPU's clocks have settled when the warmup starts "
+                         "(-1: as many as bring settle + warmup to 64; the first ~40 steps after idle run up to 17 %% slower, "
+                         "tools/probe_step_transient.py); reported as settle_steps")
     ap.add_argument("--workload", default="cfg3", choices=["cfg3", "cfg2", "cfg4", "cfg5"],
                     help="cfg3 = headline (3M x 59); cfg2 = 1M x 14; cfg4 = one independent 1-6M x 59 scene per rank; "
                          "cfg5 = 50M x 59 single-GPU equivalent, generated on device")
@@ -239,6 +243,9 @@ def main():
             import torch.distributed as dist
             dist.barrier()
 
+    settle = a.settle_steps if a.settle_steps >= 0 else max(0, 64 - a.warmup)
+    for _ in range(settle):
+        step()
     for _ in range(a.warmup):
         step()
     barrier(); torch.cuda.synchronize()
@@ -259,7 +266,7 @@ def main():
 
     out = {
         "metric": "M-Gaussians/s fwd+inv RAHT, 59-ch SH3 3DGS" if D == 59 else "M-Gaussians/s fwd+inv RAHT, 14-ch SH0 3DGS",
-        "value": round(value, 2), "unit": "M-Gaussians/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        "value": round(value, 2), "unit": "M-Gaussians/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "settle_steps": settle,
         "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {
@@ -282,7 +289,7 @@ def main():
             e1.record(); e1.synchronize()
             return e0.elapsed_time(e1) / reps
 
-        reps = max(5, a.steps)
+        reps = min(max(5, a.steps), 100)
         br = {"fwd_ms": timed(fwd, reps), "inv_ms": timed(lambda: inv(T), reps)}
         if not a.no_quant:
             br["quant_reorder_ms"] = timed(quant, reps)
@@ -323,7 +330,7 @@ def main():
                     e = vp()
                     assert hip.hipEventCreate(C.byref(e)) == 0
                     return e
-                nrep = max(5, a.steps)
+                nrep = min(max(5, a.steps), 100)
                 evs = [[new_event() for _ in range(4)] for _ in range(nrep)]
                 one_fwd, one_inv = ((fwd, lambda: inv(T)) if a.no_quant else
                                     (fwd, lambda: inv(Td)) if a.unfused else (fwd_quant, dequant_inv))
