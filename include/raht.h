@@ -19,7 +19,11 @@
  *     raht_voxelize allocate and synchronise `stream` (they size outputs from device counts);
  *   - the caller owns every data buffer; a plan is an opaque handle owning its own HBM;
  *   - rows of C / T are the points in Morton order, row-major, `ld*` = row stride in ELEMENTS;
- *   - N < 2^31 rows; element offsets are 64-bit.
+ *   - N < 2^31 rows; element offsets are 64-bit;
+ *   - devices and threads: every call works on the calling thread's current HIP device, which must be the
+ *     device the plan and the buffers live on (one process per GPU is the intended use). Different plans
+ *     may be used from different host threads at once; ONE plan runs one transform at a time (it owns its
+ *     workspaces), i.e. calls on the same plan must be ordered on one stream or serialised by the caller.
  */
 #ifndef RAHT_H
 #define RAHT_H
