@@ -24,6 +24,8 @@
  *     device the plan and the buffers live on (one process per GPU is the intended use). Different plans
  *     may be used from different host threads at once; ONE plan runs one transform at a time (it owns its
  *     workspaces), i.e. calls on the same plan must be ordered on one stream or serialised by the caller.
+ *     Temporary device blocks are pooled per host thread and reused in call order: a host thread that
+ *     switches streams between calls must order those streams itself (event or synchronise).
  */
 #ifndef RAHT_H
 #define RAHT_H
