@@ -1,7 +1,7 @@
 # GPU timing of the float64 kernels (the reference's default precision) on cfg3
-import sys, time
+import os, sys, time
 import numpy as np, torch
-sys.path.insert(0, '.')
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import raht_3dgs_codec_amd as R
 from raht_3dgs_codec_amd import synth
 n, J, D, seed = synth.CONFIGS["cfg3"]
@@ -11,7 +11,8 @@ kd = torch.from_numpy(keys.view(np.int64)).cuda()
 p = R.RahtPlan.from_keys(kd, 3 * J)
 for dt in (torch.float32, torch.float64):
     C = torch.from_numpy(Ch).to(dt).cuda()
-    T, _ = p.forward(C); Rc = p.inverse(T)
+    for _ in range(3):                 # warm: the allocator's blocks for T / Rc exist before the timed loop
+        T = p.forward(C, want_w=False); Rc = p.inverse(T)
     torch.cuda.synchronize()
     es = 8 if dt == torch.float64 else 4
     st = p.stage_stats(es, D)
