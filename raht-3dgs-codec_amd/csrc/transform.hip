@@ -429,27 +429,17 @@ __global__ __launch_bounds__(512, (sizeof(T) == 4 ? 6 : 4)) void tile_kernel(con
 
     // inverse of the later stages / fused inverse: gather every slot's coefficient row now (survivor
     // slots get overwritten in P3b) -- the addresses need srow / sdst
-    RawChunk g_late[TILE_IO_U];
-    int itg_late = -1;
     if (INV && !input_done) {
-        if (active) {
-            auto gather = [&](int it0, RawChunk (&x)[TILE_IO_U]) {
+        if (active) for (int it0 = wid; (it0 << lr) < nt; it0 += nw * TILE_IO_U) {
+            RawChunk x[TILE_IO_U];
 #pragma unroll
-                for (int u = 0; u < TILE_IO_U; ++u) {
-                    const int j = min(((it0 + u * nw) << lr) + g, nt - 1);
-                    if constexpr (QM) x[u] = ld_chunk<RawT, true>(row_far((const RawT *)A.Q, (uint32_t)sdst[j], (uint32_t)A.ldq, (uint32_t)goff));
-                    else x[u] = ld_chunk<RawT, true>(row_far((const RawT *)A.fin, (uint32_t)srow[j], (uint32_t)A.ld_fin, (uint32_t)goff));
-                }
-            };
-            int it0 = wid;
-            for (; ((it0 + nw * TILE_IO_U) << lr) < nt; it0 += nw * TILE_IO_U) {
-                RawChunk x[TILE_IO_U];
-                gather(it0, x);
-#pragma unroll
-                for (int u = 0; u < TILE_IO_U; ++u) put_row((it0 + u * nw) << lr, x[u]);
+            for (int u = 0; u < TILE_IO_U; ++u) {
+                const int j = min(((it0 + u * nw) << lr) + g, nt - 1);
+                if constexpr (QM) x[u] = ld_chunk<RawT, true>(row_far((const RawT *)A.Q, (uint32_t)sdst[j], (uint32_t)A.ldq, (uint32_t)goff));
+                else x[u] = ld_chunk<RawT, true>(row_far((const RawT *)A.fin, (uint32_t)srow[j], (uint32_t)A.ld_fin, (uint32_t)goff));
             }
-            // the last (usually the only) step stays in flight during P1 and P2 and lands after sync #3
-            if ((it0 << lr) < nt) { gather(it0, g_late); itg_late = it0; }
+#pragma unroll
+            for (int u = 0; u < TILE_IO_U; ++u) put_row((it0 + u * nw) << lr, x[u]);
         }
     }
 
@@ -513,30 +503,6 @@ __global__ __launch_bounds__(512, (sizeof(T) == 4 ? 6 : 4)) void tile_kernel(con
         for (int u = 0; u < TILE_IO_U; ++u) {
             const int j = min(((it_late + u * nw) << lr) + g, nt - 1);
             *(V16 *)&tile[__mul24(j, Dp) + coff] = x_late[u];
-        }
-    }
-    // inverse: the gathered rows land now, except in the slots P3b fills from the stage above (survivors)
-    // or from the caller's root buffer -- no barrier separates the two writers
-    if (INV && itg_late >= 0) {
-        // lane geometry re-derived from an opaque copy of the thread id: otherwise the six LDS addresses are
-        // computed next to the loads and held, with the rows, across P1 and P2 -- and a row gets spilled
-        int tid2 = tid0;
-        asm volatile("" : "+v"(tid2));
-        const int lane2 = tid2 & 63, g2 = lane2 >> lg, coff2 = min(lane2 & ((1 << lg) - 1), NC - 1) * VN;
-        const int itl = __builtin_amdgcn_readfirstlane(itg_late);
-#pragma unroll
-        for (int u = 0; u < TILE_IO_U; ++u) {
-            const int j = min(((itl + u * nw) << lr) + g2, nt - 1);
-            const int fl = (int)sflag[j];
-            if (fl == 1 || (fl == 2 && !A.root_buf)) {
-                V16 x;
-#pragma unroll
-                for (int i = 0; i < VN; ++i) {
-                    x.v[i] = (T)g_late[u].v[i];
-                    if constexpr (QM) x.v[i] = x.v[i] * (T)my_step[i];                    // encode_3dgs.py:261
-                }
-                *(V16 *)&tile[__mul24(j, Dp) + coff2] = x;
-            }
         }
     }
 
