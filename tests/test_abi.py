@@ -70,3 +70,18 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp", "Makefile")):
                 txt = open(os.path.join(dp, f)).read()
                 assert not bad.search(txt), (dp, f)
+
+
+def test_bench_refuses_to_run_without_a_gpu():
+    """bench.py measures the HIP path or nothing: on a host without a GPU it stops with a clear message
+    (no CPU number is ever printed as the metric)."""
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
+    assert "needs an MI355X" in (r.stderr + r.stdout)
+    assert '"metric"' not in r.stdout
