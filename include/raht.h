@@ -21,7 +21,11 @@
  *   - rows of C / T are the points in Morton order, row-major, `ld*` = row stride in ELEMENTS;
  *   - N < 2^31 rows; element offsets are 64-bit;
  *   - devices and threads: every call works on the calling thread's current HIP device, which must be the
- *     device the plan and the buffers live on (one process per GPU is the intended use). Different plans
+ *     device the plan and the buffers live on (one process per GPU is the intended use, but a process may
+ *     hold plans on several devices: a plan remembers its device, all cached device memory is kept per
+ *     device, and an entry point called with a plan while ANOTHER device is current returns
+ *     RAHT_ERR_INVALID instead of mixing memory of two GPUs; raht_plan_destroy alone may be called with any
+ *     device current). Different plans
  *     may be used from different host threads at once; ONE plan runs one transform at a time (it owns its
  *     workspaces), i.e. calls on the same plan must be ordered on one stream or serialised by the caller.
  *     Temporary device blocks are pooled per host thread and reused in call order: a host thread that
@@ -36,7 +40,7 @@
 extern "C" {
 #endif
 
-#define RAHT_VERSION 100
+#define RAHT_VERSION 200
 
 enum raht_status {
     RAHT_OK = 0,
@@ -117,6 +121,11 @@ int raht_plan_nbits(const raht_plan *plan);             /* 3 * depth */
  * finishes the tree (0 = automatic: 4096; at most 8192). */
 int raht_plan_set_engine(raht_plan *plan, int engine, int tile_rows);
 int raht_plan_set_tail_tile(raht_plan *plan, int tail_rows, int tail_channels, int final_rows);
+/* Upper bound on the number of stages (= kernel launches per direction) of a tile schedule, 1..64,
+ * default 24. A scene whose schedule would need more falls back to the one-launch-per-level engine (same
+ * results): with >= 64 rows per tile every stage makes progress, so the bound is what decides. Mainly a
+ * testing aid for that fallback; call before the first transform (drops the cached schedules). */
+int raht_plan_set_max_stages(raht_plan *plan, int max_stages);
 
 /* Plans, schedules and workspaces take their device memory from a process-wide cache of freed blocks
  * (a codec that builds one plan per frame stops paying hipMalloc / hipFree once the cache is warm;
@@ -176,6 +185,15 @@ int raht_fwd_quant(const raht_plan *plan, const float *C, int64_t ldc, int D, co
 int raht_dequant_inv(const raht_plan *plan, const int32_t *Q, int64_t ldq, int D, const float *steps,
                      int n_steps, float *C, int64_t ldc, raht_stream_t stream);
 
+/* The same two at the reference's own precision (python/encode_3dgs.py:82-83: float64 coefficients are what
+ * :204 quantizes): float64 transform + float64 quantizer with float64 steps, run as TWO passes through a
+ * pooled N x D float64 temporary (not fused: this path exists for parity with the reference's arithmetic;
+ * Q is bit-identical to floor(T64 / step + 0.5) of the float64 transform except at exact rounding ties). */
+int raht_fwd_quant_f64(const raht_plan *plan, const double *C, int64_t ldc, int D, const double *steps,
+                       int n_steps, int32_t *Q, int64_t ldq, raht_stream_t stream);
+int raht_dequant_inv_f64(const raht_plan *plan, const int32_t *Q, int64_t ldq, int D, const double *steps,
+                         int n_steps, double *C, int64_t ldc, raht_stream_t stream);
+
 /* Pre-build the tile schedule and the per-stage workspaces for (elem_size in {4, 8}, D). The
  * first transform with a new (element type, D) does this implicitly (allocating and synchronising
  * once); after raht_plan_prepare the transform entry points only enqueue kernels (hipGraph-safe).
@@ -193,7 +211,9 @@ int raht_plan_set_stage0_events(raht_plan *plan, void *ev_before, void *ev_after
  *   Q == NULL : plain kernels   (forward: mat = C in, mat2 = T out;  inverse: mat = T in, mat2 = C out)
  *   Q != NULL : fused-quantization kernels (forward: mat = C in, Q out;  inverse: Q in, mat2 = C out)
  * ablate: 0 = the real kernel; 1 = skip the butterflies; 2 = also skip merge resolution (a pure
- * staged copy) -- timing experiments only, the output is then not a transform. */
+ * staged copy) -- timing experiments only, the output is then not a transform. Ablations exist only in a
+ * profiling build of the library (make ABLATE=1); the product build returns RAHT_ERR_UNSUPPORTED for
+ * ablate != 0 and its kernels carry no ablation branches. */
 int raht_debug_run_stage(const raht_plan *plan, int inverse, int stage, const float *mat, int64_t ld_mat,
                          int D, float *mat2, int64_t ld_mat2, int32_t *Q, int64_t ldq, float step,
                          int ablate, raht_stream_t stream);
@@ -209,6 +229,12 @@ int raht_quant_reorder(const raht_plan *plan, const float *T, int64_t ldt, int D
 int raht_dequant_unreorder(const raht_plan *plan, const int32_t *Q, int64_t ldq, int D,
                            const float *steps, int n_steps, float *T, int64_t ldt,
                            raht_stream_t stream);
+/* float64 coefficients and steps (the reference's precision): IEEE double division, as torch on the CPU. */
+int raht_quant_reorder_f64(const raht_plan *plan, const double *T, int64_t ldt, int D, const double *steps,
+                           int n_steps, int32_t *Q, int64_t ldq, raht_stream_t stream);
+int raht_dequant_unreorder_f64(const raht_plan *plan, const int32_t *Q, int64_t ldq, int D,
+                               const double *steps, int n_steps, double *T, int64_t ldt,
+                               raht_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Voxelizer.  Replaces voxelize_pc_batched(PC, vmin, width, J) (reference

@@ -23,6 +23,7 @@ EXPORTS = [
     "raht_plan_levels", "raht_plan_export_level", "raht_plan_order", "raht_plan_arrays",
     "raht_plan_copy_array", "raht_plan_stage_stats", "raht_fwd", "raht_fwd_f64", "raht_inv", "raht_inv_f64", "raht_debug_run_stage", "raht_plan_set_stage0_events", "raht_fwd_quant", "raht_dequant_inv", "raht_plan_prepare",
     "raht_quant_reorder", "raht_dequant_unreorder", "raht_voxelize", "raht_morton", "raht_sort_keys",
+    "raht_plan_set_max_stages", "raht_quant_reorder_f64", "raht_dequant_unreorder_f64", "raht_fwd_quant_f64", "raht_dequant_inv_f64",
     "raht_rlgr_bound", "raht_rlgr_encode", "raht_rlgr_decode", "raht_rlgr_encode_channels", "raht_rlgr_decode_channels", "raht_transpose_i32", "raht_merge_clusters",
 ]
 
@@ -90,6 +91,9 @@ def lib():
     L.raht_fwd_quant.argtypes = [vp, vp, i64, i32, C.POINTER(C.c_float), i32, vp, i64, vp]
     L.raht_dequant_inv.argtypes = [vp, vp, i64, i32, C.POINTER(C.c_float), i32, vp, i64, vp]
     L.raht_plan_prepare.argtypes = [vp, i32, i32, vp]
+    L.raht_plan_set_max_stages.argtypes = [vp, i32]
+    for f in (L.raht_quant_reorder_f64, L.raht_dequant_unreorder_f64, L.raht_fwd_quant_f64, L.raht_dequant_inv_f64):
+        f.argtypes = [vp, vp, i64, i32, C.POINTER(dbl), i32, vp, i64, vp]
     L.raht_quant_reorder.argtypes = [vp, vp, i64, i32, C.POINTER(C.c_float), i32, vp, i64, vp]
     L.raht_dequant_unreorder.argtypes = [vp, vp, i64, i32, C.POINTER(C.c_float), i32, vp, i64, vp]
     L.raht_quant_rows.argtypes = [vp, i64, i64, i32, C.POINTER(C.c_float), i32, vp, vp, i64, vp]

@@ -11,6 +11,8 @@
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
+#include <exception>
+#include <new>
 
 namespace raht {
 
@@ -24,6 +26,18 @@ void set_error(const char *fmt, ...)
     va_start(ap, fmt);
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
+}
+
+int check_plan_device(const raht_plan *plan, const char *what)
+{
+    if (!plan) { set_error("%s: NULL plan", what); return RAHT_ERR_INVALID; }
+    const int cur = current_device();
+    if (cur != plan->device) {
+        set_error("%s: the plan lives on HIP device %d but device %d is current (make the plan's device current "
+                  "before calling; see raht.h, devices and threads)", what, plan->device, cur);
+        return RAHT_ERR_INVALID;
+    }
+    return RAHT_OK;
 }
 
 // ---- device error word -------------------------------------------------------------------------
@@ -494,7 +508,8 @@ int get_schedule(raht_plan *plan, int R0, int R1, int Rf, hipStream_t s, Schedul
     uint32_t *rows = nullptr;      // rows of the current stage (nullptr = identity)
     int64_t n = N;
     int rc = RAHT_OK;
-    for (int k = 0; k < 24; ++k) {
+    const int max_stages = std::max(1, plan->max_stages);
+    for (int k = 0; k < max_stages; ++k) {
         const int R = (k == 0) ? R0 : R1;
         if (n <= Rf) {                                       // few entries left: the TOP stage finishes the tree
             Stage st;
@@ -522,7 +537,10 @@ int get_schedule(raht_plan *plan, int R0, int R1, int Rf, hipStream_t s, Schedul
         if (rc != RAHT_OK) break;
         const int64_t cnt = cnt32;
         const bool last = (cnt == plan->n_roots);            // only the roots are left: tree finished
-        if (!last && (cnt >= n || k == 23)) {                // no progress: pathological key pattern
+        // no progress, or more stages than the plan allows. (With >= 64 rows per tile and <= 63 key bits a stage
+        // always merges something -- the minimum-level entry of the first tile cannot reach past it, DESIGN.md
+        // 4.2 -- so in practice only the stage limit, raht_plan_set_max_stages, ends up here.)
+        if (!last && (cnt >= n || k == max_stages - 1)) {
             sc.stages.push_back(st);
             sc.valid = false;
             break;
@@ -547,7 +565,7 @@ int get_schedule(raht_plan *plan, int R0, int R1, int Rf, hipStream_t s, Schedul
         set_error("schedule build failed");
         return rc;
     }
-    plan->schedules.push_back(sc);
+    plan->schedules.push_back(sc);                   // std::deque: earlier schedules keep their addresses
     *out = &plan->schedules.back();
     return RAHT_OK;
 }
@@ -659,6 +677,13 @@ extern "C" {
 const char *raht_last_error(void) { return g_err; }
 int raht_version(void) { return RAHT_VERSION; }
 
+// Owns a half-built plan: whatever way a constructor leaves (error code or exception), the plan is destroyed.
+struct PlanHolder {
+    raht_plan *p = nullptr;
+    ~PlanHolder() { if (p) raht_plan_destroy(p); }
+    raht_plan *release() { raht_plan *q = p; p = nullptr; return q; }
+};
+
 int raht_plan_create(const void *V, int v_dtype, int64_t N, const double minV[3], double width,
                      int depth, raht_stream_t stream, raht_plan **out)
 {
@@ -666,41 +691,40 @@ int raht_plan_create(const void *V, int v_dtype, int64_t N, const double minV[3]
     if (N < 1 || N >= ((int64_t)1 << 31)) { set_error("raht_plan_create: N=%lld out of range", (long long)N); return RAHT_ERR_INVALID; }
     if (depth < 1 || depth > 21) { set_error("raht_plan_create: depth=%d (1..21)", depth); return RAHT_ERR_INVALID; }
     if (!(width > 0)) { set_error("raht_plan_create: width must be > 0"); return RAHT_ERR_INVALID; }
+    if (v_dtype < RAHT_F32 || v_dtype > RAHT_I64) { set_error("raht_plan_create: bad v_dtype %d", v_dtype); return RAHT_ERR_INVALID; }
     hipStream_t s = (hipStream_t)stream;
-    raht_plan *p = new raht_plan();
-    p->N = N;
-    p->nbits = 3 * depth;
-    int rc = RAHT_OK;
-    do {
-        if (dev_malloc(&p->keys, sizeof(uint64_t) * (size_t)N) != hipSuccess) { rc = RAHT_ERR_NOMEM; set_error("hipMalloc keys"); break; }
-        PlanErr *derr = nullptr;
-        if (dev_malloc(&derr, sizeof(PlanErr)) != hipSuccess) { rc = RAHT_ERR_NOMEM; break; }
+    return guarded("raht_plan_create", [&]() -> int {
+        PlanHolder h;
+        h.p = new raht_plan();
+        raht_plan *p = h.p;
+        p->device = current_device();
+        p->N = N;
+        p->nbits = 3 * depth;
+        if (dev_malloc(&p->keys, sizeof(uint64_t) * (size_t)N) != hipSuccess) { set_error("hipMalloc keys"); return RAHT_ERR_NOMEM; }
+        Scratch errw(sizeof(PlanErr));
+        if (!errw.ok()) return RAHT_ERR_NOMEM;
+        PlanErr *derr = errw.as<PlanErr>();
         PlanErr h0 = {0, 0xffffffffu};
-        (void)hipMemcpyAsync(derr, &h0, sizeof(h0), hipMemcpyHostToDevice, s);
+        RAHT_HIP_CHECK(hipMemcpyAsync(derr, &h0, sizeof(h0), hipMemcpyHostToDevice, s));
         const double Q = width / (double)((uint64_t)1 << depth);
         const unsigned gb = (unsigned)ceil_div(N, 256);
         switch (v_dtype) {
         case RAHT_F64: hipLaunchKernelGGL(keys_from_coords_kernel<double>, dim3(gb), dim3(256), 0, s, (const double *)V, N, minV[0], minV[1], minV[2], Q, depth, p->keys, derr); break;
         case RAHT_F32: hipLaunchKernelGGL(keys_from_coords_kernel<float>, dim3(gb), dim3(256), 0, s, (const float *)V, N, minV[0], minV[1], minV[2], Q, depth, p->keys, derr); break;
         case RAHT_I32: hipLaunchKernelGGL(keys_from_coords_kernel<int32_t>, dim3(gb), dim3(256), 0, s, (const int32_t *)V, N, minV[0], minV[1], minV[2], Q, depth, p->keys, derr); break;
-        case RAHT_I64: hipLaunchKernelGGL(keys_from_coords_kernel<int64_t>, dim3(gb), dim3(256), 0, s, (const int64_t *)V, N, minV[0], minV[1], minV[2], Q, depth, p->keys, derr); break;
-        default: rc = RAHT_ERR_INVALID; set_error("raht_plan_create: bad v_dtype %d", v_dtype); break;
+        default:       hipLaunchKernelGGL(keys_from_coords_kernel<int64_t>, dim3(gb), dim3(256), 0, s, (const int64_t *)V, N, minV[0], minV[1], minV[2], Q, depth, p->keys, derr); break;
         }
-        if (rc != RAHT_OK) { dev_free(derr); break; }
+        RAHT_HIP_CHECK(hipGetLastError());
         PlanErr he;
-        rc = read_back_u32((uint32_t *)&he, (const uint32_t *)derr, 2, nullptr, nullptr, 0, s);
-        dev_free(derr);
-        if (rc != RAHT_OK) break;
+        RAHT_RET(read_back_u32((uint32_t *)&he, (const uint32_t *)derr, 2, nullptr, nullptr, 0, s));
         if (he.code != 0) {
-            rc = he.code;
             set_error("coordinate out of [0, 2^%d) at row %u (reference RAHT_param.py:26-27 raises ValueError)", depth, he.row);
-            break;
+            return he.code;
         }
-        rc = finish_plan(p, nullptr, s);
-    } while (0);
-    if (rc != RAHT_OK) { raht_plan_destroy(p); return rc; }
-    *out = p;
-    return RAHT_OK;
+        RAHT_RET(finish_plan(p, nullptr, s));
+        *out = h.release();
+        return RAHT_OK;
+    });
 }
 
 int raht_plan_create_from_keys(const uint64_t *keys_sorted, int64_t N, int nbits,
@@ -710,21 +734,27 @@ int raht_plan_create_from_keys(const uint64_t *keys_sorted, int64_t N, int nbits
     if (N < 1 || N >= ((int64_t)1 << 31)) { set_error("raht_plan_create_from_keys: N=%lld out of range", (long long)N); return RAHT_ERR_INVALID; }
     if (nbits < 1 || nbits > 63) { set_error("raht_plan_create_from_keys: nbits=%d (1..63)", nbits); return RAHT_ERR_INVALID; }
     hipStream_t s = (hipStream_t)stream;
-    raht_plan *p = new raht_plan();
-    p->N = N;
-    p->nbits = nbits;
-    int rc = RAHT_OK;
-    if (dev_malloc(&p->keys, sizeof(uint64_t) * (size_t)N) != hipSuccess) { rc = RAHT_ERR_NOMEM; set_error("hipMalloc keys"); }
-    if (rc == RAHT_OK && hipMemcpyAsync(p->keys, keys_sorted, sizeof(uint64_t) * (size_t)N, hipMemcpyDeviceToDevice, s) != hipSuccess) { rc = RAHT_ERR_HIP; set_error("copy keys"); }
-    if (rc == RAHT_OK) rc = finish_plan(p, leaf_weights, s);
-    if (rc != RAHT_OK) { raht_plan_destroy(p); return rc; }
-    *out = p;
-    return RAHT_OK;
+    return guarded("raht_plan_create_from_keys", [&]() -> int {
+        PlanHolder h;
+        h.p = new raht_plan();
+        raht_plan *p = h.p;
+        p->device = current_device();
+        p->N = N;
+        p->nbits = nbits;
+        if (dev_malloc(&p->keys, sizeof(uint64_t) * (size_t)N) != hipSuccess) { set_error("hipMalloc keys"); return RAHT_ERR_NOMEM; }
+        RAHT_HIP_CHECK(hipMemcpyAsync(p->keys, keys_sorted, sizeof(uint64_t) * (size_t)N, hipMemcpyDeviceToDevice, s));
+        RAHT_RET(finish_plan(p, leaf_weights, s));
+        *out = h.release();
+        return RAHT_OK;
+    });
 }
 
 int raht_plan_destroy(raht_plan *p)
 {
     if (!p) return RAHT_OK;
+    // destruction may be called with any device current (a Python finaliser runs wherever the
+    // interpreter happens to be): work on the plan's own device
+    DeviceGuard on_plan_device(p->device);
     // the plan's blocks go back to the cache and may be handed to another plan at once: nothing
     // enqueued on any stream may still be using them (hipFree used to imply the same wait)
     (void)hipDeviceSynchronize();
@@ -755,6 +785,17 @@ int raht_plan_set_tail_tile(raht_plan *p, int tail_rows, int tail_channels, int 
     p->tail_rows_override = tail_rows;
     p->tail_chunk_override = tail_channels;
     p->final_rows_override = final_rows;
+    return RAHT_OK;
+}
+
+int raht_plan_set_max_stages(raht_plan *p, int max_stages)
+{
+    if (!p || max_stages < 1 || max_stages > 64) { set_error("raht_plan_set_max_stages: 1..64"); return RAHT_ERR_INVALID; }
+    RAHT_RET(check_plan_device(p, "raht_plan_set_max_stages"));
+    if (max_stages == p->max_stages) return RAHT_OK;
+    for (auto &sc : p->schedules) free_schedule(sc);       // schedules were built under the old limit
+    p->schedules.clear();
+    p->max_stages = max_stages;
     return RAHT_OK;
 }
 
@@ -789,6 +830,8 @@ int raht_plan_export_level(const raht_plan *cp, int level, int64_t *list, uint8_
     raht_plan *p = const_cast<raht_plan *>(cp);
     if (!p || !n_out) { set_error("raht_plan_export_level: NULL argument"); return RAHT_ERR_INVALID; }
     if (level < 0 || level >= raht_plan_levels(p)) { set_error("raht_plan_export_level: level %d out of range", level); return RAHT_ERR_INVALID; }
+    RAHT_RET(check_plan_device(p, "raht_plan_export_level"));
+    try {
     if (p->lvl_host.empty()) {
         p->lvl_host.resize((size_t)p->N);
         RAHT_HIP_CHECK(hipMemcpy(p->lvl_host.data(), p->lvl, (size_t)p->N, hipMemcpyDeviceToHost));
@@ -814,6 +857,10 @@ int raht_plan_export_level(const raht_plan *cp, int level, int64_t *list, uint8_
     if (weights) weights[n - 1] = p->wsum ? ws[(size_t)p->N] - ws[(size_t)prev] : p->N - prev;
     if (flags) flags[n - 1] = 0;
     *n_out = n;
+    } catch (const std::exception &) {               // host allocation of the N-sized staging copies
+        set_error("raht_plan_export_level: out of host memory");
+        return RAHT_ERR_NOMEM;
+    }
     return RAHT_OK;
 }
 
@@ -826,6 +873,7 @@ __global__ void order_to_i64_kernel(const uint32_t *__restrict__ o, int64_t N, i
 int raht_plan_order(const raht_plan *p, int64_t *order_dev, raht_stream_t stream)
 {
     if (!p || !order_dev) { set_error("raht_plan_order: NULL argument"); return RAHT_ERR_INVALID; }
+    RAHT_RET(check_plan_device(p, "raht_plan_order"));
     hipLaunchKernelGGL(order_to_i64_kernel, dim3((unsigned)ceil_div(p->N, 256)), dim3(256), 0,
                        (hipStream_t)stream, p->order, p->N, order_dev);
     RAHT_HIP_CHECK(hipGetLastError());
@@ -846,6 +894,7 @@ int raht_plan_arrays(const raht_plan *p, const uint64_t **keys, const uint8_t **
 int raht_plan_set_top_level(raht_plan *p, int top_level, raht_stream_t stream)
 {
     if (!p || top_level < 1 || top_level > 64) { set_error("raht_plan_set_top_level: bad argument"); return RAHT_ERR_INVALID; }
+    RAHT_RET(check_plan_device(p, "raht_plan_set_top_level"));
     if (top_level == p->top_level) return RAHT_OK;
     for (auto &sc : p->schedules) free_schedule(sc);
     p->schedules.clear();
@@ -858,6 +907,7 @@ int raht_plan_roots(const raht_plan *p, int64_t *n_roots, int64_t *rows_dev, rah
     if (!p || !n_roots) { set_error("raht_plan_roots: NULL argument"); return RAHT_ERR_INVALID; }
     *n_roots = p->n_roots;
     if (rows_dev) {
+        RAHT_RET(check_plan_device(p, "raht_plan_roots"));
         hipLaunchKernelGGL(order_to_i64_kernel, dim3((unsigned)ceil_div(p->n_roots, 256)), dim3(256), 0,
                            (hipStream_t)stream, p->root_rows, p->n_roots, rows_dev);
         RAHT_HIP_CHECK(hipGetLastError());
@@ -875,6 +925,7 @@ int raht_plan_set_root_buffer(raht_plan *p, void *buf_dev)
 int raht_plan_copy_array(const raht_plan *p, int which, void *dst, raht_stream_t stream)
 {
     if (!p || !dst || which < 0 || which > 3) { set_error("raht_plan_copy_array: bad argument"); return RAHT_ERR_INVALID; }
+    RAHT_RET(check_plan_device(p, "raht_plan_copy_array"));
     const void *src[4] = {p->keys, p->lvl, p->wl, p->wr};
     const size_t es[4] = {8, 1, 4, 4};
     RAHT_HIP_CHECK(hipMemcpyAsync(dst, src[which], es[which] * (size_t)p->N, hipMemcpyDeviceToDevice, (hipStream_t)stream));
@@ -885,13 +936,14 @@ int raht_plan_stage_stats(raht_plan *p, int elem_size, int D, int *n_stages, int
                           int max_stages, int *tile_rows)
 {
     if (!p || !n_stages) return RAHT_ERR_INVALID;
+    RAHT_RET(check_plan_device(p, "raht_plan_stage_stats"));
     const int Dc = pick_chunk_channels(elem_size, D);
     const int R = pick_tile_rows(p, elem_size, Dc);
     if (R == 0) { set_error("no tile size fits"); return RAHT_ERR_UNSUPPORTED; }
     Schedule *sc = nullptr;
     int R1 = 0, Dc1 = 0, Rf = 0;
     pick_tail_geometry(p, elem_size, D, R, &R1, &Dc1, &Rf);
-    RAHT_RET(get_schedule(p, R, R1, Rf, nullptr, &sc));
+    RAHT_RET(guarded("raht_plan_stage_stats", [&]() { return get_schedule(p, R, R1, Rf, nullptr, &sc); }));
     *n_stages = sc->valid ? (int)sc->stages.size() : -(int)sc->stages.size();
     if (tile_rows) *tile_rows = R;
     for (int k = 0; k < (int)sc->stages.size() && k < max_stages; ++k)

@@ -139,6 +139,40 @@ __global__ __launch_bounds__(256) void dequant_rows_kernel(const int32_t *__rest
     }
 }
 
+// float64 (the reference's own precision, python/encode_3dgs.py:82-83,204): one lane per element, rows gathered
+// through the permutation as above. The division is the IEEE double division of the reference's CPU path.
+struct StepTable64 { int n; double v[MAX_STEP_CH]; };
+
+template <bool QUANT>
+__global__ __launch_bounds__(256) void reorder_f64_kernel(const void *__restrict__ src_, int64_t lds, int D,
+                                                          const uint32_t *__restrict__ perm, int64_t N,
+                                                          const StepTable64 steps, void *__restrict__ dst_, int64_t ldd)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (int64_t k = wave; k < N; k += nwaves) {
+        const int64_t r = (int64_t)perm[k];
+        for (int c = lane; c < D; c += 64) {
+            const double st = steps.v[steps.n == 1 ? 0 : c];
+            if constexpr (QUANT) ((int32_t *)dst_)[k * ldd + c] = (int32_t)floor(((const double *)src_)[r * lds + c] / st + 0.5);   // :204, :210, :215
+            else ((double *)dst_)[k * ldd + c] = (double)((const int32_t *)src_)[r * lds + c] * st;                                // :261, :267-268
+        }
+    }
+}
+
+static int fill_steps64(StepTable64 &t, const double *steps, int n_steps, int D)
+{
+    if (!steps || !(n_steps == 1 || n_steps == D)) { set_error("quant: n_steps must be 1 or D"); return RAHT_ERR_INVALID; }
+    if (n_steps > MAX_STEP_CH) { set_error("quant: per-channel steps support D <= %d", MAX_STEP_CH); return RAHT_ERR_UNSUPPORTED; }
+    t.n = n_steps;
+    for (int c = 0; c < n_steps; ++c) {
+        if (!(steps[c] > 0.0)) { set_error("quant: step[%d] must be > 0", c); return RAHT_ERR_INVALID; }
+        t.v[c] = steps[c];
+    }
+    return RAHT_OK;
+}
+
 // int32 matrix transpose through an LDS tile (64 rows x 64 columns, padded): row-major N x D  <->
 // channel-major D x N, so that the entropy stage reads / writes contiguous channels. Both global
 // sides are coalesced (lanes along the contiguous dimension).
@@ -188,6 +222,7 @@ int raht_quant_reorder(const raht_plan *p, const float *T, int64_t ldt, int D, c
                        int32_t *Q, int64_t ldq, raht_stream_t stream)
 {
     if (!p || !T || !Q || D < 1 || ldt < D || ldq < D) { set_error("raht_quant_reorder: bad argument"); return RAHT_ERR_INVALID; }
+    RAHT_RET(check_plan_device(p, "raht_quant_reorder"));
     StepTable st;
     RAHT_RET(fill_steps(st, steps, n_steps, D));
     if (D >= 4) {
@@ -209,6 +244,7 @@ int raht_dequant_unreorder(const raht_plan *p, const int32_t *Q, int64_t ldq, in
                            int n_steps, float *T, int64_t ldt, raht_stream_t stream)
 {
     if (!p || !T || !Q || D < 1 || ldt < D || ldq < D) { set_error("raht_dequant_unreorder: bad argument"); return RAHT_ERR_INVALID; }
+    RAHT_RET(check_plan_device(p, "raht_dequant_unreorder"));
     StepTable st;
     RAHT_RET(fill_steps(st, steps, n_steps, D));
     if (D >= 4) {
@@ -224,6 +260,63 @@ int raht_dequant_unreorder(const raht_plan *p, const int32_t *Q, int64_t ldq, in
     }
     RAHT_HIP_CHECK(hipGetLastError());
     return RAHT_OK;
+}
+
+int raht_quant_reorder_f64(const raht_plan *p, const double *T, int64_t ldt, int D, const double *steps, int n_steps,
+                           int32_t *Q, int64_t ldq, raht_stream_t stream)
+{
+    if (!p || !T || !Q || D < 1 || ldt < D || ldq < D) { set_error("raht_quant_reorder_f64: bad argument"); return RAHT_ERR_INVALID; }
+    RAHT_RET(check_plan_device(p, "raht_quant_reorder_f64"));
+    StepTable64 st;
+    RAHT_RET(fill_steps64(st, steps, n_steps, D));
+    const unsigned gb = (unsigned)std::min<int64_t>(ceil_div(p->N, 4), 16384);
+    hipLaunchKernelGGL(reorder_f64_kernel<true>, dim3(gb), dim3(256), 0, (hipStream_t)stream, (const void *)T, ldt, D, p->order,
+                       p->N, st, (void *)Q, ldq);
+    RAHT_HIP_CHECK(hipGetLastError());
+    return RAHT_OK;
+}
+
+int raht_dequant_unreorder_f64(const raht_plan *p, const int32_t *Q, int64_t ldq, int D, const double *steps, int n_steps,
+                               double *T, int64_t ldt, raht_stream_t stream)
+{
+    if (!p || !T || !Q || D < 1 || ldt < D || ldq < D) { set_error("raht_dequant_unreorder_f64: bad argument"); return RAHT_ERR_INVALID; }
+    RAHT_RET(check_plan_device(p, "raht_dequant_unreorder_f64"));
+    StepTable64 st;
+    RAHT_RET(fill_steps64(st, steps, n_steps, D));
+    const unsigned gb = (unsigned)std::min<int64_t>(ceil_div(p->N, 4), 16384);
+    hipLaunchKernelGGL(reorder_f64_kernel<false>, dim3(gb), dim3(256), 0, (hipStream_t)stream, (const void *)Q, ldq, D,
+                       p->inv_order, p->N, st, (void *)T, ldt);
+    RAHT_HIP_CHECK(hipGetLastError());
+    return RAHT_OK;
+}
+
+/* Reference-precision counterparts of raht_fwd_quant / raht_dequant_inv: float64 transform + float64
+ * quantizer, as TWO passes through a pooled N x D float64 temporary (not fused: the float64 path exists for
+ * parity with the reference's arithmetic, python/encode_3dgs.py:82-83, the float32 path for speed). */
+int raht_fwd_quant_f64(const raht_plan *p, const double *C, int64_t ldc, int D, const double *steps, int n_steps,
+                       int32_t *Q, int64_t ldq, raht_stream_t stream)
+{
+    if (!p || !C || !Q || D < 1 || ldc < D || ldq < D) { set_error("raht_fwd_quant_f64: bad argument"); return RAHT_ERR_INVALID; }
+    RAHT_RET(check_plan_device(p, "raht_fwd_quant_f64"));
+    StepTable64 st;
+    RAHT_RET(fill_steps64(st, steps, n_steps, D));
+    Scratch tmp(sizeof(double) * (size_t)p->N * (size_t)D);
+    if (!tmp.ok()) return RAHT_ERR_NOMEM;
+    RAHT_RET(raht_fwd_f64(p, C, ldc, D, tmp.as<double>(), D, nullptr, stream));
+    return raht_quant_reorder_f64(p, tmp.as<double>(), D, D, steps, n_steps, Q, ldq, stream);
+}
+
+int raht_dequant_inv_f64(const raht_plan *p, const int32_t *Q, int64_t ldq, int D, const double *steps, int n_steps,
+                         double *C, int64_t ldc, raht_stream_t stream)
+{
+    if (!p || !C || !Q || D < 1 || ldc < D || ldq < D) { set_error("raht_dequant_inv_f64: bad argument"); return RAHT_ERR_INVALID; }
+    RAHT_RET(check_plan_device(p, "raht_dequant_inv_f64"));
+    StepTable64 st;
+    RAHT_RET(fill_steps64(st, steps, n_steps, D));
+    Scratch tmp(sizeof(double) * (size_t)p->N * (size_t)D);
+    if (!tmp.ok()) return RAHT_ERR_NOMEM;
+    RAHT_RET(raht_dequant_unreorder_f64(p, Q, ldq, D, steps, n_steps, tmp.as<double>(), D, stream));
+    return raht_inv_f64(p, tmp.as<double>(), D, D, C, ldc, stream);
 }
 
 int raht_quant_rows(const float *X, int64_t ldx, int64_t n, int D, const float *steps, int n_steps,

@@ -7,6 +7,9 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <deque>
+#include <exception>
+#include <new>
 #include <vector>
 
 #include "raht.h"
@@ -36,10 +39,64 @@ void set_error(const char *fmt, ...);
 
 static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
-// Device scratch memory from a thread-local grow-only pool: plan / sort / voxelizer temporaries are
-// reused across calls instead of paying hipMalloc + hipFree (each a device synchronisation) per use.
-// Stream-ordered reuse is safe because every user of the pool runs its work on the caller's stream
-// in program order and the pool is per host thread.
+// No C++ exception crosses the C ABI (raht.h): every extern "C" entry point that can allocate host
+// memory (std::vector / std::deque growth, std::thread) runs its body through this.
+template <typename F>
+static inline int guarded(const char *what, F &&body) noexcept
+{
+    try {
+        return body();
+    } catch (const std::bad_alloc &) {
+        set_error("%s: out of host memory", what);
+        return RAHT_ERR_NOMEM;
+    } catch (const std::exception &e) {
+        set_error("%s: %s", what, e.what());
+        return RAHT_ERR_INVALID;
+    } catch (...) {
+        set_error("%s: unknown C++ exception", what);
+        return RAHT_ERR_INVALID;
+    }
+}
+
+// ---- devices -------------------------------------------------------------------------------------
+// One process per GPU is the intended use, but nothing below assumes it: every piece of cached device
+// state (block cache, scratch pool, kernel attributes, CU counts) is keyed by the HIP device ordinal, a
+// plan remembers the device it was built on, and every entry point that takes a plan refuses to run
+// while another device is current (RAHT_ERR_INVALID) instead of mixing memory of two devices.
+constexpr int RAHT_MAX_DEVICES = 64;
+static inline int current_device()
+{
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= RAHT_MAX_DEVICES) d = 0;
+    return d;
+}
+// Makes `device` current for the lifetime of the object (plan destruction from a thread whose current
+// device is another one: Python finalisers run wherever the interpreter happens to be).
+class DeviceGuard {
+public:
+    explicit DeviceGuard(int device) : prev_(current_device()), dev_(device)
+    {
+        if (prev_ != dev_) (void)hipSetDevice(dev_);
+    }
+    ~DeviceGuard() { if (prev_ != dev_) (void)hipSetDevice(prev_); }
+    DeviceGuard(const DeviceGuard &) = delete;
+    DeviceGuard &operator=(const DeviceGuard &) = delete;
+private:
+    int prev_, dev_;
+};
+// Once-per-device flag for hipFuncSetAttribute calls (the attribute belongs to the function ON the current
+// device): true exactly the first time it is asked about a device. Idempotent work only -- two threads racing
+// on the first call may both get true.
+struct PerDeviceOnce {
+    bool done[RAHT_MAX_DEVICES] = {};
+    bool first(int device) { if (done[device]) return false; done[device] = true; return true; }
+};
+
+// Device scratch memory from a thread-local grow-only pool (one per device): plan / sort / voxelizer
+// temporaries are reused across calls instead of paying hipMalloc + hipFree (each a device
+// synchronisation) per use. Stream-ordered reuse is safe because every user of the pool runs its work on
+// the caller's stream in program order and the pool is per host thread. Blocks belong to the device that
+// was current when they were allocated and are only handed out while that device is current.
 class Scratch {
 public:
     explicit Scratch(size_t bytes);
@@ -58,6 +115,8 @@ private:
 // blocks in ~12 % size classes: a codec that builds one plan per frame pays hipMalloc / hipFree (each a
 // device synchronisation, ~0.1-0.3 ms for the six N-sized plan arrays) only until the cache is warm.
 // dev_free keeps at most RAHT_POOL_MAX_BYTES (default 8 GiB) cached; raht_release_cached_memory() empties it.
+// The cache is keyed by (device, size class): a block freed by a plan on device 0 is never handed to a
+// plan on device 1.
 hipError_t dev_malloc(void **p, size_t bytes);
 template <typename T> inline hipError_t dev_malloc(T **p, size_t bytes) { return dev_malloc((void **)p, bytes); }
 void dev_free(void *p);
@@ -136,6 +195,7 @@ struct Schedule {
 }  // namespace raht
 
 struct raht_plan {
+    int device = 0;              // HIP device ordinal the plan (and every block it owns) lives on
     int64_t N = 0;
     int nbits = 0;
     int max_level = -1;          // highest binary level with a pair (-1 when N == 1)
@@ -158,11 +218,15 @@ struct raht_plan {
     int tail_chunk_override = 0; // channels per chunk of the later stages (0 = automatic)
     int final_rows_override = 0; // single-tile finishing stage up to this many entries (0 = automatic)
     hipEvent_t ev_before = nullptr, ev_after = nullptr;   // profiling: recorded around the stage-0 launch
-    std::vector<raht::Schedule> schedules;   // cache keyed by tile_rows
+    int max_stages = 24;         // a tile schedule that needs more stages than this is abandoned (level engine)
+    std::deque<raht::Schedule> schedules;    // cache keyed by tile geometry; a deque: references handed out by
+                                             // get_schedule stay valid when another geometry is added
     std::vector<uint8_t> lvl_host;           // lazily downloaded for export_level
 };
 
 namespace raht {
+// RAHT_OK when the plan's device is the calling thread's current device (see "devices" above).
+int check_plan_device(const raht_plan *plan, const char *what);
 // Weights of the two children of the butterfly at row i (left extent l, right extent r): row counts,
 // or sums of leaf weights (weighted plans: prefix populations of a sharded scene).
 __device__ __forceinline__ void pair_weights(int64_t i, int l, int r, const int64_t *wsum, double &w0, double &w1)

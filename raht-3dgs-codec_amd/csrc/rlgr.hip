@@ -226,16 +226,30 @@ static void decode(const uint8_t *buf, int64_t nbytes, int64_t n, int flag_signe
     }
 }
 
+// nthreads - 1 helpers + the calling thread run `work` (which pulls items until none are left). A helper that
+// cannot be started (std::system_error) is simply absent: the others finish its share. Never leaves a joinable
+// std::thread behind on the way out (that would be std::terminate).
+template <typename W>
+static void run_pool(int nthreads, W &work)
+{
+    std::vector<std::thread> pool;
+    try {
+        pool.reserve((size_t)std::max(nthreads - 1, 0));
+        for (int t = 1; t < nthreads; ++t) pool.emplace_back([&]() { work(); });
+    } catch (...) {
+    }
+    work();
+    for (auto &t : pool) t.join();
+}
+
 template <typename F>
 static void parallel_channels(int D, int nthreads, F fn)
 {
     nthreads = std::min(nthreads, D);
     if (nthreads <= 1) { for (int c = 0; c < D; ++c) fn(c); return; }
     std::atomic<int> next(0);
-    std::vector<std::thread> pool;
-    for (int t = 0; t < nthreads; ++t)
-        pool.emplace_back([&]() { for (int c = next++; c < D; c = next++) fn(c); });
-    for (auto &t : pool) t.join();
+    auto work = [&]() { for (int c = next++; c < D; c = next++) fn(c); };
+    run_pool(nthreads, work);
 }
 
 }  // namespace rlgr
@@ -287,10 +301,7 @@ static void transpose_to_channels(const int32_t *Q, int64_t N, int D, int64_t ld
                 }
         }
     };
-    if (nthreads <= 1) { work(); return; }
-    std::vector<std::thread> pool;
-    for (int t = 0; t < nthreads; ++t) pool.emplace_back(work);
-    for (auto &t : pool) t.join();
+    raht::rlgr::run_pool(nthreads, work);
 }
 
 static void transpose_from_channels(const int32_t *T, int64_t N, int D, int32_t *Q, int64_t ldq, int nthreads)
@@ -308,10 +319,7 @@ static void transpose_from_channels(const int32_t *T, int64_t N, int D, int32_t 
                 }
         }
     };
-    if (nthreads <= 1) { work(); return; }
-    std::vector<std::thread> pool;
-    for (int t = 0; t < nthreads; ++t) pool.emplace_back(work);
-    for (auto &t : pool) t.join();
+    raht::rlgr::run_pool(nthreads, work);
 }
 
 static int resolve_threads(int nthreads, int D)
@@ -330,39 +338,50 @@ int raht_rlgr_encode_channels(const int32_t *Q, int64_t N, int D, int64_t sym_st
         set_error("raht_rlgr_encode_channels: bad argument");
         return RAHT_ERR_INVALID;
     }
-    const int nt = resolve_threads(nthreads, D);
-    std::vector<int32_t> tmp;
-    const int32_t *src = Q;
-    int64_t ss = sym_stride, cs = chan_stride;
-    if (sym_stride != 1 && chan_stride == 1 && D > 1 && N > 4096) {          // row-major: go channel-major first
-        tmp.resize((size_t)N * (size_t)D);
-        rlgr::transpose_to_channels(Q, N, D, sym_stride, tmp.data(), nt);
-        src = tmp.data(); ss = 1; cs = N;
-    }
-    std::atomic<int> bad(0);
-    rlgr::parallel_channels(D, nt, [&](int c) {
-        const int64_t r = rlgr::encode(src + (int64_t)c * cs, N, ss, flag_signed, out + (int64_t)c * cap_per_channel, cap_per_channel);
-        if (r < 0) { bad = 1; nbytes[c] = -1; } else nbytes[c] = r;
+    // std::vector / std::thread may throw (708 MB of staging on cfg3): no exception crosses the C ABI
+    return raht::guarded("raht_rlgr_encode_channels", [&]() -> int {
+        const int nt = resolve_threads(nthreads, D);
+        std::vector<int32_t> tmp;
+        const int32_t *src = Q;
+        int64_t ss = sym_stride, cs = chan_stride;
+        if (sym_stride != 1 && chan_stride == 1 && D > 1 && N > 4096) {          // row-major: go channel-major first
+            tmp.resize((size_t)N * (size_t)D);
+            rlgr::transpose_to_channels(Q, N, D, sym_stride, tmp.data(), nt);
+            src = tmp.data(); ss = 1; cs = N;
+        }
+        std::atomic<int> bad(0);
+        rlgr::parallel_channels(D, nt, [&](int c) {
+            const int64_t r = rlgr::encode(src + (int64_t)c * cs, N, ss, flag_signed, out + (int64_t)c * cap_per_channel, cap_per_channel);
+            if (r < 0) { bad = 1; nbytes[c] = -1; } else nbytes[c] = r;
+        });
+        if (bad) { set_error("raht_rlgr_encode_channels: cap_per_channel too small (use raht_rlgr_bound)"); return RAHT_ERR_NOMEM; }
+        return RAHT_OK;
     });
-    if (bad) { set_error("raht_rlgr_encode_channels: cap_per_channel too small (use raht_rlgr_bound)"); return RAHT_ERR_NOMEM; }
-    return RAHT_OK;
 }
 
 int raht_rlgr_decode_channels(const uint8_t *bufs, int64_t cap_per_channel, const int64_t *nbytes, int64_t N, int D,
                               int flag_signed, int32_t *Q, int64_t sym_stride, int64_t chan_stride, int nthreads)
 {
-    if (!bufs || !nbytes || !Q || N < 0 || D < 1 || sym_stride < 1 || chan_stride < 1) { set_error("raht_rlgr_decode_channels: bad argument"); return RAHT_ERR_INVALID; }
-    const int nt = resolve_threads(nthreads, D);
-    std::vector<int32_t> tmp;
-    int32_t *dst = Q;
-    int64_t ss = sym_stride, cs = chan_stride;
-    const bool via_tmp = (sym_stride != 1 && chan_stride == 1 && D > 1 && N > 4096);
-    if (via_tmp) { tmp.resize((size_t)N * (size_t)D); dst = tmp.data(); ss = 1; cs = N; }
-    rlgr::parallel_channels(D, nt, [&](int c) {
-        rlgr::decode(bufs + (int64_t)c * cap_per_channel, nbytes[c], N, flag_signed, dst + (int64_t)c * cs, ss);
+    if (!bufs || !nbytes || !Q || N < 0 || D < 1 || sym_stride < 1 || chan_stride < 1 || cap_per_channel < 0) { set_error("raht_rlgr_decode_channels: bad argument"); return RAHT_ERR_INVALID; }
+    // the length table comes off the wire: a stream never extends past its channel's slot
+    for (int c = 0; c < D; ++c)
+        if (nbytes[c] < 0 || nbytes[c] > cap_per_channel) {
+            set_error("raht_rlgr_decode_channels: nbytes[%d] = %lld outside [0, cap_per_channel = %lld]", c, (long long)nbytes[c], (long long)cap_per_channel);
+            return RAHT_ERR_INVALID;
+        }
+    return raht::guarded("raht_rlgr_decode_channels", [&]() -> int {
+        const int nt = resolve_threads(nthreads, D);
+        std::vector<int32_t> tmp;
+        int32_t *dst = Q;
+        int64_t ss = sym_stride, cs = chan_stride;
+        const bool via_tmp = (sym_stride != 1 && chan_stride == 1 && D > 1 && N > 4096);
+        if (via_tmp) { tmp.resize((size_t)N * (size_t)D); dst = tmp.data(); ss = 1; cs = N; }
+        rlgr::parallel_channels(D, nt, [&](int c) {
+            rlgr::decode(bufs + (int64_t)c * cap_per_channel, nbytes[c], N, flag_signed, dst + (int64_t)c * cs, ss);
+        });
+        if (via_tmp) rlgr::transpose_from_channels(tmp.data(), N, D, Q, sym_stride, nt);
+        return RAHT_OK;
     });
-    if (via_tmp) rlgr::transpose_from_channels(tmp.data(), N, D, Q, sym_stride, nt);
-    return RAHT_OK;
 }
 
 }  // extern "C"

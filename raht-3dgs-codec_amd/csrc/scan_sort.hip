@@ -14,32 +14,42 @@ namespace raht {
 // ------------------------------------------------------------------------------------------------
 // Scratch pool
 // ------------------------------------------------------------------------------------------------
-struct PoolBlock { void *p; size_t bytes; bool used; };
+struct PoolBlock { void *p; size_t bytes; bool used; int device; };
 static thread_local std::vector<PoolBlock> g_pool;
 
 Scratch::Scratch(size_t bytes)
 {
     if (bytes == 0) bytes = 16;
-    int best = -1;
-    for (int i = 0; i < (int)g_pool.size(); ++i)
-        if (!g_pool[(size_t)i].used && g_pool[(size_t)i].bytes >= bytes &&
-            (best < 0 || g_pool[(size_t)i].bytes < g_pool[(size_t)best].bytes)) best = i;
+    const int dev = current_device();
+    int best = -1, n_dev = 0;
+    for (int i = 0; i < (int)g_pool.size(); ++i) {
+        const PoolBlock &b = g_pool[(size_t)i];
+        if (b.device != dev || !b.p) continue;
+        ++n_dev;
+        if (!b.used && b.bytes >= bytes && (best < 0 || b.bytes < g_pool[(size_t)best].bytes)) best = i;
+    }
     if (best < 0) {
-        // recycle the largest free block that is too small, else grow the pool
-        int victim = -1;
-        for (int i = 0; i < (int)g_pool.size(); ++i)
-            if (!g_pool[(size_t)i].used && (victim < 0 || g_pool[(size_t)i].bytes > g_pool[(size_t)victim].bytes)) victim = i;
+        // recycle the largest free block (of this device) that is too small, else grow the pool
+        int victim = -1, empty = -1;
+        for (int i = 0; i < (int)g_pool.size(); ++i) {
+            const PoolBlock &b = g_pool[(size_t)i];
+            if (!b.p && !b.used) { if (empty < 0) empty = i; continue; }
+            if (b.device == dev && !b.used && (victim < 0 || b.bytes > g_pool[(size_t)victim].bytes)) victim = i;
+        }
         void *q = nullptr;
         const size_t want = bytes + bytes / 4;                 // head-room against slow growth
-        if (victim >= 0 && g_pool.size() >= 24) {
+        if (victim >= 0 && n_dev >= 24) {
             (void)hipFree(g_pool[(size_t)victim].p);
-            if (hipMalloc(&q, want) != hipSuccess) { g_pool.erase(g_pool.begin() + victim); set_error("scratch: out of device memory (%zu bytes)", want); return; }
-            g_pool[(size_t)victim] = {q, want, false};
+            // a failed allocation leaves an EMPTY slot behind: erasing it would shift the slot indices that
+            // live Scratch objects hold, and a later destructor would release somebody else's block
+            g_pool[(size_t)victim] = {nullptr, 0, false, dev};
+            if (hipMalloc(&q, want) != hipSuccess) { (void)hipGetLastError(); set_error("scratch: out of device memory (%zu bytes)", want); return; }
+            g_pool[(size_t)victim] = {q, want, false, dev};
             best = victim;
         } else {
-            if (hipMalloc(&q, want) != hipSuccess) { set_error("scratch: out of device memory (%zu bytes)", want); return; }
-            g_pool.push_back({q, want, false});
-            best = (int)g_pool.size() - 1;
+            if (hipMalloc(&q, want) != hipSuccess) { (void)hipGetLastError(); set_error("scratch: out of device memory (%zu bytes)", want); return; }
+            if (empty >= 0) { g_pool[(size_t)empty] = {q, want, false, dev}; best = empty; }
+            else { g_pool.push_back({q, want, false, dev}); best = (int)g_pool.size() - 1; }
         }
     }
     g_pool[(size_t)best].used = true;
@@ -56,10 +66,11 @@ Scratch::~Scratch()
 // Cache of long-lived device blocks (see raht_common.h).
 // ------------------------------------------------------------------------------------------------
 namespace {
+struct LiveBlock { size_t cls; int device; };
 struct DevCache {
     std::mutex mu;
-    std::unordered_map<void *, size_t> live;             // block -> class size
-    std::multimap<size_t, void *> free_blocks;           // class size -> block
+    std::unordered_map<void *, LiveBlock> live;                    // block -> (class size, device)
+    std::multimap<std::pair<int, size_t>, void *> free_blocks;     // (device, class size) -> block
     size_t cached = 0, limit = 0;
 };
 DevCache &dev_cache()
@@ -85,25 +96,27 @@ hipError_t dev_malloc(void **p, size_t bytes)
 {
     DevCache &c = dev_cache();
     const size_t cls = size_class(bytes);
+    const int dev = current_device();
     {
         std::lock_guard<std::mutex> g(c.mu);
-        auto it = c.free_blocks.find(cls);
+        auto it = c.free_blocks.find(std::make_pair(dev, cls));
         if (it != c.free_blocks.end()) {
             *p = it->second;
             c.free_blocks.erase(it);
             c.cached -= cls;
-            c.live[*p] = cls;
+            c.live[*p] = LiveBlock{cls, dev};
             return hipSuccess;
         }
     }
     hipError_t e = hipMalloc(p, cls);
     if (e != hipSuccess) {                               // under memory pressure: drop the cache and retry
+        (void)hipGetLastError();
         raht_release_cached_memory();
         e = hipMalloc(p, cls);
     }
     if (e == hipSuccess) {
         std::lock_guard<std::mutex> g(c.mu);
-        c.live[*p] = cls;
+        c.live[*p] = LiveBlock{cls, dev};
     }
     return e;
 }
@@ -115,10 +128,11 @@ void dev_free(void *p)
     size_t cls = 0;
     {
         std::lock_guard<std::mutex> g(c.mu);
+        int dev = 0;
         auto it = c.live.find(p);
-        if (it != c.live.end()) { cls = it->second; c.live.erase(it); }
+        if (it != c.live.end()) { cls = it->second.cls; dev = it->second.device; c.live.erase(it); }
         if (cls && c.cached + cls <= c.limit) {
-            c.free_blocks.emplace(cls, p);
+            c.free_blocks.emplace(std::make_pair(dev, cls), p);      // back to the bucket of the block's OWN device
             c.cached += cls;
             return;
         }

@@ -145,8 +145,9 @@ struct TileArgs {
     int Dp;              // LDS row stride: Dc rounded up to a whole 16-byte chunk
     int lg;              // log2 of the lanes per row (2^lg >= chunks per row)
     int last_stage;      // this is the top stage of the schedule
-    int dbg;             // profiling ablations (raht_debug_run_stage only): 1 = skip butterflies,
-                         // 2 = skip merge resolution too (pure staged copy). Always 0 in transforms.
+    int dbg;             // profiling ablations, -DRAHT_ABLATE builds only (raht_debug_run_stage): 1 = skip
+                         // butterflies, 2 = skip merge resolution too (pure staged copy). The product build
+                         // compiles TILE_DBG to the constant 0: its kernels carry no ablation branches.
     const uint8_t *lvl;
     const int32_t *wl;
     const int32_t *wr;
@@ -207,6 +208,13 @@ __device__ __forceinline__ void load_tile_meta(const TileArgs<T> &A, int64_t t, 
         }
     }
 }
+
+// Ablation branches exist only in a profiling build (make ABLATE=1, tools/ablate.sh)
+#ifdef RAHT_ABLATE
+#define TILE_DBG(A) ((A).dbg)
+#else
+#define TILE_DBG(A) 0
+#endif
 
 // Profiling build only (-DRAHT_PHASE_CLOCKS, tools/phase_clocks.py): thread 0 of the first workgroups stamps
 // the shader clock at the phase boundaries of its first tile.
@@ -452,7 +460,7 @@ __global__ __launch_bounds__(512, (sizeof(T) == 4 ? 6 : 4)) void tile_kernel(con
         const int j = tid + s * nthreads;
         m_merged[s] = false;
         bool surv = false;
-        if (j < nt && !(A.dbg & 2)) {
+        if (j < nt && !(TILE_DBG(A) & 2)) {
             const int64_t r = m_row[s];
             m_merged[s] = (r > 0) && (m_lv[s] < A.top_level) && (r - m_wl[s] >= start_row) && (r + m_wr[s] <= end_row);
             surv = !m_merged[s];
@@ -462,7 +470,7 @@ __global__ __launch_bounds__(512, (sizeof(T) == 4 ? 6 : 4)) void tile_kernel(con
             if (QM && !INV) sdst[j] = m_pos[s] | ((m_merged[s] || (A.last_stage && !A.root_buf)) ? (int32_t)0x80000000 : 0);
             if (m_merged[s]) atomicAdd(&hist[m_lv[s]], 1u);
         }
-        if (j < nt && (A.dbg & 2)) { sflag[j] = 1; if (QM && !INV) sdst[j] = m_pos[s] | (int32_t)0x80000000; }
+        if (j < nt && (TILE_DBG(A) & 2)) { sflag[j] = 1; if (QM && !INV) sdst[j] = m_pos[s] | (int32_t)0x80000000; }
         const uint64_t bal = __ballot(surv);
         m_rank[s] = __popcll(bal & lt);
         if (lane == 0 && s * nw + wid < 32) scnt[s * nw + wid] = (uint32_t)__popcll(bal);
@@ -486,7 +494,7 @@ __global__ __launch_bounds__(512, (sizeof(T) == 4 ? 6 : 4)) void tile_kernel(con
 #pragma unroll
         for (int s = 0; s < SLOTS; ++s) {
             const int j = tid + s * nthreads;
-            if (j < nt && !m_merged[s] && !(A.dbg & 2)) {
+            if (j < nt && !m_merged[s] && !(TILE_DBG(A) & 2)) {
                 uint32_t before = 0;
                 for (int q = 0; q < s * nw + wid; ++q) before += scnt[q];
                 const uint32_t rk = before + (uint32_t)m_rank[s];            // rank among this tile's survivors
@@ -538,7 +546,7 @@ __global__ __launch_bounds__(512, (sizeof(T) == 4 ? 6 : 4)) void tile_kernel(con
         }
     }
     // ---- P3b. inverse: drop the survivors' low-pass rows (from the stage above) into their slots
-    if (INV && !A.last_stage && !(A.dbg & 2)) {
+    if (INV && !A.last_stage && !(TILE_DBG(A) & 2)) {
         // (a) the first TILE_PRE_ROWS survivors were prefetched into spre: LDS -> LDS, no wait on HBM
         //     (kept apart from (b): a value that may come from either source makes hipcc wait for
         //     every outstanding global load, including the next tile's prefetch)
@@ -556,7 +564,7 @@ __global__ __launch_bounds__(512, (sizeof(T) == 4 ? 6 : 4)) void tile_kernel(con
         }
     }
     // top stage of the inverse: the roots' low-pass values may come from a compact caller buffer
-    if (INV && A.last_stage && A.root_buf && !(A.dbg & 2)) {
+    if (INV && A.last_stage && A.root_buf && !(TILE_DBG(A) & 2)) {
         if (active) for (uint32_t it = wid; (it << lr) < surv_cnt; it += nw) {
             const uint32_t qc = min((it << lr) + g, surv_cnt - 1);
             const V16 x = ld_chunk<T>(A.root_buf + (int64_t)(surv_base + qc) * A.D + goff);
@@ -578,7 +586,7 @@ __global__ __launch_bounds__(512, (sizeof(T) == 4 ? 6 : 4)) void tile_kernel(con
         // Fetching the next chained level's record one link ahead as well measured no further gain.
         const int loff_v = (int)loff[lane], hist_v = (int)hist[lane];
         uint64_t mask = __ballot(hist_v > 0);            // levels present in this tile
-        if (A.dbg & 1) mask = 0;
+        if (TILE_DBG(A) & 1) mask = 0;
         while (mask) {
             const int l = INV ? (63 - __clzll((long long)mask)) : (__ffsll((long long)mask) - 1);
             mask &= ~(1ull << l);
@@ -650,7 +658,7 @@ __global__ __launch_bounds__(512, (sizeof(T) == 4 ? 6 : 4)) void tile_kernel(con
         }
     } else {
         // survivors, compacted, to the next stage's workspace (top stage: the caller's root buffer)
-        if (!(A.dbg & 2) && (!A.last_stage || A.root_buf)) {
+        if (!(TILE_DBG(A) & 2) && (!A.last_stage || A.root_buf)) {
             T *dstb = A.last_stage ? A.root_buf : A.wsn;
             const int64_t ldb = A.last_stage ? (int64_t)A.D : A.ld_ws;
             if (active) for (uint32_t it = wid; (it << lr) < surv_cnt; it += nw) {
@@ -920,14 +928,14 @@ static int tile_threads()
 
 static int device_cus()
 {
-    static int n = 0;
-    if (n == 0) {
-        int dev = 0, v = 0;
-        if (hipGetDevice(&dev) == hipSuccess &&
-            hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) n = v;
-        else n = 256;                                       // MI355X
+    static int n[RAHT_MAX_DEVICES] = {};
+    const int dev = current_device();
+    if (n[dev] == 0) {
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) n[dev] = v;
+        else n[dev] = 256;                                  // MI355X
     }
-    return n;
+    return n[dev];
 }
 
 // RAHT_TILE_PERSIST (tuning knob): 0 / unset = one tile per workgroup (default, measured fastest);
@@ -959,12 +967,11 @@ struct XformIO {
 template <typename T, bool INV, bool IDENT, bool QM, int SLOTS>
 static int launch_tile_one(const TileArgs<T> &A, const XformIO<T> &io, dim3 grid, int threads, size_t lds, hipStream_t s)
 {
-    static bool attr_set = false;
-    if (!attr_set) {
+    // > 64 KiB of dynamic LDS must be allowed per function AND per device
+    static PerDeviceOnce attr;
+    if (attr.first(current_device()))
         RAHT_HIP_CHECK(hipFuncSetAttribute((const void *)tile_kernel<T, INV, IDENT, QM, SLOTS>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
-    }
     if constexpr (QM) {
         StepTable st;
         fill_step_table(st, io.steps, io.n_steps);
@@ -999,12 +1006,10 @@ static int launch_top_stage(const raht_plan *p, const Schedule &sc, int k, const
     const dim3 grid((unsigned)((D + VN - 1) / VN));
     const size_t n_small = st.n_merges - st.t_small_start;
     const size_t lds = (size_t)st.n_entries * 16 + ((n_small + 3) & ~(size_t)3) * 4 + n_small * 2 * sizeof(T);   // + 512 B static
-    static bool attr_set = false;
-    if (!attr_set) {
+    static PerDeviceOnce attr;
+    if (attr.first(current_device()))
         RAHT_HIP_CHECK(hipFuncSetAttribute((const void *)top_kernel<T, INV, QM>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                            160 * 1024 - 1024));
-        attr_set = true;
-    }
     if constexpr (QM) {
         StepTable stp;
         fill_step_table(stp, io.steps, io.n_steps);
@@ -1071,6 +1076,21 @@ static int launch_stage_impl(const raht_plan *p, const Schedule &sc, int k, cons
         A.in = nullptr; A.ld_in = 0;
         A.fin = const_cast<T *>(io.src); A.ld_fin = io.ld_src;
         A.out = (k == 0) ? io.dst : ws_k; A.ld_out = (k == 0) ? io.ld_dst : D;
+    }
+    // Every pointer the kernel will dereference for THIS (direction, stage) must be there before it is
+    // launched: a tile kernel handed a null workspace reads address 0 and the process dies in ROCr's
+    // fault handler at the next synchronisation (the round-1 abort). In particular the LAST
+    // tile stage has no stage above it (wsn == nullptr): its survivors are the roots.
+    {
+        const char *bad = nullptr;
+        if (!A.lvl || !A.wl || !A.wr) bad = "plan arrays";
+        else if (!A.last_stage && (!A.wsn || !A.surv_off)) bad = "survivor workspace of a non-final stage";
+        else if (k >= 1 && !ws_k) bad = "stage workspace";
+        else if (QM && (!A.Q || !A.inv_order)) bad = "Q / inv_order";
+        else if (!INV && (!A.in || (!QM && !A.fin))) bad = "forward input / output";
+        else if (INV && (!A.out || (!QM && !A.fin))) bad = "inverse input / output";
+        else if (st.tile_rows < 1 || (int64_t)st.tile_rows * std::max<int64_t>(std::max(A.ld_in, A.ld_out), A.ld_fin) * (int64_t)sizeof(T) >= ((int64_t)1 << 32)) bad = "tile geometry (32-bit row offsets)";
+        if (bad) { set_error("tile stage %d (%s): missing %s", k, INV ? "inverse" : "forward", bad); return RAHT_ERR_INVALID; }
     }
     const int nchunks = (D + Dc - 1) / Dc;
     const size_t lds = tile_lds_bytes(st.tile_rows, (int)sizeof(T), Dc, st.rows == nullptr, QM);
@@ -1167,6 +1187,7 @@ static int run_transform(const raht_plan *cp, const T *src, int64_t ld_src, int 
 {
     raht_plan *p = const_cast<raht_plan *>(cp);
     if (!p || !src || !dst) { set_error("raht transform: NULL argument"); return RAHT_ERR_INVALID; }
+    RAHT_RET(check_plan_device(p, INV ? "raht_inv" : "raht_fwd"));
     if (D < 1 || ld_src < D || ld_dst < D) { set_error("raht transform: bad D/ld (D=%d ld_src=%lld ld_dst=%lld)", D, (long long)ld_src, (long long)ld_dst); return RAHT_ERR_INVALID; }
     Schedule *sc = nullptr;
     int Dc = 0;
@@ -1209,35 +1230,36 @@ extern "C" {
 int raht_fwd(const raht_plan *plan, const float *C, int64_t ldc, int D, float *T, int64_t ldt, float *w,
              raht_stream_t stream)
 {
-    return run_transform<float, false>(plan, C, ldc, D, T, ldt, w, (hipStream_t)stream);
+    return guarded("raht_fwd", [&]() { return run_transform<float, false>(plan, C, ldc, D, T, ldt, w, (hipStream_t)stream); });
 }
 
 int raht_fwd_f64(const raht_plan *plan, const double *C, int64_t ldc, int D, double *T, int64_t ldt,
                  double *w, raht_stream_t stream)
 {
-    return run_transform<double, false>(plan, C, ldc, D, T, ldt, w, (hipStream_t)stream);
+    return guarded("raht_fwd_f64", [&]() { return run_transform<double, false>(plan, C, ldc, D, T, ldt, w, (hipStream_t)stream); });
 }
 
 int raht_inv(const raht_plan *plan, const float *T, int64_t ldt, int D, float *C, int64_t ldc,
              raht_stream_t stream)
 {
-    return run_transform<float, true>(plan, T, ldt, D, C, ldc, nullptr, (hipStream_t)stream);
+    return guarded("raht_inv", [&]() { return run_transform<float, true>(plan, T, ldt, D, C, ldc, nullptr, (hipStream_t)stream); });
 }
 
 int raht_inv_f64(const raht_plan *plan, const double *T, int64_t ldt, int D, double *C, int64_t ldc,
                  raht_stream_t stream)
 {
-    return run_transform<double, true>(plan, T, ldt, D, C, ldc, nullptr, (hipStream_t)stream);
+    return guarded("raht_inv_f64", [&]() { return run_transform<double, true>(plan, T, ldt, D, C, ldc, nullptr, (hipStream_t)stream); });
 }
 
 /* Fused forward RAHT + quantize + reorder: Q[k, c] = floor(T[order[k], c] / step_c + 0.5) without
  * ever materialising T (encode_3dgs.py:159,204,210,215 in one pass). */
-int raht_fwd_quant(const raht_plan *cp, const float *C, int64_t ldc, int D, const float *steps, int n_steps,
-                   int32_t *Q, int64_t ldq, raht_stream_t stream)
+static int fwd_quant_impl(const raht_plan *cp, const float *C, int64_t ldc, int D, const float *steps, int n_steps,
+                          int32_t *Q, int64_t ldq, raht_stream_t stream)
 {
     raht_plan *p = const_cast<raht_plan *>(cp);
     hipStream_t s = (hipStream_t)stream;
     if (!p || !C || !Q || D < 1 || ldc < D || ldq < D) { set_error("raht_fwd_quant: bad argument"); return RAHT_ERR_INVALID; }
+    RAHT_RET(check_plan_device(p, "raht_fwd_quant"));
     RAHT_RET(check_steps(steps, n_steps, D));
     Schedule *sc = nullptr;
     int Dc = 0;
@@ -1257,13 +1279,20 @@ int raht_fwd_quant(const raht_plan *cp, const float *C, int64_t ldc, int D, cons
     return RAHT_OK;
 }
 
+int raht_fwd_quant(const raht_plan *plan, const float *C, int64_t ldc, int D, const float *steps, int n_steps,
+                   int32_t *Q, int64_t ldq, raht_stream_t stream)
+{
+    return guarded("raht_fwd_quant", [&]() { return fwd_quant_impl(plan, C, ldc, D, steps, n_steps, Q, ldq, stream); });
+}
+
 /* Fused un-reorder + dequantize + inverse RAHT (encode_3dgs.py:261,267-268,274 in one pass). */
-int raht_dequant_inv(const raht_plan *cp, const int32_t *Q, int64_t ldq, int D, const float *steps, int n_steps,
-                     float *C, int64_t ldc, raht_stream_t stream)
+static int dequant_inv_impl(const raht_plan *cp, const int32_t *Q, int64_t ldq, int D, const float *steps, int n_steps,
+                            float *C, int64_t ldc, raht_stream_t stream)
 {
     raht_plan *p = const_cast<raht_plan *>(cp);
     hipStream_t s = (hipStream_t)stream;
     if (!p || !C || !Q || D < 1 || ldc < D || ldq < D) { set_error("raht_dequant_inv: bad argument"); return RAHT_ERR_INVALID; }
+    RAHT_RET(check_plan_device(p, "raht_dequant_inv"));
     RAHT_RET(check_steps(steps, n_steps, D));
     Schedule *sc = nullptr;
     int Dc = 0;
@@ -1281,15 +1310,24 @@ int raht_dequant_inv(const raht_plan *cp, const int32_t *Q, int64_t ldq, int D, 
     return RAHT_OK;
 }
 
+int raht_dequant_inv(const raht_plan *plan, const int32_t *Q, int64_t ldq, int D, const float *steps, int n_steps,
+                     float *C, int64_t ldc, raht_stream_t stream)
+{
+    return guarded("raht_dequant_inv", [&]() { return dequant_inv_impl(plan, Q, ldq, D, steps, n_steps, C, ldc, stream); });
+}
+
 /* Pre-build the tile schedule and workspaces for (elem_size, D) so that later transform calls
  * neither allocate nor synchronise (e.g. before hipGraph capture). */
 int raht_plan_prepare(raht_plan *p, int elem_size, int D, raht_stream_t stream)
 {
     if (!p || (elem_size != 4 && elem_size != 8) || D < 1) { set_error("raht_plan_prepare: bad argument"); return RAHT_ERR_INVALID; }
-    Schedule *sc = nullptr;
-    int Dc = 0;
-    if (elem_size == 4) return tile_setup<float>(p, D, D, (hipStream_t)stream, &sc, &Dc);
-    return tile_setup<double>(p, D, D, (hipStream_t)stream, &sc, &Dc);
+    RAHT_RET(check_plan_device(p, "raht_plan_prepare"));
+    return guarded("raht_plan_prepare", [&]() {
+        Schedule *sc = nullptr;
+        int Dc = 0;
+        if (elem_size == 4) return tile_setup<float>(p, D, D, (hipStream_t)stream, &sc, &Dc);
+        return tile_setup<double>(p, D, D, (hipStream_t)stream, &sc, &Dc);
+    });
 }
 
 #ifdef RAHT_PHASE_CLOCKS
@@ -1316,6 +1354,10 @@ int raht_debug_run_stage(const raht_plan *cp, int inverse, int stage, const floa
         set_error("raht_debug_run_stage: bad argument");
         return RAHT_ERR_INVALID;
     }
+    RAHT_RET(check_plan_device(p, "raht_debug_run_stage"));
+#ifndef RAHT_ABLATE
+    if (ablate != 0) { set_error("raht_debug_run_stage: ablations need a -DRAHT_ABLATE build of the library (make ABLATE=1)"); return RAHT_ERR_UNSUPPORTED; }
+#endif
     Schedule *sc = nullptr;
     int Dc = 0;
     RAHT_RET(tile_setup<float>(p, D, std::max(std::max(ld_mat, ld_mat2), ldq), s, &sc, &Dc));

@@ -281,7 +281,8 @@ int raht_voxelize(const float *PC, int64_t ldpc, int64_t N, int d, const float *
     Scratch partb(sizeof(float) * 4 * (size_t)nb);
     if (!partb.ok()) return RAHT_ERR_NOMEM;
     float *part = partb.as<float>();
-    std::vector<float> hp((size_t)nb * 4);
+    float hp_buf[1024 * 4];                          // nb <= 1024 partial results (no host allocation: nothing can throw)
+    struct { float *p; size_t n; float *data() { return p; } size_t size() const { return n; } float &operator[](size_t i) { return p[i]; } } hp = {hp_buf, (size_t)nb * 4};
     if (vmin_in) { vmin[0] = vmin_in[0]; vmin[1] = vmin_in[1]; vmin[2] = vmin_in[2]; }
     else {
         hipLaunchKernelGGL(minmax_kernel, dim3(nb), dim3(256), 0, s, PC, ldpc, N, 0.f, 0.f, 0.f, part);

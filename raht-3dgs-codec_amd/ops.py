@@ -257,9 +257,26 @@ class RahtPlan:
         with torch.cuda.device(self.device):
             check(_lib.lib().raht_plan_prepare(self._h, es, int(D), _stream()))
 
+    def set_max_stages(self, max_stages):
+        """Bound on the launches per direction of the tile schedule; above it the level engine runs."""
+        with torch.cuda.device(self.device):
+            check(_lib.lib().raht_plan_set_max_stages(self._h, int(max_stages)))
+
+    def _f64_quant_call(self, fn, src, D, steps, dst):
+        st = _steps64(steps, D)
+        with torch.cuda.device(src.device):
+            check(fn(self._h, C.c_void_p(src.data_ptr()), src.stride(0), D, st, len(st), C.c_void_p(dst.data_ptr()),
+                     dst.stride(0), _stream()))
+        return dst
+
     def forward_quant(self, Cmat, steps, roots=None):
-        """Fused forward RAHT + quantize + reorder -> int32 Q (T is never materialised)."""
+        """Forward RAHT + quantize + reorder -> int32 Q. float32 (default): ONE fused pass, T is never
+        materialised. float64 input: the reference's precision (encode_3dgs.py:82-83,204), two passes."""
         _need_cuda(Cmat, "C")
+        if Cmat.dtype == torch.float64 and roots is None:
+            X = Cmat if (Cmat.stride(1) == 1 and Cmat.stride(0) >= Cmat.shape[1]) else Cmat.contiguous()
+            Q = torch.empty((self.N, X.shape[1]), dtype=torch.int32, device=X.device)
+            return self._f64_quant_call(_lib.lib().raht_fwd_quant_f64, X, X.shape[1], steps, Q)
         X = Cmat.to(torch.float32)
         if X.stride(1) != 1 or X.stride(0) < X.shape[1]:
             X = X.contiguous()
@@ -276,11 +293,15 @@ class RahtPlan:
                 self._set_roots_buffer(None, D, torch.float32)
         return Q
 
-    def dequant_inverse(self, Q, steps, roots=None):
-        """Fused un-reorder + dequantize + inverse RAHT -> float32 C."""
+    def dequant_inverse(self, Q, steps, roots=None, dtype=torch.float32):
+        """Un-reorder + dequantize + inverse RAHT -> C (float32: one fused pass; dtype=torch.float64: the
+        reference's precision, two passes)."""
         _need_cuda(Q, "Q")
         Q = Q.to(torch.int32).contiguous()
         D = Q.shape[1]
+        if dtype == torch.float64 and roots is None:
+            out = torch.empty((self.N, D), dtype=torch.float64, device=Q.device)
+            return self._f64_quant_call(_lib.lib().raht_dequant_inv_f64, Q, D, steps, out)
         st = _steps(steps, D)
         out = torch.empty((self.N, D), dtype=torch.float32, device=Q.device)
         self._set_roots_buffer(roots, D, torch.float32)
@@ -296,6 +317,10 @@ class RahtPlan:
     def quant_reorder(self, T, steps):
         """int32 Q[k] = floor(T[order[k]] / step + 0.5)  (encode_3dgs.py:204,210,215)."""
         _need_cuda(T, "T")
+        if T.dtype == torch.float64:
+            T = T.contiguous()
+            Q = torch.empty((self.N, T.shape[1]), dtype=torch.int32, device=T.device)
+            return self._f64_quant_call(_lib.lib().raht_quant_reorder_f64, T, T.shape[1], steps, Q)
         T = T.to(torch.float32).contiguous()
         D = T.shape[1]
         st = _steps(steps, D)
@@ -305,11 +330,14 @@ class RahtPlan:
                                                 C.c_void_p(Q.data_ptr()), D, _stream()))
         return Q
 
-    def dequant_unreorder(self, Q, steps):
-        """float32 T[order[k]] = Q[k] * step  (encode_3dgs.py:261,267-268)."""
+    def dequant_unreorder(self, Q, steps, dtype=torch.float32):
+        """T[order[k]] = Q[k] * step  (encode_3dgs.py:261,267-268); float32, or float64 like the reference."""
         _need_cuda(Q, "Q")
         Q = Q.to(torch.int32).contiguous()
         D = Q.shape[1]
+        if dtype == torch.float64:
+            T = torch.empty((self.N, D), dtype=torch.float64, device=Q.device)
+            return self._f64_quant_call(_lib.lib().raht_dequant_unreorder_f64, Q, D, steps, T)
         st = _steps(steps, D)
         T = torch.empty((self.N, D), dtype=torch.float32, device=Q.device)
         with torch.cuda.device(Q.device):
@@ -325,6 +353,15 @@ def _steps(steps, D):
     if len(steps) not in (1, D):
         raise ValueError("steps must be a scalar or have D entries")
     return (C.c_float * len(steps))(*steps)
+
+
+def _steps64(steps, D):
+    if isinstance(steps, (int, float)):
+        steps = [float(steps)]
+    steps = [float(s) for s in steps]
+    if len(steps) not in (1, D):
+        raise ValueError("steps must be a scalar or have D entries")
+    return (C.c_double * len(steps))(*steps)
 
 
 def quant_rows(X, steps, pos, Q):
