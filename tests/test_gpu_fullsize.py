@@ -110,7 +110,11 @@ def test_full_scene_matches_oracle(rt, oracle, name):
             q = To[order[bad[0]], bad[1]] / step
             assert np.all(np.abs(Q64[bad] - Qo[bad]) == 1)
             assert np.all(np.abs(q + 0.5 - np.round(q + 0.5)) <= 1e-9 * np.maximum(1.0, np.abs(q))), (name, step, bad[0].size)
-        assert bad[0].size <= 1e-6 * Qo.size + 2
+        # (the integer-valued xyz columns are full of EXACT ties at step 1: the high-pass of two equal-weight
+        # two-point nodes is ((x2 + x3) - (x0 + x1)) / 2; which way 1-ulp noise tips them is implementation-defined,
+        # also between the reference's own CPU and GPU runs.) The attribute columns have next to none:
+        a0 = 3 if D in (14, 59) else 0
+        assert int((bad[1] >= a0).sum()) <= 1e-6 * Qo.size + 2, (name, step, int((bad[1] >= a0).sum()))
         del Q64
         # float32 fused kernel against the float64 oracle: the bound the float32 coefficient error implies
         Q32 = plan.forward_quant(Cd, step).cpu().numpy()
@@ -118,7 +122,6 @@ def test_full_scene_matches_oracle(rt, oracle, name):
         dq = np.abs(Q32.astype(np.int64) - Qo.astype(np.int64))
         assert np.all(dq <= lim), (name, step, int((dq > lim).sum()))
         # attribute channels (not the xyz columns, whose coefficients reach 1e6): almost every integer equal
-        a0 = 3 if D in (14, 59) else 0
         rate = float((dq[:, a0:] != 0).mean())
         assert rate <= (2e-4 if step < 0.1 else 2e-6), (name, step, rate)
         del lim, dq, Q32
