@@ -7,17 +7,33 @@
 
 One step = one pass of the codec's transform path over one scene that is already resident in HBM:
 forward RAHT -> quantize + reorder -> dequantize + un-reorder -> inverse RAHT (BASELINE.json
-configs[2]: "~3M Gaussians, SH deg 3 (59 ch), fwd+inv + quantize").  `--no-quant` times fwd+inv
-only.  N > 1: every rank owns one Morton-prefix shard of an N-times larger scene (weak scaling);
-the top three octree levels are stitched with one small all-gather over RCCL per direction.
-`--workload cfg4` (BASELINE.json configs[3]): every rank codes its own scene of 1-6 M Gaussians,
-no collective on the data path (replicas only).
+configs[2]: "~3M Gaussians, SH deg 3 (59 ch), fwd+inv + quantize").  `--no-quant` times fwd+inv only.
 
-Prints ONE JSON line (rank 0) with the driver's contract fields plus `roofline` (dominant kernel,
-HIP-event timed, algorithmic bytes) and `cpu_baseline` (the C oracle on the host cores).
+Workloads (`--workload`):
+  cfg3 (default)  N = 1: the headline 3 M x 59 scene. N > 1: WEAK scaling -- every rank owns one 3 M-row
+                  Morton-prefix shard of an N-times larger scene; the top three octree levels are stitched
+                  with one <= 121 KB all-gather over RCCL per direction.
+  cfg2            1 M x 14 (BASELINE configs[1]).
+  cfg4            BASELINE configs[3]: every rank codes its own scene of 1-6 M Gaussians, no collective on
+                  the data path (replicas only).
+  cfg5            BASELINE configs[4]: ONE 50 M-Gaussian scene. N = 1: the whole scene on one GPU. N > 1:
+                  STRONG scaling -- the same scene (same seed on every rank) cut into N Morton-prefix shards
+                  by `balanced_prefix_cuts`, one shard per rank, top-3-level all-gather per direction.
+
+Correctness gate: no value is printed for a wrong transform. N = 1: the float32 forward coefficients and
+the fused quantized integers are compared with the CPU oracle on the WHOLE scene (the float64 restatement
+of the reference's RAHT.py; the same run is the cpu_baseline measurement). N > 1: every rank compares its
+shard of the sharded transform with the same rows of an unsharded transform of the gathered scene.
+
+Prints ONE JSON line (rank 0) with the driver's contract fields plus `roofline` (dominant kernel, HIP-event
+timed, algorithmic bytes), `cpu_baseline` (the C oracle on the host cores), `oracle_gate`, the reference-
+precision leg `f64`, the `cfg2` leg, and `prelude` (plan build / radix sort / voxelizer with their own
+algorithmic-bytes fractions).
 """
 import argparse
 import ctypes as C
+import glob
+import hashlib
 import json
 import os
 import sys
@@ -42,9 +58,7 @@ def parse():
                     help="untimed steps BEFORE the warmup so that the GPU's clocks have settled when the warmup starts "
                          "(-1: as many as bring settle + warmup to 64; the first ~40 steps after idle run up to 17 %% slower, "
                          "tools/probe_step_transient.py); reported as settle_steps")
-    ap.add_argument("--workload", default="cfg3", choices=["cfg3", "cfg2", "cfg4", "cfg5"],
-                    help="cfg3 = headline (3M x 59); cfg2 = 1M x 14; cfg4 = one independent 1-6M x 59 scene per rank; "
-                         "cfg5 = 50M x 59 single-GPU equivalent, generated on device")
+    ap.add_argument("--workload", default="cfg3", choices=["cfg3", "cfg2", "cfg4", "cfg5"])
     ap.add_argument("--no-quant", action="store_true", help="time forward + inverse only")
     ap.add_argument("--engine", default="tile", choices=["tile", "level"])
     ap.add_argument("--tile-rows", type=int, default=0)
@@ -53,58 +67,217 @@ def parse():
     ap.add_argument("--tail-ch", type=int, default=0, help="channels per chunk of the stages >= 1 (0 = automatic)")
     ap.add_argument("--top-rows", type=int, default=0, help="entries at which the single-launch top stage takes over (0 = automatic)")
     ap.add_argument("--quant-step", type=float, default=0.01)
-    ap.add_argument("--skip-cpu-baseline", action="store_true")
+    ap.add_argument("--skip-cpu-baseline", action="store_true", help="skip the single-core timing and the repeats of the oracle (the gate still runs it once)")
+    ap.add_argument("--skip-oracle-gate", action="store_true", help="profiling runs only: the JSON line then says oracle_gate: skipped")
     ap.add_argument("--skip-prelude", action="store_true", help="do not time plan build / sort / voxelizer")
+    ap.add_argument("--skip-legs", action="store_true", help="do not run the extra f64 and cfg2 legs")
     ap.add_argument("--cpu-repeats", type=int, default=2)
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend for --gpus > 1 (gloo: ranks may share one GPU; testing only)")
     ap.add_argument("--unfused", action="store_true", help="quantize / dequantize as separate passes")
-    ap.add_argument("--ablate", type=int, default=0, help="kernel-timing experiment for the roofline probe only (0 = real kernel)")
+    ap.add_argument("--ablate", type=int, default=0, help="kernel-timing experiment for the roofline probe only (0 = real kernel; needs a make ABLATE=1 library)")
     return ap.parse_args()
 
 
-def cpu_baseline(V, C32, J, repeats):
-    """The C oracle (scalar restatement of the reference, float64 like the reference) on this host:
-    one core, and all cores (the transform is independent per channel: one thread per channel block,
-    ctypes releases the GIL). -> (single-core M-G/s, s per pass, all-cores M-G/s, s per pass, threads, err)"""
-    import threading
+def kernel_source_hash():
+    """sha1 over the kernel sources: profiles/traffic.json records the hash of the build its PMC passes measured,
+    and the bench only repeats those HBM bytes next to live timings when the hash is that of the library it runs."""
+    h = hashlib.sha1()
+    files = sorted(glob.glob(os.path.join(ROOT, "raht-3dgs-codec_amd", "csrc", "*.hip")) +
+                   glob.glob(os.path.join(ROOT, "raht-3dgs-codec_amd", "csrc", "*.h")) + [os.path.join(ROOT, "include", "raht.h")])
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def oracle_pass(V, C32, J, repeats, single_core):
+    """The C oracle (scalar restatement of the reference, float64 like the reference) on this host, one thread per
+    channel block on every core (oracle/threaded.py) and optionally on one core.
+    -> dict(param, T (float64 forward coefficients), all-cores / single-core seconds per fwd+inv pass, threads, err)"""
     from oracle import oracle as orc
+    from oracle import threaded
     orc.lib()
     p = orc.raht_param(V.astype(np.float64), np.zeros(3), 2 ** J, J)
     C64 = C32.astype(np.float64)
-    best = None
+    nthr = threaded.host_threads(C64.shape[1])
+    best_all, T = None, None
     for _ in range(max(1, repeats)):
         t0 = time.perf_counter()
-        T, _ = orc.raht_fwd(C64, p)
-        R = orc.raht_inv(T, p)
-        dt = time.perf_counter() - t0
-        best = dt if best is None else min(best, dt)
-    err = float(np.abs(R - C64).max())
-    del T, R
-    D = C64.shape[1]
-    try:
-        ncpu = len(os.sched_getaffinity(0))
-    except Exception:
-        ncpu = os.cpu_count() or 1
-    nthr = max(1, min(ncpu, D, 16))        # every thread re-walks the plan's lists: more, narrower blocks stop paying
-    cuts = [round(i * D / nthr) for i in range(nthr + 1)]
-    blocks = [np.ascontiguousarray(C64[:, cuts[i]:cuts[i + 1]]) for i in range(nthr)]
-
-    def work(b):
-        Tb, _ = orc.raht_fwd(b, p)
-        orc.raht_inv(Tb, p)
-    best_all = None
-    for _ in range(max(1, repeats)):
-        th = [threading.Thread(target=work, args=(b,)) for b in blocks]
-        t0 = time.perf_counter()
-        for t in th:
-            t.start()
-        for t in th:
-            t.join()
+        T, _ = threaded.forward(orc, C64, p, nthr)
+        R = threaded.inverse(orc, T, p, nthr)
         dt = time.perf_counter() - t0
         best_all = dt if best_all is None else min(best_all, dt)
-    n = V.shape[0]
-    return n / best / 1e6, best, n / best_all / 1e6, best_all, nthr, err
+    err = float(np.abs(R - C64).max())
+    del R
+    best_one = None
+    if single_core:
+        for _ in range(max(1, repeats)):
+            t0 = time.perf_counter()
+            T1, _ = orc.raht_fwd(C64, p)
+            orc.raht_inv(T1, p)
+            dt = time.perf_counter() - t0
+            best_one = dt if best_one is None else min(best_one, dt)
+        del T1
+    return dict(orc=orc, param=p, T=T, s_all=best_all, s_one=best_one, threads=nthr, err=err)
+
+
+def oracle_gate(ob, T32, Q32, step):
+    """float32 coefficients / fused integers of the HIP path against the oracle on the whole scene. Raises on failure."""
+    To = ob["T"]
+    N, D = To.shape
+    err = np.zeros(D); se = np.zeros(D); colmax = np.zeros(D); sq = np.zeros(D)
+    for r0 in range(0, N, 1 << 19):
+        b = To[r0:r0 + (1 << 19)]
+        d = T32[r0:r0 + (1 << 19)].astype(np.float64) - b
+        err = np.maximum(err, np.abs(d).max(axis=0)); se += (d * d).sum(axis=0)
+        colmax = np.maximum(colmax, np.abs(b).max(axis=0)); sq += (b * b).sum(axis=0)
+    rel = float((err / np.maximum(colmax, 1e-30)).max())
+    rms = float((np.sqrt(se / N) / np.maximum(np.sqrt(sq / N), 1e-30)).max())
+    g = {"kind": "oracle (float64 C restatement of RAHT.py, whole scene)", "rows": N, "channels": D,
+         "max_rel_err_T": rel, "rms_rel_err_T": rms, "tolerance": "per column: max <= 2e-6 * colmax, rms <= 1e-6 * rms"}
+    if not (rel <= 2e-6 and rms <= 1e-6):
+        raise AssertionError(f"oracle gate: float32 coefficients out of tolerance {g}")
+    if Q32 is not None:
+        order = ob["param"].order
+        Qo = ob["orc"].quant_reorder(To, step, order)
+        dq = np.abs(Q32.astype(np.int64) - Qo.astype(np.int64))
+        lim = 1.0 + (np.abs(T32.astype(np.float64) - To) + 1.2e-7 * np.abs(To))[order] / step
+        nbad = int((dq > lim).sum())
+        a0 = 3 if D in (14, 59) else 0
+        g["q_step"] = step
+        g["q_mismatch_rate_attr_channels"] = float((dq[:, a0:] != 0).mean())
+        g["q_beyond_coefficient_error_bound"] = nbad
+        if nbad:
+            raise AssertionError(f"oracle gate: {nbad} fused quantized integers differ from the oracle by more than the coefficient error allows")
+    return g
+
+
+def hip_events():
+    hip = C.CDLL("libamdhip64.so")
+    vp = C.c_void_p
+    hip.hipEventCreate.argtypes = [C.POINTER(vp)]
+    hip.hipEventElapsedTime.argtypes = [C.POINTER(C.c_float), vp, vp]
+    hip.hipEventDestroy.argtypes = [vp]
+    return hip
+
+
+def timed(fn, reps):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record(); e1.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+def wall(fn, reps=3):
+    best = None
+    for _ in range(reps):
+        torch.cuda.synchronize(); t = time.perf_counter(); fn(); torch.cuda.synchronize()
+        dtt = time.perf_counter() - t
+        best = dtt if best is None else min(best, dtt)
+    return best * 1e3
+
+
+class SoloScene:
+    """One scene on one GPU: plan + buffers + the step functions, all through the C ABI."""
+
+    def __init__(self, R, L, _lib, kd, Cd, nbits, a, dev, dtype=torch.float32):
+        self.L, self._lib, self.dev = L, _lib, dev
+        self.N, self.D = int(Cd.shape[0]), int(Cd.shape[1])
+        N, D = self.N, self.D
+        self.plan = R.RahtPlan.from_keys(kd, nbits)
+        self.plan.set_engine(a.engine, a.tile_rows, a.tail_rows, a.tail_ch, a.top_rows)
+        self.f64 = dtype == torch.float64
+        es = 8 if self.f64 else 4
+        if a.pooled_buffers and not self.f64:
+            # one allocation, buffers 64 MiB apart (DESIGN.md 4.3, buffer placement)
+            nb = N * D * 4
+            stride = ((nb + (1 << 21) - 1) >> 21 << 21) + (64 << 20)
+            pool = torch.empty(5 * stride, dtype=torch.uint8, device=dev)
+            al = (-pool.data_ptr()) % (1 << 21)
+
+            def carve(i, dt):
+                return pool[al + i * stride: al + i * stride + nb].view(dt).view(N, D)
+            C0 = Cd
+            Cd = carve(0, torch.float32); Cd.copy_(C0); del C0
+            self.T, self.Q, self.Td, self.Crec = carve(1, torch.float32), carve(2, torch.int32), carve(3, torch.float32), carve(4, torch.float32)
+        else:
+            self.T = torch.empty_like(Cd)
+            self.Q = torch.empty((N, D), dtype=torch.int32, device=dev)
+            self.Td = torch.empty_like(Cd)
+            self.Crec = torch.empty_like(Cd)
+        self.Cd = Cd
+        self.es = es
+        self.steps32 = (C.c_float * 1)(a.quant_step)
+        self.steps64 = (C.c_double * 1)(a.quant_step)
+
+    def s_(self):
+        return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    # each of these enqueues kernels through the C ABI only
+    def fwd(self):
+        f = self.L.raht_fwd_f64 if self.f64 else self.L.raht_fwd
+        vp = C.c_void_p
+        self._lib.check(f(self.plan._h, vp(self.Cd.data_ptr()), self.D, self.D, vp(self.T.data_ptr()), self.D, None, self.s_()))
+
+    def inv(self, src=None):
+        f = self.L.raht_inv_f64 if self.f64 else self.L.raht_inv
+        vp = C.c_void_p
+        src = self.T if src is None else src
+        self._lib.check(f(self.plan._h, vp(src.data_ptr()), self.D, self.D, vp(self.Crec.data_ptr()), self.D, self.s_()))
+
+    def quant(self):
+        vp = C.c_void_p
+        if self.f64:
+            self._lib.check(self.L.raht_quant_reorder_f64(self.plan._h, vp(self.T.data_ptr()), self.D, self.D, self.steps64, 1, vp(self.Q.data_ptr()), self.D, self.s_()))
+        else:
+            self._lib.check(self.L.raht_quant_reorder(self.plan._h, vp(self.T.data_ptr()), self.D, self.D, self.steps32, 1, vp(self.Q.data_ptr()), self.D, self.s_()))
+
+    def dequant(self):
+        vp = C.c_void_p
+        if self.f64:
+            self._lib.check(self.L.raht_dequant_unreorder_f64(self.plan._h, vp(self.Q.data_ptr()), self.D, self.D, self.steps64, 1, vp(self.Td.data_ptr()), self.D, self.s_()))
+        else:
+            self._lib.check(self.L.raht_dequant_unreorder(self.plan._h, vp(self.Q.data_ptr()), self.D, self.D, self.steps32, 1, vp(self.Td.data_ptr()), self.D, self.s_()))
+
+    def fwd_quant(self):
+        vp = C.c_void_p
+        self._lib.check(self.L.raht_fwd_quant(self.plan._h, vp(self.Cd.data_ptr()), self.D, self.D, self.steps32, 1, vp(self.Q.data_ptr()), self.D, self.s_()))
+
+    def dequant_inv(self):
+        vp = C.c_void_p
+        self._lib.check(self.L.raht_dequant_inv(self.plan._h, vp(self.Q.data_ptr()), self.D, self.D, self.steps32, 1, vp(self.Crec.data_ptr()), self.D, self.s_()))
+
+    def step_fn(self, no_quant, unfused):
+        if no_quant:
+            return lambda: (self.fwd(), self.inv(self.T))
+        if unfused or self.f64:
+            return lambda: (self.fwd(), self.quant(), self.dequant(), self.inv(self.Td))
+        return lambda: (self.fwd_quant(), self.dequant_inv())
+
+
+def device_scene(n_draws, J, D, seed, dev):
+    """cfg5: sorted unique 3J-bit keys and N(0,1) attributes generated ON THE DEVICE from `seed` (host generation of
+    50 M rows takes minutes). Every rank that calls this with the same seed holds the same scene."""
+    g5 = torch.Generator(device=dev); g5.manual_seed(seed)
+    kraw = torch.randint(0, 1 << (3 * J), (int(n_draws * 1.002),), device=dev, dtype=torch.int64, generator=g5)
+    kd = torch.unique(kraw)[:n_draws].contiguous()
+    del kraw
+    return kd, g5
+
+
+def device_attributes(N, D, g5, dev, rows=None):
+    """(N, D) float32 N(0,1) in column blocks of 8 (bounded temporaries); rows=(lo, hi) keeps only that row range of
+    the SAME matrix (a shard of the scene)."""
+    lo, hi = (0, N) if rows is None else rows
+    Cd = torch.empty((hi - lo, D), dtype=torch.float32, device=dev)
+    for c0 in range(0, D, 8):
+        blk = torch.randn((N, min(8, D - c0)), device=dev, generator=g5)
+        Cd[:, c0:c0 + 8] = blk[lo:hi]
+        del blk
+    return Cd
 
 
 def main():
@@ -121,6 +294,7 @@ def main():
     local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    dist = None
     if world > 1:
         import torch.distributed as dist
         if a.backend == "nccl":
@@ -134,91 +308,70 @@ def main():
 
     n_draws, J, D, seed = synth.CONFIGS[a.workload]
     solo = world == 1 or a.workload == "cfg4"          # this rank runs the whole transform of its own scene
+    scaling = "strong" if (a.workload == "cfg5" and world > 1) else "weak"
     if a.workload == "cfg4":
         n_draws, seed = synth.CFG4_DRAWS[rank % len(synth.CFG4_DRAWS)], seed + rank
-    # ---- synthetic scene (host, seeded), one Morton-prefix shard per rank ----
+    V = keys = Ch = None
+    shard_rows = None
     if a.workload == "cfg5":
-        # 50 M rows: generated on the device (host generation would take minutes); no CPU baseline
-        assert world == 1, "cfg5 is a single-GPU scaling data point"
-        g5 = torch.Generator(device=dev); g5.manual_seed(seed)
-        kraw = torch.randint(0, 1 << (3 * J), (int(n_draws * 1.002),), device=dev, dtype=torch.int64, generator=g5)
-        kd5 = torch.unique(kraw)[:n_draws].contiguous()
-        del kraw
-        keys = None; V = None
-        Ch = None
-        a.skip_cpu_baseline = True; a.skip_prelude = True
+        kd_all, g5 = device_scene(n_draws, J, D, seed, dev)
+        if world == 1:
+            kd = kd_all
+            Cd = device_attributes(int(kd.shape[0]), D, g5, dev)
+        else:
+            from raht_3dgs_codec_amd import sharded
+            cuts = sharded.balanced_prefix_cuts(kd_all, 3 * J, world, prefix_bits=9)
+            shard_rows = (cuts[rank], cuts[rank + 1])
+            kd = kd_all[shard_rows[0]:shard_rows[1]].contiguous()
+            Cd = device_attributes(int(kd_all.shape[0]), D, g5, dev, rows=shard_rows)
+        del kd_all
     elif solo:
         V, keys, Ch = synth.scene(n_draws, J, D, seed)
     else:
         per = 512 // world
         V, keys, Ch = synth.scene(n_draws, J, D, seed + 100 * rank, prefix_range=(rank * per, (rank + 1) * per, 9))
-    if a.workload == "cfg5":
-        N = int(kd5.shape[0])
-        kd = kd5
-        Cd = torch.empty((N, D), dtype=torch.float32, device=dev)
-        for c0 in range(0, D, 8):                               # fill in column blocks: bounded temporaries
-            Cd[:, c0:c0 + 8] = torch.randn((N, min(8, D - c0)), device=dev, generator=g5)
-    else:
-        N = V.shape[0]
+    if a.workload != "cfg5":
         Cd = torch.from_numpy(Ch).to(dev)
         kd = torch.from_numpy(keys.view(np.int64)).to(dev)
-    steps_arr = (C.c_float * 1)(a.quant_step)
+    N = int(kd.shape[0])
 
+    gate = None
+    sc = None
     if solo:
-        plan = R.RahtPlan.from_keys(kd, 3 * J)
-        plan.set_engine(a.engine, a.tile_rows, a.tail_rows, a.tail_ch, a.top_rows)
-        if a.pooled_buffers:
-            # one allocation, buffers 64 MiB apart (buffer placement: the duration of a
-            # streaming kernel has a bump over a window of input->output distances that moves with the
-            # physical mapping; inside ONE allocation gaps >= 32 MiB were outside it on every box tried)
-            nb = N * D * 4
-            stride = ((nb + (1 << 21) - 1) >> 21 << 21) + (64 << 20)
-            pool = torch.empty(5 * stride, dtype=torch.uint8, device=dev)
-            al = (-pool.data_ptr()) % (1 << 21)
-            def carve(i, dt):
-                return pool[al + i * stride: al + i * stride + nb].view(dt).view(N, D)
-            C0 = Cd
-            Cd = carve(0, torch.float32); Cd.copy_(C0); del C0
-            T, Q, Td, Crec = carve(1, torch.float32), carve(2, torch.int32), carve(3, torch.float32), carve(4, torch.float32)
-        else:
-            T = torch.empty_like(Cd)
-            Q = torch.empty((N, D), dtype=torch.int32, device=dev)
-            Td = torch.empty_like(Cd)
-            Crec = torch.empty_like(Cd)
-        h = plan._h
-        vp = C.c_void_p
-
-        def s_():
-            return C.c_void_p(torch.cuda.current_stream().cuda_stream)
-
-        def fwd():
-            _lib.check(L.raht_fwd(h, vp(Cd.data_ptr()), D, D, vp(T.data_ptr()), D, None, s_()))
-
-        def quant():
-            _lib.check(L.raht_quant_reorder(h, vp(T.data_ptr()), D, D, steps_arr, 1, vp(Q.data_ptr()), D, s_()))
-
-        def dequant():
-            _lib.check(L.raht_dequant_unreorder(h, vp(Q.data_ptr()), D, D, steps_arr, 1, vp(Td.data_ptr()), D, s_()))
-
-        def inv(src):
-            _lib.check(L.raht_inv(h, vp(src.data_ptr()), D, D, vp(Crec.data_ptr()), D, s_()))
-
-        def fwd_quant():
-            _lib.check(L.raht_fwd_quant(h, vp(Cd.data_ptr()), D, D, steps_arr, 1, vp(Q.data_ptr()), D, s_()))
-
-        def dequant_inv():
-            _lib.check(L.raht_dequant_inv(h, vp(Q.data_ptr()), D, D, steps_arr, 1, vp(Crec.data_ptr()), D, s_()))
-
-        if a.no_quant:
-            def step():
-                fwd(); inv(T)
-        elif a.unfused:
-            def step():
-                fwd(); quant(); dequant(); inv(Td)
-        else:
-            def step():
-                fwd_quant(); dequant_inv()
+        sc = SoloScene(R, L, _lib, kd, Cd, 3 * J, a, dev)
+        step = sc.step_fn(a.no_quant, a.unfused)
         total_rows = N
+        # ---- correctness gate: never report a number for a wrong transform ----
+        sc.fwd(); sc.inv(sc.T)
+        torch.cuda.synchronize()
+        rt_err = (sc.Crec - sc.Cd).abs().max().item() / sc.Cd.abs().max().item()
+        assert rt_err <= 1e-5, f"round trip error {rt_err}"
+        ob = None
+        if V is not None and rank == 0 and not a.skip_oracle_gate:
+            ob = oracle_pass(V, Ch, J, 1 if a.skip_cpu_baseline else a.cpu_repeats, single_core=not a.skip_cpu_baseline)
+            T32 = sc.T.cpu().numpy()
+            Q32 = None
+            if not a.no_quant:
+                sc.fwd_quant(); torch.cuda.synchronize()
+                Q32 = sc.Q.cpu().numpy()
+            gate = oracle_gate(ob, T32, Q32, a.quant_step)          # raises -> no JSON line
+            gate["order_RAGFT_equal"] = bool(np.array_equal(sc.plan.order_RAGFT.cpu().numpy(), ob["param"].order))
+            assert gate["order_RAGFT_equal"], "oracle gate: order_RAGFT differs"
+            del T32, Q32
+            ob["T"] = None
+        elif a.skip_oracle_gate:
+            gate = {"kind": "skipped (--skip-oracle-gate: profiling run)"}
+        elif V is None:
+            # 50 M rows: the oracle would need ~50 GB of float64 and minutes; size-independent properties instead
+            sc.fwd_quant(); sc.quant(); torch.cuda.synchronize()
+            Q2 = sc.Q.clone(); sc.fwd_quant(); torch.cuda.synchronize()
+            assert torch.equal(Q2, sc.Q), "fused != two-call"
+            e_in = sum(float((sc.Cd[:, c].double() ** 2).sum()) for c in range(D))
+            e_out = sum(float((sc.T[:, c].double() ** 2).sum()) for c in range(D))
+            assert abs(e_in - e_out) <= 1e-5 * e_in, "Parseval"
+            gate = {"kind": "properties (no oracle at 50 M rows): round trip, Parseval, fused == two-call", "roundtrip_rel_err": rt_err,
+                    "note": "the same kernels are oracle-checked on whole 1 M / 3 M / 6 M scenes (tests/test_gpu_fullsize.py) and in the cfg3 run of this bench"}
+            del Q2
     else:
         from raht_3dgs_codec_amd import sharded
         sh = sharded.ShardedRaht(kd, 3 * J, prefix_bits=9)
@@ -227,20 +380,17 @@ def main():
         def step():
             sh.step(Cd, qs)
         total_rows = None
-
-    # ---- correctness gate: never report a number for a wrong transform ----
-    if solo:
-        fwd(); inv(T)
-        torch.cuda.synchronize()
-        rt_err = (Crec - Cd).abs().max().item() / Cd.abs().max().item()
-        assert rt_err <= 1e-5, f"round trip error {rt_err}"
-    else:
         rt_err = sh.roundtrip_error(Cd)
         assert rt_err <= 1e-5, f"round trip error {rt_err}"
+        # sharded == unsharded: gather the scene, transform it whole on this GPU, compare this rank's rows
+        if not a.skip_oracle_gate:
+            gate = sh.check_against_unsharded(Cd, qs)
+            assert gate["ok"], f"sharded transform differs from the unsharded one: {gate}"
+        else:
+            gate = {"kind": "skipped (--skip-oracle-gate: profiling run)"}
 
     def barrier():
         if world > 1:
-            import torch.distributed as dist
             dist.barrier()
 
     settle = a.settle_steps if a.settle_steps >= 0 else max(0, 64 - a.warmup)
@@ -255,7 +405,6 @@ def main():
     torch.cuda.synchronize(); barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        import torch.distributed as dist
         tt = torch.tensor([dt, float(N)], dtype=torch.float64, device=dev if a.backend == "nccl" else "cpu")
         tmax = tt.clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         tsum = tt.clone(); dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
@@ -264,38 +413,41 @@ def main():
     ms_per_step = dt / a.steps * 1e3
     value = total_rows / (dt / a.steps) / 1e6
 
+    quant_txt = ("fwd + inv RAHT" if a.no_quant else "fwd RAHT + quantize/reorder + dequantize/un-reorder + inv RAHT"
+                 + (" (separate passes)" if a.unfused else " (quantization fused into the transform kernels)"))
+    if solo:
+        par = "1 GPU" if world == 1 else f"{world} independent scenes, one per GPU, no collective"
+    else:
+        par = (f"ONE scene morton-prefix sharded x{world} (balanced 9-bit prefix cuts)" if scaling == "strong" else f"morton-prefix sharded x{world}, one shard per rank") \
+              + f", top-3-octree-level all-gather ({'RCCL' if a.backend == 'nccl' else 'gloo, TEST ONLY'})"
     out = {
         "metric": "M-Gaussians/s fwd+inv RAHT, 59-ch SH3 3DGS" if D == 59 else "M-Gaussians/s fwd+inv RAHT, 14-ch SH0 3DGS",
         "value": round(value, 2), "unit": "M-Gaussians/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "settle_steps": settle,
-        "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {
-            "workload": (f"{a.workload}: {total_rows} Gaussians ({'1-6 M' if a.workload == 'cfg4' and world > 1 else n_draws} draws/GPU, J={J}, {D} channels), "
-                         + ("fwd + inv RAHT" if a.no_quant else "fwd RAHT + quantize/reorder + dequantize/un-reorder + inv RAHT"
-                            + (" (separate passes)" if a.unfused else " (quantization fused into the transform kernels)"))),
+            "workload": f"{a.workload}: {total_rows} Gaussians ({'1-6 M' if a.workload == 'cfg4' and world > 1 else n_draws} draws{'' if scaling == 'strong' else '/GPU'}, J={J}, {D} channels), " + quant_txt,
             "rows_per_gpu": N, "channels": D, "depth_J": J, "engine": a.engine, "quantize": not a.no_quant,
-            "parallelism": "1 GPU" if world == 1 else f"{world} independent scenes, one per GPU, no collective" if solo else f"morton-prefix sharded x{world}, top-3-octree-level all-gather ({'RCCL' if a.backend == 'nccl' else 'gloo, TEST ONLY'})",
+            "parallelism": par, "world": world, "backend": None if world == 1 else ("RCCL" if a.backend == "nccl" else "gloo"),
             "roundtrip_rel_err": rt_err,
         },
+        "oracle_gate": gate,
     }
+    if not solo:
+        out["config"]["gathered_bytes_per_step"] = sh.gathered_bytes_per_step(D)
+        out["config"]["roots_per_rank"] = sh.sizes
 
     if rank == 0 and world == 1:
+        plan, h = sc.plan, sc.plan._h
+        vp = C.c_void_p
         # ---- per-stage breakdown (HIP events on the launch stream) ----
-        def timed(fn, reps):
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(reps):
-                fn()
-            e1.record(); e1.synchronize()
-            return e0.elapsed_time(e1) / reps
-
         reps = min(max(5, a.steps), 100)
-        br = {"fwd_ms": timed(fwd, reps), "inv_ms": timed(lambda: inv(T), reps)}
+        br = {"fwd_ms": timed(sc.fwd, reps), "inv_ms": timed(lambda: sc.inv(sc.T), reps)}
         if not a.no_quant:
-            br["quant_reorder_ms"] = timed(quant, reps)
-            br["dequant_unreorder_ms"] = timed(dequant, reps)
-            br["fwd_quant_fused_ms"] = timed(fwd_quant, reps)
-            br["dequant_inv_fused_ms"] = timed(dequant_inv, reps)
+            br["quant_reorder_ms"] = timed(sc.quant, reps)
+            br["dequant_unreorder_ms"] = timed(sc.dequant, reps)
+            br["fwd_quant_fused_ms"] = timed(sc.fwd_quant, reps)
+            br["dequant_inv_fused_ms"] = timed(sc.dequant_inv, reps)
         out["breakdown_ms"] = {k: round(v, 4) for k, v in br.items()}
         st = plan.stage_stats(4, D)
         out["config"]["tile_rows"] = st["tile_rows"]
@@ -306,25 +458,20 @@ def main():
         alg = 8.0 * N * D + 8.0 * N
         if a.engine == "tile":
             fused = not (a.no_quant or a.unfused)
-            qp, qs = (vp(Q.data_ptr()), a.quant_step) if fused else (None, 0.0)
+            qp, qs_ = (vp(sc.Q.data_ptr()), a.quant_step) if fused else (None, 0.0)
 
             def k_fwd():
-                _lib.check(L.raht_debug_run_stage(h, 0, 0, vp(Cd.data_ptr()), D, D, vp(T.data_ptr()), D, qp, D, qs,
-                                                  a.ablate, s_()))
+                _lib.check(L.raht_debug_run_stage(h, 0, 0, vp(sc.Cd.data_ptr()), D, D, vp(sc.T.data_ptr()), D, qp, D, qs_, a.ablate, sc.s_()))
 
             def k_inv():
-                _lib.check(L.raht_debug_run_stage(h, 1, 0, vp(T.data_ptr()), D, D, vp(Crec.data_ptr()), D, qp, D, qs,
-                                                  a.ablate, s_()))
+                _lib.check(L.raht_debug_run_stage(h, 1, 0, vp(sc.T.data_ptr()), D, D, vp(sc.Crec.data_ptr()), D, qp, D, qs_, a.ablate, sc.s_()))
             k_fwd(); k_inv()
             tf_iso, ti_iso = timed(k_fwd, reps), timed(k_inv, reps)
             tf, ti = tf_iso, ti_iso
             if a.ablate == 0:
                 # The same two kernels timed INSIDE real steps: the library records a HIP event pair on the
                 # launch stream around the stage-0 launch of each direction (raht_plan_set_stage0_events).
-                hip = C.CDLL("libamdhip64.so")
-                hip.hipEventCreate.argtypes = [C.POINTER(vp)]
-                hip.hipEventElapsedTime.argtypes = [C.POINTER(C.c_float), vp, vp]
-                hip.hipEventDestroy.argtypes = [vp]
+                hip = hip_events()
 
                 def new_event():
                     e = vp()
@@ -332,12 +479,12 @@ def main():
                     return e
                 nrep = min(max(5, a.steps), 100)
                 evs = [[new_event() for _ in range(4)] for _ in range(nrep)]
-                one_fwd, one_inv = ((fwd, lambda: inv(T)) if a.no_quant else
-                                    (fwd, lambda: inv(Td)) if a.unfused else (fwd_quant, dequant_inv))
+                one_fwd, one_inv = ((sc.fwd, lambda: sc.inv(sc.T)) if a.no_quant else
+                                    (sc.fwd, lambda: sc.inv(sc.Td)) if a.unfused else (sc.fwd_quant, sc.dequant_inv))
                 for e4 in evs:
                     _lib.check(L.raht_plan_set_stage0_events(h, e4[0], e4[1])); one_fwd()
                     if a.unfused and not a.no_quant:
-                        _lib.check(L.raht_plan_set_stage0_events(h, None, None)); quant(); dequant()
+                        _lib.check(L.raht_plan_set_stage0_events(h, None, None)); sc.quant(); sc.dequant()
                     _lib.check(L.raht_plan_set_stage0_events(h, e4[2], e4[3])); one_inv()
                 _lib.check(L.raht_plan_set_stage0_events(h, None, None))
                 torch.cuda.synchronize()
@@ -350,18 +497,25 @@ def main():
                     for e in e4:
                         hip.hipEventDestroy(e)
                 tf, ti = acc[0] / nrep, acc[1] / nrep
-            traffic = None
+            # HBM bytes from the PMC counters: only repeated here when profiles/traffic.json was measured on THIS build
+            traffic, traffic_note = None, "no profiles/traffic.json entry for this workload"
             tp = os.path.join(ROOT, "profiles", "traffic.json")
             if os.path.exists(tp):
                 try:
-                    traffic = json.load(open(tp)).get(a.workload, {}).get("fused" if fused else "plain", {}).get("fwd_stage0_bytes")
+                    tj = json.load(open(tp)).get(a.workload, {})
+                    if tj.get("source_hash") == kernel_source_hash():
+                        traffic = tj.get("fused" if fused else "plain", {}).get("fwd_stage0_bytes")
+                        traffic_note = f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this build ({tj.get('source')}, source_hash {tj.get('source_hash')})"
+                    else:
+                        traffic_note = (f"profiles/traffic.json was measured on another build (source_hash {tj.get('source_hash')} != "
+                                        f"{kernel_source_hash()}): not repeated next to live timings")
                 except Exception:
-                    traffic = None
+                    pass
             tq = "true" if fused else "false"
             out["roofline"] = {"kernel": f"raht::tile_kernel<float, false, true, {tq}, 1> (forward, stage 0"
                                          + (", fused quantize+reorder)" if fused else ")"), "bound": "hbm",
                                "achieved": round(alg / (tf * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": round(alg / (tf * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": traffic,
+                               "frac": round(alg / (tf * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_note,
                                "alg_bytes_per_launch": alg, "avg_launch_ms": round(tf, 4),
                                "timed": "HIP events around the stage-0 launch inside real steps" if a.ablate == 0 else "isolated launches",
                                "isolated_launch_ms": round(tf_iso, 4)}
@@ -376,47 +530,79 @@ def main():
         out["path_hbm"] = {"alg_bytes_fwd_inv": 2 * alg, "fwd_inv_ms": round(tot, 4),
                            "achieved_GBs": round(2 * alg / (tot * 1e-3) / 1e9, 1),
                            "frac_of_peak": round(2 * alg / (tot * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                           "fwd_inv_only_MGs": round(N / (tot * 1e-3) / 1e6, 1)}
+                           "fwd_inv_only_MGs": round(N / (tot * 1e-3) / 1e6, 1),
+                           "whole_step_frac_of_peak": round(2 * alg / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
 
-        # ---- prelude stages, reported separately: plan build, radix sort, voxelizer ----
-        if not a.skip_prelude:
-            def wall(fn, reps=3):
-                best = None
-                for _ in range(reps):
-                    torch.cuda.synchronize(); t = time.perf_counter(); fn(); torch.cuda.synchronize()
-                    dtt = time.perf_counter() - t
-                    best = dtt if best is None else min(best, dtt)
-                return best * 1e3
+        # ---- prelude stages, reported separately, each against its own algorithmic bytes ----
+        if not a.skip_prelude and V is not None:
+            def roof(ms, alg_b):
+                return {"ms": round(ms, 4), "alg_bytes": alg_b, "achieved_GBs": round(alg_b / (ms * 1e-3) / 1e9, 1),
+                        "frac_of_peak": round(alg_b / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "bound": "hbm"}
             pre = {}
-            # plan arrays + the default tile schedule (built speculatively at creation) + destroy
-            pre["plan_from_sorted_keys_ms"] = wall(lambda: R.RahtPlan.from_keys(kd, 3 * J))
+            # plan arrays + the default tile schedule (built speculatively at creation) + destroy;
+            # >= 8 N read (keys) + ~9 N written (lvl, wl, wr)  -> 17 N
+            pre["plan_from_sorted_keys"] = roof(wall(lambda: R.RahtPlan.from_keys(kd, 3 * J)), 17.0 * N)
             g = torch.Generator(device=dev); g.manual_seed(1)
             perm = torch.randperm(N, device=dev, generator=g)
             ku = kd[perm].contiguous()
-            pre["radix_sort_%dbit_ms" % (3 * J)] = wall(lambda: R.sort_keys(ku, nbits=3 * J))
-            k60 = (ku << (60 - 3 * J)) | (ku & ((1 << (60 - 3 * J)) - 1))
-            pre["radix_sort_60bit_ms"] = wall(lambda: R.sort_keys(k60, nbits=60))
-            pre["torch_sort_int64_ms"] = wall(lambda: torch.sort(ku))
-            # voxelizer on the unsorted cloud: xyz (voxel centres) + the D-3 (or D) attribute columns
+            # one 8-bit radix pass moves ~24 N (key 8 + index 4, read and written)
+            for nb_ in (3 * J, 60):
+                kk = ku if nb_ == 3 * J else ((ku << (60 - 3 * J)) | (ku & ((1 << (60 - 3 * J)) - 1)))
+                pre["radix_sort_%dbit" % nb_] = roof(wall(lambda: R.sort_keys(kk, nbits=nb_)), 24.0 * N * ((nb_ + 7) // 8))
+            pre["torch_sort_int64_ms"] = round(wall(lambda: torch.sort(ku)), 4)
+            # voxelizer on the unsorted cloud: xyz (voxel centres) + the attribute columns
             xyz = torch.from_numpy(V.astype(np.float32)).to(dev)[perm] + 0.5
-            PC = torch.cat([xyz, Cd[perm][:, : min(D, 56)]], dim=1).contiguous()
-            pre["voxelize_ms"] = wall(lambda: R.voxelize_pc_batched(PC, [0.0, 0.0, 0.0], float(2 ** J), J, device=dev, residuals=False, sorted_points=False))
-            pre["voxelize_points"] = N
-            pre["voxelize_columns"] = int(PC.shape[1])
-            out["prelude_ms"] = {k: (round(v, 3) if isinstance(v, float) else v) for k, v in pre.items()}
-            del PC, xyz, ku, k60, perm
+            PC = torch.cat([xyz, sc.Cd[perm][:, : min(D, 56)]], dim=1).contiguous()
+            ld = int(PC.shape[1])
+            # read the cloud once (gathered in sorted order), write PCvox once, plus the key sort
+            vox_alg = 4.0 * N * ld * 2 + 24.0 * N * ((3 * J + 7) // 8)
+            pre["voxelize"] = roof(wall(lambda: R.voxelize_pc_batched(PC, [0.0, 0.0, 0.0], float(2 ** J), J, device=dev, residuals=False, sorted_points=False)), vox_alg)
+            pre["voxelize"]["points"], pre["voxelize"]["columns"] = N, ld
+            out["prelude"] = pre
+            del PC, xyz, ku, perm
 
-        if not a.skip_cpu_baseline:
-            v1, s1, va, sa, nthr, err = cpu_baseline(V, Ch, J, a.cpu_repeats)
-            out["cpu_baseline"] = {"value": round(va, 4), "unit": "M-Gaussians/s", "cores": nthr, "kind": "port",
-                                   "sample": (f"the full {a.workload} scene ({N} rows x {D} ch), fwd+inv RAHT only, float64, "
-                                              f"best of {a.cpu_repeats}; scalar C oracle (oracle/raht_oracle.c), one thread per "
-                                              f"channel block on {nthr} threads: {sa:.2f} s per pass; on one core {s1:.2f} s"),
-                                   "single_core_value": round(v1, 4), "roundtrip_abs_err": err}
+        # ---- cpu_baseline: the oracle run that fed the gate ----
+        if ob is not None:
+            nthr = ob["threads"]
+            cb = {"value": round(N / ob["s_all"] / 1e6, 4), "unit": "M-Gaussians/s", "cores": nthr, "kind": "port",
+                  "sample": (f"the full {a.workload} scene ({N} rows x {D} ch), fwd+inv RAHT only, float64, best of {1 if a.skip_cpu_baseline else a.cpu_repeats}; "
+                             f"scalar C oracle (oracle/raht_oracle.c), one thread per channel block on {nthr} threads: {ob['s_all']:.2f} s per pass"
+                             + (f"; on one core {ob['s_one']:.2f} s" if ob["s_one"] else "")),
+                  "roundtrip_abs_err": ob["err"]}
+            if ob["s_one"]:
+                cb["single_core_value"] = round(N / ob["s_one"] / 1e6, 4)
+            out["cpu_baseline"] = cb
+
+        # ---- extra legs on the same box: reference precision (float64), and cfg2 ----
+        if not a.skip_legs and a.workload == "cfg3" and a.engine == "tile" and not a.unfused:
+            kreps = 50
+            s64 = SoloScene(R, L, _lib, kd, sc.Cd.double(), 3 * J, a, dev, dtype=torch.float64)
+            f_fi, f_q = s64.step_fn(True, False), s64.step_fn(False, False)
+            for _ in range(10):
+                f_q()
+            t_fi, t_q = timed(f_fi, kreps), timed(f_q, kreps)
+            alg64 = 2 * (16.0 * N * D + 8.0 * N)
+            out["f64"] = {"what": "the reference's own precision (encode_3dgs.py:82-83): raht_fwd_f64 + raht_inv_f64; with_quant adds the float64 quantize/reorder and dequantize/un-reorder passes (not fused)",
+                          "fwd_inv_ms": round(t_fi, 4), "fwd_inv_MGs": round(N / (t_fi * 1e-3) / 1e6, 1), "alg_bytes_fwd_inv": alg64,
+                          "frac_of_peak": round(alg64 / (t_fi * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                          "with_quant_ms": round(t_q, 4), "with_quant_MGs": round(N / (t_q * 1e-3) / 1e6, 1)}
+            del s64
+            n2, J2, D2, seed2 = synth.CONFIGS["cfg2"]
+            V2, keys2, C2 = synth.scene(n2, J2, D2, seed2)
+            s2 = SoloScene(R, L, _lib, torch.from_numpy(keys2.view(np.int64)).to(dev), torch.from_numpy(C2).to(dev), 3 * J2, a, dev)
+            f2 = s2.step_fn(a.no_quant, False)
+            for _ in range(64):
+                f2()
+            t2 = timed(f2, 200)
+            alg2 = 2 * (8.0 * s2.N * D2 + 8.0 * s2.N)
+            out["cfg2"] = {"workload": f"cfg2: {s2.N} Gaussians, J={J2}, {D2} channels, same step", "ms_per_step": round(t2, 4),
+                           "value": round(s2.N / (t2 * 1e-3) / 1e6, 1), "unit": "M-Gaussians/s", "alg_bytes_fwd_inv": alg2,
+                           "frac_of_peak": round(alg2 / (t2 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                           "active_rows_per_stage": s2.plan.stage_stats(4, D2)["rows_per_stage"]}
+            del s2
     if rank == 0:
         print(json.dumps(out))
     if world > 1:
-        import torch.distributed as dist
         dist.destroy_process_group()
 
 

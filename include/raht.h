@@ -110,6 +110,13 @@ int raht_plan_set_top_level(raht_plan *plan, int top_level, raht_stream_t stream
 int raht_plan_roots(const raht_plan *plan, int64_t *n_roots, int64_t *rows_dev, raht_stream_t stream);
 int raht_plan_set_root_buffer(raht_plan *plan, void *buf_dev);
 
+/* Row map (small plans only: N <= 8192, they run as ONE launch): plan row i lives in row map[i] of the
+ * matrices handed to raht_fwd* / raht_inv* (which then have n_matrix_rows rows; rows outside the map are not
+ * touched). map_dev: DEVICE int64[N], copied; NULL removes the map. This is how the replicated top tree of a
+ * Morton-prefix sharded scene works IN PLACE on the padded all-gather buffer (world x max_roots rows) instead
+ * of on a compacted copy of it. Not available with the fused-quantization entries or with w != NULL. */
+int raht_plan_set_row_map(raht_plan *plan, const int64_t *map_dev, int64_t n_matrix_rows, raht_stream_t stream);
+
 int raht_plan_destroy(raht_plan *plan);
 int64_t raht_plan_size(const raht_plan *plan);          /* N */
 int raht_plan_nbits(const raht_plan *plan);             /* 3 * depth */
@@ -254,6 +261,12 @@ int raht_voxelize(const float *PC, int64_t ldpc, int64_t N, int d, const float *
                   float vmin_out[3], double *width_out, double *voxel_size_out,
                   raht_stream_t stream);
 
+/* The voxelizer's first phase alone: the (unsorted) 3J-bit Morton key of every point for a GIVEN bounding box
+ * (vmin: HOST float[3]; width > 0), same arithmetic as raht_voxelize. A Morton-prefix sharded front end buckets
+ * points by the top key bits with it before the all-to-all (sharded.exchange_by_prefix). keys: DEVICE uint64[N]. */
+int raht_voxel_keys(const float *PC, int64_t ldpc, int64_t N, const float vmin[3], double width, int J,
+                    uint64_t *keys, raht_stream_t stream);
+
 /* Morton keys of integer coordinates (get_morton_code, voxelize_pc.py:25-59). V: N x 3 int64. */
 int raht_morton(const int64_t *V, int64_t N, int J, uint64_t *keys, raht_stream_t stream);
 
@@ -283,6 +296,15 @@ int raht_quant_rows(const float *X, int64_t ldx, int64_t n, int D, const float *
                     const int64_t *pos, int32_t *Q, int64_t ldq, raht_stream_t stream);
 int raht_dequant_rows(const int32_t *Q, int64_t ldq, const int64_t *pos, int64_t n, int D, const float *steps,
                       int n_steps, float *X, int64_t ldx, raht_stream_t stream);
+
+/* Rows at explicit positions, no arithmetic (elem_size 4 or 8 bytes per element; pos: DEVICE int64[n]):
+ *   raht_rows_gather :  dst[i, :] = src[pos[i], :]        raht_rows_scatter :  dst[pos[i], :] = src[i, :]
+ * One launch each; the sharded driver moves a shard's <= 512 root rows between the coefficient matrix and the
+ * all-gather buffers with them. */
+int raht_rows_gather(const void *src, int64_t ld_src, const int64_t *pos, int64_t n, int D, int elem_size, void *dst,
+                     int64_t ld_dst, raht_stream_t stream);
+int raht_rows_scatter(const void *src, int64_t ld_src, const int64_t *pos, int64_t n, int D, int elem_size, void *dst,
+                      int64_t ld_dst, raht_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * RLGR entropy stage: adaptive Run-Length / Golomb-Rice coder, byte-exact with the

@@ -23,6 +23,7 @@ EXPORTS = [
     "raht_plan_levels", "raht_plan_export_level", "raht_plan_order", "raht_plan_arrays",
     "raht_plan_copy_array", "raht_plan_stage_stats", "raht_fwd", "raht_fwd_f64", "raht_inv", "raht_inv_f64", "raht_debug_run_stage", "raht_plan_set_stage0_events", "raht_fwd_quant", "raht_dequant_inv", "raht_plan_prepare",
     "raht_quant_reorder", "raht_dequant_unreorder", "raht_voxelize", "raht_morton", "raht_sort_keys",
+    "raht_voxel_keys", "raht_plan_set_row_map", "raht_rows_gather", "raht_rows_scatter",
     "raht_plan_set_max_stages", "raht_quant_reorder_f64", "raht_dequant_unreorder_f64", "raht_fwd_quant_f64", "raht_dequant_inv_f64",
     "raht_rlgr_bound", "raht_rlgr_encode", "raht_rlgr_decode", "raht_rlgr_encode_channels", "raht_rlgr_decode_channels", "raht_transpose_i32", "raht_merge_clusters",
 ]
@@ -92,6 +93,9 @@ def lib():
     L.raht_dequant_inv.argtypes = [vp, vp, i64, i32, C.POINTER(C.c_float), i32, vp, i64, vp]
     L.raht_plan_prepare.argtypes = [vp, i32, i32, vp]
     L.raht_plan_set_max_stages.argtypes = [vp, i32]
+    L.raht_plan_set_row_map.argtypes = [vp, vp, i64, vp]
+    for f in (L.raht_rows_gather, L.raht_rows_scatter):
+        f.argtypes = [vp, i64, vp, i64, i32, i32, vp, i64, vp]
     for f in (L.raht_quant_reorder_f64, L.raht_dequant_unreorder_f64, L.raht_fwd_quant_f64, L.raht_dequant_inv_f64):
         f.argtypes = [vp, vp, i64, i32, C.POINTER(dbl), i32, vp, i64, vp]
     L.raht_quant_reorder.argtypes = [vp, vp, i64, i32, C.POINTER(C.c_float), i32, vp, i64, vp]
@@ -101,6 +105,7 @@ def lib():
     L.raht_voxelize.argtypes = [vp, i64, i64, i32, C.POINTER(C.c_float), dbl, i32, vp, vp, vp, vp, vp,
                                 C.POINTER(i64), C.POINTER(C.c_float), C.POINTER(dbl), C.POINTER(dbl), vp]
     L.raht_morton.argtypes = [vp, i64, i32, vp, vp]
+    L.raht_voxel_keys.argtypes = [vp, i64, i64, C.POINTER(C.c_float), dbl, i32, vp, vp]
     L.raht_sort_keys.argtypes = [vp, i64, i32, vp, vp, vp]
     L.raht_rlgr_bound.argtypes = [i64]
     L.raht_rlgr_bound.restype = i64

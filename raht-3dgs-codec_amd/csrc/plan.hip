@@ -768,6 +768,7 @@ int raht_plan_destroy(raht_plan *p)
     if (p->inv_order) dev_free(p->inv_order);
     if (p->level_rows) dev_free(p->level_rows);
     if (p->root_rows) dev_free(p->root_rows);
+    if (p->row_map) dev_free(p->row_map);
     delete p;
     return RAHT_OK;
 }
@@ -912,6 +913,43 @@ int raht_plan_roots(const raht_plan *p, int64_t *n_roots, int64_t *rows_dev, rah
                            (hipStream_t)stream, p->root_rows, p->n_roots, rows_dev);
         RAHT_HIP_CHECK(hipGetLastError());
     }
+    return RAHT_OK;
+}
+
+__global__ void row_map_kernel(const int64_t *__restrict__ map, int64_t n, int64_t n_rows, uint32_t *__restrict__ out, PlanErr *err)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int64_t r = map[i];
+    if (r < 0 || r >= n_rows) report(err, RAHT_ERR_BOUNDS, i);
+    out[i] = (uint32_t)r;
+}
+
+int raht_plan_set_row_map(raht_plan *p, const int64_t *map_dev, int64_t n_matrix_rows, raht_stream_t stream)
+{
+    if (!p) { set_error("raht_plan_set_row_map: NULL plan"); return RAHT_ERR_INVALID; }
+    RAHT_RET(check_plan_device(p, "raht_plan_set_row_map"));
+    hipStream_t s = (hipStream_t)stream;
+    if (!map_dev) {
+        if (p->row_map) { (void)hipDeviceSynchronize(); dev_free(p->row_map); p->row_map = nullptr; p->map_rows = 0; }
+        return RAHT_OK;
+    }
+    if (p->N > RAHT_TOP_MAX_ROWS) { set_error("raht_plan_set_row_map: plans of at most %d rows", RAHT_TOP_MAX_ROWS); return RAHT_ERR_UNSUPPORTED; }
+    if (n_matrix_rows < p->N || n_matrix_rows >= ((int64_t)1 << 31)) { set_error("raht_plan_set_row_map: n_matrix_rows=%lld", (long long)n_matrix_rows); return RAHT_ERR_INVALID; }
+    if (!p->row_map) RAHT_HIP_CHECK(dev_malloc(&p->row_map, sizeof(uint32_t) * (size_t)p->N));
+    Scratch errw(sizeof(PlanErr));
+    if (!errw.ok()) return RAHT_ERR_NOMEM;
+    PlanErr h0 = {0, 0xffffffffu}, he;
+    RAHT_HIP_CHECK(hipMemcpyAsync(errw.ptr(), &h0, sizeof(h0), hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(row_map_kernel, dim3((unsigned)ceil_div(p->N, 256)), dim3(256), 0, s, map_dev, p->N, n_matrix_rows, p->row_map, errw.as<PlanErr>());
+    RAHT_HIP_CHECK(hipGetLastError());
+    RAHT_RET(read_back_u32((uint32_t *)&he, (const uint32_t *)errw.ptr(), 2, nullptr, nullptr, 0, s));
+    if (he.code != 0) {
+        dev_free(p->row_map); p->row_map = nullptr; p->map_rows = 0;
+        set_error("raht_plan_set_row_map: map[%u] outside [0, %lld)", he.row, (long long)n_matrix_rows);
+        return RAHT_ERR_BOUNDS;
+    }
+    p->map_rows = n_matrix_rows;
     return RAHT_OK;
 }
 

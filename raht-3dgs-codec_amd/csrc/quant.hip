@@ -173,6 +173,24 @@ static int fill_steps64(StepTable64 &t, const double *steps, int n_steps, int D)
     return RAHT_OK;
 }
 
+// Rows of 32-bit words at explicit positions, without arithmetic: GATHER dst[i, :] = src[pos[i], :] or
+// SCATTER dst[pos[i], :] = src[i, :]. The <= 512 root rows of a Morton-prefix sharded scene travel between the
+// coefficient matrix and the all-gather buffers with one launch of this instead of a chain of torch index ops.
+template <bool SCATTER>
+__global__ __launch_bounds__(256) void rows_move_kernel(const uint32_t *__restrict__ src, int64_t lds, const int64_t *__restrict__ pos,
+                                                        int64_t n, int words, uint32_t *__restrict__ dst, int64_t ldd)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (int64_t i = wave; i < n; i += nwaves) {
+        const int64_t r = pos[i];
+        const uint32_t *a = src + (SCATTER ? i : r) * lds;
+        uint32_t *b = dst + (SCATTER ? r : i) * ldd;
+        for (int c = lane; c < words; c += 64) b[c] = a[c];
+    }
+}
+
 // int32 matrix transpose through an LDS tile (64 rows x 64 columns, padded): row-major N x D  <->
 // channel-major D x N, so that the entropy stage reads / writes contiguous channels. Both global
 // sides are coalesced (lanes along the contiguous dimension).
@@ -343,6 +361,33 @@ int raht_dequant_rows(const int32_t *Q, int64_t ldq, const int64_t *pos, int64_t
     hipLaunchKernelGGL(dequant_rows_kernel, dim3(gb), dim3(256), 0, (hipStream_t)stream, Q, ldq, pos, n, D, st, X, ldx);
     RAHT_HIP_CHECK(hipGetLastError());
     return RAHT_OK;
+}
+
+static int rows_move(bool scatter, const void *src, int64_t ld_src, const int64_t *pos, int64_t n, int D, int elem_size,
+                     void *dst, int64_t ld_dst, raht_stream_t stream, const char *what)
+{
+    if (!src || !dst || !pos || n < 0 || D < 1 || ld_src < D || ld_dst < D || (elem_size != 4 && elem_size != 8)) { set_error("%s: bad argument", what); return RAHT_ERR_INVALID; }
+    if (n == 0) return RAHT_OK;
+    const int wpe = elem_size / 4;
+    const unsigned gb = (unsigned)std::min<int64_t>(ceil_div(n, 4), 4096);
+    if (scatter)
+        hipLaunchKernelGGL(rows_move_kernel<true>, dim3(gb), dim3(256), 0, (hipStream_t)stream, (const uint32_t *)src, ld_src * wpe, pos, n, D * wpe, (uint32_t *)dst, ld_dst * wpe);
+    else
+        hipLaunchKernelGGL(rows_move_kernel<false>, dim3(gb), dim3(256), 0, (hipStream_t)stream, (const uint32_t *)src, ld_src * wpe, pos, n, D * wpe, (uint32_t *)dst, ld_dst * wpe);
+    RAHT_HIP_CHECK(hipGetLastError());
+    return RAHT_OK;
+}
+
+int raht_rows_gather(const void *src, int64_t ld_src, const int64_t *pos, int64_t n, int D, int elem_size, void *dst,
+                     int64_t ld_dst, raht_stream_t stream)
+{
+    return rows_move(false, src, ld_src, pos, n, D, elem_size, dst, ld_dst, stream, "raht_rows_gather");
+}
+
+int raht_rows_scatter(const void *src, int64_t ld_src, const int64_t *pos, int64_t n, int D, int elem_size, void *dst,
+                      int64_t ld_dst, raht_stream_t stream)
+{
+    return rows_move(true, src, ld_src, pos, n, D, elem_size, dst, ld_dst, stream, "raht_rows_scatter");
 }
 
 int raht_transpose_i32(const int32_t *in, int64_t ld_in, int64_t rows, int64_t cols, int32_t *out, int64_t ld_out,

@@ -212,6 +212,8 @@ struct raht_plan {
     int64_t n_roots = 1;         // row 0 plus every row whose level is >= top_level
     uint32_t *root_rows = nullptr;   // device, ascending
     void *root_buf = nullptr;    // caller-owned device buffer (n_roots x D), see raht_plan_set_root_buffer
+    uint32_t *row_map = nullptr; // device [N] or nullptr: plan row i lives in matrix row row_map[i] (raht_plan_set_row_map)
+    int64_t map_rows = 0;        // rows of the mapped matrices
     int engine = RAHT_ENGINE_TILE;
     int tile_rows_override = 0;
     int tail_rows_override = 0;  // rows per tile of the later stages (0 = automatic)

@@ -60,7 +60,8 @@ __global__ __launch_bounds__(256) void level_pass_kernel(T *__restrict__ data, i
                                                          const uint32_t *__restrict__ level_rows,
                                                          uint32_t count, const int32_t *__restrict__ wl,
                                                          const int32_t *__restrict__ wr,
-                                                         const int64_t *__restrict__ wsum, int lp_shift)
+                                                         const int64_t *__restrict__ wsum, int lp_shift,
+                                                         const uint32_t *__restrict__ row_map)
 {
     const int lane = threadIdx.x & 63;
     const int Lp = 1 << lp_shift;
@@ -89,8 +90,9 @@ __global__ __launch_bounds__(256) void level_pass_kernel(T *__restrict__ data, i
         a = __shfl(a, g << lp_shift, 64);
         b = __shfl(b, g << lp_shift, 64);
         if (act) {
-            T *r0 = data + (i - l) * ld;
-            T *r1 = data + i * ld;
+            // row_map (raht_plan_set_row_map): plan row -> matrix row, e.g. the padded all-gather buffer of a sharded scene
+            T *r0 = data + (row_map ? (int64_t)row_map[i - l] : i - l) * ld;
+            T *r1 = data + (row_map ? (int64_t)row_map[i] : i) * ld;
             for (int c = c0; c < D; c += Lp) {
                 const T x0 = r0[c], x1 = r1[c];
                 if (!INV) {                               // RAHT.py:331-332
@@ -721,6 +723,8 @@ struct TopArgs {
     T *out;       int64_t ld_out;      // inv: the stage's entries, entry order (C or ws)
     int32_t *Q;   int64_t ldq;         // fused quantization
     const uint32_t *rows;              // entry -> row (nullptr: identity)
+    int io_mapped;                     // the stage's entry-ordered input / output is addressed through rows[] as well
+                                       // (a plan with a row map, raht_plan_set_row_map: entry e lives in matrix row rows[e])
     const uint32_t *e_pos;             // entry -> position in Q
     const uint32_t *pj;                // butterflies sorted by level: partner entry | own entry << 16
     const T *ab;                       // a, b per butterfly
@@ -791,7 +795,7 @@ __global__ __launch_bounds__(TOP_THREADS) void top_kernel(const TopArgs<T> A,
         for (int k = 0; k < TOP_SLOTS; ++k) {
             const int e = min(k * TOP_THREADS + tid, n - 1);
             if constexpr (!INV) {
-                x[k] = ld_chunk<RawT>((const RawT *)A.in + (int64_t)e * A.ld_in + goff);
+                x[k] = ld_chunk<RawT>((const RawT *)A.in + (int64_t)(A.io_mapped ? m_dst[k] : (uint32_t)e) * A.ld_in + goff);
             } else if constexpr (QM) {
                 x[k] = ld_chunk<RawT>((const RawT *)A.Q + (int64_t)m_dst[k] * A.ldq + goff);
             } else {
@@ -882,7 +886,7 @@ __global__ __launch_bounds__(TOP_THREADS) void top_kernel(const TopArgs<T> A,
         if (e >= n) continue;
         const V16 v = tile[e];
         if constexpr (INV) {
-            st_chunk<T>(A.out + (int64_t)e * A.ld_out + goff, v);
+            st_chunk<T>(A.out + (int64_t)(A.io_mapped ? m_dst[k] : (uint32_t)e) * A.ld_out + goff, v);
         } else {
             const uint32_t rr = m_rr[k];
             const bool to_buf = A.root_buf && rr != 0xffffffffu;   // still a low-pass value: the caller's top stage takes it
@@ -996,6 +1000,12 @@ static int launch_top_stage(const raht_plan *p, const Schedule &sc, int k, const
     else { A.fin = const_cast<T *>(io.src); A.ld_fin = io.ld_src; A.out = (k == 0) ? io.dst : ws_k; A.ld_out = (k == 0) ? io.ld_dst : D; }
     A.Q = io.Q; A.ldq = io.ldq;
     A.rows = st.rows;
+    A.io_mapped = 0;
+    if (p->row_map) {                                      // only single-stage plans carry a row map (run_transform checks)
+        if (k != 0 || st.rows || QM) { set_error("row-mapped plans run as ONE top stage without fused quantization"); return RAHT_ERR_UNSUPPORTED; }
+        A.rows = p->row_map;
+        A.io_mapped = 1;
+    }
     A.e_pos = st.rows ? st.e_pos : p->inv_order;
     A.pj = st.t_pj;
     if constexpr (sizeof(T) == 4) A.ab = (const T *)st.t_ab32; else A.ab = (const T *)st.t_ab64;
@@ -1117,29 +1127,31 @@ static int launch_stage_impl(const raht_plan *p, const Schedule &sc, int k, cons
 
 template <typename T>
 __global__ void root_rows_kernel(T *__restrict__ mat, int64_t ld, int D, const uint32_t *__restrict__ rows,
-                                 int64_t n_roots, T *__restrict__ buf, int to_buf)
+                                 int64_t n_roots, T *__restrict__ buf, int to_buf, const uint32_t *__restrict__ row_map)
 {
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= n_roots * D) return;
     const int64_t q = e / D;
     const int c = (int)(e - q * D);
-    if (to_buf) buf[e] = mat[(int64_t)rows[q] * ld + c];
-    else mat[(int64_t)rows[q] * ld + c] = buf[e];
+    const int64_t r = row_map ? (int64_t)row_map[rows[q]] : (int64_t)rows[q];
+    if (to_buf) buf[e] = mat[r * ld + c];
+    else mat[r * ld + c] = buf[e];
 }
 
 template <typename T, bool INV>
 static int run_level_engine(const raht_plan *p, const T *src, int64_t ld_src, T *dst, int64_t ld_dst,
                             int D, hipStream_t s)
 {
+    const int64_t mat_rows = p->row_map ? p->map_rows : p->N;
     if ((const void *)src != (const void *)dst) {
-        const int64_t total = p->N * D;
+        const int64_t total = mat_rows * D;
         const unsigned gb = (unsigned)std::min<int64_t>(ceil_div(total, 256), 8192);
-        hipLaunchKernelGGL(copy_rows_kernel<T>, dim3(gb), dim3(256), 0, s, src, ld_src, dst, ld_dst, p->N, D);
+        hipLaunchKernelGGL(copy_rows_kernel<T>, dim3(gb), dim3(256), 0, s, src, ld_src, dst, ld_dst, mat_rows, D);
     }
     const unsigned gr = (unsigned)ceil_div(p->n_roots * D, 256);
     if (INV && p->root_buf)
         hipLaunchKernelGGL(root_rows_kernel<T>, dim3(gr), dim3(256), 0, s, dst, ld_dst, D, p->root_rows, p->n_roots,
-                           (T *)p->root_buf, 0);
+                           (T *)p->root_buf, 0, p->row_map);
     const int lps = lp_shift_for(std::min(D, 64));
     const int gpw = 64 >> lps;
     const int top = std::min(p->max_level, p->top_level - 1);
@@ -1150,11 +1162,11 @@ static int run_level_engine(const raht_plan *p, const T *src, int64_t ld_src, T 
         const int64_t steps = ceil_div(cnt, gpw * 4);
         const unsigned gb = (unsigned)std::min<int64_t>(steps, 2048);
         hipLaunchKernelGGL((level_pass_kernel<T, INV>), dim3(gb), dim3(256), 0, s, dst, ld_dst, D,
-                           p->level_rows + p->level_off[l], cnt, p->wl, p->wr, p->wsum, lps);
+                           p->level_rows + p->level_off[l], cnt, p->wl, p->wr, p->wsum, lps, p->row_map);
     }
     if (!INV && p->root_buf)
         hipLaunchKernelGGL(root_rows_kernel<T>, dim3(gr), dim3(256), 0, s, dst, ld_dst, D, p->root_rows, p->n_roots,
-                           (T *)p->root_buf, 1);
+                           (T *)p->root_buf, 1, p->row_map);
     RAHT_HIP_CHECK(hipGetLastError());
     return RAHT_OK;
 }
@@ -1164,6 +1176,10 @@ template <typename T>
 static int tile_setup(raht_plan *p, int D, int64_t max_ld, hipStream_t s, Schedule **sc_out, int *Dc_out)
 {
     *sc_out = nullptr;
+    if (p->row_map && p->N > RAHT_TOP_MAX_ROWS) {
+        set_error("row-mapped plans hold at most %d rows (they run as one top stage)", RAHT_TOP_MAX_ROWS);
+        return RAHT_ERR_UNSUPPORTED;
+    }
     if (p->engine == RAHT_ENGINE_LEVEL) return RAHT_OK;
     if (max_ld > ((int64_t)1 << 18)) return RAHT_OK;  // row_at(): 32-bit byte offsets inside a tile; wider strides: level engine
     if (D < 16 / (int)sizeof(T)) return RAHT_OK;      // rows shorter than one 16-byte chunk: level engine
@@ -1173,6 +1189,7 @@ static int tile_setup(raht_plan *p, int D, int64_t max_ld, hipStream_t s, Schedu
     Schedule *sc = nullptr;
     int R1 = 0, Dc1 = 0, Rf = 0;
     pick_tail_geometry(p, (int)sizeof(T), D, R, &R1, &Dc1, &Rf);
+    if (p->row_map) Rf = RAHT_TOP_MAX_ROWS;           // ONE top stage (the only kernel that addresses rows through the map)
     RAHT_RET(get_schedule(p, R, R1, Rf, s, &sc));
     if (!sc->valid) return RAHT_OK;                   // pathological key pattern, see plan.hip
     RAHT_RET(ensure_workspace(sc, (size_t)D * sizeof(T)));
@@ -1204,6 +1221,7 @@ static int run_transform(const raht_plan *cp, const T *src, int64_t ld_src, int 
             rc = launch_tile_stage<T, INV, false>(p, *sc, k, io, D, Dc, s);
         }
     }
+    if (rc == RAHT_OK && w && p->row_map) { set_error("node weights are not available from a row-mapped plan"); return RAHT_ERR_UNSUPPORTED; }
     if (rc == RAHT_OK && w) {
         hipLaunchKernelGGL(node_weight_kernel<T>, dim3((unsigned)ceil_div(p->N, 256)), dim3(256), 0, s,
                            p->wl, p->wr, p->wsum, p->N, w);
@@ -1260,6 +1278,7 @@ static int fwd_quant_impl(const raht_plan *cp, const float *C, int64_t ldc, int 
     hipStream_t s = (hipStream_t)stream;
     if (!p || !C || !Q || D < 1 || ldc < D || ldq < D) { set_error("raht_fwd_quant: bad argument"); return RAHT_ERR_INVALID; }
     RAHT_RET(check_plan_device(p, "raht_fwd_quant"));
+    if (p->row_map) { set_error("raht_fwd_quant: not available for a row-mapped plan"); return RAHT_ERR_UNSUPPORTED; }
     RAHT_RET(check_steps(steps, n_steps, D));
     Schedule *sc = nullptr;
     int Dc = 0;
@@ -1293,6 +1312,7 @@ static int dequant_inv_impl(const raht_plan *cp, const int32_t *Q, int64_t ldq, 
     hipStream_t s = (hipStream_t)stream;
     if (!p || !C || !Q || D < 1 || ldc < D || ldq < D) { set_error("raht_dequant_inv: bad argument"); return RAHT_ERR_INVALID; }
     RAHT_RET(check_plan_device(p, "raht_dequant_inv"));
+    if (p->row_map) { set_error("raht_dequant_inv: not available for a row-mapped plan"); return RAHT_ERR_UNSUPPORTED; }
     RAHT_RET(check_steps(steps, n_steps, D));
     Schedule *sc = nullptr;
     int Dc = 0;

@@ -266,6 +266,18 @@ int raht_sort_keys(const uint64_t *keys_in, int64_t N, int nbits, uint64_t *keys
     return rc;
 }
 
+int raht_voxel_keys(const float *PC, int64_t ldpc, int64_t N, const float vmin[3], double width, int J,
+                    uint64_t *keys, raht_stream_t stream)
+{
+    if (!PC || !keys || !vmin || N < 0 || ldpc < 3 || J < 1 || J > 21 || !(width > 0)) { set_error("raht_voxel_keys: bad argument"); return RAHT_ERR_INVALID; }
+    if (N == 0) return RAHT_OK;
+    const float vs = (float)(width / (double)((uint64_t)1 << J));        // voxelize_pc.py:97, as raht_voxelize
+    hipLaunchKernelGGL(vox_keys_kernel, dim3((unsigned)ceil_div(N, 256)), dim3(256), 0, (hipStream_t)stream, PC, ldpc, N,
+                       vmin[0], vmin[1], vmin[2], vs, J, keys);
+    RAHT_HIP_CHECK(hipGetLastError());
+    return RAHT_OK;
+}
+
 int raht_voxelize(const float *PC, int64_t ldpc, int64_t N, int d, const float *vmin_in, double width_in,
                   int J, uint64_t *keys_sorted, int64_t *sort_idx, int64_t *voxel_indices, float *PCvox,
                   int64_t *Vvox, int64_t *n_vox, float vmin_out[3], double *width_out,

@@ -60,6 +60,7 @@ class RahtPlan:
         self._order = None
         self._inv_order = None
         self._roots = None
+        self.map_rows = None             # rows of the matrices of a row-mapped plan (set_row_map)
 
     @property
     def inv_order(self):
@@ -190,6 +191,13 @@ class RahtPlan:
             weights.append(torch.from_numpy(w))
         return List, Flags, weights
 
+    def keys_tensor(self):
+        """The plan's sorted Morton keys as an int64 device tensor (a copy)."""
+        t = torch.empty(self.N, dtype=torch.int64, device=self.device)
+        with torch.cuda.device(self.device):
+            check(_lib.lib().raht_plan_copy_array(self._h, 0, C.c_void_p(t.data_ptr()), _stream()))
+        return t
+
     def arrays(self):
         """(keys, lvl, wl, wr) copied to CPU numpy arrays (inspection / tests)."""
         import numpy as np
@@ -211,16 +219,20 @@ class RahtPlan:
         return dict(valid=n.value > 0, tile_rows=tr.value, rows_per_stage=[int(rows[i]) for i in range(k)])
 
     # -- transforms -----------------------------------------------------------------------------
-    def _xform(self, X, inverse, want_w=False, roots=None):
+    def _xform(self, X, inverse, want_w=False, roots=None, out=None):
         _need_cuda(X, "C" if not inverse else "T")
-        if X.dim() != 2 or X.shape[0] != self.N:
-            raise ValueError(f"expected ({self.N}, D) tensor, got {tuple(X.shape)}")
+        rows = self.N if self.map_rows is None else self.map_rows
+        if X.dim() != 2 or X.shape[0] != rows:
+            raise ValueError(f"expected ({rows}, D) tensor, got {tuple(X.shape)}")
         if X.dtype not in (torch.float32, torch.float64):
             X = X.to(torch.float32)
         if X.stride(1) != 1 or X.stride(0) < X.shape[1]:
             X = X.contiguous()
         D = X.shape[1]
-        out = torch.empty((self.N, D), dtype=X.dtype, device=X.device)
+        if out is None:
+            out = torch.empty((rows, D), dtype=X.dtype, device=X.device)
+        elif out.dtype != X.dtype or tuple(out.shape) != (rows, D) or not out.is_contiguous() or out.device != X.device:
+            raise ValueError(f"out must be a contiguous ({rows}, {D}) {X.dtype} tensor on {X.device}")
         w = torch.empty((self.N, 1), dtype=X.dtype, device=X.device) if want_w else None
         L = _lib.lib()
         f64 = X.dtype == torch.float64
@@ -243,19 +255,32 @@ class RahtPlan:
                 check(fn(self._h, C.c_void_p(X.data_ptr()), X.stride(0), D, C.c_void_p(out.data_ptr()), D,
                          _stream()))
 
-    def forward(self, Cmat, want_w=True, roots=None):
-        """roots: optional (n_roots, D) output buffer receiving the rows that still carry a low-pass."""
-        return self._xform(Cmat, False, want_w, roots)
+    def forward(self, Cmat, want_w=True, roots=None, out=None):
+        """roots: optional (n_roots, D) output buffer receiving the rows that still carry a low-pass;
+        out: optional preallocated result matrix."""
+        return self._xform(Cmat, False, want_w, roots, out)
 
-    def inverse(self, T, roots=None):
+    def inverse(self, T, roots=None, out=None):
         """roots: optional (n_roots, D) buffer the root rows are read from instead of T."""
-        return self._xform(T, True, False, roots)
+        return self._xform(T, True, False, roots, out)
 
     def prepare(self, D, dtype=torch.float32):
         """Pre-build schedule + workspaces so later calls only enqueue kernels (hipGraph-safe)."""
         es = 8 if dtype == torch.float64 else 4
         with torch.cuda.device(self.device):
             check(_lib.lib().raht_plan_prepare(self._h, es, int(D), _stream()))
+
+    def set_row_map(self, row_map, n_matrix_rows):
+        """Plan row i lives in row ``row_map[i]`` of the (n_matrix_rows, D) matrices given to forward / inverse
+        (small plans: the replicated top tree of a sharded scene works in place on the padded all-gather buffer)."""
+        with torch.cuda.device(self.device):
+            if row_map is None:
+                check(_lib.lib().raht_plan_set_row_map(self._h, None, 0, _stream()))
+                self.map_rows = None
+                return
+            m = row_map.to(device=self.device, dtype=torch.int64).contiguous()
+            check(_lib.lib().raht_plan_set_row_map(self._h, C.c_void_p(m.data_ptr()), int(n_matrix_rows), _stream()))
+        self.map_rows = int(n_matrix_rows)
 
     def set_max_stages(self, max_stages):
         """Bound on the launches per direction of the tile schedule; above it the level engine runs."""
@@ -379,19 +404,43 @@ def quant_rows(X, steps, pos, Q):
     return Q
 
 
-def dequant_rows(Q, steps, pos):
-    """-> float32 (n, D): Q[pos[i], :] * step."""
+def dequant_rows(Q, steps, pos, out=None):
+    """-> float32 (n, D): Q[pos[i], :] * step (written into ``out`` when given: a contiguous float32 (n, D) view)."""
     _need_cuda(Q, "Q")
     if Q.dtype != torch.int32 or Q.stride(1) != 1:
         raise ValueError("Q must be an int32 matrix with contiguous rows")
     D = Q.shape[1]
     st = _steps(steps, D)
     pos = pos.to(torch.int64).contiguous()
-    X = torch.empty((pos.shape[0], D), dtype=torch.float32, device=Q.device)
+    X = torch.empty((pos.shape[0], D), dtype=torch.float32, device=Q.device) if out is None else out
+    if X.dtype != torch.float32 or tuple(X.shape) != (pos.shape[0], D) or not X.is_contiguous():
+        raise ValueError("out must be a contiguous float32 (n, D) tensor")
     with torch.cuda.device(Q.device):
         check(_lib.lib().raht_dequant_rows(C.c_void_p(Q.data_ptr()), Q.stride(0), C.c_void_p(pos.data_ptr()), pos.shape[0], D,
                                            st, len(st), C.c_void_p(X.data_ptr()), D, _stream()))
     return X
+
+
+def _rows_move(fn, src, pos, dst):
+    _need_cuda(src, "src")
+    if src.dtype != dst.dtype or src.dtype not in (torch.float32, torch.float64, torch.int32) or src.stride(1) != 1 or dst.stride(1) != 1:
+        raise ValueError("rows: float32 / float64 / int32 matrices with contiguous rows of one dtype")
+    if pos.dtype != torch.int64 or not pos.is_contiguous():
+        pos = pos.to(torch.int64).contiguous()
+    with torch.cuda.device(src.device):
+        check(fn(C.c_void_p(src.data_ptr()), src.stride(0), C.c_void_p(pos.data_ptr()), pos.shape[0], src.shape[1],
+                 src.element_size(), C.c_void_p(dst.data_ptr()), dst.stride(0), _stream()))
+    return dst
+
+
+def rows_gather(src, pos, out):
+    """out[i, :] = src[pos[i], :] in one launch (pos int64 (n,))."""
+    return _rows_move(_lib.lib().raht_rows_gather, src, pos, out)
+
+
+def rows_scatter(src, pos, out):
+    """out[pos[i], :] = src[i, :] in one launch."""
+    return _rows_move(_lib.lib().raht_rows_scatter, src, pos, out)
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -469,6 +518,21 @@ def get_morton_code(V, J):
     with torch.cuda.device(V.device):
         check(_lib.lib().raht_morton(C.c_void_p(V.data_ptr()), V.shape[0], int(J), C.c_void_p(out.data_ptr()),
                                      _stream()))
+    return out
+
+
+@torch.no_grad()
+def voxel_keys(PC, vmin, width, J):
+    """Unsorted 3J-bit Morton keys (int64) of the points of PC (n, >= 3) float32 for a given bounding box: the
+    voxelizer's first phase (reference python/voxelize_pc.py:92-100)."""
+    _need_cuda(PC, "PC")
+    if PC.dtype != torch.float32 or PC.stride(1) != 1:
+        PC = PC.to(torch.float32).contiguous()
+    out = torch.empty(PC.shape[0], dtype=torch.int64, device=PC.device)
+    vm = (C.c_float * 3)(*[float(x) for x in vmin])
+    with torch.cuda.device(PC.device):
+        check(_lib.lib().raht_voxel_keys(C.c_void_p(PC.data_ptr()), PC.stride(0), PC.shape[0], vm, float(width), int(J),
+                                         C.c_void_p(out.data_ptr()), _stream()))
     return out
 
 

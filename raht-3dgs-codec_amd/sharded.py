@@ -8,9 +8,25 @@ rows (<= 512 x D floats ~ 121 KB at D = 59: latency-bound on xGMI) lets every GP
 the top 9 binary levels on a weighted <= 512-row tree and keep the coefficients of its own prefixes.
 The inverse mirrors it: gather the top coefficients, invert the top tree, continue shard-locally.
 
+What one direction of a step enqueues besides the shard-local transform -- nothing else, no torch ops:
+
+    forward   local kernels write their root rows STRAIGHT into this rank's slot of the send buffer
+              -> all_gather_into_tensor (padded slots of max_roots rows per rank)
+              -> ONE launch of the replicated top tree, in place on the padded gather buffer (row map)
+              -> ONE launch that quantizes this rank's top coefficients into their places in Q
+                 (or scatters them into T)
+    inverse   ONE launch dequantizes (gathers) this rank's top coefficients into the send buffer
+              -> all_gather_into_tensor -> ONE launch of the top tree
+              -> local kernels read their roots straight from this rank's slot of the result
+
 One process per GPU, ``torch.distributed`` (backend "nccl" = RCCL on ROCm; "gloo" in the CPU tests).
 The shard-local work goes through the C ABI (``ops.RahtPlan``); ``local_ops`` lets the CPU tests
 inject a reference implementation of the same interface -- the product default has no CPU path.
+
+Un-partitioned input (every rank holds an arbitrary part of the cloud): ``exchange_by_prefix`` is the
+distributed counterpart of the reference's single ``torch.sort`` (python/voxelize_pc.py:97-118): global
+bounding box, 512-bin prefix histogram, balanced cuts, ONE all-to-all of the points by destination rank,
+then the local voxelizer (stable radix sort + per-voxel mean) on what arrived.
 """
 import torch
 
@@ -18,6 +34,30 @@ import torch
 def _dist():
     import torch.distributed as dist
     return dist if dist.is_available() and dist.is_initialized() else None
+
+
+def cuts_from_histogram(hist, world):
+    """Prefix boundaries [0 = c_0 <= c_1 <= ... <= c_world = len(hist)] that balance the row counts of
+    ``world`` contiguous prefix ranges: rank r owns prefixes [c_r, c_{r+1})."""
+    cum = torch.cumsum(hist.to(torch.int64), 0).cpu().tolist()                    # rows with prefix <= p
+    nb = len(cum)
+    N = cum[-1] if cum else 0
+    cuts, lo = [0], 0
+    for r in range(1, world):
+        target = N * r / world
+        # the prefix boundary whose row count is closest to the target, never moving backwards
+        best, best_err = lo, None
+        for p in range(lo, nb + 1):
+            rows_below = cum[p - 1] if p > 0 else 0
+            err = abs(rows_below - target)
+            if best_err is None or err < best_err:
+                best, best_err = p, err
+            if rows_below > target:
+                break
+        lo = best
+        cuts.append(best)
+    cuts.append(nb)
+    return cuts
 
 
 def balanced_prefix_cuts(keys_sorted, nbits, world, prefix_bits=9):
@@ -28,23 +68,12 @@ def balanced_prefix_cuts(keys_sorted, nbits, world, prefix_bits=9):
     N = int(keys_sorted.shape[0])
     nb = 1 << prefix_bits
     pref = (keys_sorted.to(torch.int64) >> (nbits - prefix_bits)).clamp_(0, nb - 1)
-    cum = torch.cumsum(torch.bincount(pref, minlength=nb), 0).cpu().tolist()     # rows with prefix <= p
-    cuts, lo = [0], 0
-    for r in range(1, world):
-        target = N * r / world
-        # the prefix boundary whose row count is closest to the target, never moving backwards
-        best, best_err = lo, None
-        for p in range(lo, nb):
-            rows_below = cum[p - 1] if p > 0 else 0
-            err = abs(rows_below - target)
-            if best_err is None or err < best_err:
-                best, best_err = p, err
-            if rows_below > target:
-                break
-        lo = best
-        cuts.append(cum[best - 1] if best > 0 else 0)
-    cuts.append(N)
-    return cuts
+    hist = torch.bincount(pref, minlength=nb)
+    pc = cuts_from_histogram(hist, world)
+    cum = [0] + torch.cumsum(hist, 0).cpu().tolist()
+    out = [cum[p] for p in pc]
+    out[-1] = N
+    return out
 
 
 class HipLocalOps:
@@ -63,9 +92,36 @@ class HipLocalOps:
         return quant_rows(X, step, pos, Q)
 
     @staticmethod
-    def dequant_rows(Q, step, pos):
+    def dequant_rows(Q, step, pos, out):
         from .ops import dequant_rows
-        return dequant_rows(Q, step, pos)
+        return dequant_rows(Q, step, pos, out=out)
+
+    @staticmethod
+    def rows_gather(src, pos, out):
+        from .ops import rows_gather
+        return rows_gather(src, pos, out)
+
+    @staticmethod
+    def rows_scatter(src, pos, out):
+        from .ops import rows_scatter
+        return rows_scatter(src, pos, out)
+
+    # front end (exchange_by_prefix)
+    @staticmethod
+    def voxel_keys(PC, vmin, width, J):
+        from .ops import voxel_keys
+        return voxel_keys(PC, vmin, width, J)
+
+    @staticmethod
+    def sort_keys(keys, nbits):
+        from .ops import sort_keys
+        return sort_keys(keys, nbits)
+
+    @staticmethod
+    def voxelize(PC, vmin, width, J):
+        from .ops import voxelize_pc_batched
+        PCvox, _, vidx, _, info = voxelize_pc_batched(PC, vmin, width, J, device=PC.device, residuals=False, sorted_points=False)
+        return PCvox, info["keys_sorted"][vidx], vidx, info
 
 
 class ShardedRaht:
@@ -91,95 +147,109 @@ class ShardedRaht:
         pref = (keys_sorted[self.root_rows] >> (self.nbits - self.prefix_bits)).to(torch.int64)
         ends = torch.cat([self.root_rows[1:], torch.tensor([self.N], dtype=torch.int64, device=dev)])
         counts = (ends - self.root_rows).to(torch.int64)
-        # exchange the root directory once (prefix id + leaf count per root)
-        self.max_roots = 1 << self.prefix_bits
-        self._pads, self._valid_idx, self._root_pos = {}, None, None
-        sizes = self._all_gather_rows(torch.tensor([[self.n_roots]], dtype=torch.int64, device=dev), 1).reshape(-1)
+        # ---- one-off exchange of the root directory: (prefix id, leaf count) per root, padded slots ----
+        sizes = self._all_gather(torch.tensor([[self.n_roots]], dtype=torch.int64, device=dev)).reshape(-1)
         self.sizes = [int(x) for x in sizes.tolist()]
-        self.offset = sum(self.sizes[:self.rank])
-        allpref = self._gather_var(pref.reshape(-1, 1)).reshape(-1)
-        allcnt = self._gather_var(counts.reshape(-1, 1)).reshape(-1)
+        self.slot = max(self.sizes)                             # rows per rank in the gather buffers
+        self.offset = sum(self.sizes[:self.rank])               # this rank's first entry in the top tree
+        directory = torch.zeros((self.slot, 2), dtype=torch.int64, device=dev)
+        directory[: self.n_roots, 0] = pref
+        directory[: self.n_roots, 1] = counts
+        alld = self._all_gather(directory)                      # (world * slot, 2)
+        valid = [r * self.slot + i for r in range(self.world) for i in range(self.sizes[r])]
+        vidx = torch.tensor(valid, dtype=torch.int64, device=dev)
+        allpref, allcnt = alld[vidx, 0].contiguous(), alld[vidx, 1].contiguous()
         if allpref.numel() > 1 and not bool((allpref[1:] > allpref[:-1]).all()):
             raise ValueError("shards must own disjoint, increasing Morton-prefix ranges")
         self.total_rows = int(allcnt.sum().item())
-        # the top tree: <= 2^prefix_bits weighted leaves, replicated on every rank
-        self.top = self.ops.make_plan(allpref.contiguous(), self.prefix_bits, leaf_weights=allcnt.contiguous())
+        # ---- the top tree: <= 2^prefix_bits weighted leaves, replicated on every rank, working IN PLACE on the
+        # padded gather buffer: entry e of the tree lives in buffer row vidx[e] ----
+        self.top = self.ops.make_plan(allpref, self.prefix_bits, leaf_weights=allcnt)
+        self.gather_rows = self.world * self.slot
+        if self.world > 1:
+            self.top.set_row_map(vidx, self.gather_rows)
+        self._bufs = {}
+        self._root_pos = None
 
     # ---- collectives ------------------------------------------------------------------------------
-    def _all_gather_rows(self, x, rows):
+    def _all_gather(self, x, out=None):
         """all-gather a (rows, cols) tensor -> (world * rows, cols)."""
         if self.world == 1:
             return x
+        rows = x.shape[0]
         if x.is_cuda and self.dist.get_backend(self.group) == "gloo":
             # test / debugging configuration (several ranks sharing one GPU): stage through the host
-            xc = x.contiguous().cpu()
             outc = torch.empty((self.world * rows, x.shape[1]), dtype=x.dtype)
-            self.dist.all_gather_into_tensor(outc, xc, group=self.group)
-            return outc.to(x.device)
-        out = torch.empty((self.world * rows, x.shape[1]), dtype=x.dtype, device=x.device)
-        self.dist.all_gather_into_tensor(out, x.contiguous(), group=self.group)
+            self.dist.all_gather_into_tensor(outc, x.contiguous().cpu(), group=self.group)
+            if out is None:
+                return outc.to(x.device)
+            out.copy_(outc)
+            return out
+        if out is None:
+            out = torch.empty((self.world * rows, x.shape[1]), dtype=x.dtype, device=x.device)
+        self.dist.all_gather_into_tensor(out, x, group=self.group)
         return out
 
-    def _gather_var(self, x):
-        """all-gather per-rank row blocks of different heights: pad to the largest block, ONE
-        all-gather, then one index_select with a precomputed index picks the valid rows."""
-        if self.world == 1:
-            return x
-        m = max(self.sizes)
-        key = (x.dtype, x.shape[1])
-        pad = self._pads.get(key)
-        if pad is None:
-            pad = torch.zeros((m, x.shape[1]), dtype=x.dtype, device=x.device)
-            self._pads[key] = pad
-        pad[: x.shape[0]].copy_(x)
-        allp = self._all_gather_rows(pad, m)
-        if self._valid_idx is None:
-            idx = [r * m + i for r in range(self.world) for i in range(self.sizes[r])]
-            self._valid_idx = torch.tensor(idx, dtype=torch.int64, device=x.device)
-        return allp.index_select(0, self._valid_idx)
-
-    def _mine(self, allrows):
-        return allrows[self.offset: self.offset + self.n_roots].contiguous()
-
-    # ---- transforms ------------------------------------------------------------------------------
-    def forward(self, C):
-        """-> T_local: every row holds its coefficient of the WHOLE scene's RAHT."""
-        roots = torch.empty((self.n_roots, C.shape[1]), dtype=C.dtype, device=C.device)
-        T = self.plan.forward(C, want_w=False, roots=roots)
-        top = self.top.forward(self._gather_var(roots), want_w=False)
-        T[self.root_rows] = self._mine(top)
-        return T
-
-    def inverse(self, T):
-        low = self.top.inverse(self._gather_var(T[self.root_rows].contiguous()))
-        return self.plan.inverse(T, roots=self._mine(low))
-
-    def forward_quant(self, C, step):
-        """-> Q_local (int32, rank-local order_RAGFT order); the top coefficients are quantized too."""
-        roots = torch.empty((self.n_roots, C.shape[1]), dtype=self.qdt, device=C.device)
-        Q = self.plan.forward_quant(C, step, roots=roots)
-        top = self._mine(self.top.forward(self._gather_var(roots), want_w=False))
-        if hasattr(self.ops, "quant_rows"):
-            self.ops.quant_rows(top, step, self._root_positions(), Q)
-        else:
-            # a tensor divisor: torch turns division by a Python scalar into a multiplication by 1 / step
-            # on the GPU, which rounds differently from the kernels' IEEE division next to a tie
-            st = torch.as_tensor(step, dtype=top.dtype, device=top.device)
-            Q[self._root_positions()] = torch.floor(top / st + 0.5).to(torch.int32)
-        return Q
+    def _buffers(self, D, dtype):
+        """send (slot x D: this rank's roots), recv (world * slot x D: everybody's), res (the top tree's output, same
+        layout) -- allocated once per (D, dtype). With one rank the three coincide in size and no collective runs."""
+        key = (int(D), dtype)
+        b = self._bufs.get(key)
+        if b is None:
+            mk = lambda rows: torch.zeros((rows, D), dtype=dtype, device=self.device)    # noqa: E731
+            send = mk(self.slot)
+            recv = mk(self.gather_rows) if self.world > 1 else send
+            res = mk(self.gather_rows)
+            lo = self.rank * self.slot
+            b = dict(send=send, send_roots=send[: self.n_roots], recv=recv, res=res, mine=res[lo: lo + self.n_roots])
+            self._bufs[key] = b
+        return b
 
     def _root_positions(self):
         if self._root_pos is None:
             self._root_pos = self.plan.inv_order[self.root_rows].contiguous()
         return self._root_pos
 
+    def gathered_bytes_per_step(self, D, elem=4):
+        """bytes every rank receives per direction x 2 directions"""
+        return 2 * self.gather_rows * D * elem if self.world > 1 else 0
+
+    # ---- transforms ------------------------------------------------------------------------------
+    def _top_forward(self, b):
+        self._all_gather(b["send"], out=b["recv"])
+        self.top.forward(b["recv"], want_w=False, out=b["res"])
+
+    def _top_inverse(self, b):
+        self._all_gather(b["send"], out=b["recv"])
+        self.top.inverse(b["recv"], out=b["res"])
+
+    def forward(self, C):
+        """-> T_local: every row holds its coefficient of the WHOLE scene's RAHT."""
+        b = self._buffers(C.shape[1], C.dtype)
+        T = self.plan.forward(C, want_w=False, roots=b["send_roots"])
+        self._top_forward(b)
+        self.ops.rows_scatter(b["mine"], self.root_rows, T)
+        return T
+
+    def inverse(self, T):
+        b = self._buffers(T.shape[1], T.dtype)
+        self.ops.rows_gather(T, self.root_rows, b["send_roots"])
+        self._top_inverse(b)
+        return self.plan.inverse(T, roots=b["mine"])
+
+    def forward_quant(self, C, step):
+        """-> Q_local (int32, rank-local order_RAGFT order); the top coefficients are quantized too."""
+        b = self._buffers(C.shape[1], self.qdt)
+        Q = self.plan.forward_quant(C, step, roots=b["send_roots"])
+        self._top_forward(b)
+        self.ops.quant_rows(b["mine"], step, self._root_positions(), Q)
+        return Q
+
     def dequant_inverse(self, Q, step):
-        if hasattr(self.ops, "dequant_rows"):
-            roots_c = self.ops.dequant_rows(Q, step, self._root_positions())
-        else:
-            roots_c = (Q[self._root_positions()].to(self.qdt) * step).contiguous()
-        low = self.top.inverse(self._gather_var(roots_c))
-        return self.plan.dequant_inverse(Q, step, roots=self._mine(low))
+        b = self._buffers(Q.shape[1], self.qdt)
+        self.ops.dequant_rows(Q, step, self._root_positions(), b["send_roots"])
+        self._top_inverse(b)
+        return self.plan.dequant_inverse(Q, step, roots=b["mine"])
 
     # ---- bench helpers -----------------------------------------------------------------------------
     def step(self, C, quant_step=None):
@@ -190,3 +260,127 @@ class ShardedRaht:
     def roundtrip_error(self, C):
         R = self.inverse(self.forward(C))
         return float(((R - C).abs().max() / C.abs().max()).item())
+
+    def _gather_var(self, x):
+        """one-off (verification): all-gather row blocks of different heights -> the concatenation in rank order"""
+        if self.world == 1:
+            return x
+        n = self._all_gather(torch.tensor([[x.shape[0]]], dtype=torch.int64, device=x.device)).reshape(-1).tolist()
+        m = int(max(n))
+        pad = torch.zeros((m, x.shape[1]), dtype=x.dtype, device=x.device)
+        pad[: x.shape[0]] = x
+        allp = self._all_gather(pad)
+        return torch.cat([allp[r * m: r * m + int(n[r])] for r in range(self.world)], dim=0)
+
+    def check_against_unsharded(self, C, quant_step=None, keys_sorted=None):
+        """Correctness gate for a multi-rank run (not on the timed path): gather the whole scene, transform it
+        UNSHARDED on this rank, and compare this rank's rows with what the sharded path produced.
+        float32: |dT| <= 4e-6 * column max (the top levels are evaluated in another order); integers: the same
+        coefficient-error bound as bench.py's oracle gate."""
+        keys = self.plan_keys() if keys_sorted is None else keys_sorted
+        allk = self._gather_var(keys.reshape(-1, 1).to(torch.int64)).reshape(-1).contiguous()
+        allC = self._gather_var(C)
+        n_before = int(self._all_gather(torch.tensor([[self.N]], dtype=torch.int64, device=C.device)).reshape(-1)[: self.rank].sum().item()) if self.world > 1 else 0
+        full = self.ops.make_plan(allk, self.nbits)
+        Tf = full.forward(allC, want_w=False)
+        mine = slice(n_before, n_before + self.N)
+        T = self.forward(C)
+        colmax = Tf.abs().amax(dim=0).clamp_min(1e-30)
+        rel = float(((T - Tf[mine]).abs().amax(dim=0) / colmax).max().item())
+        out = {"kind": "sharded == unsharded (whole scene gathered and transformed on every rank)", "rows_total": int(allk.shape[0]),
+               "max_rel_err_T_vs_unsharded": rel, "ok": rel <= 4e-6}
+        if quant_step is not None:
+            Q = self.forward_quant(C, quant_step)
+            Tq = torch.empty_like(T)
+            Tq[self.plan.order_RAGFT] = Q.to(T.dtype) * quant_step
+            # dequantized integers sit within half a step (+ the coefficient error) of the unsharded coefficients
+            worst = float(((Tq - Tf[mine]).abs() - 4e-6 * colmax).max().item())
+            out["max_dequantized_distance_over_step"] = worst / quant_step
+            out["ok"] = out["ok"] and worst <= 0.5 * quant_step * 1.0001
+            R = self.dequant_inverse(Q, quant_step)
+            out["quantized_roundtrip_max_err_over_step"] = float((R - C).abs().max().item()) / quant_step
+        if self.world > 1:
+            flag = torch.tensor([[1 if out["ok"] else 0]], dtype=torch.int64, device=C.device)
+            out["ok"] = bool(self._all_gather(flag).min().item() == 1)
+        return out
+
+    def plan_keys(self):
+        ks = getattr(self.plan, "keys_tensor", None)
+        if ks is None:
+            raise ValueError("pass keys_sorted")
+        return ks()
+
+
+# ---------------------------------------------------------------------------------------------------
+# front end for un-partitioned input: all-to-all by Morton prefix + local voxelizer
+# ---------------------------------------------------------------------------------------------------
+def exchange_by_prefix(PC, J, prefix_bits=9, vmin=None, width=None, group=None, local_ops=None):
+    """Every rank holds an ARBITRARY part of the cloud: PC (n_r, 3 + d) float32, positions first. Returns this
+    rank's Morton-prefix shard, voxelized: (PCvox (Nvox_r, 3 + d), keys (Nvox_r,) sorted unique int64, info).
+
+    The concatenation of the shards over the ranks equals what the single-GPU voxelizer
+    (``voxelize_pc_batched``, reference python/voxelize_pc.py:62-172) produces for the concatenation of the
+    inputs in rank order, bit for bit: the bounding box is global, every voxel's points end up on one rank in
+    their global order (the all-to-all delivers source ranks in order, the radix sort is stable), and the
+    per-voxel mean is sequential in that order."""
+    ops = local_ops or HipLocalOps
+    dist = _dist()
+    world = dist.get_world_size(group) if dist else 1
+    dev = PC.device
+    gloo_staged = bool(dist and PC.is_cuda and dist.get_backend(group) == "gloo")
+
+    def allreduce(t, op):
+        if world == 1:
+            return t
+        if gloo_staged:
+            c = t.cpu(); dist.all_reduce(c, op=op, group=group); return c.to(dev)
+        dist.all_reduce(t, op=op, group=group)
+        return t
+
+    # ---- global bounding box (voxelize_pc.py:87-95: per-axis minimum, ONE scalar width = max extent) ----
+    xyz = PC[:, :3]
+    if vmin is None:
+        lo = xyz.amin(dim=0) if PC.shape[0] else torch.full((3,), float("inf"), device=dev)
+        vmin_t = allreduce(lo.clone(), dist.ReduceOp.MIN if dist else None)
+    else:
+        vmin_t = torch.as_tensor(vmin, dtype=torch.float32, device=dev)
+    if width is None:
+        hi = (xyz - vmin_t).amax() if PC.shape[0] else torch.tensor(float("-inf"), device=dev)
+        width = float(allreduce(hi.reshape(1).clone(), dist.ReduceOp.MAX if dist else None).item())
+    vmin_l = [float(v) for v in vmin_t.tolist()]
+    nbits = 3 * J
+    # ---- keys, 2^prefix_bits-bin population histogram, balanced prefix cuts (same on every rank) ----
+    keys = ops.voxel_keys(PC, vmin_l, width, J)
+    nb = 1 << prefix_bits
+    pref = (keys >> (nbits - prefix_bits)).clamp(0, nb - 1) if nbits > prefix_bits else keys.clamp(0, nb - 1)
+    hist = allreduce(torch.bincount(pref, minlength=nb), dist.ReduceOp.SUM if dist else None)
+    cuts = cuts_from_histogram(hist, world)                  # rank r owns prefixes [cuts[r], cuts[r+1])
+    info = {"vmin": vmin_t, "width": width, "voxel_size": width / (1 << J), "prefix_cuts": cuts, "N_global": int(hist.sum().item())}
+    if world == 1:
+        mine = PC
+    else:
+        # ---- bucket the points by destination rank (stable), ONE all-to-all of the rows ----
+        dest = torch.bucketize(pref, torch.tensor(cuts[1:-1], dtype=pref.dtype, device=dev), right=True)
+        _, perm = ops.sort_keys(dest, max(1, (world - 1).bit_length()))      # stable: keeps the local order per bucket
+        send = torch.empty_like(PC)
+        ops.rows_gather(PC, perm, send)
+        scnt = torch.bincount(dest, minlength=world)
+        if gloo_staged:
+            scnt_c = scnt.cpu(); rcnt_c = torch.empty_like(scnt_c)
+            dist.all_to_all_single(rcnt_c, scnt_c, group=group)
+            ss, rs = scnt_c.tolist(), rcnt_c.tolist()
+            recv_c = torch.empty((sum(rs), PC.shape[1]), dtype=PC.dtype)
+            dist.all_to_all_single(recv_c, send.cpu(), output_split_sizes=rs, input_split_sizes=ss, group=group)
+            mine = recv_c.to(dev)
+        else:
+            rcnt = torch.empty_like(scnt)
+            dist.all_to_all_single(rcnt, scnt, group=group)
+            ss, rs = scnt.tolist(), rcnt.tolist()
+            mine = torch.empty((sum(rs), PC.shape[1]), dtype=PC.dtype, device=dev)
+            dist.all_to_all_single(mine, send, output_split_sizes=rs, input_split_sizes=ss, group=group)
+        info["sent_rows"], info["received_rows"] = ss, rs
+    if mine.shape[0] == 0:
+        return mine, torch.empty(0, dtype=torch.int64, device=dev), info
+    PCvox, vkeys, _, vinfo = ops.voxelize(mine, vmin_l, width, J)
+    info["Nvox_local"] = int(PCvox.shape[0])
+    return PCvox, vkeys, info

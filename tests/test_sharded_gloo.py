@@ -101,6 +101,79 @@ def test_sharded_matches_unsharded_oracle(world, J, n, D, balanced):
         assert msg == "ok", f"rank {rank}:\n{msg}"
 
 
+def _worker_frontend(rank, world, port, J, n, d, q):
+    """Un-partitioned input: every rank holds an arbitrary third / half of an unsorted cloud with duplicates.
+    exchange_by_prefix + ShardedRaht must reproduce the single-process pipeline on the WHOLE cloud:
+    oracle voxelizer (reference voxelize_pc.py:62-172) -> oracle RAHT."""
+    try:
+        sys.path.insert(0, ROOT)
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        from raht_3dgs_codec_amd import sharded, synth
+        from tests.numpy_ops import NumpyLocalOps
+        from oracle import oracle as orc
+
+        rng = np.random.default_rng(123)
+        P = synth.blob_positions(n, seed=9, nblobs=12, sigma=0.05).astype(np.float32) * np.float32(7.5) - np.float32(1.25)
+        P[::7] = P[1::7][: P[::7].shape[0]]                           # duplicates: several points per voxel
+        A = rng.standard_normal((n, d)).astype(np.float32)
+        PC = np.concatenate([P, A], axis=1)
+        # arbitrary, uneven parts in rank order (their concatenation is the whole cloud)
+        bounds = [0] + sorted(rng.choice(np.arange(1, n), size=world - 1, replace=False).tolist()) + [n]
+        mine = torch.from_numpy(PC[bounds[rank]:bounds[rank + 1]].copy())
+
+        PCvox, keys, info = sharded.exchange_by_prefix(mine, J, prefix_bits=9, local_ops=NumpyLocalOps)
+        ref = orc.voxelize(PC, J)                                     # whole cloud, one process
+        assert info["N_global"] == n
+        np.testing.assert_array_equal(info["vmin"].numpy(), ref["vmin"])
+        assert info["width"] == ref["width"]
+        # this rank's shard = a contiguous run of the reference's voxels, bit for bit
+        cnt = torch.tensor([PCvox.shape[0]], dtype=torch.int64)
+        allc = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
+        dist.all_gather(allc, cnt)
+        lo = int(sum(int(c.item()) for c in allc[:rank]))
+        assert int(sum(int(c.item()) for c in allc)) == ref["Nvox"]
+        ref_keys = ref["keys_sorted"][ref["voxel_indices"]]
+        np.testing.assert_array_equal(keys.numpy().view(np.uint64), ref_keys[lo:lo + PCvox.shape[0]])
+        np.testing.assert_array_equal(PCvox.numpy(), ref["PCvox"][lo:lo + PCvox.shape[0]])      # means bit-exact
+        sizes = [int(c.item()) for c in allc]
+        assert max(sizes) - min(sizes) <= max(np.bincount((ref_keys >> np.uint64(3 * J - 9)).astype(np.int64))) + 1
+
+        # ... and the sharded transform of the exchanged shards == the oracle on the whole voxelized cloud
+        sh = sharded.ShardedRaht(keys, 3 * J, prefix_bits=9, local_ops=NumpyLocalOps)
+        C_loc = PCvox[:, 3:].to(torch.float64)
+        V = synth.keys_to_coords(ref_keys, J)
+        po = orc.raht_param(V.astype(np.float64), np.zeros(3), 2 ** J, J)
+        To, _ = orc.raht_fwd(ref["PCvox"][:, 3:].astype(np.float64), po)
+        T = sh.forward(C_loc)
+        np.testing.assert_allclose(T.numpy(), To[lo:lo + PCvox.shape[0]], rtol=1e-11, atol=1e-11 * np.abs(To).max())
+        chk = sh.check_against_unsharded(C_loc, 0.05)
+        assert chk["ok"], chk
+        dist.barrier()
+        dist.destroy_process_group()
+        q.put((rank, "ok"))
+    except Exception:
+        q.put((rank, traceback.format_exc()))
+
+
+@pytest.mark.parametrize("world,J,n,d", [(2, 6, 5000, 3), (3, 8, 7000, 5)])
+def test_unpartitioned_cloud_exchange_then_sharded_transform(world, J, n, d):
+    """all-to-all bucket exchange by 9-bit Morton prefix + local radix sort / voxelizer, against the
+    oracle's sort of the whole cloud (reference python/voxelize_pc.py:97-118)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_frontend, args=(r, world, port, J, n, d, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, msg in res:
+        assert msg == "ok", f"rank {rank}:\n{msg}"
+
+
 def test_single_process_degenerates_to_plain_transform():
     """world = 1 (no process group): the sharded driver is just local + top stages."""
     sys.path.insert(0, ROOT)
