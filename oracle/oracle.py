@@ -21,14 +21,15 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "_build", "libraht_oracle.so")
+CPU_TWINS_SO = os.path.join(_HERE, "_build", "libraht_cpu.so")     # raht_cpu_*: host twins of the product's C ABI
 
 
 def build(force=False):
     """Compile the oracle with gcc (seconds). Building the checker is not using it."""
-    src = os.path.join(_HERE, "raht_oracle.c")
-    hdr = os.path.join(_HERE, "raht_oracle.h")
-    if (not force and os.path.exists(_SO)
-            and os.path.getmtime(_SO) >= max(os.path.getmtime(src), os.path.getmtime(hdr))):
+    srcs = [os.path.join(_HERE, f) for f in ("raht_oracle.c", "raht_oracle.h", "raht_cpu.c", "raht_cpu.h")]
+    outs = [_SO, CPU_TWINS_SO]
+    if (not force and all(os.path.exists(o) for o in outs)
+            and min(os.path.getmtime(o) for o in outs) >= max(os.path.getmtime(f) for f in srcs)):
         return _SO
     subprocess.run(["make", "-C", _HERE, "-B"], check=True, capture_output=True)
     return _SO

@@ -64,11 +64,20 @@ def encode_frame(V_int, attributes, J, steps, frame=1, device="cuda:0", dtype=to
 
     rows = []
     for step in steps:
-        r = dict(Frame=frame, Quantization_Step=step)
+        # a scalar step (the drivers' colorStep entries) or one step per channel (per_attribute_steps below)
+        per_channel = not isinstance(step, (int, float))
+        if per_channel:
+            step_list = [float(x) for x in (step.tolist() if hasattr(step, "tolist") else step)]
+            step_t = torch.tensor(step_list, dtype=dtype, device=device)           # tensor divisor: true division on the GPU
+            step_arg = step_list
+        else:
+            step_t, step_arg = step, float(step)
+        r = dict(Frame=frame, Quantization_Step="per_attribute" if per_channel else step)
+        step = step_t
         # ---------------- encoder ----------------
         if use_fused:
             t0 = time.time()
-            coeff_reordered = plan.forward_quant(C, float(step))                    # :159 + :204 + :210 + :215
+            coeff_reordered = plan.forward_quant(C, step_arg)                       # :159 + :204 + :210 + :215
             _sync()
             r["RAHT_transform_time"], r["Quant_time"], r["Coeff_reorder_enc_time"] = time.time() - t0, 0.0, 0.0
         else:
@@ -96,7 +105,7 @@ def encode_frame(V_int, attributes, J, steps, frame=1, device="cuda:0", dtype=to
             qd = rlgr_mod.transpose_on_device(qd)
         if use_fused:
             t0 = time.time()
-            C_rec = plan.dequant_inverse(qd, float(step))                           # :261 + :267-268 + :274
+            C_rec = plan.dequant_inverse(qd, step_arg)                              # :261 + :267-268 + :274
             _sync()
             r["iRAHT_time"], r["Dequant_time"], r["Coeff_reorder_dec_time"] = time.time() - t0, 0.0, 0.0
         else:
@@ -272,8 +281,8 @@ def per_attribute_steps(Coeff, total_levels_budget=1024, importance=None):
     (reference python/encode_3dgs_debug.py:326-369): channels are grouped quats(4) / scales(3) /
     opacity(1) / colors(rest); each group gets `budget * importance / sum(importance)` quantization
     levels (at least 2, truncated to int) and the step range / (levels - 1), floored at 1e-6, where
-    range = max - min of the group's RAHT coefficients. Returns a float32 tensor with one step per
-    channel, usable with every quantize entry point (`forward_quant`, `quant_reorder`, ...), and the
+    range = max - min of the group's RAHT coefficients. Returns a float64 tensor with one step per
+    channel (the driver's Python floats; the float32 entry points round them once), usable with every quantize entry point (`forward_quant`, `quant_reorder`, ...), and the
     per-group table {name: dict(step, levels, range, channels)}.
 
     Coeff: (N, n_channels) RAHT coefficients (any device). The ranges need the coefficients, so the
@@ -283,7 +292,7 @@ def per_attribute_steps(Coeff, total_levels_budget=1024, importance=None):
     n_channels = int(Coeff.shape[1])
     ranges = {"quats": (0, 4), "scales": (4, 7), "opacity": (7, 8), "colors": (8, n_channels)}
     total = sum(imp.values())
-    steps = torch.ones(n_channels, dtype=torch.float32)
+    steps = torch.ones(n_channels, dtype=torch.float64)
     table = {}
     for name, (c0, c1) in ranges.items():
         if c0 >= n_channels:

@@ -343,6 +343,60 @@ if __name__ == "__main__" and os.environ.get("GOLDEN_ONLY", "") in ("", "pipelin
     pipeline_case()
 
 
+def policy_case():
+    """Per-attribute quantization policy of the reference's debug driver (python/encode_3dgs_debug.py:326-381,
+    dequantization :433-442) on the pipeline_small frame, with the reference's operators and its RLGR build.
+    The driver itself cannot be imported (it runs at import against /ssd1 paths): its arithmetic is restated
+    here statement by statement, each line citing the driver line it follows."""
+    import math
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(HERE)), "oracle", "_ref"))
+    import rlgr
+    z = np.load(os.path.join(HERE, "pipeline_small.npz"))
+    V, A, J = z["V"].astype(np.int64), z["A"], int(z["J"])
+    C = torch.from_numpy(A).to(torch.float64)                                   # encode_3dgs_debug.py: DTYPE float64
+    Vd = torch.from_numpy(V).to(torch.float64)
+    List, Flags, weights, order = RAHT_param_reorder_fast(Vd, torch.zeros(3, dtype=torch.float64), 2 ** J, J)
+    Coeff, _ = RAHT2_optimized(C, List, Flags, weights)
+    n_channels = Coeff.shape[1]
+    groups = [("quats", 0, 4), ("scales", 4, 7), ("opacity", 7, 8), ("colors", 8, n_channels)]        # :328-333
+    imp = {"quats": 1.0 / 21.93, "scales": 1.0 / 26.36, "opacity": 1.0 / 42.22, "colors": 1.0 / 38.67}    # :338-343
+    total_imp, budget = sum(imp.values()), 1024                                                       # :347-348
+    step_of, levels_of = [], []
+    enc = torch.zeros_like(Coeff)
+    for name, a, b in groups:
+        blk = Coeff[:, a:b]
+        rng = blk.max() - blk.min()                                              # :357-358
+        levels = max(int(budget * imp[name] / total_imp), 2)                     # :361-362
+        step = max(rng / max(levels - 1, 1), 1e-6)                               # :365-366
+        step = step.item()                                                       # :369
+        enc[:, a:b] = torch.floor(Coeff[:, a:b] / step + 0.5)                    # :378-381
+        step_of.append(step); levels_of.append(levels)
+    q = enc.index_select(0, order).to(torch.int32).numpy()                       # :388-389
+    total, cols = 0, []
+    for ch in range(n_channels):
+        m = rlgr.membuf(); m.rlgrWrite(q[:, ch].tolist(), 1); m.close()
+        buf = m.get_buffer(); total += len(buf)
+        _, back = rlgr.membuf(buf).rlgrRead(q.shape[0], 1)
+        cols.append(back)
+    dec = torch.from_numpy(np.stack(cols, axis=1).astype(np.int32)).to(torch.float64)                 # :427-429
+    for (name, a, b), step in zip(groups, step_of):
+        dec[:, a:b] = dec[:, a:b] * step                                         # :433-436
+    dec = dec[torch.argsort(order), :]                                           # :440-441
+    rec = inverse_RAHT_optimized(dec, List, Flags, weights)                      # :442
+
+    def ps(x, y):
+        return -10 * math.log10(torch.mean((x - y) ** 2).item() + 1e-10)         # :445-447
+    psnr = [ps(C, rec), ps(C[:, 0:4], rec[:, 0:4]), ps(C[:, 4:7], rec[:, 4:7]), ps(C[:, 7], rec[:, 7]), ps(C[:, 8:], rec[:, 8:])]
+    np.savez_compressed(os.path.join(HERE, "pipeline_policy.npz"), steps=np.array(step_of), levels=np.array(levels_of, dtype=np.int64),
+                        group_start=np.array([g[1] for g in groups], dtype=np.int64), group_end=np.array([g[2] for g in groups], dtype=np.int64),
+                        q=q, size_bytes=np.int64(total), psnr=np.array(psnr))
+    print("pipeline_policy: steps=%s levels=%s bytes=%d psnr_all=%.3f" % ([round(s, 5) for s in step_of], levels_of, total, psnr[0]))
+
+
+if __name__ == "__main__" and os.environ.get("GOLDEN_ONLY", "") in ("", "policy"):
+    policy_case()
+
+
 def encode_ply_case():
     """BASELINE configs[0]: the reference's encode_ply.py loop (:102-222) on a 10k-point RGB cloud
     (positions U[0,1)^3 voxelized at J=10, RGB randint(0,256), seed 0), with the

@@ -1,0 +1,210 @@
+"""Host twins of the C ABI (last row): oracle/_build/libraht_cpu.so exports raht_cpu_* with the
+parameter lists of their namesakes in include/raht.h, so a host can swap the CPU restatement and the MI355X
+path by symbol name. Checked here: (1) the prototypes, textually, against include/raht.h; (2) the twins'
+results against the golden vectors from the reference; (3) on the GPU box, the same ctypes call sequence
+through both libraries. The twins are test infrastructure: the product package never loads them."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from .conftest import golden_names, load_golden
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _protos(path, prefix):
+    txt = open(path).read()
+    txt = re.sub(r"/\*.*?\*/", " ", txt, flags=re.S)
+    out = {}
+    for m in re.finditer(r"\b(int64_t|int|const char \*)\s*(" + prefix + r"\w+)\s*\(([^;{]*?)\)\s*;", txt, flags=re.S):
+        out[m.group(2)] = (m.group(1).strip(), re.sub(r"\s+", " ", m.group(3)).strip())
+    return out
+
+
+@pytest.fixture(scope="module")
+def twins(oracle):
+    from oracle import oracle as orc
+    L = C.CDLL(orc.CPU_TWINS_SO)
+    L.raht_cpu_last_error.restype = C.c_char_p
+    L.raht_cpu_plan_size.restype = C.c_int64
+    return L
+
+
+def test_twin_prototypes_equal_the_product_prototypes(twins):
+    prod = _protos(os.path.join(ROOT, "include", "raht.h"), "raht_")
+    twin = _protos(os.path.join(ROOT, "oracle", "raht_cpu.h"), "raht_cpu_")
+    assert len(twin) >= 25
+    for name, (ret, args) in twin.items():
+        pname = name.replace("raht_cpu_", "raht_")
+        assert pname in prod, f"{name}: no product entry {pname}"
+        pret, pargs = prod[pname]
+        assert ret == pret, name
+        assert args.replace("raht_cpu_plan", "raht_plan") == pargs, f"{name}:\n  twin    {args}\n  product {pargs}"
+        assert hasattr(twins, name), f"{name} not exported"
+    # the path's core entry points all have a twin
+    for core in ("raht_plan_create", "raht_plan_create_from_keys", "raht_plan_destroy", "raht_plan_levels", "raht_plan_export_level",
+                 "raht_plan_order", "raht_fwd", "raht_fwd_f64", "raht_inv", "raht_inv_f64", "raht_fwd_quant", "raht_dequant_inv",
+                 "raht_quant_reorder", "raht_dequant_unreorder", "raht_voxelize", "raht_morton", "raht_sort_keys"):
+        assert core.replace("raht_", "raht_cpu_", 1) in twin, core
+
+
+def _vp(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class Api:
+    """One ctypes call sequence, parameterised by the library and the symbol prefix: `raht_` + device pointers
+    (the product) or `raht_cpu_` + host pointers (the twins)."""
+
+    def __init__(self, lib, prefix):
+        self.lib, self.prefix = lib, prefix
+
+    def fn(self, name):
+        f = getattr(self.lib, self.prefix + name)
+        return f
+
+    def err(self):
+        e = getattr(self.lib, self.prefix + "last_error")
+        e.restype = C.c_char_p
+        return e().decode()
+
+
+def _run_path(api, ptr, V, Cm, J, step, alloc, fetch):
+    """plan -> levels / lists / order -> fwd (f32, f64) -> quantize (fused) -> dequantize + inverse. `ptr` turns a
+    buffer into a pointer argument, `alloc(shape, dtype)` makes an output buffer, `fetch` brings it to numpy."""
+    N, D = Cm.shape
+    h = C.c_void_p()
+    minV = (C.c_double * 3)(0.0, 0.0, 0.0)
+    Vb = alloc(V.shape, np.float64, V)
+    rc = api.fn("plan_create")(ptr(Vb), 1, C.c_int64(N), minV, C.c_double(2.0 ** J), J, None, C.byref(h))
+    assert rc == 0, api.err()
+    out = {"levels": api.fn("plan_levels")(h)}
+    lists = []
+    for l in range(out["levels"]):
+        n = C.c_int64()
+        assert api.fn("plan_export_level")(h, l, None, None, None, C.byref(n)) == 0
+        a, f, w = np.empty(n.value, np.int64), np.empty(n.value, np.uint8), np.empty(n.value, np.int64)
+        assert api.fn("plan_export_level")(h, l, _vp(a), _vp(f), _vp(w), C.byref(n)) == 0
+        lists.append((a, f.astype(bool), w))
+    out["lists"] = lists
+    ob = alloc((N,), np.int64)
+    assert api.fn("plan_order")(h, ptr(ob), None) == 0
+    out["order"] = fetch(ob)
+    C32, C64 = alloc((N, D), np.float32, Cm.astype(np.float32)), alloc((N, D), np.float64, Cm.astype(np.float64))
+    T32, T64 = alloc((N, D), np.float32), alloc((N, D), np.float64)
+    w64 = alloc((N,), np.float64)
+    assert api.fn("fwd")(h, ptr(C32), C.c_int64(D), D, ptr(T32), C.c_int64(D), None, None) == 0, api.err()
+    assert api.fn("fwd_f64")(h, ptr(C64), C.c_int64(D), D, ptr(T64), C.c_int64(D), ptr(w64), None) == 0, api.err()
+    out["T32"], out["T64"], out["w"] = fetch(T32), fetch(T64), fetch(w64)
+    Q = alloc((N, D), np.int32)
+    st32, st64 = (C.c_float * 1)(step), (C.c_double * 1)(step)
+    assert api.fn("fwd_quant_f64")(h, ptr(C64), C.c_int64(D), D, st64, 1, ptr(Q), C.c_int64(D), None) == 0, api.err()
+    out["Q64"] = fetch(Q).copy()
+    assert api.fn("fwd_quant")(h, ptr(C32), C.c_int64(D), D, st32, 1, ptr(Q), C.c_int64(D), None) == 0, api.err()
+    out["Q32"] = fetch(Q).copy()
+    R = alloc((N, D), np.float64)
+    Qin = alloc((N, D), np.int32, out["Q64"])
+    assert api.fn("dequant_inv_f64")(h, ptr(Qin), C.c_int64(D), D, st64, 1, ptr(R), C.c_int64(D), None) == 0, api.err()
+    out["R64"] = fetch(R)
+    Ri = alloc((N, D), np.float64)
+    assert api.fn("inv_f64")(h, ptr(T64), C.c_int64(D), D, ptr(Ri), C.c_int64(D), None) == 0, api.err()
+    out["C_back"] = fetch(Ri)
+    assert api.fn("plan_destroy")(h) == 0
+    return out
+
+
+def _host_api(twins):
+    api = Api(twins, "raht_cpu_")
+    twins.raht_cpu_plan_destroy.argtypes = [C.c_void_p]
+    twins.raht_cpu_plan_levels.argtypes = [C.c_void_p]
+    twins.raht_cpu_plan_export_level.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int64)]
+    twins.raht_cpu_plan_order.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    twins.raht_cpu_plan_create.argtypes = [C.c_void_p, C.c_int, C.c_int64, C.POINTER(C.c_double), C.c_double, C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]
+    for n in ("fwd", "fwd_f64"):
+        getattr(twins, "raht_cpu_" + n).argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
+    for n in ("inv", "inv_f64"):
+        getattr(twins, "raht_cpu_" + n).argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_int64, C.c_void_p]
+    for n in ("fwd_quant", "dequant_inv"):
+        getattr(twins, "raht_cpu_" + n).argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.POINTER(C.c_float), C.c_int, C.c_void_p, C.c_int64, C.c_void_p]
+    for n in ("fwd_quant_f64", "dequant_inv_f64"):
+        getattr(twins, "raht_cpu_" + n).argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.POINTER(C.c_double), C.c_int, C.c_void_p, C.c_int64, C.c_void_p]
+
+    def alloc(shape, dtype, init=None):
+        a = np.empty(shape, dtype)
+        if init is not None:
+            a[...] = init
+        return a
+    return api, _vp, alloc, (lambda a: a)
+
+
+@pytest.mark.parametrize("name", [n for n in golden_names(exclude_prefix="vox_") if "q_step1" in load_golden(n) and load_golden(n)["V"].shape[0] >= 8])
+def test_twins_reproduce_the_reference(twins, name):
+    g = load_golden(name)
+    J = int(g["J"])
+    api, ptr, alloc, fetch = _host_api(twins)
+    o = _run_path(api, ptr, g["V"].astype(np.float64), g["C"], J, 1.0, alloc, fetch)
+    assert o["levels"] == len(g["List"])
+    for (a, f, w), La, Fa, Wa in zip(o["lists"], g["List"], g["Flags"], g["weights"]):
+        assert np.array_equal(a, La) and np.array_equal(f, Fa) and np.array_equal(w, Wa)
+    assert np.array_equal(o["order"], g["order"])
+    np.testing.assert_allclose(o["T64"], g["T"], rtol=1e-12, atol=1e-12)
+    assert np.array_equal(o["w"], g["w"].reshape(-1))
+    colmax = np.abs(g["T"]).max(axis=0)
+    assert np.all(np.abs(o["T32"].astype(np.float64) - g["T"]).max(axis=0) <= 2e-7 * np.maximum(colmax, 1e-30))   # float64 rounded once
+    bad = np.nonzero(o["Q64"] != g["q_step1"])
+    if bad[0].size:                                       # only where the reference's quotient sits on a rounding tie
+        q = g["T"][g["order"][bad[0]], bad[1]] + 0.5      # (integer-valued inputs produce many exact ties)
+        assert np.all(np.abs(o["Q64"].astype(np.int64) - g["q_step1"])[bad] == 1)
+        assert np.all(np.abs(q - np.round(q)) <= 1e-9 * np.maximum(1.0, np.abs(q)))
+    np.testing.assert_allclose(o["C_back"], g["C"].astype(np.float64), rtol=1e-10, atol=1e-10 * max(1.0, float(np.abs(g["C"]).max())))
+
+
+def test_twins_share_the_error_behaviour(twins):
+    api, ptr, alloc, fetch = _host_api(twins)
+    h = C.c_void_p()
+    minV = (C.c_double * 3)(0.0, 0.0, 0.0)
+    V = np.array([[0, 0, 1], [0, 0, 0]], dtype=np.float64)                       # unsorted
+    assert api.fn("plan_create")(_vp(V), 1, C.c_int64(2), minV, C.c_double(4.0), 2, None, C.byref(h)) == -2
+    V = np.array([[0, 0, 0], [0, 0, 0]], dtype=np.float64)                       # duplicate
+    assert api.fn("plan_create")(_vp(V), 1, C.c_int64(2), minV, C.c_double(4.0), 2, None, C.byref(h)) == -2
+    V = np.array([[0, 0, 0], [4, 0, 0]], dtype=np.float64)                       # out of bounds
+    assert api.fn("plan_create")(_vp(V), 1, C.c_int64(2), minV, C.c_double(4.0), 2, None, C.byref(h)) == -3
+    assert b"out of" in twins.raht_cpu_last_error()
+
+
+@pytest.mark.gpu
+def test_same_call_sequence_through_both_libraries(twins):
+    """The swap by symbol name, end to end: one ctypes call sequence, `raht_` + device buffers vs `raht_cpu_` +
+    host buffers, same results (integers equal; float64 1e-12; float32 2e-6 of the column max)."""
+    import torch
+    from raht_3dgs_codec_amd import _lib, synth
+    L = _lib.lib()
+    V, keys, Cm = synth.scene(20000, 9, 14, seed=5)
+    host = _run_path(*_host_api(twins)[:2], V.astype(np.float64), Cm, 9, 0.5, *_host_api(twins)[2:])
+
+    keep = []
+
+    def alloc(shape, dtype, init=None):
+        t = torch.empty(tuple(shape), dtype=getattr(torch, np.dtype(dtype).name), device="cuda")
+        if init is not None:
+            t.copy_(torch.from_numpy(np.ascontiguousarray(init, dtype=dtype)))
+        keep.append(t)
+        return t
+    dev = _run_path(Api(L, "raht_"), lambda t: C.c_void_p(t.data_ptr()), V.astype(np.float64), Cm, 9, 0.5, alloc,
+                    lambda t: (torch.cuda.synchronize(), t.cpu().numpy())[1])
+    assert dev["levels"] == host["levels"] and np.array_equal(dev["order"], host["order"])
+    for (a, f, w), (b, g_, x) in zip(dev["lists"], host["lists"]):
+        assert np.array_equal(a, b) and np.array_equal(f, g_) and np.array_equal(w, x)
+    assert np.array_equal(dev["w"], host["w"])
+    colmax = np.maximum(np.abs(host["T64"]).max(axis=0), 1.0)
+    assert np.all(np.abs(dev["T64"] - host["T64"]).max(axis=0) <= 1e-12 * colmax)
+    assert np.all(np.abs(dev["T32"].astype(np.float64) - host["T64"]).max(axis=0) <= 2e-6 * colmax)
+    bad = np.nonzero(dev["Q64"] != host["Q64"])
+    if bad[0].size:                                       # exact ties (integer xyz columns) only
+        q = host["T64"][host["order"][bad[0]], bad[1]] / 0.5 + 0.5
+        assert np.all(np.abs(dev["Q64"].astype(np.int64) - host["Q64"])[bad] == 1)
+        assert np.all(np.abs(q - np.round(q)) <= 1e-9 * np.maximum(1.0, np.abs(q)))
+    assert np.all(np.abs(dev["C_back"] - host["C_back"]).max(axis=0) <= 1e-10 * np.maximum(np.abs(Cm).max(axis=0), 1.0))
