@@ -106,14 +106,24 @@ __global__ void morton_i64_kernel(const int64_t *__restrict__ V, int64_t N, uint
 // cfg3; one global queue for the whole grid serialised on its counter: 1 ms.)
 static constexpr int EXT_THREADS = 1024;
 
+// The same pass also counts, per block of EXT_THREADS rows, the rows of every order_RAGFT bucket (ORDER_BUCKETS
+// bins -> bucket_hist[bucket * gridDim.x + block], the input of the stable counting sort that produces
+// order_RAGFT: no separate histogram pass over the rows) and the global population of every binary level
+// (level_hist[64]: max_level / len(Flags) and the level engine's level offsets).
+static constexpr int ORDER_BUCKETS = 32;             // bucket(0) = 0, bucket(i) = 1 + (20 - lvl / 3) <= 21
+
 __global__ void __launch_bounds__(EXT_THREADS) level_extent_kernel(const uint64_t *__restrict__ keys, int64_t N, int nbits,
                                                                     uint8_t *__restrict__ lvl, uint8_t *__restrict__ order_bucket,
-                                                                    int32_t *__restrict__ wl, int32_t *__restrict__ wr, PlanErr *err)
+                                                                    int32_t *__restrict__ wl, int32_t *__restrict__ wr, PlanErr *err,
+                                                                    uint32_t *__restrict__ bucket_hist, uint32_t *__restrict__ level_hist)
 {
     __shared__ uint32_t queue[2 * EXT_THREADS];      // row within the block | direction << 31
     __shared__ uint8_t s_lvl[EXT_THREADS];
     __shared__ uint32_t n_queued;
+    __shared__ uint32_t s_bh[ORDER_BUCKETS], s_lh[64];
     if (threadIdx.x == 0) n_queued = 0;
+    if (threadIdx.x < ORDER_BUCKETS) s_bh[threadIdx.x] = 0;
+    if (threadIdx.x < 64) s_lh[threadIdx.x] = 0;
     __syncthreads();
     const int64_t b0 = (int64_t)blockIdx.x * EXT_THREADS;
     const int64_t i = b0 + threadIdx.x;
@@ -136,7 +146,10 @@ __global__ void __launch_bounds__(EXT_THREADS) level_extent_kernel(const uint64_
         // order_RAGFT (RAHT_param.py:251-274): [root] ++ groups of rows that stop being node starts within
         // octree level g = lvl / 3, coarse to fine, ascending row index inside a group  ==  a stable bucket
         // sort by bucket(0) = 0, bucket(i) = 1 + (20 - lvl[i] / 3)
-        order_bucket[i] = (i == 0) ? 0 : (uint8_t)(1 + (20 - l / 3));
+        const uint32_t ob = (i == 0) ? 0u : (uint32_t)(1 + (20 - l / 3));
+        order_bucket[i] = (uint8_t)ob;
+        atomicAdd(&s_bh[ob], 1u);
+        atomicAdd(&s_lh[l & 63], 1u);                // row 0 (lvl 255) lands alone in bin 63
     }
     const bool searching = valid && i != 0;
     const uint64_t below = ((uint64_t)1 << lane) - 1, above = ~(below | ((uint64_t)1 << lane));
@@ -170,6 +183,8 @@ __global__ void __launch_bounds__(EXT_THREADS) level_extent_kernel(const uint64_
         wl[0] = 0; wr[0] = 0;
     }
     __syncthreads();
+    if (threadIdx.x < ORDER_BUCKETS) bucket_hist[(size_t)threadIdx.x * gridDim.x + blockIdx.x] = s_bh[threadIdx.x];
+    if (threadIdx.x < 64 && s_lh[threadIdx.x]) atomicAdd(&level_hist[threadIdx.x], s_lh[threadIdx.x]);
     // The queued searches, over a monotone predicate on the keys ((key >> l) == prefix holds exactly on the
     // node): gallop away from the wave by x8, then split the bracket in 8 with 7 independent probes per
     // step -- the chain of dependent loads is what a search costs. Every probe address is a valid row.
@@ -212,6 +227,44 @@ __global__ void __launch_bounds__(EXT_THREADS) level_extent_kernel(const uint64_
 }
 
 // ---- order_RAGFT -------------------------------------------------------------------------------
+// Stable counting sort of the rows by order bucket, second half: bucket_pos holds, for every (bucket, block),
+// where that block's first row of that bucket goes (exclusive scan of bucket_hist, bucket-major). Inside the
+// block the rank of a row among the rows of its bucket is (rows of that bucket in earlier waves) + (earlier
+// lanes of its wave with the same bucket). Writes the permutation AND its inverse: inv_order[i] = pos.
+__global__ void __launch_bounds__(EXT_THREADS) order_scatter_kernel(const uint8_t *__restrict__ order_bucket, int64_t N,
+                                                                     const uint32_t *__restrict__ bucket_pos,
+                                                                     uint32_t *__restrict__ order, uint32_t *__restrict__ inv_order)
+{
+    __shared__ uint32_t wcnt[EXT_THREADS / 64][ORDER_BUCKETS];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int64_t i = (int64_t)blockIdx.x * EXT_THREADS + threadIdx.x;
+    const bool valid = i < N;
+    const uint32_t b = valid ? order_bucket[i] : 0u;
+    // lanes of this wave with the same bucket (5 ballots)
+    uint64_t same = __ballot(valid);
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        const uint64_t bal = __ballot((b >> k) & 1u);
+        same &= ((b >> k) & 1u) ? bal : ~bal;
+    }
+    const uint64_t below = ((uint64_t)1 << lane) - 1;
+    const uint32_t rank = (uint32_t)__popcll(same & below);
+    if (threadIdx.x < ORDER_BUCKETS) {
+#pragma unroll
+        for (int w = 0; w < EXT_THREADS / 64; ++w) wcnt[w][threadIdx.x] = 0;
+    }
+    __syncthreads();
+    if (valid && rank == 0) wcnt[wid][b] = (uint32_t)__popcll(same);
+    __syncthreads();
+    if (valid) {
+        uint32_t before = 0;
+        for (int w = 0; w < wid; ++w) before += wcnt[w][b];
+        const uint32_t pos = bucket_pos[(size_t)b * gridDim.x + blockIdx.x] + before + rank;
+        order[pos] = (uint32_t)i;
+        inv_order[i] = pos;
+    }
+}
+
 __global__ void order_to_identity_kernel(uint32_t *order, int64_t N)
 {
     const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -492,10 +545,341 @@ static int build_top_stage(raht_plan *plan, uint32_t *rows, int64_t n, hipStream
     return RAHT_OK;                                  // (the scratch goes back to the pool: stream-ordered reuse)
 }
 
+// ---- schedule build, device-driven ----------------------------------------------------------------
+// The exact builder below (get_schedule_exact) reads every stage's size back to the host before it can size
+// and launch the next stage: 4-5 round trips of ~20 us each, during which the GPU idles -- more than half of
+// a cfg3 plan build. Here the chain of stages runs on the device: every stage is two launches
+// (sched_count_kernel: survivor flags + per-block counts; sched_emit_kernel: the next stage's entry list,
+// its entry-ordered plan metadata and this stage's per-tile survivor offsets in one pass), the TOP stage is
+// ONE single-workgroup launch (sched_top_kernel), each kernel decides from the device-resident SchedState
+// whether it has anything to do, buffers are sized from generous bounds (a stage keeps < 1/3 of its entries:
+// measured 1/20 at 184 rows per tile, 1/6 at 64), and ONE read-back at the end tells the host how it went.
+// Anything unusual (a bound exceeded, more stages than were enqueued, no progress) -> the exact builder.
+constexpr int SB_THREADS = 256, SB_ITEMS = 8, SB_BLOCK = SB_THREADS * SB_ITEMS;
+constexpr int SCHED_SPEC_MAX = 8;                  // stages enqueued speculatively, at most
+enum { SK_NONE = 0, SK_TILE = 1, SK_TOP = 2 };
+
+struct SchedState {
+    uint32_t n[SCHED_SPEC_MAX + 2];                // entries of stage k
+    uint32_t kind[SCHED_SPEC_MAX + 2];             // what stage k is (written by the stage before it)
+    uint32_t finished;                             // the tree is done: last_stage / last_is_top are valid
+    uint32_t last_stage, last_is_top;
+    uint32_t trouble;                              // 1 = a buffer bound was exceeded, 2 = a stage made no progress
+    uint32_t top[4];                               // TOP stage: n_merges, nlev, nbig, small_start
+};
+constexpr int SCHED_STATE_WORDS = sizeof(SchedState) / 4;
+
+__device__ __forceinline__ uint32_t block_sum_256(uint32_t v, uint32_t *red /* [4] */)
+{
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    const uint32_t t = red[0] + red[1] + red[2] + red[3];
+    __syncthreads();
+    return t;
+}
+
+// wl / wr / lvl are ENTRY-ordered for this stage (stage 0: the plan arrays, entry = row)
+__global__ __launch_bounds__(SB_THREADS) void sched_count_kernel(const SchedState *__restrict__ S, int k, const uint32_t *__restrict__ rows,
+                                                                 const int32_t *__restrict__ wl, const int32_t *__restrict__ wr,
+                                                                 const uint8_t *__restrict__ lvl, int R, int64_t N, int top_level,
+                                                                 uint8_t *__restrict__ flags, uint32_t *__restrict__ blk_cnt)
+{
+    __shared__ uint32_t red[4];
+    if (S->kind[k] != SK_TILE) return;
+    const int64_t n = S->n[k];
+    const int64_t base = (int64_t)blockIdx.x * SB_BLOCK + (int64_t)threadIdx.x * SB_ITEMS;
+    if ((int64_t)blockIdx.x * SB_BLOCK >= n) return;
+    uint32_t cnt = 0;
+#pragma unroll
+    for (int q = 0; q < SB_ITEMS; ++q) {
+        const int64_t j = base + q;
+        if (j < n) {
+            const int64_t r = rows ? (int64_t)rows[j] : j;
+            const int64_t j0 = j / R * R, j1 = j0 + R;
+            const int64_t start = rows ? (int64_t)rows[j0] : j0;
+            const int64_t end = (j1 < n) ? (rows ? (int64_t)rows[j1] : j1) : N;
+            const bool merged = (r > 0) && ((int)lvl[j] < top_level) && (r - wl[j] >= start) && (r + wr[j] <= end);
+            flags[j] = merged ? 0 : 1;
+            cnt += merged ? 0u : 1u;
+        }
+    }
+    const uint32_t tot = block_sum_256(cnt, red);
+    if (threadIdx.x == 0) blk_cnt[blockIdx.x] = tot;
+}
+
+// p_* are the PLAN arrays (row-indexed): the next stage's entry-ordered copies are gathered from them here
+__global__ __launch_bounds__(SB_THREADS) void sched_emit_kernel(SchedState *__restrict__ S, int k, const uint32_t *__restrict__ rows,
+                                                                const uint8_t *__restrict__ flags, const uint32_t *__restrict__ blk_cnt,
+                                                                int R, uint32_t Rf, uint32_t n_roots,
+                                                                const int32_t *__restrict__ p_wl, const int32_t *__restrict__ p_wr,
+                                                                const uint8_t *__restrict__ p_lvl, const uint32_t *__restrict__ p_inv,
+                                                                uint32_t *__restrict__ n_rows, int32_t *__restrict__ n_wl, int32_t *__restrict__ n_wr,
+                                                                uint8_t *__restrict__ n_lvl, uint32_t *__restrict__ n_pos, uint32_t cap_next,
+                                                                uint32_t *__restrict__ surv_off)
+{
+    __shared__ uint32_t red[4];
+    __shared__ uint32_t wsum[4];
+    if (S->kind[k] != SK_TILE) return;
+    const int64_t n = S->n[k];
+    const int64_t nblk = (n + SB_BLOCK - 1) / SB_BLOCK;
+    if ((int64_t)blockIdx.x >= nblk) return;
+    // survivors in the blocks before this one (<= a few thousand words from L2)
+    uint32_t part = 0;
+    for (int64_t b = threadIdx.x; b < (int64_t)blockIdx.x; b += SB_THREADS) part += blk_cnt[b];
+    const uint32_t block_base = block_sum_256(part, red);
+    // exclusive scan of this block's flags (8 consecutive entries per thread)
+    const int64_t base = (int64_t)blockIdx.x * SB_BLOCK + (int64_t)threadIdx.x * SB_ITEMS;
+    uint8_t f[SB_ITEMS];
+    uint32_t mine = 0;
+#pragma unroll
+    for (int q = 0; q < SB_ITEMS; ++q) { f[q] = (base + q < n) ? flags[base + q] : 0; mine += f[q]; }
+    uint32_t inc = mine;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const uint32_t t = __shfl_up(inc, d, 64); if (lane >= d) inc += t; }
+    if (lane == 63) wsum[wid] = inc;
+    __syncthreads();
+    uint32_t before = 0, block_tot = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) { if (w < wid) before += wsum[w]; block_tot += wsum[w]; }
+    uint32_t pos = block_base + before + inc - mine;
+#pragma unroll
+    for (int q = 0; q < SB_ITEMS; ++q) {
+        const int64_t j = base + q;
+        if (j < n) {
+            if (j % R == 0) surv_off[j / R] = pos;           // first survivor of tile j / R
+            if (f[q]) {
+                if (pos < cap_next) {
+                    const uint32_t r = rows ? rows[j] : (uint32_t)j;
+                    n_rows[pos] = r; n_wl[pos] = p_wl[r]; n_wr[pos] = p_wr[r]; n_lvl[pos] = p_lvl[r]; n_pos[pos] = p_inv[r];
+                }
+                ++pos;
+            }
+        }
+    }
+    if ((int64_t)blockIdx.x == nblk - 1 && threadIdx.x == 0) {
+        const uint32_t total = block_base + block_tot;
+        surv_off[(n + R - 1) / R] = total;
+        S->n[k + 1] = total;
+        if (total > cap_next) S->trouble = 1;
+        if (total == n_roots) { S->finished = 1; S->last_stage = (uint32_t)k; S->last_is_top = 0; }   // only the roots are left
+        else if (total >= (uint32_t)n) S->trouble = 2;                                              // no progress
+        else S->kind[k + 1] = (total <= Rf) ? SK_TOP : SK_TILE;
+    }
+}
+
+// The TOP stage in one workgroup: every butterfly still to do, resolved against the stage's entry list, bucketed by
+// level; root ranks; the level program (what build_top_stage does with a dozen launches and a read-back).
+constexpr int ST_THREADS = 1024;
+__global__ __launch_bounds__(ST_THREADS) void sched_top_kernel(SchedState *__restrict__ S, int k, const uint32_t *__restrict__ rows,
+                                                               const int32_t *__restrict__ p_wl, const int32_t *__restrict__ p_wr,
+                                                               const uint8_t *__restrict__ p_lvl, const int64_t *__restrict__ wsum,
+                                                               int top_level, uint32_t *__restrict__ t_pj, float *__restrict__ t_ab32,
+                                                               double *__restrict__ t_ab64, uint32_t *__restrict__ t_root,
+                                                               uint32_t *__restrict__ t_lev)
+{
+    __shared__ uint32_t s_rows[RAHT_TOP_MAX_ROWS];
+    __shared__ uint32_t hist[64], cursor[64], wtot[ST_THREADS / 64];
+    __shared__ uint32_t root_base;
+    if (S->kind[k] != SK_TOP) return;
+    const int n = (int)S->n[k];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    if (tid < 64) hist[tid] = 0;
+    if (tid == 0) root_base = 0;
+    for (int e = tid; e < n; e += ST_THREADS) s_rows[e] = rows ? rows[e] : (uint32_t)e;
+    __syncthreads();
+    // pass 1: level histogram of the butterflies; root ranks in entry order
+    for (int e0 = 0; e0 < n; e0 += ST_THREADS) {
+        const int e = e0 + tid;
+        bool root = false;
+        if (e < n) {
+            const uint32_t r = s_rows[e];
+            const int l = (int)p_lvl[r];
+            const bool merged = (r > 0) && (l < top_level);
+            root = !merged;
+            if (merged) atomicAdd(&hist[l], 1u);
+        }
+        const uint64_t bal = __ballot(root);
+        if (lane == 0) wtot[wid] = (uint32_t)__popcll(bal);
+        __syncthreads();
+        uint32_t before = root_base;
+        for (int w = 0; w < wid; ++w) before += wtot[w];
+        if (e < n) t_root[e] = root ? before + (uint32_t)__popcll(bal & (((uint64_t)1 << lane) - 1)) : 0xffffffffu;
+        __syncthreads();
+        if (tid == 0) { uint32_t t = 0; for (int w = 0; w < ST_THREADS / 64; ++w) t += wtot[w]; root_base += t; }
+        __syncthreads();
+    }
+    // level offsets + the level program (thread 0: 64 levels)
+    if (tid == 0) {
+        uint32_t run = 0;
+        uint32_t lev[128];
+        int nlev = 0;
+        for (int l = 0; l < 64; ++l) {
+            cursor[l] = run;
+            if (hist[l] && l < 63) { lev[2 * nlev] = run; lev[2 * nlev + 1] = run + hist[l]; ++nlev; }
+            run += hist[l];
+        }
+        const uint32_t n_merges = run;
+        // non-empty levels ascending; the trailing run with <= 64 butterflies each is chained by one wave, its records
+        // live in LDS next to the entries (16 B per entry + 12 / 20 B per record; 160 KiB - 1 KiB)
+        int nbig = nlev;
+        while (nbig > 0 && lev[2 * (nbig - 1) + 1] - lev[2 * (nbig - 1)] <= 64) --nbig;
+        const size_t lds_budget = 160 * 1024 - 1024;
+        while (nbig < nlev && (size_t)n * 16 + (size_t)(n_merges - lev[2 * nbig]) * 20 > lds_budget) ++nbig;
+        for (int i = 0; i < 2 * nlev; ++i) t_lev[i] = lev[i];
+        S->top[0] = n_merges; S->top[1] = (uint32_t)nlev; S->top[2] = (uint32_t)nbig;
+        S->top[3] = (nbig < nlev) ? lev[2 * nbig] : n_merges;
+        S->finished = 1; S->last_stage = (uint32_t)k; S->last_is_top = 1;
+    }
+    __syncthreads();
+    // pass 2: resolve and place every butterfly (any order inside a level: they are independent)
+    for (int e = tid; e < n; e += ST_THREADS) {
+        const uint32_t r = s_rows[e];
+        const int l = (int)p_lvl[r];
+        if (!((r > 0) && (l < top_level))) continue;
+        const int32_t wlr = p_wl[r], wrr = p_wr[r];
+        const uint32_t want = r - (uint32_t)wlr;            // the partner row is an entry of this stage as well
+        int lo = 0, hi = e - 1;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (s_rows[mid] < want) lo = mid + 1; else hi = mid;
+        }
+        double w0, w1;
+        pair_weights((int64_t)r, wlr, wrr, wsum, w0, w1);
+        const double den = w0 + w1;
+        const double a = sqrt(w0 / den), b = sqrt(w1 / den);        // RAHT.py:321-322
+        const uint32_t pos = atomicAdd(&cursor[l], 1u);
+        t_pj[pos] = (uint32_t)lo | ((uint32_t)e << 16);
+        t_ab64[2 * pos] = a; t_ab64[2 * pos + 1] = b;
+        t_ab32[2 * pos] = (float)a; t_ab32[2 * pos + 1] = (float)b;
+    }
+}
+
+static int get_schedule_exact(raht_plan *plan, int R0, int R1, int Rf, hipStream_t s, Schedule **out);
+
+// -> RAHT_OK and *built = true when the schedule was built; *built = false: use the exact builder
+static int build_schedule_fast(raht_plan *plan, int R0, int R1, int Rf, hipStream_t s, Schedule &sc, bool *built)
+{
+    *built = false;
+    const int64_t N = plan->N;
+    // how many stages to enqueue: sizes are unknown, assume a stage keeps at most 1/8 of its entries (measured 1/20
+    // at 184 rows per tile, 1/6 at 64); buffers hold 1/3 (+ slack). Too few stages enqueued -> exact builder.
+    int64_t cap[SCHED_SPEC_MAX + 2];
+    cap[0] = N;
+    int KS = 0;                                           // tile stages enqueued: k = 0 .. KS - 1
+    {
+        double expect = (double)N;
+        while (KS < SCHED_SPEC_MAX && KS < plan->max_stages && expect > (double)Rf * 0.5) { ++KS; expect /= (R0 >= 128 && KS > 0 ? 8.0 : 4.0); }
+        for (int k = 0; k <= KS; ++k) cap[k + 1] = std::min<int64_t>(cap[k], cap[k] / 3 + 2048);
+    }
+    if (N <= Rf) KS = 0;
+    struct Bufs { uint32_t *rows = nullptr; int32_t *wl = nullptr, *wr = nullptr; uint8_t *lvl = nullptr; uint32_t *pos = nullptr; uint32_t *surv = nullptr; };
+    std::vector<Bufs> B((size_t)KS + 2);
+    uint32_t *t_pj = nullptr, *t_root = nullptr, *t_lev = nullptr;
+    float *t_ab32 = nullptr;
+    double *t_ab64 = nullptr;
+    bool ok = true;
+    auto take = [&](auto **ptr, size_t bytes) { if (ok && dev_malloc(ptr, std::max<size_t>(bytes, 16)) != hipSuccess) ok = false; };
+    for (int k = 0; k < KS; ++k) {
+        const int R = (k == 0) ? R0 : R1;
+        take(&B[(size_t)k].surv, sizeof(uint32_t) * (size_t)(ceil_div(cap[k], R) + 1));
+        Bufs &nx = B[(size_t)k + 1];
+        const size_t c = (size_t)cap[k + 1];
+        take(&nx.rows, 4 * c); take(&nx.wl, 4 * c); take(&nx.wr, 4 * c); take(&nx.lvl, c); take(&nx.pos, 4 * c);
+    }
+    const size_t tm = (size_t)std::max(Rf, 1);
+    take(&t_pj, 4 * tm); take(&t_ab32, 8 * tm); take(&t_ab64, 16 * tm); take(&t_root, 4 * tm); take(&t_lev, 4 * 128);
+    // scratch: state | per-block counts | flags
+    const size_t nblk0 = (size_t)ceil_div(N, SB_BLOCK);
+    Scratch scr(sizeof(SchedState) + sizeof(uint32_t) * nblk0 + (size_t)N);
+    auto release = [&]() {
+        for (auto &b : B) { dev_free(b.rows); dev_free(b.wl); dev_free(b.wr); dev_free(b.lvl); dev_free(b.pos); dev_free(b.surv); }
+        dev_free(t_pj); dev_free(t_ab32); dev_free(t_ab64); dev_free(t_root); dev_free(t_lev);
+    };
+    if (!ok || !scr.ok()) { (void)hipDeviceSynchronize(); release(); return RAHT_ERR_NOMEM; }
+    SchedState *dS = scr.as<SchedState>();
+    uint32_t *blk_cnt = (uint32_t *)(dS + 1);
+    uint8_t *flags = (uint8_t *)(blk_cnt + nblk0);
+    SchedState h0;
+    memset(&h0, 0, sizeof(h0));
+    h0.n[0] = (uint32_t)N;
+    h0.kind[0] = (N <= Rf) ? SK_TOP : SK_TILE;
+    hipError_t e = hipMemcpyAsync(dS, &h0, sizeof(h0), hipMemcpyHostToDevice, s);     // pageable: copied before return
+    for (int k = 0; k <= KS && e == hipSuccess; ++k) {
+        const Bufs &cur = B[(size_t)k];
+        // stage k as the TOP stage (k = 0 only when the whole tree fits; later stages decide on the device)
+        if (k > 0 || N <= Rf)
+            hipLaunchKernelGGL(sched_top_kernel, dim3(1), dim3(ST_THREADS), 0, s, dS, k, cur.rows, plan->wl, plan->wr, plan->lvl,
+                               plan->wsum, plan->top_level, t_pj, t_ab32, t_ab64, t_root, t_lev);
+        if (k == KS) break;
+        const int R = (k == 0) ? R0 : R1;
+        const unsigned gb = (unsigned)ceil_div(cap[k], SB_BLOCK);
+        const Bufs &nx = B[(size_t)k + 1];
+        hipLaunchKernelGGL(sched_count_kernel, dim3(gb), dim3(SB_THREADS), 0, s, dS, k, cur.rows, k ? cur.wl : plan->wl,
+                           k ? cur.wr : plan->wr, k ? cur.lvl : plan->lvl, R, N, plan->top_level, flags, blk_cnt);
+        hipLaunchKernelGGL(sched_emit_kernel, dim3(gb), dim3(SB_THREADS), 0, s, dS, k, cur.rows, flags, blk_cnt, R, (uint32_t)Rf,
+                           (uint32_t)plan->n_roots, plan->wl, plan->wr, plan->lvl, plan->inv_order, nx.rows, nx.wl, nx.wr, nx.lvl,
+                           nx.pos, (uint32_t)cap[k + 1], cur.surv);
+        e = hipGetLastError();
+    }
+    SchedState hs;
+    int rc = (e == hipSuccess) ? read_back_u32((uint32_t *)&hs, (const uint32_t *)dS, SCHED_STATE_WORDS, nullptr, nullptr, 0, s) : RAHT_ERR_HIP;
+    if (rc != RAHT_OK || !hs.finished || hs.trouble || (int)hs.last_stage >= plan->max_stages) {
+        (void)hipStreamSynchronize(s);
+        release();
+        (void)hipGetLastError();
+        return rc == RAHT_OK ? RAHT_OK : rc;             // *built stays false: the exact builder decides
+    }
+    const int K = (int)hs.last_stage + 1;
+    for (int k = 0; k < K; ++k) {
+        Stage st;
+        Bufs &b = B[(size_t)k];
+        st.n_entries = hs.n[k];
+        st.rows = b.rows; st.e_wl = b.wl; st.e_wr = b.wr; st.e_lvl = b.lvl; st.e_pos = b.pos;
+        b.rows = nullptr; b.wl = nullptr; b.wr = nullptr; b.lvl = nullptr; b.pos = nullptr;
+        if (k == K - 1 && hs.last_is_top) {
+            st.is_top = true;
+            st.n_tiles = 1;
+            st.tile_rows = (int)st.n_entries;
+            st.n_merges = hs.top[0]; st.t_nlev = (int)hs.top[1]; st.t_nbig = (int)hs.top[2]; st.t_small_start = hs.top[3];
+            st.t_pj = t_pj; st.t_ab32 = t_ab32; st.t_ab64 = t_ab64; st.t_root = t_root; st.t_lev = t_lev;
+            t_pj = nullptr; t_ab32 = nullptr; t_ab64 = nullptr; t_root = nullptr; t_lev = nullptr;
+        } else {
+            st.tile_rows = (k == 0) ? R0 : R1;
+            st.n_tiles = ceil_div(st.n_entries, st.tile_rows);
+            st.surv_off = b.surv;
+            b.surv = nullptr;
+        }
+        sc.stages.push_back(st);
+    }
+    release();                                            // buffers of stages that were not needed
+    *built = true;
+    return RAHT_OK;
+}
+
 int get_schedule(raht_plan *plan, int R0, int R1, int Rf, hipStream_t s, Schedule **out)
 {
     for (auto &sc : plan->schedules)
         if (sc.tile_rows == R0 && sc.tail_rows == R1 && sc.final_rows == Rf) { *out = &sc; return RAHT_OK; }
+    static const bool exact_only = getenv("RAHT_SCHEDULE_EXACT") != nullptr;     // A/B and debugging knob
+    if (!exact_only && R0 >= 64 && R1 >= 64 && Rf >= 1 && Rf <= RAHT_TOP_MAX_ROWS) {
+        Schedule sc;
+        sc.tile_rows = R0; sc.tail_rows = R1; sc.final_rows = Rf; sc.valid = true;
+        bool built = false;
+        RAHT_RET(build_schedule_fast(plan, R0, R1, Rf, s, sc, &built));
+        if (built) {
+            plan->schedules.push_back(sc);
+            *out = &plan->schedules.back();
+            return RAHT_OK;
+        }
+    }
+    return get_schedule_exact(plan, R0, R1, Rf, s, out);
+}
+
+static int get_schedule_exact(raht_plan *plan, int R0, int R1, int Rf, hipStream_t s, Schedule **out)
+{
     Schedule sc;
     sc.tile_rows = R0;
     sc.tail_rows = R1;
@@ -601,37 +985,52 @@ static int compute_roots(raht_plan *p, hipStream_t s)
     return RAHT_OK;
 }
 
+// Rows bucketed by binary level (the LEVEL engine's pair lists): built on first use only -- the tile engine
+// never reads them. level_off (host) comes from the level histogram of the plan build.
+int ensure_level_rows(raht_plan *p, hipStream_t s)
+{
+    if (p->level_rows) return RAHT_OK;
+    RAHT_HIP_CHECK(dev_malloc(&p->level_rows, sizeof(uint32_t) * (size_t)p->N));
+    // the low 6 bits of lvl are the bucket (row 0, lvl 255, is alone in bucket 63); stable: ascending rows per level
+    return bucket_sort_u8(p->lvl, p->level_rows, p->N, 6, nullptr, s);
+}
+
 // ---- plan construction ---------------------------------------------------------------------------
 static int finish_plan(raht_plan *p, const int64_t *leaf_weights, hipStream_t s)
 {
     const int64_t N = p->N;
     const unsigned gb = (unsigned)ceil_div(N, 256);
-    Scratch tmp(sizeof(PlanErr) + sizeof(uint32_t) * 65 + (size_t)N);     // error word | bucket offsets | bucket ids
+    const unsigned nblk = (unsigned)ceil_div(N, EXT_THREADS);
+    // scratch: error word | level histogram [64] | bucket histogram / positions [ORDER_BUCKETS x nblk] | bucket ids [N]
+    Scratch tmp(sizeof(PlanErr) + sizeof(uint32_t) * (64 + (size_t)ORDER_BUCKETS * nblk) + (size_t)N);
     if (!tmp.ok()) return RAHT_ERR_NOMEM;
     PlanErr *derr = tmp.as<PlanErr>();
-    uint32_t *boff = (uint32_t *)((char *)tmp.ptr() + sizeof(PlanErr));
-    uint8_t *bucket = (uint8_t *)(boff + 65);
-    PlanErr h0 = {0, 0xffffffffu};
-    RAHT_HIP_CHECK(hipMemcpyAsync(derr, &h0, sizeof(h0), hipMemcpyHostToDevice, s));
+    uint32_t *lhist = (uint32_t *)((char *)tmp.ptr() + sizeof(PlanErr));
+    uint32_t *bhist = lhist + 64;
+    uint8_t *bucket = (uint8_t *)(bhist + (size_t)ORDER_BUCKETS * nblk);
+    // error word {0, ~0u} and the zeroed level histogram in ONE host-to-device copy (pageable: copied before return)
+    uint32_t init[2 + 64] = {0};
+    init[1] = 0xffffffffu;
+    static_assert(sizeof(PlanErr) == 2 * sizeof(uint32_t), "PlanErr is read back as two words");
+    RAHT_HIP_CHECK(hipMemcpyAsync(derr, init, sizeof(init), hipMemcpyHostToDevice, s));
     RAHT_HIP_CHECK(dev_malloc(&p->lvl, (size_t)N));
     RAHT_HIP_CHECK(dev_malloc(&p->wl, sizeof(int32_t) * (size_t)N));
     RAHT_HIP_CHECK(dev_malloc(&p->wr, sizeof(int32_t) * (size_t)N));
     RAHT_HIP_CHECK(dev_malloc(&p->order, sizeof(uint32_t) * (size_t)N));
     RAHT_HIP_CHECK(dev_malloc(&p->inv_order, sizeof(uint32_t) * (size_t)N));
-    RAHT_HIP_CHECK(dev_malloc(&p->level_rows, sizeof(uint32_t) * (size_t)N));
     // everything below is enqueued speculatively; the error word is checked at the single sync
-    hipLaunchKernelGGL(level_extent_kernel, dim3((unsigned)ceil_div(N, EXT_THREADS)), dim3(EXT_THREADS), 0, s, p->keys, N,
-                       p->nbits, p->lvl, bucket, p->wl, p->wr, derr);
-    // order_RAGFT and the per-level row buckets: two stable bucket sorts
-    RAHT_RET(bucket_sort_u8(bucket, p->order, N, 5, nullptr, s));
-    if (getenv("RAHT_DEBUG_IDENTITY_ORDER"))      // timing experiments only: order_RAGFT := identity
+    hipLaunchKernelGGL(level_extent_kernel, dim3(nblk), dim3(EXT_THREADS), 0, s, p->keys, N,
+                       p->nbits, p->lvl, bucket, p->wl, p->wr, derr, bhist, lhist);
+    // order_RAGFT and its inverse: stable counting sort by bucket (histogram from the pass above)
+    RAHT_RET(exclusive_scan_u32(bhist, bhist, (int64_t)ORDER_BUCKETS * nblk, nullptr, s));
+    hipLaunchKernelGGL(order_scatter_kernel, dim3(nblk), dim3(EXT_THREADS), 0, s, bucket, N, bhist, p->order, p->inv_order);
+    if (getenv("RAHT_DEBUG_IDENTITY_ORDER")) {    // timing experiments only: order_RAGFT := identity
         hipLaunchKernelGGL(order_to_identity_kernel, dim3(gb), dim3(256), 0, s, p->order, N);
-    hipLaunchKernelGGL(invert_perm_kernel, dim3(gb), dim3(256), 0, s, p->order, N, p->inv_order);
-    // rows bucketed by level: the low 6 bits of lvl are the bucket (row 0, lvl 255, is alone in bucket 63)
-    RAHT_RET(bucket_sort_u8(p->lvl, p->level_rows, N, 6, boff, s));
+        hipLaunchKernelGGL(invert_perm_kernel, dim3(gb), dim3(256), 0, s, p->order, N, p->inv_order);
+    }
     PlanErr he;
-    static_assert(sizeof(PlanErr) == 2 * sizeof(uint32_t), "PlanErr is read back as two words");
-    RAHT_RET(read_back_u32((uint32_t *)&he, (const uint32_t *)derr, 2, p->level_off, boff, 65, s));
+    uint32_t lh[64];
+    RAHT_RET(read_back_u32((uint32_t *)&he, (const uint32_t *)derr, 2, lh, lhist, 64, s));
     if (he.code != 0) {
         if (he.code == RAHT_ERR_UNSORTED)
             set_error("Morton keys are not strictly increasing at row %u (input must be Morton-sorted "
@@ -640,6 +1039,8 @@ static int finish_plan(raht_plan *p, const int64_t *leaf_weights, hipStream_t s)
             set_error("coordinate / key out of bounds at row %u for depth %d", he.row, p->nbits / 3);
         return he.code;
     }
+    p->level_off[0] = 0;                            // rows bucketed by level (bucket 63 = row 0), see ensure_level_rows
+    for (int l = 0; l < 64; ++l) p->level_off[l + 1] = p->level_off[l] + lh[l];
     p->max_level = -1;                              // highest level that has a pair (bucket 63 = row 0)
     for (int l = 0; l < 63; ++l)
         if (p->level_off[l + 1] > p->level_off[l]) p->max_level = l;

@@ -206,7 +206,7 @@ struct raht_plan {
     int64_t *wsum = nullptr;     // device int64[N+1] prefix of leaf weights, or nullptr (all ones)
     uint32_t *order = nullptr;   // device, order_RAGFT
     uint32_t *inv_order = nullptr;  // device, inverse permutation: inv_order[order[k]] = k
-    uint32_t *level_rows = nullptr;          // device, rows 1..N-1 stably sorted by lvl
+    uint32_t *level_rows = nullptr;          // device, rows 1..N-1 stably sorted by lvl (LEVEL engine only: ensure_level_rows)
     uint32_t level_off[RAHT_MAX_LEVELS + 1]; // host, start of every level inside level_rows
     int top_level = 64;          // butterflies at binary levels >= top_level are NOT performed
     int64_t n_roots = 1;         // row 0 plus every row whose level is >= top_level
@@ -242,6 +242,8 @@ __device__ __forceinline__ void pair_weights(int64_t i, int l, int r, const int6
     }
 }
 
+// The level engine's per-level row lists (built on first use).
+int ensure_level_rows(raht_plan *plan, hipStream_t s);
 // Tile schedule for `tile_rows` rows per tile (built on first use, cached in the plan).
 int get_schedule(raht_plan *plan, int tile_rows, int tail_rows, int final_rows, hipStream_t s, Schedule **out);
 // Tile geometry of the later (small, latency-bound) stages: as many rows as one workgroup per CU can

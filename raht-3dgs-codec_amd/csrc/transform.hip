@@ -1142,6 +1142,7 @@ template <typename T, bool INV>
 static int run_level_engine(const raht_plan *p, const T *src, int64_t ld_src, T *dst, int64_t ld_dst,
                             int D, hipStream_t s)
 {
+    RAHT_RET(ensure_level_rows(const_cast<raht_plan *>(p), s));
     const int64_t mat_rows = p->row_map ? p->map_rows : p->N;
     if ((const void *)src != (const void *)dst) {
         const int64_t total = mat_rows * D;
