@@ -99,44 +99,91 @@ __global__ void morton_i64_kernel(const int64_t *__restrict__ V, int64_t N, uint
 // wr[i]  = rows of the level-lvl[i] node that starts at row i  = (first m > i with lvl[m] >= lvl[i], or N) - i
 // wl[i]  = rows of the level-lvl[i] node that ends at row i-1  = i - (last m < i with lvl[m] >= lvl[i]); lvl[0] = 255
 //
-// Most of these neighbours are a few rows away: the ones inside the row's own wave (64 consecutive rows)
-// come from ballots, with no memory traffic at all. The rows whose node reaches past the wave (about one
-// in six) are queued in LDS and the workgroup then searches for their ends in the keys with every lane
-// busy. (One search per row made each wave pay the instruction stream of its longest search: 76 us on
-// cfg3; one global queue for the whole grid serialised on its counter: 1 ms.)
+// (how the neighbours are found: see level_extent_kernel below)
 static constexpr int EXT_THREADS = 1024;
+static constexpr int EXT_WAVES = EXT_THREADS / 64;
 
 // The same pass also counts, per block of EXT_THREADS rows, the rows of every order_RAGFT bucket (ORDER_BUCKETS
-// bins -> bucket_hist[bucket * gridDim.x + block], the input of the stable counting sort that produces
-// order_RAGFT: no separate histogram pass over the rows) and the global population of every binary level
-// (level_hist[64]: max_level / len(Flags) and the level engine's level offsets).
+// bins) and of every binary level (64 bins) -> bucket_hist[bin * gridDim.x + block]: the input of the stable
+// counting sort that produces order_RAGFT (no separate histogram pass over the rows) and, scanned, the start of
+// every level among the rows (max_level / len(Flags), the level engine's level offsets).
 static constexpr int ORDER_BUCKETS = 32;             // bucket(0) = 0, bucket(i) = 1 + (20 - lvl / 3) <= 21
 
+// One queued search, over a monotone predicate on the keys ((key >> l) == prefix holds exactly on the node):
+// gallop away from the block by x8, then split the bracket in 8 with 7 independent probes per step -- the chain
+// of dependent loads is what a search costs. Every probe address is a valid row.
+// q = row within the block | direction << 31 (0 = right: where does the node STARTING at the row end;
+// 1 = left: where does the node ENDING at the row before it start).
+static constexpr int EXT_QCAP = 96;                  // queue slots per block handed to extent_search_kernel
+__device__ __forceinline__ void extent_search(const uint64_t *__restrict__ keys, int64_t N, int64_t b0, uint32_t q, int ql,
+                                              int32_t *__restrict__ wl, int32_t *__restrict__ wr)
+{
+    const bool right = (q >> 31) == 0;
+    const int64_t r = b0 + (q & 0x7fffffffu);
+    const int64_t dir = right ? 1 : -1;
+    // right: the node starting at row r reaches at least to the end of its BLOCK; left: the node
+    // ending at row r - 1 reaches back at least to the row before the block (never block 0: it holds row 0)
+    const uint64_t pref = keys[right ? r : r - 1] >> ql;
+    int64_t in = right ? min(b0 + 1024 - 1, N - 1) : max(b0 - 1, (int64_t)0);
+    int64_t out = right ? N : -1;
+    for (int64_t step = 1;; step <<= 3) {
+        const int64_t p = in + dir * step;
+        const bool in_range = right ? p < N : p >= 0;
+        const uint64_t k = keys[min(max(p, (int64_t)0), N - 1)];
+        if (in_range && (k >> ql) == pref) in = p;
+        else { out = right ? min(p, N) : max(p, (int64_t)-1); break; }
+    }
+    while ((right ? out - in : in - out) > 1) {
+        const int64_t w = right ? out - in : in - out;
+        uint64_t k[7];
+#pragma unroll
+        for (int j = 0; j < 7; ++j) k[j] = keys[in + dir * ((w * (j + 1)) >> 3)];     // between in and out
+        int64_t nin = in, nout = out;
+        bool hit = false;
+#pragma unroll
+        for (int j = 0; j < 7; ++j) {
+            const int64_t p = in + dir * ((w * (j + 1)) >> 3);
+            if (!hit) { if ((k[j] >> ql) == pref) nin = p; else { nout = p; hit = true; } }
+        }
+        in = nin; out = nout;
+    }
+    if (right) wr[r] = (int32_t)(out - r);
+    else wl[r] = (int32_t)(r - in);
+}
+
+// How the neighbours are found. A row's right (left) neighbour is the next (previous) row whose level is >= its
+// own. For every binary level t < nbits every wave publishes ONE 64-bit word: which of its rows have a level
+// >= t (a v_cmp into a scalar register pair, stored by one lane: 8 KiB of LDS per 1024-row block). A row of
+// level l then reads the words of column l: its own wave's word gives the neighbour inside the wave, the
+// following (preceding) waves' words the neighbour inside the block -- typically one to three 8-byte LDS reads,
+// no dependent chain, no memory traffic. Only rows whose node leaves the block (~1 %) are queued and search
+// the keys (gallop x8, then 8-way splits). Rows past the end of the scene and row 0 count as level 255: they
+// end every node. (Earlier versions: one key search per row, 76 us on cfg3 -- every wave paid the instruction
+// stream of its longest search; a loop over the distinct levels of each wave with the key search for the one
+// row in six that left its wave, 62 us -- ~22 iterations per wave serialised on a scalar read-lane each.)
 __global__ void __launch_bounds__(EXT_THREADS) level_extent_kernel(const uint64_t *__restrict__ keys, int64_t N, int nbits,
                                                                     uint8_t *__restrict__ lvl, uint8_t *__restrict__ order_bucket,
                                                                     int32_t *__restrict__ wl, int32_t *__restrict__ wr, PlanErr *err,
-                                                                    uint32_t *__restrict__ bucket_hist, uint32_t *__restrict__ level_hist)
+                                                                    uint32_t *__restrict__ bucket_hist, uint32_t *__restrict__ gq,
+                                                                    uint32_t *__restrict__ gq_count)
 {
+    __shared__ uint64_t s_ge[64][EXT_WAVES];         // [level][wave]: rows of the wave with a level >= `level`
     __shared__ uint32_t queue[2 * EXT_THREADS];      // row within the block | direction << 31
     __shared__ uint8_t s_lvl[EXT_THREADS];
     __shared__ uint32_t n_queued;
-    __shared__ uint32_t s_bh[ORDER_BUCKETS], s_lh[64];
+    __shared__ uint32_t s_lh[64];
     if (threadIdx.x == 0) n_queued = 0;
-    if (threadIdx.x < ORDER_BUCKETS) s_bh[threadIdx.x] = 0;
     if (threadIdx.x < 64) s_lh[threadIdx.x] = 0;
     __syncthreads();
     const int64_t b0 = (int64_t)blockIdx.x * EXT_THREADS;
     const int64_t i = b0 + threadIdx.x;
-    const int lane = threadIdx.x & 63;
-    const int64_t w0 = i - lane;                     // first row of this wave
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const bool valid = i < N;
-    int l = -1;                                      // rows past the end never bound a node
+    int l = 255;                                     // rows past the end (and row 0) end every node
     if (valid) {
         const uint64_t k = keys[i];
         if (nbits < 64 && (k >> nbits) != 0) report(err, RAHT_ERR_BOUNDS, i);
-        if (i == 0) {
-            l = 255;
-        } else {
+        if (i != 0) {
             const uint64_t p = keys[i - 1];
             if (k <= p) { report(err, RAHT_ERR_UNSORTED, i); l = 0; }
             else l = 63 - __clzll((long long)(k ^ p));
@@ -146,27 +193,53 @@ __global__ void __launch_bounds__(EXT_THREADS) level_extent_kernel(const uint64_
         // order_RAGFT (RAHT_param.py:251-274): [root] ++ groups of rows that stop being node starts within
         // octree level g = lvl / 3, coarse to fine, ascending row index inside a group  ==  a stable bucket
         // sort by bucket(0) = 0, bucket(i) = 1 + (20 - lvl[i] / 3)
-        const uint32_t ob = (i == 0) ? 0u : (uint32_t)(1 + (20 - l / 3));
-        order_bucket[i] = (uint8_t)ob;
-        atomicAdd(&s_bh[ob], 1u);
-        atomicAdd(&s_lh[l & 63], 1u);                // row 0 (lvl 255) lands alone in bin 63
+        order_bucket[i] = (i == 0) ? 0 : (uint8_t)(1 + (20 - l / 3));
     }
     const bool searching = valid && i != 0;
-    const uint64_t below = ((uint64_t)1 << lane) - 1, above = ~(below | ((uint64_t)1 << lane));
-    int next_j = -1, prev_j = -1;                    // lane of the neighbour inside the wave, -1 = none
-    uint64_t todo = __ballot(searching);
-    while (todo) {                                   // one pass per distinct level in the wave (uniform)
-        const int t = __builtin_amdgcn_readlane(l, __ffsll((unsigned long long)todo) - 1);
+    // one word per (level, wave), and the level histogram (one LDS atomic per wave and level present)
+    const int top = min(max(nbits, 1), 63);          // levels are < nbits
+    for (int t = 0; t < top; ++t) {
         const uint64_t ge = __ballot(l >= t);
-        if (l == t) {
-            const uint64_t hi = ge & above, lo = ge & below;
-            next_j = hi ? __ffsll((unsigned long long)hi) - 1 : -1;
-            prev_j = lo ? 63 - __clzll((long long)lo) : -1;
+        const uint32_t eq = (uint32_t)__popcll(__ballot(l == t));
+        if (lane == 0) {
+            s_ge[t][wv] = ge;
+            if (eq) atomicAdd(&s_lh[t], eq);
         }
-        todo &= ~__ballot(l == t);
     }
-    const bool last_wave = w0 + 64 >= N;
-    const bool q_r = searching && next_j < 0 && !last_wave, q_l = searching && prev_j < 0;   // (wave 0 holds row 0: no q_l)
+    if (i == 0) s_lh[63] = 1;                        // row 0 (lvl 255): alone in level bin 63
+    __syncthreads();
+    const uint64_t below = ((uint64_t)1 << lane) - 1, above = ~(below | ((uint64_t)1 << lane));
+    bool q_r = false, q_l = false;
+    if (searching) {
+        const int lc = min(l, 63);
+        // right neighbour: own wave, then the following waves of the block
+        int found = -1;
+        {
+            const uint64_t m = s_ge[lc][wv] & above;
+            if (m) found = wv * 64 + __ffsll((unsigned long long)m) - 1;
+            for (int w2 = wv + 1; found < 0 && w2 < EXT_WAVES; ++w2) {
+                const uint64_t m2 = s_ge[lc][w2];
+                if (m2) found = w2 * 64 + __ffsll((unsigned long long)m2) - 1;
+            }
+        }
+        if (found >= 0) wr[i] = (int32_t)(min((int64_t)found + b0, N) - i);   // (a row past the end stands for row N)
+        else if (b0 + EXT_THREADS >= N) wr[i] = (int32_t)(N - i);
+        else q_r = true;
+        // left neighbour: own wave, then the preceding waves
+        found = -1;
+        {
+            const uint64_t m = s_ge[lc][wv] & below;
+            if (m) found = wv * 64 + 63 - __clzll((long long)m);
+            for (int w2 = wv - 1; found < 0 && w2 >= 0; --w2) {
+                const uint64_t m2 = s_ge[lc][w2];
+                if (m2) found = w2 * 64 + 63 - __clzll((long long)m2);
+            }
+        }
+        if (found >= 0) wl[i] = (int32_t)((int)threadIdx.x - found);
+        else q_l = true;                              // (never in block 0: it holds row 0)
+    } else if (valid) {
+        wl[0] = 0; wr[0] = 0;
+    }
     const uint64_t m_r = __ballot(q_r), m_l = __ballot(q_l);
     if (m_r | m_l) {
         uint32_t base = 0;
@@ -175,55 +248,41 @@ __global__ void __launch_bounds__(EXT_THREADS) level_extent_kernel(const uint64_
         if (q_r) queue[base + __popcll(m_r & below)] = threadIdx.x;
         if (q_l) queue[base + __popcll(m_r) + __popcll(m_l & below)] = threadIdx.x | 0x80000000u;
     }
-    if (searching) {
-        if (next_j >= 0) wr[i] = (int32_t)(next_j - lane);
-        else if (last_wave) wr[i] = (int32_t)(N - i);
-        if (prev_j >= 0) wl[i] = (int32_t)(lane - prev_j);
-    } else if (valid) {
-        wl[0] = 0; wr[0] = 0;
+    // per-block histograms, bin-major: [ORDER_BUCKETS order buckets | 64 binary levels] x gridDim.x. ONE exclusive scan
+    // over the whole array turns the first part into the order scatter's positions and, read at every level's first
+    // block, the second part into the start of every level among the rows (no global atomics)
+    if (threadIdx.x < 64) bucket_hist[(size_t)(ORDER_BUCKETS + threadIdx.x) * gridDim.x + blockIdx.x] = s_lh[threadIdx.x];
+    if (threadIdx.x < ORDER_BUCKETS) {
+        uint32_t c = 0;                               // order bucket b >= 1 = levels 3 (21 - b) .. 3 (21 - b) + 2; bucket 0 = row 0
+        const int b = threadIdx.x;
+        if (b == 0) c = s_lh[63];
+        else if (b <= 21) { const int l0 = 3 * (21 - b); c = s_lh[l0] + s_lh[l0 + 1] + s_lh[l0 + 2]; }
+        bucket_hist[(size_t)b * gridDim.x + blockIdx.x] = c;
     }
     __syncthreads();
-    if (threadIdx.x < ORDER_BUCKETS) bucket_hist[(size_t)threadIdx.x * gridDim.x + blockIdx.x] = s_bh[threadIdx.x];
-    if (threadIdx.x < 64 && s_lh[threadIdx.x]) atomicAdd(&level_hist[threadIdx.x], s_lh[threadIdx.x]);
-    // The queued searches, over a monotone predicate on the keys ((key >> l) == prefix holds exactly on the
-    // node): gallop away from the wave by x8, then split the bracket in 8 with 7 independent probes per
-    // step -- the chain of dependent loads is what a search costs. Every probe address is a valid row.
+    // The queued searches go to extent_search_kernel: a block that ran them itself kept its 16 wave slots
+    // until its slowest search (a chain of ~5 dependent loads) had finished, and the next block of the CU could
+    // not start -- that tail, not the work, was two thirds of this kernel's 75 us. Each block owns EXT_QCAP slots
+    // of a global queue; the (pathological) rest it still searches itself.
     const uint32_t nq = n_queued;
-    for (uint32_t t = threadIdx.x; t < nq; t += EXT_THREADS) {
+    if (threadIdx.x == 0) gq_count[blockIdx.x] = min(nq, (uint32_t)EXT_QCAP);
+    if (threadIdx.x < min(nq, (uint32_t)EXT_QCAP)) gq[(size_t)blockIdx.x * EXT_QCAP + threadIdx.x] = queue[threadIdx.x];
+    for (uint32_t t = EXT_QCAP + threadIdx.x; t < nq; t += EXT_THREADS) {
         const uint32_t q = queue[t];
-        const bool right = (q >> 31) == 0;
-        const int64_t r = b0 + (q & 0x7fffffffu);
-        const int64_t dir = right ? 1 : -1;
-        const int ql = s_lvl[q & 0x7fffffffu];
-        // right: the node starting at row r reaches at least to the end of its wave; left: the node
-        // ending at row r - 1 reaches back at least to the row before the wave (never wave 0)
-        const uint64_t pref = keys[right ? r : r - 1] >> ql;
-        int64_t in = right ? min((r | 63), N - 1) : max((r & ~(int64_t)63) - 1, (int64_t)0);
-        int64_t out = right ? N : -1;
-        for (int64_t step = 1;; step <<= 3) {
-            const int64_t p = in + dir * step;
-            const bool in_range = right ? p < N : p >= 0;
-            const uint64_t k = keys[min(max(p, (int64_t)0), N - 1)];
-            if (in_range && (k >> ql) == pref) in = p;
-            else { out = right ? min(p, N) : max(p, (int64_t)-1); break; }
-        }
-        while ((right ? out - in : in - out) > 1) {
-            const int64_t w = right ? out - in : in - out;
-            uint64_t k[7];
-#pragma unroll
-            for (int j = 0; j < 7; ++j) k[j] = keys[in + dir * ((w * (j + 1)) >> 3)];     // between in and out
-            int64_t nin = in, nout = out;
-            bool hit = false;
-#pragma unroll
-            for (int j = 0; j < 7; ++j) {
-                const int64_t p = in + dir * ((w * (j + 1)) >> 3);
-                if (!hit) { if ((k[j] >> ql) == pref) nin = p; else { nout = p; hit = true; } }
-            }
-            in = nin; out = nout;
-        }
-        if (right) wr[r] = (int32_t)(out - r);
-        else wl[r] = (int32_t)(r - in);
+        extent_search(keys, N, b0, q, s_lvl[q & 0x7fffffffu], wl, wr);
     }
+}
+
+__global__ void __launch_bounds__(256) extent_search_kernel(const uint64_t *__restrict__ keys, int64_t N, const uint8_t *__restrict__ lvl,
+                                                            const uint32_t *__restrict__ gq, const uint32_t *__restrict__ gq_count,
+                                                            uint32_t nblk, int32_t *__restrict__ wl, int32_t *__restrict__ wr)
+{
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t b = g / EXT_QCAP, slot = g - b * EXT_QCAP;
+    if (b >= nblk || slot >= gq_count[b]) return;
+    const uint32_t q = gq[(size_t)b * EXT_QCAP + slot];
+    const int64_t b0 = (int64_t)b * EXT_THREADS;
+    extent_search(keys, N, b0, q, (int)lvl[b0 + (q & 0x7fffffffu)], wl, wr);
 }
 
 // ---- order_RAGFT -------------------------------------------------------------------------------
@@ -233,10 +292,15 @@ __global__ void __launch_bounds__(EXT_THREADS) level_extent_kernel(const uint64_
 // lanes of its wave with the same bucket). Writes the permutation AND its inverse: inv_order[i] = pos.
 __global__ void __launch_bounds__(EXT_THREADS) order_scatter_kernel(const uint8_t *__restrict__ order_bucket, int64_t N,
                                                                      const uint32_t *__restrict__ bucket_pos,
-                                                                     uint32_t *__restrict__ order, uint32_t *__restrict__ inv_order)
+                                                                     uint32_t *__restrict__ order, uint32_t *__restrict__ inv_order,
+                                                                     uint32_t *__restrict__ level_start)
 {
     __shared__ uint32_t wcnt[EXT_THREADS / 64][ORDER_BUCKETS];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    // level_start[l] = rows with a binary level < l (the scanned level histogram at every level's first block,
+    // minus the N rows counted by the order buckets before it): gathered here for the host's one read-back
+    if (blockIdx.x == 0 && threadIdx.x < 64)
+        level_start[threadIdx.x] = bucket_pos[(size_t)(ORDER_BUCKETS + threadIdx.x) * gridDim.x] - (uint32_t)N;
     const int64_t i = (int64_t)blockIdx.x * EXT_THREADS + threadIdx.x;
     const bool valid = i < N;
     const uint32_t b = valid ? order_bucket[i] : 0u;
@@ -592,14 +656,23 @@ __global__ __launch_bounds__(SB_THREADS) void sched_count_kernel(const SchedStat
     const int64_t base = (int64_t)blockIdx.x * SB_BLOCK + (int64_t)threadIdx.x * SB_ITEMS;
     if ((int64_t)blockIdx.x * SB_BLOCK >= n) return;
     uint32_t cnt = 0;
+    // tile bounds by 32-bit arithmetic, carried along the thread's 8 consecutive entries (a 64-bit division per
+    // entry was most of this kernel's time)
+    uint32_t j0 = (uint32_t)base / (uint32_t)R * (uint32_t)R;
+    int64_t start = 0, end = 0;
+    bool fresh = true;
 #pragma unroll
     for (int q = 0; q < SB_ITEMS; ++q) {
         const int64_t j = base + q;
         if (j < n) {
+            if ((uint32_t)j >= j0 + (uint32_t)R) { j0 += (uint32_t)R; fresh = true; }
+            if (fresh) {
+                const int64_t j1 = (int64_t)j0 + R;
+                start = rows ? (int64_t)rows[j0] : (int64_t)j0;
+                end = (j1 < n) ? (rows ? (int64_t)rows[j1] : j1) : N;
+                fresh = false;
+            }
             const int64_t r = rows ? (int64_t)rows[j] : j;
-            const int64_t j0 = j / R * R, j1 = j0 + R;
-            const int64_t start = rows ? (int64_t)rows[j0] : j0;
-            const int64_t end = (j1 < n) ? (rows ? (int64_t)rows[j1] : j1) : N;
             const bool merged = (r > 0) && ((int)lvl[j] < top_level) && (r - wl[j] >= start) && (r + wr[j] <= end);
             flags[j] = merged ? 0 : 1;
             cnt += merged ? 0u : 1u;
@@ -645,11 +718,14 @@ __global__ __launch_bounds__(SB_THREADS) void sched_emit_kernel(SchedState *__re
 #pragma unroll
     for (int w = 0; w < 4; ++w) { if (w < wid) before += wsum[w]; block_tot += wsum[w]; }
     uint32_t pos = block_base + before + inc - mine;
+    uint32_t tile = (uint32_t)base / (uint32_t)R;
+    uint32_t next_start = tile * (uint32_t)R;               // first tile boundary at or after `base`
+    if (next_start < (uint32_t)base) { ++tile; next_start += (uint32_t)R; }
 #pragma unroll
     for (int q = 0; q < SB_ITEMS; ++q) {
         const int64_t j = base + q;
         if (j < n) {
-            if (j % R == 0) surv_off[j / R] = pos;           // first survivor of tile j / R
+            if ((uint32_t)j == next_start) { surv_off[tile] = pos; ++tile; next_start += (uint32_t)R; }   // first survivor of the tile
             if (f[q]) {
                 if (pos < cap_next) {
                     const uint32_t r = rows ? rows[j] : (uint32_t)j;
@@ -711,27 +787,40 @@ __global__ __launch_bounds__(ST_THREADS) void sched_top_kernel(SchedState *__res
         if (tid == 0) { uint32_t t = 0; for (int w = 0; w < ST_THREADS / 64; ++w) t += wtot[w]; root_base += t; }
         __syncthreads();
     }
-    // level offsets + the level program (thread 0: 64 levels)
-    if (tid == 0) {
-        uint32_t run = 0;
-        uint32_t lev[128];
-        int nlev = 0;
-        for (int l = 0; l < 64; ++l) {
-            cursor[l] = run;
-            if (hist[l] && l < 63) { lev[2 * nlev] = run; lev[2 * nlev + 1] = run + hist[l]; ++nlev; }
-            run += hist[l];
-        }
-        const uint32_t n_merges = run;
-        // non-empty levels ascending; the trailing run with <= 64 butterflies each is chained by one wave, its records
-        // live in LDS next to the entries (16 B per entry + 12 / 20 B per record; 160 KiB - 1 KiB)
-        int nbig = nlev;
-        while (nbig > 0 && lev[2 * (nbig - 1) + 1] - lev[2 * (nbig - 1)] <= 64) --nbig;
+    // level offsets + the level program: wave 0, lane l = binary level l
+    if (wid == 0) {
+        const uint32_t h = (lane < 63) ? hist[lane] : 0u;
+        uint32_t inc = h;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t t = __shfl_up(inc, d, 64); if (lane >= d) inc += t; }
+        const uint32_t first = inc - h;
+        cursor[lane] = first;
+        const uint32_t n_merges = (uint32_t)__shfl((int)inc, 63, 64);
+        const uint64_t nonempty = __ballot(h > 0), below = ((uint64_t)1 << lane) - 1;
+        const int nlev = __popcll(nonempty);
+        const int my = __popcll(nonempty & below);              // index of this level among the non-empty ones
+        if (h > 0) { t_lev[2 * my] = first; t_lev[2 * my + 1] = first + h; }
+        // the trailing run of levels with <= 64 butterflies each is chained by one wave; its records live in LDS next
+        // to the entries (16 B per entry + 12 / 20 B per record; 160 KiB - 1 KiB): walk it down from the top while it fits
+        const uint64_t big = __ballot(h > 64);
+        int nbig = big ? __popcll(nonempty & (((uint64_t)2 << (63 - __clzll((long long)big))) - 1)) : 0;
         const size_t lds_budget = 160 * 1024 - 1024;
-        while (nbig < nlev && (size_t)n * 16 + (size_t)(n_merges - lev[2 * nbig]) * 20 > lds_budget) ++nbig;
-        for (int i = 0; i < 2 * nlev; ++i) t_lev[i] = lev[i];
-        S->top[0] = n_merges; S->top[1] = (uint32_t)nlev; S->top[2] = (uint32_t)nbig;
-        S->top[3] = (nbig < nlev) ? lev[2 * nbig] : n_merges;
-        S->finished = 1; S->last_stage = (uint32_t)k; S->last_is_top = 1;
+        uint32_t small_start = n_merges;
+        // first butterfly of the non-empty level with index q: broadcast from the lane that owns it
+        for (;;) {
+            uint32_t cand = n_merges;
+            if (nbig < nlev) {
+                const uint64_t owner = __ballot(h > 0 && my == nbig);
+                cand = (uint32_t)__shfl((int)first, __ffsll((unsigned long long)owner) - 1, 64);
+            }
+            if (nbig < nlev && (size_t)n * 16 + (size_t)(n_merges - cand) * 20 > lds_budget) { ++nbig; continue; }
+            small_start = cand;
+            break;
+        }
+        if (lane == 0) {
+            S->top[0] = n_merges; S->top[1] = (uint32_t)nlev; S->top[2] = (uint32_t)nbig; S->top[3] = small_start;
+            S->finished = 1; S->last_stage = (uint32_t)k; S->last_is_top = 1;
+        }
     }
     __syncthreads();
     // pass 2: resolve and place every butterfly (any order inside a level: they are independent)
@@ -825,7 +914,11 @@ static int build_schedule_fast(raht_plan *plan, int R0, int R1, int Rf, hipStrea
         e = hipGetLastError();
     }
     SchedState hs;
-    int rc = (e == hipSuccess) ? read_back_u32((uint32_t *)&hs, (const uint32_t *)dS, SCHED_STATE_WORDS, nullptr, nullptr, 0, s) : RAHT_ERR_HIP;
+    int rc = RAHT_ERR_HIP;
+    if (e == hipSuccess) {
+        rc = read_back_u32((uint32_t *)&hs, (const uint32_t *)dS, SCHED_STATE_WORDS, plan->pend_host, plan->pend_dev, plan->pend_n, s);
+        if (rc == RAHT_OK) plan->pend_n = 0;              // delivered
+    }
     if (rc != RAHT_OK || !hs.finished || hs.trouble || (int)hs.last_stage >= plan->max_stages) {
         (void)hipStreamSynchronize(s);
         release();
@@ -1001,16 +1094,16 @@ static int finish_plan(raht_plan *p, const int64_t *leaf_weights, hipStream_t s)
     const int64_t N = p->N;
     const unsigned gb = (unsigned)ceil_div(N, 256);
     const unsigned nblk = (unsigned)ceil_div(N, EXT_THREADS);
-    // scratch: error word | level histogram [64] | bucket histogram / positions [ORDER_BUCKETS x nblk] | bucket ids [N]
-    Scratch tmp(sizeof(PlanErr) + sizeof(uint32_t) * (64 + (size_t)ORDER_BUCKETS * nblk) + (size_t)N);
+    // scratch: error word | level starts [64] | (order bucket + level) histograms / positions [(ORDER_BUCKETS + 64) x nblk]
+    //          | search queue [EXT_QCAP x nblk] + counts [nblk] | bucket ids [N]
+    Scratch tmp(sizeof(PlanErr) + sizeof(uint32_t) * (64 + (size_t)(ORDER_BUCKETS + 64 + EXT_QCAP + 1) * nblk) + (size_t)N);
     if (!tmp.ok()) return RAHT_ERR_NOMEM;
     PlanErr *derr = tmp.as<PlanErr>();
     uint32_t *lhist = (uint32_t *)((char *)tmp.ptr() + sizeof(PlanErr));
     uint32_t *bhist = lhist + 64;
-    uint8_t *bucket = (uint8_t *)(bhist + (size_t)ORDER_BUCKETS * nblk);
-    // error word {0, ~0u} and the zeroed level histogram in ONE host-to-device copy (pageable: copied before return)
-    uint32_t init[2 + 64] = {0};
-    init[1] = 0xffffffffu;
+    uint32_t *gq = bhist + (size_t)(ORDER_BUCKETS + 64) * nblk, *gq_count = gq + (size_t)EXT_QCAP * nblk;
+    uint8_t *bucket = (uint8_t *)(gq_count + nblk);
+    uint32_t init[2] = {0, 0xffffffffu};              // error word (pageable source: copied before the call returns)
     static_assert(sizeof(PlanErr) == 2 * sizeof(uint32_t), "PlanErr is read back as two words");
     RAHT_HIP_CHECK(hipMemcpyAsync(derr, init, sizeof(init), hipMemcpyHostToDevice, s));
     RAHT_HIP_CHECK(dev_malloc(&p->lvl, (size_t)N));
@@ -1020,31 +1113,21 @@ static int finish_plan(raht_plan *p, const int64_t *leaf_weights, hipStream_t s)
     RAHT_HIP_CHECK(dev_malloc(&p->inv_order, sizeof(uint32_t) * (size_t)N));
     // everything below is enqueued speculatively; the error word is checked at the single sync
     hipLaunchKernelGGL(level_extent_kernel, dim3(nblk), dim3(EXT_THREADS), 0, s, p->keys, N,
-                       p->nbits, p->lvl, bucket, p->wl, p->wr, derr, bhist, lhist);
+                       p->nbits, p->lvl, bucket, p->wl, p->wr, derr, bhist, gq, gq_count);
+    hipLaunchKernelGGL(extent_search_kernel, dim3((unsigned)ceil_div((int64_t)nblk * EXT_QCAP, 256)), dim3(256), 0, s, p->keys, N, p->lvl,
+                       gq, gq_count, nblk, p->wl, p->wr);
     // order_RAGFT and its inverse: stable counting sort by bucket (histogram from the pass above)
-    RAHT_RET(exclusive_scan_u32(bhist, bhist, (int64_t)ORDER_BUCKETS * nblk, nullptr, s));
-    hipLaunchKernelGGL(order_scatter_kernel, dim3(nblk), dim3(EXT_THREADS), 0, s, bucket, N, bhist, p->order, p->inv_order);
+    RAHT_RET(exclusive_scan_u32(bhist, bhist, (int64_t)(ORDER_BUCKETS + 64) * nblk, nullptr, s));
+    hipLaunchKernelGGL(order_scatter_kernel, dim3(nblk), dim3(EXT_THREADS), 0, s, bucket, N, bhist, p->order, p->inv_order, lhist);
     if (getenv("RAHT_DEBUG_IDENTITY_ORDER")) {    // timing experiments only: order_RAGFT := identity
         hipLaunchKernelGGL(order_to_identity_kernel, dim3(gb), dim3(256), 0, s, p->order, N);
         hipLaunchKernelGGL(invert_perm_kernel, dim3(gb), dim3(256), 0, s, p->order, N, p->inv_order);
     }
-    PlanErr he;
-    uint32_t lh[64];
-    RAHT_RET(read_back_u32((uint32_t *)&he, (const uint32_t *)derr, 2, lh, lhist, 64, s));
-    if (he.code != 0) {
-        if (he.code == RAHT_ERR_UNSORTED)
-            set_error("Morton keys are not strictly increasing at row %u (input must be Morton-sorted "
-                      "and duplicate-free)", he.row);
-        else
-            set_error("coordinate / key out of bounds at row %u for depth %d", he.row, p->nbits / 3);
-        return he.code;
-    }
-    p->level_off[0] = 0;                            // rows bucketed by level (bucket 63 = row 0), see ensure_level_rows
-    for (int l = 0; l < 64; ++l) p->level_off[l + 1] = p->level_off[l] + lh[l];
-    p->max_level = -1;                              // highest level that has a pair (bucket 63 = row 0)
-    for (int l = 0; l < 63; ++l)
-        if (p->level_off[l + 1] > p->level_off[l]) p->max_level = l;
-
+    // The error word and the level histogram travel with the schedule builder's read-back (ONE host round trip per
+    // plan). Everything up to it is enqueued speculatively: kernels running on unsorted keys read and write inside
+    // their arrays all the same, and their results are thrown away with the plan.
+    uint32_t back[2 + 64];
+    p->pend_dev = (const uint32_t *)derr; p->pend_host = back; p->pend_n = 2 + 64;
     if (leaf_weights) {
         // prefix sums of the leaf weights on the host: weighted plans are tiny (<= 512 rows when
         // they stitch the top octree levels of a sharded scene)
@@ -1059,13 +1142,35 @@ static int finish_plan(raht_plan *p, const int64_t *leaf_weights, hipStream_t s)
         RAHT_HIP_CHECK(hipMemcpy(p->wsum, ps.data(), sizeof(int64_t) * ((size_t)N + 1), hipMemcpyHostToDevice));
     }
     RAHT_HIP_CHECK(hipGetLastError());
-    RAHT_RET(compute_roots(p, s));
+    RAHT_RET(compute_roots(p, s));                  // top_level = 64 at creation: row 0 alone, nothing to wait for
     // Build the default schedule now so that float32 transforms with D <= 64 never allocate.
     Schedule *sc = nullptr;
     const int R0 = pick_tile_rows(p, 4, 59);
     int R1 = 0, Dc1 = 0, Rf = 0;
     pick_tail_geometry(p, 4, 59, R0, &R1, &Dc1, &Rf);
-    RAHT_RET(get_schedule(p, R0, R1, Rf, s, &sc));
+    int rc_sched = get_schedule(p, R0, R1, Rf, s, &sc);
+    if (p->pend_n) {                                // the builder did not take them along (exact path, or it failed early)
+        p->pend_n = 0;
+        RAHT_RET(read_back_u32(back, (const uint32_t *)derr, 2 + 64, nullptr, nullptr, 0, s));
+    }
+    p->pend_dev = nullptr; p->pend_host = nullptr;
+    PlanErr he;
+    he.code = (int)back[0]; he.row = back[1];
+    const uint32_t *lh = back + 2;
+    if (he.code != 0) {
+        if (he.code == RAHT_ERR_UNSORTED)
+            set_error("Morton keys are not strictly increasing at row %u (input must be Morton-sorted "
+                      "and duplicate-free)", he.row);
+        else
+            set_error("coordinate / key out of bounds at row %u for depth %d", he.row, p->nbits / 3);
+        return he.code;
+    }
+    RAHT_RET(rc_sched);
+    for (int l = 0; l < 64; ++l) p->level_off[l] = lh[l];      // rows bucketed by level (bucket 63 = row 0), see ensure_level_rows
+    p->level_off[64] = (uint32_t)N;
+    p->max_level = -1;                              // highest level that has a pair (bucket 63 = row 0)
+    for (int l = 0; l < 63; ++l)
+        if (p->level_off[l + 1] > p->level_off[l]) p->max_level = l;
     return RAHT_OK;
 }
 

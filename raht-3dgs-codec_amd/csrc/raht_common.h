@@ -219,6 +219,9 @@ struct raht_plan {
     int tail_rows_override = 0;  // rows per tile of the later stages (0 = automatic)
     int tail_chunk_override = 0; // channels per chunk of the later stages (0 = automatic)
     int final_rows_override = 0; // single-tile finishing stage up to this many entries (0 = automatic)
+    // plan construction only: words the next host read-back on the build stream should fetch along (the schedule
+    // builder's single read-back also carries the plan's error word and level histogram: one round trip per plan)
+    const uint32_t *pend_dev = nullptr; uint32_t *pend_host = nullptr; int pend_n = 0;
     hipEvent_t ev_before = nullptr, ev_after = nullptr;   // profiling: recorded around the stage-0 launch
     int max_stages = 24;         // a tile schedule that needs more stages than this is abandoned (level engine)
     std::deque<raht::Schedule> schedules;    // cache keyed by tile geometry; a deque: references handed out by
