@@ -147,7 +147,7 @@ int read_back_u32(uint32_t *dst_a, const uint32_t *dev_a, int na, uint32_t *dst_
 // out[k] = in[j] (or j when in == NULL) for the k-th j with flag[j] != 0. *count_host gets the
 // number of kept items (synchronises the stream).
 int compact_u32(const uint32_t *in, const uint32_t *flag, uint32_t *out, int64_t n,
-                int64_t *count_host, hipStream_t s);
+                int64_t *count_host, hipStream_t s, const uint32_t *extra_dev = nullptr, uint32_t *extra_host = nullptr);
 
 // ---- plan (plan.hip) ---------------------------------------------------------------------------
 constexpr int RAHT_TOP_MAX_ROWS = 8192;   // entries the TOP stage can hold (16 bytes each in LDS)

@@ -219,7 +219,7 @@ __global__ __launch_bounds__(256) void voxel_mean_chunk_kernel(const float *__re
 }
 
 static int sort_keys_u32idx(const uint64_t *keys_in, int64_t N, int nbits, uint64_t *keys_out,
-                            uint32_t *idx_out, hipStream_t s)
+                                  uint32_t *idx_out, hipStream_t s)
 {
     // LSD passes of 8 bits; ping-pong between two (key, index) buffers, last pass lands in *_out
     const int npass = std::max(1, (nbits + 7) / 8);
@@ -258,12 +258,12 @@ int raht_sort_keys(const uint64_t *keys_in, int64_t N, int nbits, uint64_t *keys
     Scratch ib(sizeof(uint32_t) * (size_t)N);
     if (!ib.ok()) return RAHT_ERR_NOMEM;
     uint32_t *idx32 = ib.as<uint32_t>();
-    int rc = sort_keys_u32idx(keys_in, N, nbits, keys_out, idx32, s);
-    if (rc == RAHT_OK && idx_out)
+    RAHT_RET(sort_keys_u32idx(keys_in, N, nbits, keys_out, idx32, s));
+    if (idx_out)
         hipLaunchKernelGGL(u32_to_i64_kernel, dim3((unsigned)ceil_div(N, 256)), dim3(256), 0, s, idx32, N, idx_out);
     hipError_t e = hipStreamSynchronize(s);       // idx32 returns to the pool when this frame ends
     if (e != hipSuccess) { set_error("raht_sort_keys: %s", hipGetErrorString(e)); return RAHT_ERR_HIP; }
-    return rc;
+    return RAHT_OK;
 }
 
 int raht_voxel_keys(const float *PC, int64_t ldpc, int64_t N, const float vmin[3], double width, int J,
