@@ -378,7 +378,12 @@ static int fit_chunk_channels(int elem_size, int D, int max_dc)
     return std::min(D, 64);                               // not reached (61..64 cover every remainder for D > 64)
 }
 
-int pick_chunk_channels(int elem_size, int D) { return fit_chunk_channels(elem_size, D, 64); }
+int pick_chunk_channels(int elem_size, int D)
+{
+    static const int forced = getenv("RAHT_STAGE0_CH") ? atoi(getenv("RAHT_STAGE0_CH")) : 0;     // tuning knob: channel chunks at stage 0
+    if (forced >= 16 / elem_size && forced < D) return fit_chunk_channels(elem_size, D, forced);
+    return fit_chunk_channels(elem_size, D, 64);
+}
 
 size_t tile_lds_bytes(int R, int elem_size, int Dc, bool ident, bool qm)
 {

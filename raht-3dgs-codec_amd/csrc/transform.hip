@@ -308,19 +308,22 @@ __global__ __launch_bounds__(512, (sizeof(T) == 4 ? 6 : 4)) void tile_kernel(con
         coff = c4c * VN;
         goff = c_base + min(coff, Dc - VN);
     };
-    // quantization steps of this lane's channels: kernarg reads at kernel start, not per row
+    // quantization steps of this lane's channels (and their refined reciprocals: once per channel instead of once per
+    // coefficient): fetched where they are used -- in front of the write-back (forward) or of the row gather
+    // (inverse) -- not at kernel start: eight registers that are NOT live while the forward keeps a tile's rows in
+    // flight across the metadata phases (LATE below), which is what lets the fused forward do that too
     float my_step[VN], my_rcp[VN];
+    auto load_steps = [&]() {
+        if constexpr (QM) {
+            const int c4c = min((tid0 & 63) & ((1 << lg) - 1), NC - 1);
+            const int g0 = c_base + min(c4c * VN, Dc - VN);
 #pragma unroll
-    for (int i = 0; i < VN; ++i) { my_step[i] = 1.0f; my_rcp[i] = 1.0f; }
-    if constexpr (QM) {
-        const int c4c = min((tid0 & 63) & ((1 << lg) - 1), NC - 1);
-        const int g0 = c_base + min(c4c * VN, Dc - VN);
-#pragma unroll
-        for (int i = 0; i < VN; ++i) {
-            my_step[i] = ST.v[ST.n == 1 ? 0 : g0 + i];
-            my_rcp[i] = refined_rcp(my_step[i]);          // once per channel instead of once per coefficient
+            for (int i = 0; i < VN; ++i) {
+                my_step[i] = ST.v[ST.n == 1 ? 0 : g0 + i];
+                my_rcp[i] = refined_rcp(my_step[i]);
+            }
         }
-    }
+    };
 
     if ((int64_t)blockIdx.x < n_tiles) load_tile_meta<T, IDENT, QM, SLOTS>(A, blockIdx.x, tid0, nthreads, M);
     for (int64_t tile_id = blockIdx.x; tile_id < n_tiles; tile_id += gridDim.x) {
@@ -365,9 +368,9 @@ __global__ __launch_bounds__(512, (sizeof(T) == 4 ? 6 : 4)) void tile_kernel(con
     PHASE_STAMP(0);
     // ---- P0b. row transfers whose addresses do not depend on the plan metadata ----
     bool input_done = false;                  // tile already holds every slot's input
-    // plain forward only: with the fused quantizer's state the rows in flight do not fit 80 VGPRs, and a
-    // spilled row is a wait for HBM right behind its load (measured +6 % instead of -3 %)
-    constexpr bool LATE = !INV && !QM;
+    // forward kernels (80 VGPRs at three workgroups per CU: the fused one fits since its step table is fetched late;
+    // a spilled row would be a wait for HBM right behind its load: +6 % instead of -3 %)
+    constexpr bool LATE = !INV;
     V16 x_late[TILE_IO_U];
     int it_late = -1;
     if (!INV || (IDENT && !QM)) {
@@ -440,6 +443,7 @@ __global__ __launch_bounds__(512, (sizeof(T) == 4 ? 6 : 4)) void tile_kernel(con
     // inverse of the later stages / fused inverse: gather every slot's coefficient row now (survivor
     // slots get overwritten in P3b) -- the addresses need srow / sdst
     if (INV && !input_done) {
+        load_steps();
         if (active) for (int it0 = wid; (it0 << lr) < nt; it0 += nw * TILE_IO_U) {
             RawChunk x[TILE_IO_U];
 #pragma unroll
@@ -692,6 +696,7 @@ __global__ __launch_bounds__(512, (sizeof(T) == 4 ? 6 : 4)) void tile_kernel(con
             }
         };
         if constexpr (QM) {
+            load_steps();
             if (ST.fast_div) store_final(std::true_type()); else store_final(std::false_type());
         } else {
             store_final(std::false_type());
@@ -930,6 +935,18 @@ static int tile_threads()
     return t;
 }
 
+// threads per workgroup of the stages >= 1 (tuning knob RAHT_TAIL_THREADS: 256 or 512; default = tile_threads())
+static int tail_threads()
+{
+    static int t = 0;
+    if (t == 0) {
+        const char *e = getenv("RAHT_TAIL_THREADS");
+        const int v = e ? atoi(e) : tile_threads();
+        t = (v == 256 || v == 512) ? v : tile_threads();
+    }
+    return t;
+}
+
 static int device_cus()
 {
     static int n[RAHT_MAX_DEVICES] = {};
@@ -1104,7 +1121,7 @@ static int launch_stage_impl(const raht_plan *p, const Schedule &sc, int k, cons
     }
     const int nchunks = (D + Dc - 1) / Dc;
     const size_t lds = tile_lds_bytes(st.tile_rows, (int)sizeof(T), Dc, st.rows == nullptr, QM);
-    const int threads = tile_threads();
+    const int threads = (k == 0) ? tile_threads() : tail_threads();
     if (st.tile_rows > TILE_MAX_SLOTS * threads) {
         set_error("tile_rows %d too large for %d threads", st.tile_rows, threads);
         return RAHT_ERR_UNSUPPORTED;

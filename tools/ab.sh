@@ -1,6 +1,6 @@
 # A/B on one box: usage bash tools/ab.sh ENVVAR [bench args]
 v=$1; shift
-for i in 1 2 3; do for x in 0 1; do env $v=$x timeout -k 10 200 python bench.py --skip-cpu-baseline --skip-prelude "$@" 2>/dev/null | python -c "
+for i in 1 2 3; do for x in 0 1; do env $v=$x timeout -k 10 200 python bench.py --skip-oracle-gate --skip-legs --skip-prelude "$@" 2>/dev/null | python -c "
 import json,sys
 d=json.loads(sys.stdin.read())
 b=d['breakdown_ms']

@@ -1,7 +1,7 @@
 # A/B of two library builds on one box: swaps the in-tree .so between runs (variants: raht-3dgs-codec_amd/lib_variant_<name>.bin)
 P=raht-3dgs-codec_amd
 cp $P/libraht_hip.so /tmp/lib_keep.so
-for i in 1 2 3; do for v in "$@"; do cp $P/lib_variant_$v.bin $P/libraht_hip.so; timeout -k 10 200 python bench.py --skip-cpu-baseline --skip-prelude 2>/dev/null | python -c "
+for i in 1 2 3; do for v in "$@"; do cp $P/lib_variant_$v.bin $P/libraht_hip.so; timeout -k 10 200 python bench.py --skip-oracle-gate --skip-legs --skip-prelude 2>/dev/null | python -c "
 import json,sys
 d=json.loads(sys.stdin.read())
 b=d['breakdown_ms']

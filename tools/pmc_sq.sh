@@ -11,6 +11,6 @@ for set in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM" \
            "SQ_LDS_BANK_CONFLICT SQ_LDS_UNALIGNED_STALL SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT" \
            "SQ_INSTS_LDS_LOAD SQ_INSTS_LDS_STORE SQ_INST_CYCLES_VMEM_RD SQ_INST_CYCLES_VMEM_WR"; do
   i=$((i+1))
-  rocprofv3 --kernel-trace --pmc $set -d gpurun_out/${tag}_pmc/p$i --output-format csv -- python bench.py --steps 3 --warmup 1 --skip-cpu-baseline --skip-prelude "$@" > gpurun_out/${tag}_pmc_p$i.log 2>&1 || echo "pass $i failed"
+  rocprofv3 --kernel-trace --pmc $set -d gpurun_out/${tag}_pmc/p$i --output-format csv -- python bench.py --steps 3 --warmup 1 --skip-oracle-gate --skip-legs --skip-prelude "$@" > gpurun_out/${tag}_pmc_p$i.log 2>&1 || echo "pass $i failed"
 done
 python tools/pmc_sq_summary.py gpurun_out/${tag}_pmc
