@@ -370,8 +370,14 @@ __global__ __launch_bounds__(512, (sizeof(T) == 4 ? 6 : 4)) void tile_kernel(con
     bool input_done = false;                  // tile already holds every slot's input
     // forward kernels (80 VGPRs at three workgroups per CU: the fused one fits since its step table is fetched late;
     // a spilled row would be a wait for HBM right behind its load: +6 % instead of -3 %)
-    constexpr bool LATE = !INV;
+    // The inverse does the same with the rows it gathers (T / Q rows of the slots finalised here): issued as soon as
+    // their addresses are known, landing after sync #3 -- in the slots that are NOT survivors: those take their value
+    // from the stage above (P3b), and nothing may overwrite it afterwards.
+    // Only where it fits the 80 registers of three workgroups per CU: the plain stage-0 inverse (77). The fused inverse
+    // would spill 16 registers (measured: 0.267 -> 0.341 ms), the later-stage inverses 8.
+    constexpr bool LATE = !INV || (IDENT && !QM);
     V16 x_late[TILE_IO_U];
+    RawChunk r_late[TILE_IO_U];
     int it_late = -1;
     if (!INV || (IDENT && !QM)) {
         // forward: this stage's entries, entry order (C or ws_k); plain inverse of stage 0: T rows [e0, e0+nt)
@@ -443,17 +449,24 @@ __global__ __launch_bounds__(512, (sizeof(T) == 4 ? 6 : 4)) void tile_kernel(con
     // inverse of the later stages / fused inverse: gather every slot's coefficient row now (survivor
     // slots get overwritten in P3b) -- the addresses need srow / sdst
     if (INV && !input_done) {
-        load_steps();
-        if (active) for (int it0 = wid; (it0 << lr) < nt; it0 += nw * TILE_IO_U) {
-            RawChunk x[TILE_IO_U];
+        if (active) {
+            auto gather = [&](int it0, RawChunk (&x)[TILE_IO_U]) {
 #pragma unroll
-            for (int u = 0; u < TILE_IO_U; ++u) {
-                const int j = min(((it0 + u * nw) << lr) + g, nt - 1);
-                if constexpr (QM) x[u] = ld_chunk<RawT, true>(row_far((const RawT *)A.Q, (uint32_t)sdst[j], (uint32_t)A.ldq, (uint32_t)goff));
-                else x[u] = ld_chunk<RawT, true>(row_far((const RawT *)A.fin, (uint32_t)srow[j], (uint32_t)A.ld_fin, (uint32_t)goff));
+                for (int u = 0; u < TILE_IO_U; ++u) {
+                    const int j = min(((it0 + u * nw) << lr) + g, nt - 1);
+                    if constexpr (QM) x[u] = ld_chunk<RawT, true>(row_far((const RawT *)A.Q, (uint32_t)sdst[j], (uint32_t)A.ldq, (uint32_t)goff));
+                    else x[u] = ld_chunk<RawT, true>(row_far((const RawT *)A.fin, (uint32_t)srow[j], (uint32_t)A.ld_fin, (uint32_t)goff));
+                }
+            };
+            int it0 = wid;
+            if (!LATE || ((it0 + nw * TILE_IO_U) << lr) < nt) load_steps();
+            for (; (LATE ? (it0 + nw * TILE_IO_U) << lr : it0 << lr) < nt; it0 += nw * TILE_IO_U) {
+                RawChunk x[TILE_IO_U];
+                gather(it0, x);
+#pragma unroll
+                for (int u = 0; u < TILE_IO_U; ++u) put_row((it0 + u * nw) << lr, x[u]);      // (survivor slots get overwritten in P3b)
             }
-#pragma unroll
-            for (int u = 0; u < TILE_IO_U; ++u) put_row((it0 + u * nw) << lr, x[u]);
+            if (LATE && (it0 << lr) < nt) { gather(it0, r_late); it_late = it0; }   // the last (usually the only) step: in flight until sync #3
         }
     }
 
@@ -510,13 +523,34 @@ __global__ __launch_bounds__(512, (sizeof(T) == 4 ? 6 : 4)) void tile_kernel(con
     }
     __syncthreads();                                                       // sync #3
     PHASE_STAMP(4);
-    // forward: the rows loaded in P0b land in the tile now (they were in flight during P1 and P2; holding
-    // them across the float64 record arithmetic of P3a as well would spill)
+    // the rows loaded in P0b (forward, plain stage-0 inverse) or gathered after sync #1 (other inverses) land in the
+    // tile now (they were in flight during P1 and P2; holding them across the float64 record arithmetic of P3a as
+    // well would spill)
     if (LATE && it_late >= 0) {
+        if constexpr (QM && INV) load_steps();
 #pragma unroll
         for (int u = 0; u < TILE_IO_U; ++u) {
             const int j = min(((it_late + u * nw) << lr) + g, nt - 1);
-            *(V16 *)&tile[__mul24(j, Dp) + coff] = x_late[u];
+            if constexpr (!INV) {
+                *(V16 *)&tile[__mul24(j, Dp) + coff] = x_late[u];
+            } else {
+                // not into survivor slots (flag 0: their value comes from the stage above, P3b) nor into roots that the
+                // caller's root buffer provides (flag 2 with a root buffer, P3b as well)
+                const int fl = sflag[j];
+                if (fl == 1 || (fl == 2 && !A.root_buf)) {
+                    if constexpr (IDENT && !QM) {
+                        *(V16 *)&tile[__mul24(j, Dp) + coff] = x_late[u];
+                    } else {
+                        V16 x;
+#pragma unroll
+                        for (int i = 0; i < VN; ++i) {
+                            x.v[i] = (T)r_late[u].v[i];
+                            if constexpr (QM) x.v[i] = x.v[i] * (T)my_step[i];                 // encode_3dgs.py:261
+                        }
+                        *(V16 *)&tile[__mul24(j, Dp) + coff] = x;
+                    }
+                }
+            }
         }
     }
 
