@@ -125,10 +125,12 @@ class HipLocalOps:
 
 
 class ShardedRaht:
-    def __init__(self, keys_sorted, nbits, prefix_bits=9, group=None, local_ops=None):
+    def __init__(self, keys_sorted, nbits, prefix_bits=9, group=None, local_ops=None, force_collectives=False):
         """keys_sorted: this rank's sorted, unique Morton keys (int64 tensor). Ranks must own disjoint,
-        increasing ranges of the top ``prefix_bits`` bits (rank 0 the lowest prefixes)."""
+        increasing ranges of the top ``prefix_bits`` bits (rank 0 the lowest prefixes).
+        force_collectives: issue the all-gathers even in a one-rank group (exercises the RCCL path on one GPU)."""
         self.ops = local_ops or HipLocalOps
+        self.force = bool(force_collectives)
         self.qdt = getattr(self.ops, "quant_dtype", torch.float32)
         self.dist = _dist()
         self.group = group
@@ -174,7 +176,7 @@ class ShardedRaht:
     # ---- collectives ------------------------------------------------------------------------------
     def _all_gather(self, x, out=None):
         """all-gather a (rows, cols) tensor -> (world * rows, cols)."""
-        if self.world == 1:
+        if self.world == 1 and not (self.force and self.dist):
             return x
         rows = x.shape[0]
         if x.is_cuda and self.dist.get_backend(self.group) == "gloo":
@@ -198,7 +200,7 @@ class ShardedRaht:
         if b is None:
             mk = lambda rows: torch.zeros((rows, D), dtype=dtype, device=self.device)    # noqa: E731
             send = mk(self.slot)
-            recv = mk(self.gather_rows) if self.world > 1 else send
+            recv = mk(self.gather_rows) if (self.world > 1 or self.force) else send
             res = mk(self.gather_rows)
             lo = self.rank * self.slot
             b = dict(send=send, send_roots=send[: self.n_roots], recv=recv, res=res, mine=res[lo: lo + self.n_roots])

@@ -194,3 +194,48 @@ def test_four_ranks_share_the_gpu_exchange_and_transform(rt, world):
         p.join(timeout=120)
     for rank, msg in res:
         assert msg == "ok", f"rank {rank}:\n{msg}"
+
+
+def _rccl_main(port, q):
+    try:
+        sys.path.insert(0, ROOT)
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(0)
+        dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+        import raht_3dgs_codec_amd as R
+        from raht_3dgs_codec_amd import sharded, synth
+        V, keys, C = synth.scene(150000, 11, 59, seed=21)
+        kd = torch.from_numpy(keys.view(np.int64)).cuda()
+        Cd = torch.from_numpy(C).cuda()
+        sh = sharded.ShardedRaht(kd, 33, prefix_bits=9, force_collectives=True)      # the two all-gathers go through RCCL
+        p = R.RahtPlan.from_keys(kd, 33)
+        T0 = p.forward(Cd, want_w=False)
+        T1 = sh.forward(Cd)
+        scale = T0.abs().amax(dim=0)
+        assert bool(((T1 - T0).abs().amax(dim=0) <= 2e-6 * scale).all())
+        for _ in range(3):
+            R1 = sh.step(Cd, 0.01)
+        assert (R1 - p.dequant_inverse(p.forward_quant(Cd, 0.01), 0.01)).abs().max().item() <= 0.02
+        chk = sh.check_against_unsharded(Cd, 0.01)
+        assert chk["ok"], chk
+        t = torch.ones(4, device="cuda")
+        dist.all_reduce(t); dist.barrier()
+        torch.cuda.synchronize()
+        dist.destroy_process_group()
+        q.put("ok")
+    except Exception:
+        q.put(traceback.format_exc())
+
+
+def test_rccl_one_rank_group_carries_the_gathers(rt):
+    """RCCL on the one GPU of this box: a one-rank NCCL process group, the sharded step with its all-gathers forced
+    through the collective (what N ranks do over xGMI, minus the wire)."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_main, args=(_free_port(), q))
+    p.start()
+    msg = q.get(timeout=600)
+    p.join(timeout=120)
+    assert msg == "ok", msg
