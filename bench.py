@@ -101,15 +101,16 @@ def oracle_pass(V, C32, J, repeats, single_core):
     p = orc.raht_param(V.astype(np.float64), np.zeros(3), 2 ** J, J)
     C64 = C32.astype(np.float64)
     nthr = threaded.host_threads(C64.shape[1])
-    best_all, T = None, None
+    blocks = threaded.split(C64, nthr)
+    best_all, Ts, Rs = None, None, None
     for _ in range(max(1, repeats)):
         t0 = time.perf_counter()
-        T, _ = threaded.forward(orc, C64, p, nthr)
-        R = threaded.inverse(orc, T, p, nthr)
+        Ts, Rs = threaded.fwd_inv_blocks(orc, blocks, p)
         dt = time.perf_counter() - t0
         best_all = dt if best_all is None else min(best_all, dt)
-    err = float(np.abs(R - C64).max())
-    del R
+    err = max(float(np.abs(r - b).max()) for r, b in zip(Rs, blocks))
+    T = np.concatenate(Ts, axis=1)
+    del Rs, Ts, blocks
     best_one = None
     if single_core:
         for _ in range(max(1, repeats)):

@@ -54,3 +54,25 @@ def inverse(orc, T64, param, nthreads=None):
     for t in th:
         t.join()
     return Cr
+
+
+def split(C64, nthreads=None):
+    """channel blocks of C64 (contiguous copies), one per thread"""
+    nthr = host_threads(C64.shape[1]) if nthreads is None else nthreads
+    return [np.ascontiguousarray(C64[:, lo:hi]) for lo, hi in _blocks(C64.shape[1], nthr)]
+
+
+def fwd_inv_blocks(orc, blocks, param):
+    """One forward + inverse pass over pre-split channel blocks, one thread each (what bench.py times as the all-cores
+    CPU baseline: no assembling of the result inside the timed region). -> (list of T blocks, list of C blocks)"""
+    Ts, Rs = [None] * len(blocks), [None] * len(blocks)
+
+    def work(i):
+        Ts[i], _ = orc.raht_fwd(blocks[i], param)
+        Rs[i] = orc.raht_inv(Ts[i], param)
+    th = [threading.Thread(target=work, args=(i,)) for i in range(len(blocks))]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    return Ts, Rs

@@ -1,6 +1,10 @@
 #!/bin/bash
 # Instruction-mix / stall counters of the tile kernels (separate rocprofv3 --pmc passes, kernel trace only).
-# (TA_* counters are left out: a pass with them hung rocprofv3 on this pool)
+# (No TA_* pass: `--pmc TA_ADDR_STALLED_BY_TC_CYCLES TA_BUSY TA_DATA_STALLED_BY_TC_CYCLES TA_TOTAL_WAVEFRONTS` made rocprofv3 itself
+#  abort before the program ran -- "Unable to find all counters ... Missing: [TA_BUSY]", then "Could not construct profile cfg
+#  failed with error code 38: Request exceeds the capabilities of the hardware to collect", then rocprofv3's own signal-6
+#  handler (gpurun_out/new_pmc_p4.log, round 1). TA_BUSY is not a basic counter of this rocprofv3 on gfx950 and four TA counters
+#  do not fit one pass; nothing on the GPU hung. One or two TA counters per pass would be the way if they are needed.)
 # usage (GPU box): bash tools/pmc_sq.sh <out-tag> [bench.py args...]   -> gpurun_out/<tag>_pmc/<pass>/
 tag=$1; shift
 export TMPDIR=/tmp

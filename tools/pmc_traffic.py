@@ -10,9 +10,23 @@ the same run (known byte counts). Writes profiles/traffic.json and profiles/<tag
 import collections
 import csv
 import glob
+import hashlib
 import json
 import os
 import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def kernel_source_hash():
+    """the same hash bench.py computes: traffic.json is only quoted next to live timings of THIS build"""
+    h = hashlib.sha1()
+    files = sorted(glob.glob(os.path.join(ROOT, "raht-3dgs-codec_amd", "csrc", "*.hip")) +
+                   glob.glob(os.path.join(ROOT, "raht-3dgs-codec_amd", "csrc", "*.h")) + [os.path.join(ROOT, "include", "raht.h")])
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
 
 
 def load(d, counter):
@@ -65,6 +79,7 @@ def main():
         "plain": {"fwd_stage0_bytes": pick("tile_kernel<float, false, true, false"),
                   "inv_stage0_bytes": pick("tile_kernel<float, true, true, false")},
         "source": f"profiles/{tag}_pmc_summary.csv",
+        "source_hash": kernel_source_hash(),
     }
     json.dump(out, open(tp, "w"), indent=1)
     print(json.dumps(out[workload], indent=1))
