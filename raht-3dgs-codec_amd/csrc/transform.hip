@@ -313,9 +313,12 @@ __global__ __launch_bounds__(512, (sizeof(T) == 4 ? 6 : 4)) void tile_kernel(con
     // (inverse) -- not at kernel start: eight registers that are NOT live while the forward keeps a tile's rows in
     // flight across the metadata phases (LATE below), which is what lets the fused forward do that too
     float my_step[VN], my_rcp[VN];
-    auto load_steps = [&]() {
+    // (`ln` = the lane id from the tile loop's OPAQUE copy of the thread id: computed from tid0 the eight step-table
+    // addresses are loop invariants that hipcc hoists to kernel start and spills -- and any scratch use at all cost the
+    // fused inverse 0.27 -> 0.35 ms)
+    auto load_steps = [&](int ln) {
         if constexpr (QM) {
-            const int c4c = min((tid0 & 63) & ((1 << lg) - 1), NC - 1);
+            const int c4c = min(ln & ((1 << lg) - 1), NC - 1);
             const int g0 = c_base + min(c4c * VN, Dc - VN);
 #pragma unroll
             for (int i = 0; i < VN; ++i) {
@@ -375,9 +378,8 @@ __global__ __launch_bounds__(512, (sizeof(T) == 4 ? 6 : 4)) void tile_kernel(con
     // from the stage above (P3b), and nothing may overwrite it afterwards.
     // Only where it fits the 80 registers of three workgroups per CU: the plain stage-0 inverse (77). The fused inverse
     // would spill 16 registers (measured: 0.267 -> 0.341 ms), the later-stage inverses 8.
-    constexpr bool LATE = !INV || (IDENT && !QM);
+    constexpr bool LATE = (!INV || (IDENT && !QM)) && SLOTS == 1;     // (two slots per thread: no room either)
     V16 x_late[TILE_IO_U];
-    RawChunk r_late[TILE_IO_U];
     int it_late = -1;
     if (!INV || (IDENT && !QM)) {
         // forward: this stage's entries, entry order (C or ws_k); plain inverse of stage 0: T rows [e0, e0+nt)
@@ -447,26 +449,23 @@ __global__ __launch_bounds__(512, (sizeof(T) == 4 ? 6 : 4)) void tile_kernel(con
     PHASE_STAMP(2);
 
     // inverse of the later stages / fused inverse: gather every slot's coefficient row now (survivor
-    // slots get overwritten in P3b) -- the addresses need srow / sdst
+    // slots get overwritten in P3b) -- the addresses need srow / sdst. The rows are consumed at once: keeping them in
+    // flight until sync #3 (as the forward kernels and the plain stage-0 inverse do) needs 4 registers more than the 80
+    // that three workgroups per CU leave, and hipcc then parks ONE row in scratch -- behind an s_waitcnt vmcnt(0),
+    // i.e. a full HBM round trip in front of the other five loads: 0.267 -> 0.341 ms, whether the gather is issued in
+    // front of P1 or behind it. This gather is the one exposed HBM round trip left in the step.
     if (INV && !input_done) {
-        if (active) {
-            auto gather = [&](int it0, RawChunk (&x)[TILE_IO_U]) {
+        load_steps(lane);
+        if (active) for (int it0 = wid; (it0 << lr) < nt; it0 += nw * TILE_IO_U) {
+            RawChunk x[TILE_IO_U];
 #pragma unroll
-                for (int u = 0; u < TILE_IO_U; ++u) {
-                    const int j = min(((it0 + u * nw) << lr) + g, nt - 1);
-                    if constexpr (QM) x[u] = ld_chunk<RawT, true>(row_far((const RawT *)A.Q, (uint32_t)sdst[j], (uint32_t)A.ldq, (uint32_t)goff));
-                    else x[u] = ld_chunk<RawT, true>(row_far((const RawT *)A.fin, (uint32_t)srow[j], (uint32_t)A.ld_fin, (uint32_t)goff));
-                }
-            };
-            int it0 = wid;
-            if (!LATE || ((it0 + nw * TILE_IO_U) << lr) < nt) load_steps();
-            for (; (LATE ? (it0 + nw * TILE_IO_U) << lr : it0 << lr) < nt; it0 += nw * TILE_IO_U) {
-                RawChunk x[TILE_IO_U];
-                gather(it0, x);
-#pragma unroll
-                for (int u = 0; u < TILE_IO_U; ++u) put_row((it0 + u * nw) << lr, x[u]);      // (survivor slots get overwritten in P3b)
+            for (int u = 0; u < TILE_IO_U; ++u) {
+                const int j = min(((it0 + u * nw) << lr) + g, nt - 1);
+                if constexpr (QM) x[u] = ld_chunk<RawT, true>(row_far((const RawT *)A.Q, (uint32_t)sdst[j], (uint32_t)A.ldq, (uint32_t)goff));
+                else x[u] = ld_chunk<RawT, true>(row_far((const RawT *)A.fin, (uint32_t)srow[j], (uint32_t)A.ld_fin, (uint32_t)goff));
             }
-            if (LATE && (it0 << lr) < nt) { gather(it0, r_late); it_late = it0; }   // the last (usually the only) step: in flight until sync #3
+#pragma unroll
+            for (int u = 0; u < TILE_IO_U; ++u) put_row((it0 + u * nw) << lr, x[u]);
         }
     }
 
@@ -527,29 +526,16 @@ __global__ __launch_bounds__(512, (sizeof(T) == 4 ? 6 : 4)) void tile_kernel(con
     // tile now (they were in flight during P1 and P2; holding them across the float64 record arithmetic of P3a as
     // well would spill)
     if (LATE && it_late >= 0) {
-        if constexpr (QM && INV) load_steps();
 #pragma unroll
         for (int u = 0; u < TILE_IO_U; ++u) {
             const int j = min(((it_late + u * nw) << lr) + g, nt - 1);
             if constexpr (!INV) {
                 *(V16 *)&tile[__mul24(j, Dp) + coff] = x_late[u];
             } else {
-                // not into survivor slots (flag 0: their value comes from the stage above, P3b) nor into roots that the
-                // caller's root buffer provides (flag 2 with a root buffer, P3b as well)
+                // plain stage-0 inverse: not into survivor slots (flag 0: their value comes from the stage above, P3b) nor
+                // into roots that the caller's root buffer provides (flag 2 with a root buffer, P3b as well)
                 const int fl = sflag[j];
-                if (fl == 1 || (fl == 2 && !A.root_buf)) {
-                    if constexpr (IDENT && !QM) {
-                        *(V16 *)&tile[__mul24(j, Dp) + coff] = x_late[u];
-                    } else {
-                        V16 x;
-#pragma unroll
-                        for (int i = 0; i < VN; ++i) {
-                            x.v[i] = (T)r_late[u].v[i];
-                            if constexpr (QM) x.v[i] = x.v[i] * (T)my_step[i];                 // encode_3dgs.py:261
-                        }
-                        *(V16 *)&tile[__mul24(j, Dp) + coff] = x;
-                    }
-                }
+                if (fl == 1 || (fl == 2 && !A.root_buf)) *(V16 *)&tile[__mul24(j, Dp) + coff] = x_late[u];
             }
         }
     }
@@ -689,6 +675,13 @@ __global__ __launch_bounds__(512, (sizeof(T) == 4 ? 6 : 4)) void tile_kernel(con
 
     PHASE_STAMP(6);
     // ---- P5. write back ----
+    // (lane geometry re-derived from a fresh opaque copy of the thread id: otherwise the write-back's per-lane addresses
+    // are computed long before they are needed and sit in registers across the phases above)
+    {
+        int tid5 = tid0;
+        asm volatile("" : "+v"(tid5));
+        lane_geom(tid5, lane, wid, g, coff, goff, active);
+    }
     if (INV) {
         // the whole tile, entry order: stage 0 -> C rows [e0, e0+nt); stage k -> ws_k
         if (active) for (int it = wid; (it << lr) < nt; it += nw) {
@@ -730,7 +723,7 @@ __global__ __launch_bounds__(512, (sizeof(T) == 4 ? 6 : 4)) void tile_kernel(con
             }
         };
         if constexpr (QM) {
-            load_steps();
+            load_steps(lane);
             if (ST.fast_div) store_final(std::true_type()); else store_final(std::false_type());
         } else {
             store_final(std::false_type());
