@@ -248,7 +248,10 @@ int raht_dequant_unreorder_f64(const raht_plan *plan, const int32_t *Q, int64_t 
  * python/voxelize_pc.py:62-172) and get_morton_code (:25-59): shift by vmin, Vint =
  * clamp(floor((V - vmin) / (width / 2^J)), 0, 2^J - 1) in float32 as torch does, 3J-bit Morton
  * key, STABLE LSD radix sort on device, voxel starts where the key changes, per-voxel attribute
- * mean (sequential in sorted order, so bit-reproducible).
+ * mean (sequential in sorted order, so bit-reproducible). The division is the IEEE float32 division torch performs on
+ * the CPU (where the reference's golden vectors come from); a GPU run of the reference multiplies by 1 / voxel_size
+ * instead and may put a point that sits within 1 ulp of a voxel face into the neighbouring voxel (fixtures
+ * tests/golden/vox_boundary*_j9.npz: width 7.3, points at k * voxel_size and one float32 step either side).
  *   PC      : N x (3 + d) float32, row stride ldpc elements
  *   vmin_in : HOST float[3] or NULL (-> per-axis minimum);  width_in < 0 -> max over axes of V - vmin
  * Outputs (DEVICE, caller-allocated for N rows; any may be NULL):

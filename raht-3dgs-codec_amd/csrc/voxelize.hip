@@ -60,22 +60,38 @@ __global__ __launch_bounds__(256) void minmax_kernel(const float *__restrict__ P
 }
 
 // ---- keys --------------------------------------------------------------------------------------
-__global__ void vox_keys_kernel(const float *__restrict__ PC, int64_t ld, int64_t N, float m0, float m1,
-                                float m2, float vs, int J, uint64_t *__restrict__ keys)
+// xyz of one point: 12 bytes at the start of a (3 + d)-float row, as ONE global_load_dwordx3 (element alignment), four
+// rows per thread in flight. Every load instruction of a wave touches 64 different 128-byte lines here (row stride 236
+// bytes at d = 56): the kernel moves one line per point (384 MB on 3 M points) whatever the instruction mix -- 126 us
+// with three dword loads per row and with this form alike (3 TB/s of lines for 36 MB of coordinates). Only a layout
+// with the positions apart from the attributes would change that, and the reference's PC matrix is the boundary.
+struct __attribute__((packed, aligned(4))) Xyz { float x, y, z; };
+
+__global__ __launch_bounds__(256) void vox_keys_kernel(const float *__restrict__ PC, int64_t ld, int64_t N, float m0, float m1,
+                                                       float m2, float vs, int J, uint64_t *__restrict__ keys)
 {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= N) return;
+    constexpr int U = 4;                                             // rows per thread: four independent loads in flight
+    const int64_t i0 = ((int64_t)blockIdx.x * blockDim.x) * U + threadIdx.x;
     const int64_t hi = ((int64_t)1 << J) - 1;
-    int64_t q[3];
-    const float m[3] = {m0, m1, m2};
+    Xyz p[U];
 #pragma unroll
-    for (int a = 0; a < 3; ++a) {
-        const float v0 = PC[i * ld + a] - m[a];                    // voxelize_pc.py:92
-        int64_t t = (int64_t)floorf(__fdiv_rn(v0, vs));            // :98 (IEEE divide, not rcp*mul)
-        t = t < 0 ? 0 : (t > hi ? hi : t);
-        q[a] = t;
+    for (int u = 0; u < U; ++u) {
+        const int64_t i = min(i0 + (int64_t)u * blockDim.x, N - 1);
+        p[u] = *(const Xyz *)(PC + i * ld);
     }
-    keys[i] = vx_spread3((uint64_t)q[2]) | (vx_spread3((uint64_t)q[1]) << 1) | (vx_spread3((uint64_t)q[0]) << 2);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int64_t i = i0 + (int64_t)u * blockDim.x;
+        if (i >= N) continue;
+        const float v[3] = {p[u].x - m0, p[u].y - m1, p[u].z - m2};  // voxelize_pc.py:92
+        int64_t q[3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            int64_t t = (int64_t)floorf(__fdiv_rn(v[a], vs));        // :98 (IEEE divide, not rcp*mul)
+            q[a] = t < 0 ? 0 : (t > hi ? hi : t);
+        }
+        keys[i] = vx_spread3((uint64_t)q[2]) | (vx_spread3((uint64_t)q[1]) << 1) | (vx_spread3((uint64_t)q[0]) << 2);
+    }
 }
 
 __global__ void boundary_kernel(const uint64_t *__restrict__ keys, int64_t N, uint32_t *__restrict__ flag)
@@ -272,7 +288,7 @@ int raht_voxel_keys(const float *PC, int64_t ldpc, int64_t N, const float vmin[3
     if (!PC || !keys || !vmin || N < 0 || ldpc < 3 || J < 1 || J > 21 || !(width > 0)) { set_error("raht_voxel_keys: bad argument"); return RAHT_ERR_INVALID; }
     if (N == 0) return RAHT_OK;
     const float vs = (float)(width / (double)((uint64_t)1 << J));        // voxelize_pc.py:97, as raht_voxelize
-    hipLaunchKernelGGL(vox_keys_kernel, dim3((unsigned)ceil_div(N, 256)), dim3(256), 0, (hipStream_t)stream, PC, ldpc, N,
+    hipLaunchKernelGGL(vox_keys_kernel, dim3((unsigned)ceil_div(N, 256 * 4)), dim3(256), 0, (hipStream_t)stream, PC, ldpc, N,
                        vmin[0], vmin[1], vmin[2], vs, J, keys);
     RAHT_HIP_CHECK(hipGetLastError());
     return RAHT_OK;
@@ -327,7 +343,7 @@ int raht_voxelize(const float *PC, int64_t ldpc, int64_t N, int d, const float *
     int64_t nv = 0;
     {
         const unsigned gb = (unsigned)ceil_div(N, 256);
-        hipLaunchKernelGGL(vox_keys_kernel, dim3(gb), dim3(256), 0, s, PC, ldpc, N, vmin[0], vmin[1], vmin[2], vs, J, keys);
+        hipLaunchKernelGGL(vox_keys_kernel, dim3((unsigned)ceil_div(N, 256 * 4)), dim3(256), 0, s, PC, ldpc, N, vmin[0], vmin[1], vmin[2], vs, J, keys);
         RAHT_RET(sort_keys_u32idx(keys, N, 3 * J, ks, idx, s));
         hipLaunchKernelGGL(boundary_kernel, dim3(gb), dim3(256), 0, s, ks, N, flag);
         RAHT_RET(compact_u32(nullptr, flag, vstart, N, &nv, s));
