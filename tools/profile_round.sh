@@ -10,17 +10,18 @@ cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
 timeout -k 10 500 python3 bench.py --steps 200 --warmup 50 > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.err || { echo "bench failed"; tail -3 gpurun_out/${tag}_bench.err; exit 1; }
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${tag}_prof -o run -- python3 bench.py --steps 200 --warmup 50 > gpurun_out/${tag}_bench_under_rocprof.json 2> gpurun_out/${tag}_prof.log || { echo "rocprof run failed"; tail -3 gpurun_out/${tag}_prof.log; exit 1; }
 cp gpurun_out/${tag}_prof/run_kernel_stats.csv gpurun_out/${tag}_kernel_stats.csv
+# the default command also times a cfg2 leg with the same kernel instantiations: per-(kernel, grid) averages keep cfg3 apart
+python3 tools/stats_by_grid.py gpurun_out/${tag}_prof/run_kernel_trace.csv gpurun_out/${tag}_kernel_stats_by_grid.csv > /dev/null
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --kernel-trace --pmc $c --output-format csv -d gpurun_out/${tag}_pmc_$c -- python3 bench.py --steps 5 --warmup 2 --skip-legs --skip-prelude --skip-oracle-gate > gpurun_out/${tag}_pmc_$c.json 2> gpurun_out/${tag}_pmc_$c.log || { echo "pmc pass $c failed"; tail -3 gpurun_out/${tag}_pmc_$c.log; exit 1; }
 done
-python3 - <<PY
-import json
-d = json.load(open("gpurun_out/${tag}_bench.json"))
-print(d["config"]["rows_per_gpu"], d["config"]["channels"])
-PY
 read N D < <(python3 -c "import json; d=json.load(open('gpurun_out/${tag}_bench.json')); print(d['config']['rows_per_gpu'], d['config']['channels'])")
 python3 tools/pmc_traffic.py gpurun_out/${tag}_pmc_FETCH_SIZE gpurun_out/${tag}_pmc_WRITE_SIZE $tag cfg3 $N $D > gpurun_out/${tag}_traffic.log 2>&1 || { echo "pmc_traffic failed"; tail -5 gpurun_out/${tag}_traffic.log; }
 cp profiles/traffic.json gpurun_out/${tag}_traffic.json; cp profiles/${tag}_pmc_summary.csv gpurun_out/ 2>/dev/null
+# once more, now that profiles/traffic.json belongs to this build: the line that quotes the measured HBM bytes
+timeout -k 10 500 python3 bench.py --steps 200 --warmup 50 > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.err
+for w in cfg2 cfg5; do timeout -k 10 500 python3 bench.py --workload $w --steps 100 --warmup 20 --skip-legs --skip-prelude > gpurun_out/${tag}_bench_$w.json 2>> gpurun_out/${tag}_bench.err; done
+timeout -k 10 300 python3 bench.py --no-quant --steps 200 --warmup 50 --skip-legs --skip-prelude > gpurun_out/${tag}_bench_plain.json 2>> gpurun_out/${tag}_bench.err
 python3 -c "
 import json
 d=json.load(open('gpurun_out/${tag}_bench.json'))
