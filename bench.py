@@ -59,6 +59,7 @@ def parse():
                          "(-1: as many as bring settle + warmup to 64; the first ~40 steps after idle run up to 17 %% slower, "
                          "tools/probe_step_transient.py); reported as settle_steps")
     ap.add_argument("--workload", default="cfg3", choices=["cfg3", "cfg2", "cfg4", "cfg5"])
+    ap.add_argument("--rows", type=int, default=0, help="override the workload's number of draws (rehearsals of the multi-rank modes on small scenes)")
     ap.add_argument("--no-quant", action="store_true", help="time forward + inverse only")
     ap.add_argument("--engine", default="tile", choices=["tile", "level"])
     ap.add_argument("--tile-rows", type=int, default=0)
@@ -308,6 +309,8 @@ def main():
     L = _lib.lib()                                     # fails loudly if the HIP library is missing
 
     n_draws, J, D, seed = synth.CONFIGS[a.workload]
+    if a.rows > 0:
+        n_draws = a.rows
     solo = world == 1 or a.workload == "cfg4"          # this rank runs the whole transform of its own scene
     scaling = "strong" if (a.workload == "cfg5" and world > 1) else "weak"
     if a.workload == "cfg4":
