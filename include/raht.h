@@ -264,6 +264,14 @@ int raht_voxelize(const float *PC, int64_t ldpc, int64_t N, int d, const float *
                   float vmin_out[3], double *width_out, double *voxel_size_out,
                   raht_stream_t stream);
 
+/* The voxelizer's secondary outputs (reference python/voxelize_pc.py:103-111, 147-156), from the primary ones of
+ * raht_voxelize: PCsorted[k, :] = PC[sort_idx[k], :] (N x (3+d), may be NULL) and the residuals DeltaPC (N x (3+d)):
+ * positions V0 - voxel_size * floor(V0 / voxel_size) with V0 = V - vmin, attributes minus their voxel's mean (PCvox).
+ * DEVICE pointers except vmin (HOST float[3]); only enqueues kernels on `stream`. */
+int raht_voxelize_residuals(const float *PC, int64_t ldpc, int64_t N, int d, const uint64_t *keys_sorted,
+                            const int64_t *sort_idx, const float *PCvox, const float vmin[3], double voxel_size,
+                            float *PCsorted, float *DeltaPC, raht_stream_t stream);
+
 /* The voxelizer's first phase alone: the (unsorted) 3J-bit Morton key of every point for a GIVEN bounding box
  * (vmin: HOST float[3]; width > 0), same arithmetic as raht_voxelize. A Morton-prefix sharded front end buckets
  * points by the top key bits with it before the all-to-all (sharded.exchange_by_prefix). keys: DEVICE uint64[N]. */

@@ -66,6 +66,7 @@ def lib():
     L.orc_quant_reorder.argtypes = [vp, i64, i32, dbl, vp, vp]
     L.orc_dequant_unreorder.argtypes = [vp, i64, i32, dbl, vp, vp]
     L.orc_voxelize.argtypes = [vp, i64, i32, vp, dbl, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    L.orc_voxel_residuals.argtypes = [vp, i64, i32, vp, vp, i64, vp, vp, dbl, vp, vp]
     L.orc_rlgr_encode.argtypes = [vp, i64, i32, vp, i64]
     L.orc_rlgr_encode.restype = i64
     L.orc_rlgr_decode.argtypes = [vp, i64, i64, i32, vp]
@@ -194,6 +195,20 @@ def voxelize(PC, J, vmin=None, width=None):
     return dict(keys_sorted=keys, sort_idx=idx, voxel_indices=vi[:n].copy(), PCvox=pcv[:n].copy(),
                 Vvox=vvox[:n].copy(), Nvox=n, vmin=vmin_out, width=w_out.value,
                 voxel_size=vs_out.value)
+
+
+def voxel_residuals(PC, r):
+    """(PCsorted, DeltaPC) of voxelize_pc_batched (voxelize_pc.py:103-111, 147-156) from voxelize()'s result dict r."""
+    PC = np.ascontiguousarray(PC, dtype=np.float32)
+    N, ld = PC.shape
+    pcs, dl = np.empty((N, ld), np.float32), np.empty((N, ld), np.float32)
+    si = np.ascontiguousarray(r["sort_idx"], dtype=np.int64)
+    vi = np.ascontiguousarray(r["voxel_indices"], dtype=np.int64)
+    pcv = np.ascontiguousarray(r["PCvox"], dtype=np.float32)
+    vm = np.ascontiguousarray(r["vmin"], dtype=np.float32)
+    lib().orc_voxel_residuals(_ptr(PC), N, ld - 3, _ptr(si), _ptr(vi), vi.shape[0], _ptr(pcv), _ptr(vm), float(r["voxel_size"]),
+                              _ptr(pcs), _ptr(dl))
+    return pcs, dl
 
 
 def rlgr_encode(seq, flag_signed=1):

@@ -323,6 +323,28 @@ int raht_cpu_voxelize(const float *PC, int64_t ldpc, int64_t N, int d, const flo
     return rc;
 }
 
+/* raht_voxelize_residuals */
+int raht_cpu_voxelize_residuals(const float *PC, int64_t ldpc, int64_t N, int d, const uint64_t *keys_sorted,
+                                const int64_t *sort_idx, const float *PCvox, const float vmin[3], double voxel_size,
+                                float *PCsorted, float *DeltaPC, raht_stream_t stream)
+{
+    (void)stream;
+    if (!PC || !keys_sorted || !sort_idx || !vmin || !DeltaPC || N < 1 || d < 0 || ldpc < 3 + d || !(voxel_size > 0) || (d > 0 && !PCvox)) {
+        set_err("raht_cpu_voxelize_residuals: bad argument");
+        return RAHT_ERR_INVALID;
+    }
+    const int ld = 3 + d;
+    float *P = (float *)malloc(sizeof(float) * (size_t)N * (size_t)ld);
+    int64_t *vi = (int64_t *)malloc(sizeof(int64_t) * (size_t)N);
+    if (!P || !vi) { free(P); free(vi); return RAHT_ERR_NOMEM; }
+    for (int64_t i = 0; i < N; ++i) memcpy(P + i * ld, PC + i * ldpc, sizeof(float) * (size_t)ld);
+    int64_t nv = 0;
+    for (int64_t i = 0; i < N; ++i) if (i == 0 || keys_sorted[i] != keys_sorted[i - 1]) vi[nv++] = i;      /* voxelize_pc.py:114-118 */
+    const int rc = orc_voxel_residuals(P, N, d, sort_idx, vi, nv, PCvox, vmin, voxel_size, PCsorted, DeltaPC);
+    free(P); free(vi);
+    return rc == 0 ? RAHT_OK : RAHT_ERR_INVALID;
+}
+
 int raht_cpu_morton(const int64_t *V, int64_t N, int J, uint64_t *keys, raht_stream_t stream)
 {
     (void)stream;

@@ -394,6 +394,31 @@ int orc_voxelize(const float *PC, int64_t N, int d, const float *vmin_in, double
     return 0;
 }
 
+/* voxelize_pc.py:103-111, 147-156: the secondary outputs of the voxelizer, from its primary ones.
+ * PCsorted[k] = PC[sort_idx[k]];  DeltaV = V0 - voxel_size * floor(V0 / voxel_size), V0 = V - vmin (float32
+ * arithmetic, the Python-float voxel_size rounded to float32 as torch does for tensor / scalar);
+ * DeltaC = C0 - Cvox[voxel of k]. */
+int orc_voxel_residuals(const float *PC, int64_t N, int d, const int64_t *sort_idx, const int64_t *voxel_indices,
+                        int64_t Nvox, const float *PCvox, const float vmin[3], double voxel_size, float *PCsorted,
+                        float *DeltaPC)
+{
+    const int ld = 3 + d;
+    const float vs = (float)voxel_size;
+    int64_t v = 0;
+    for (int64_t k = 0; k < N; ++k) {
+        while (v + 1 < Nvox && voxel_indices[v + 1] <= k) ++v;            /* :129-132 voxel_id */
+        const float *src = PC + sort_idx[k] * ld;
+        if (PCsorted) memcpy(PCsorted + k * ld, src, sizeof(float) * (size_t)ld);      /* :103-108 */
+        for (int a = 0; a < 3; ++a) {
+            const float v0 = src[a] - vmin[a];                            /* :92, :103 */
+            const float vox = vs * floorf(v0 / vs);                       /* :110 */
+            DeltaPC[k * ld + a] = v0 - vox;                               /* :111 */
+        }
+        for (int c = 0; c < d; ++c) DeltaPC[k * ld + 3 + c] = src[3 + c] - PCvox[v * ld + 3 + c];   /* :147-148 */
+    }
+    return 0;
+}
+
 /* ---------------------------------------------------------------- PyRLGR membuf.cpp
  * Literal restatement of the bit buffer (membuf.cpp:74-189) and of the coder (:228-423). */
 #define ORC_L 4

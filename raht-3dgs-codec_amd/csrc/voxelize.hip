@@ -101,6 +101,29 @@ __global__ void boundary_kernel(const uint64_t *__restrict__ keys, int64_t N, ui
     flag[i] = (i == 0 || keys[i] != keys[i - 1]) ? 1u : 0u;       // voxelize_pc.py:114-118
 }
 
+// The voxelizer's secondary outputs (voxelize_pc.py:103-111, 147-156): one lane per output element, rows gathered
+// through the sort permutation. vid[k] = voxel of sorted point k (boundary flags scanned).
+__global__ __launch_bounds__(256) void residual_kernel(const float *__restrict__ PC, int64_t ldpc, int64_t N, int ld,
+                                                       const int64_t *__restrict__ sort_idx, const uint32_t *__restrict__ pos,
+                                                       const uint32_t *__restrict__ flag, const float *__restrict__ PCvox,
+                                                       float m0, float m1, float m2, float vs, float *__restrict__ PCsorted,
+                                                       float *__restrict__ Delta)
+{
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= N * ld) return;
+    const int64_t k = e / ld;
+    const int c = (int)(e - k * ld);
+    const float x = PC[sort_idx[k] * ldpc + c];
+    if (PCsorted) PCsorted[e] = x;                                      // :103-108
+    if (c < 3) {
+        const float v0 = x - (c == 0 ? m0 : (c == 1 ? m1 : m2));        // :92, :103
+        Delta[e] = v0 - vs * floorf(__fdiv_rn(v0, vs));                 // :110-111 (IEEE divide, as torch on the CPU)
+    } else {
+        const int64_t v = (int64_t)pos[k] + (int64_t)flag[k] - 1;       // :129-132
+        Delta[e] = x - PCvox[v * ld + c];                               // :147-148
+    }
+}
+
 __global__ void u32_to_i64_kernel(const uint32_t *__restrict__ in, int64_t n, int64_t *__restrict__ out)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -290,6 +313,28 @@ int raht_voxel_keys(const float *PC, int64_t ldpc, int64_t N, const float vmin[3
     const float vs = (float)(width / (double)((uint64_t)1 << J));        // voxelize_pc.py:97, as raht_voxelize
     hipLaunchKernelGGL(vox_keys_kernel, dim3((unsigned)ceil_div(N, 256 * 4)), dim3(256), 0, (hipStream_t)stream, PC, ldpc, N,
                        vmin[0], vmin[1], vmin[2], vs, J, keys);
+    RAHT_HIP_CHECK(hipGetLastError());
+    return RAHT_OK;
+}
+
+int raht_voxelize_residuals(const float *PC, int64_t ldpc, int64_t N, int d, const uint64_t *keys_sorted,
+                            const int64_t *sort_idx, const float *PCvox, const float vmin[3], double voxel_size,
+                            float *PCsorted, float *DeltaPC, raht_stream_t stream)
+{
+    if (!PC || !keys_sorted || !sort_idx || !vmin || !DeltaPC || N < 1 || d < 0 || ldpc < 3 + d || !(voxel_size > 0) || (d > 0 && !PCvox)) {
+        set_error("raht_voxelize_residuals: bad argument");
+        return RAHT_ERR_INVALID;
+    }
+    if (N >= ((int64_t)1 << 31)) { set_error("raht_voxelize_residuals: N too large"); return RAHT_ERR_INVALID; }
+    hipStream_t s = (hipStream_t)stream;
+    Scratch buf(sizeof(uint32_t) * 2 * (size_t)N);
+    if (!buf.ok()) return RAHT_ERR_NOMEM;
+    uint32_t *flag = buf.as<uint32_t>(), *pos = flag + N;
+    hipLaunchKernelGGL(boundary_kernel, dim3((unsigned)ceil_div(N, 256)), dim3(256), 0, s, keys_sorted, N, flag);
+    RAHT_RET(exclusive_scan_u32(flag, pos, N, nullptr, s));
+    const int ld = 3 + d;
+    hipLaunchKernelGGL(residual_kernel, dim3((unsigned)ceil_div(N * ld, 256)), dim3(256), 0, s, PC, ldpc, N, ld, sort_idx, pos, flag,
+                       PCvox, vmin[0], vmin[1], vmin[2], (float)voxel_size, PCsorted, DeltaPC);
     RAHT_HIP_CHECK(hipGetLastError());
     return RAHT_OK;
 }

@@ -555,10 +555,9 @@ def voxelize_pc_batched(PC, vmin=None, width=None, J=10, device="cuda", residual
 
     Returns (PCvox, PCsorted, voxel_indices, DeltaPC, info) like the reference. PCvox,
     voxel_indices, info['sort_idx'] and the sorted Morton keys (info['keys_sorted'], extra) come
-    from the HIP voxelizer; PCsorted / DeltaPC are secondary outputs derived from them with two
-    torch gathers (``residuals=False`` skips DeltaPC; ``sorted_points=False`` also skips PCsorted -- a
-    full gather of the cloud, 0.47 ms on 3 M x 59 -- and returns None in its place; the codec path only
-    consumes PCvox).
+    from the HIP voxelizer; PCsorted / DeltaPC are its secondary outputs (``raht_voxelize_residuals``;
+    ``residuals=False`` skips DeltaPC; ``sorted_points=False`` also skips PCsorted -- a full gather of the
+    cloud -- and returns None in its place; the codec path only consumes PCvox).
     """
     PC = PC.to(device)
     _need_cuda(PC, "PC")
@@ -584,19 +583,20 @@ def voxelize_pc_batched(PC, vmin=None, width=None, J=10, device="cuda", residual
     nv = nvox.value
     voxel_indices = vidx[:nv]
     PCvox = pcv[:nv]
-    PCsorted = PC[idx] if (sorted_points or residuals) else None
     vmin_t = torch.tensor(list(vmin_out), dtype=torch.float32, device=dev)
-    DeltaPC = None
-    if residuals:
-        V0 = PCsorted[:, :3] - vmin_t.unsqueeze(0)
-        DeltaV = V0 - vs_out.value * torch.floor(V0 / vs_out.value)          # voxelize_pc.py:110-111
-        if d > 0:
-            counts = torch.diff(torch.cat([voxel_indices, torch.tensor([N], device=dev)]))
-            vid = torch.repeat_interleave(torch.arange(nv, device=dev), counts)
-            DeltaC = PCsorted[:, 3:] - PCvox[:, 3:][vid]                      # voxelize_pc.py:147-148
-            DeltaPC = torch.cat([DeltaV, DeltaC], dim=1)
+    PCsorted, DeltaPC = None, None
+    if residuals or sorted_points:
+        # the secondary outputs, behind the C ABI as well (voxelize_pc.py:103-111, 147-156)
+        PCsorted = torch.empty((N, ld), dtype=torch.float32, device=dev) if (sorted_points or not residuals) else None
+        if residuals:
+            DeltaPC = torch.empty((N, ld), dtype=torch.float32, device=dev)
+            with torch.cuda.device(dev):
+                check(_lib.lib().raht_voxelize_residuals(C.c_void_p(PC.data_ptr()), ld, N, d, C.c_void_p(keys.data_ptr()),
+                                                         C.c_void_p(idx.data_ptr()), C.c_void_p(PCvox.data_ptr()), vmin_out,
+                                                         vs_out.value, C.c_void_p(PCsorted.data_ptr()) if PCsorted is not None else None,
+                                                         C.c_void_p(DeltaPC.data_ptr()), _stream()))
         else:
-            DeltaPC = DeltaV
+            rows_gather(PC, idx, PCsorted)
     info = {"Nvox": nv, "voxel_size": vs_out.value, "vmin": vmin_t, "width": w_out.value, "N": N,
             "sort_idx": idx, "keys_sorted": keys}
     return PCvox, PCsorted, voxel_indices, DeltaPC, info

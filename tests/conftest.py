@@ -18,7 +18,7 @@ def pytest_configure(config):
 def golden_names(prefix=None, exclude_prefix=None):
     names = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "*.npz")))
     if prefix is None:
-        names = [n for n in names if not n.startswith(("rlgr_", "pipeline_"))]   # have their own tests
+        names = [n for n in names if not n.startswith(("rlgr_", "pipeline_", "voxres_"))]   # have their own tests
     if prefix is not None:
         names = [n for n in names if n.startswith(prefix)]
     if exclude_prefix is not None:

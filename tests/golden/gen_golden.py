@@ -443,3 +443,43 @@ def encode_ply_case():
 
 if __name__ == "__main__" and os.environ.get("GOLDEN_ONLY", "") in ("", "ply"):
     encode_ply_case()
+
+
+def voxel_residual_cases():
+    """The voxelizer's secondary outputs PCsorted / DeltaPC (reference python/voxelize_pc.py:103-111, 147-156), straight
+    from voxelize_pc_batched on the CPU. torch.sort (:101) is not asked to be stable and is not (equal keys come out in
+    another order than they went in), so the fixtures keep the reference's own permutation: consumers compare per POINT
+    (row k of the reference <-> point sort_idx[k]), not per sorted position."""
+    rng = np.random.default_rng(20262)
+
+    def case(name, PC32, J, vmin=None, width=None):
+        PC = torch.from_numpy(PC32)
+        vm = None if vmin is None else torch.tensor(vmin, dtype=torch.float32)
+        PCvox, PCsorted, vox_idx, DeltaPC, info = voxelize_pc_batched(PC, vm, width, J, device="cpu")
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), PC=PC32, J=np.int32(J),
+                            vmin_in=(np.zeros(0, np.float32) if vmin is None else np.asarray(vmin, np.float32)),
+                            width_in=np.float64(-1.0 if width is None else width),
+                            sort_idx=info["sort_idx"].numpy().astype(np.int64), voxel_indices=vox_idx.numpy().astype(np.int64),
+                            PCvox=PCvox.numpy().astype(np.float32), PCsorted=PCsorted.numpy().astype(np.float32),
+                            DeltaPC=DeltaPC.numpy().astype(np.float32), vmin=info["vmin"].numpy().astype(np.float32),
+                            width=np.float64(info["width"]), voxel_size=np.float64(info["voxel_size"]))
+        print(f"{name}: N={PC32.shape[0]} J={J} Nvox={info['Nvox']}")
+
+    PC = np.concatenate([rng.uniform(-3, 5, size=(3000, 3)), rng.normal(size=(3000, 4))], axis=1).astype(np.float32)
+    PC[::3, :3] = PC[1::3, :3][: PC[::3].shape[0]]                 # several points per voxel
+    case("voxres_n3000_j5_d4", PC, 5)
+    case("voxres_n3000_j7_given", PC, 7, vmin=[-3.5, -3.5, -3.5], width=9.0)
+    case("voxres_posonly_j4", rng.uniform(0, 1, size=(2000, 3)).astype(np.float32), 4)
+    # voxel-face positions, non-power-of-two width (the division-semantics case of DESIGN.md 13)
+    J, width = 6, 7.3
+    vs = width / (1 << J)
+    k = rng.integers(0, 1 << J, size=(1500, 3))
+    base = (k * vs).astype(np.float32)
+    bump = rng.integers(-1, 2, size=(1500, 3))
+    pts = np.where(bump == 0, base, np.nextafter(base, np.where(bump > 0, np.float32(np.inf), np.float32(-np.inf)), dtype=np.float32)).astype(np.float32)
+    pts = np.clip(pts, 0, None)
+    case("voxres_boundary_j6", np.concatenate([pts, rng.normal(size=(1500, 2)).astype(np.float32)], axis=1), J, vmin=[0, 0, 0], width=width)
+
+
+if __name__ == "__main__" and os.environ.get("GOLDEN_ONLY", "") in ("", "voxres"):
+    voxel_residual_cases()

@@ -261,6 +261,28 @@ def test_voxelize(rt, name):
     assert np.array_equal(m, g["morton"])
 
 
+@pytest.mark.parametrize("name", golden_names(prefix="voxres_"))
+def test_voxelizer_residuals(rt, oracle, name):
+    """PCsorted / DeltaPC (voxelize_pc.py:103-111, 147-156) through raht_voxelize_residuals: bit-identical to the oracle
+    (same stable order, same float32 arithmetic), and per point against the reference's own outputs."""
+    from .test_oracle_golden import check_residuals_against_reference
+    g = load_golden(name)
+    vmin = None if g["vmin_in"].size == 0 else g["vmin_in"].tolist()
+    width = None if float(g["width_in"]) < 0 else float(g["width_in"])
+    PCvox, PCsorted, vidx, DeltaPC, info = rt.voxelize_pc_batched(_dev(g["PC"]), vmin, width, int(g["J"]), device="cuda")
+    r = oracle.voxelize(g["PC"], int(g["J"]), vmin=None if vmin is None else g["vmin_in"], width=width)
+    pcs, dl = oracle.voxel_residuals(g["PC"], r)
+    assert np.array_equal(info["sort_idx"].cpu().numpy(), r["sort_idx"])
+    np.testing.assert_array_equal(PCsorted.cpu().numpy(), pcs)
+    np.testing.assert_array_equal(DeltaPC.cpu().numpy(), dl)
+    check_residuals_against_reference(g, PCsorted.cpu().numpy(), DeltaPC.cpu().numpy(), r["sort_idx"], vidx.cpu().numpy())
+    # the optional outputs stay optional
+    out = rt.voxelize_pc_batched(_dev(g["PC"]), vmin, width, int(g["J"]), device="cuda", residuals=True, sorted_points=False)
+    assert out[1] is None and np.array_equal(out[3].cpu().numpy(), dl)
+    out = rt.voxelize_pc_batched(_dev(g["PC"]), vmin, width, int(g["J"]), device="cuda", residuals=False, sorted_points=True)
+    assert out[3] is None and np.array_equal(out[1].cpu().numpy(), pcs)
+
+
 def test_voxelize_matches_oracle_bitwise(rt, oracle):
     """Same stable order and sequential float32 sums as the C oracle -> means are bit-identical."""
     rng = np.random.default_rng(5)
