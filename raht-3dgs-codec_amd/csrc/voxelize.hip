@@ -117,7 +117,8 @@ __global__ __launch_bounds__(256) void residual_kernel(const float *__restrict__
     if (PCsorted) PCsorted[e] = x;                                      // :103-108
     if (c < 3) {
         const float v0 = x - (c == 0 ? m0 : (c == 1 ? m1 : m2));        // :92, :103
-        Delta[e] = v0 - vs * floorf(__fdiv_rn(v0, vs));                 // :110-111 (IEEE divide, as torch on the CPU)
+        // :110-111: IEEE divide as torch on the CPU, and product and difference rounded SEPARATELY (two torch ops): no fma
+        Delta[e] = __fsub_rn(v0, __fmul_rn(vs, floorf(__fdiv_rn(v0, vs))));
     } else {
         const int64_t v = (int64_t)pos[k] + (int64_t)flag[k] - 1;       // :129-132
         Delta[e] = x - PCvox[v * ld + c];                               // :147-148
