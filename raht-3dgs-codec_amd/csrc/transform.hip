@@ -1409,7 +1409,7 @@ int raht_debug_read_phase_clocks(unsigned long long *dst, int n_tiles)
  * kernel in isolation with HIP events. Q != NULL selects the fused-quantization kernels
  * (forward: mat = C in, Q out; inverse: Q in, mat = C out), Q == NULL the plain ones
  * (forward: mat = C in, mat2 = T out; inverse: mat = T in, mat2 = C out). */
-int raht_debug_run_stage(const raht_plan *cp, int inverse, int stage, const float *mat, int64_t ld_mat, int D,
+static int debug_run_stage_impl(const raht_plan *cp, int inverse, int stage, const float *mat, int64_t ld_mat, int D,
                          float *mat2, int64_t ld_mat2, int32_t *Q, int64_t ldq, float step, int ablate,
                          raht_stream_t stream)
 {
@@ -1441,6 +1441,14 @@ int raht_debug_run_stage(const raht_plan *cp, int inverse, int stage, const floa
     }
     io.src = mat; io.ld_src = ld_mat;
     return launch_tile_stage<float, false, true>(p, *sc, stage, io, D, Dc, s, ablate);
+}
+
+
+int raht_debug_run_stage(const raht_plan *plan, int inverse, int stage, const float *mat, int64_t ld_mat, int D,
+                         float *mat2, int64_t ld_mat2, int32_t *Q, int64_t ldq, float step, int ablate,
+                         raht_stream_t stream)
+{
+    return guarded("raht_debug_run_stage", [&]() { return debug_run_stage_impl(plan, inverse, stage, mat, ld_mat, D, mat2, ld_mat2, Q, ldq, step, ablate, stream); });
 }
 
 }  // extern "C"
