@@ -246,6 +246,18 @@ __device__ __forceinline__ P *row_far(P *base, uint32_t row, uint32_t ld, uint32
     return base + ((uint64_t)row * ld + goff);
 }
 
+// LDS-direct load: 16 bytes per lane from the lane's global address to LDS byte (lds_base + 16 * lane), no register in
+// between (global_load_lds_dwordx4; M0 = the wave's LDS base, inactive lanes write nothing, the global address needs
+// element alignment only: tools/probes/glds_probe.hip). Issued through inline assembly ON PURPOSE: hipcc does not know
+// that LDS is being written, so it neither drains the load at the next LDS access it cannot tell apart from the
+// destination (every one, with one dynamic LDS block) nor counts it -- its own s_waitcnt vmcnt(n) are then merely
+// stricter than needed (the counter retires in order). The kernel waits for the data itself: tile_kernel, sync #3.
+__device__ __forceinline__ void glds16(const void *g, uint32_t lds_base)
+{
+    const uint32_t b = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_base);
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(g), "s"(b) : "memory");
+}
+
 // IDENT = true is stage 0 (entries are the rows themselves: the HBM-heavy launch); IDENT = false
 // are the later, much smaller stages. QM = true fuses quantize+reorder (forward) / un-reorder+
 // dequantize (inverse). Separate instantiations keep them apart in rocprof kernel statistics.
@@ -276,6 +288,25 @@ __global__ __launch_bounds__(512, (sizeof(T) == 4 ? 6 : 4)) void tile_kernel(con
     const int Dp = A.Dp;                                  // LDS row stride in elements
     const int lg = A.lg, lr = 6 - A.lg;                   // log2(lanes per row), log2(rows per wave instruction)
     const int NC = (Dc + VN - 1) / VN;                    // chunks per row
+    // Inverse kernels that GATHER their rows (T rows of the later stages, Q rows when fused): the addresses need the plan
+    // metadata, so the loads cannot be issued at tile start, and kept in registers across the metadata phases they spill
+    // (see LATE below). They go straight to LDS instead, lane-linear: chunk c = 64 * instruction + lane of the tile's
+    // nt * NCp chunk places sits at tile + 16 * c (an LDS row is NCp whole chunks; NCp > NC only in the last channel block of
+    // a chunked stage, whose rows end early: those lanes load nothing), in flight from sync #1 to sync #3. The fused
+    // inverse's integers are dequantized where they are consumed: in the butterfly that reads the row as its high-pass
+    // operand (every row finalised in a tile is read that way exactly once, before anything is written to it).
+#ifdef RAHT_NO_GLDS                                       // A/B build: the register path (make NO_GLDS=1)
+    constexpr bool GLDS = false;
+#else
+    constexpr bool GLDS = INV && !(IDENT && !QM);
+#endif
+    const int NCp = Dp / VN;
+    const uint32_t NCm = ((1u << 20) + (uint32_t)NCp - 1) / (uint32_t)NCp;   // c / NCp == (c * NCm) >> 20 for c < 2^15
+    // workgroup barrier that leaves the LDS-direct loads in flight (__syncthreads() drains the vector memory counter)
+    auto sync_lds = [&]() {
+        if constexpr (GLDS) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        else __syncthreads();
+    };
 
     // ---- LDS carve-up (must match tile_lds_bytes) ----
     size_t off = (size_t)R * Dp * sizeof(T);
@@ -433,6 +464,18 @@ __global__ __launch_bounds__(512, (sizeof(T) == 4 ? 6 : 4)) void tile_kernel(con
         // survivors of this tile were produced by the stage above: one contiguous chunk of ws_{k+1}
         // (the top stage has no stage above it: its survivors are the roots, handled in P3b)
         const int npre = A.last_stage ? 0 : (int)min(surv_cnt, (uint32_t)TILE_PRE_ROWS);
+        if constexpr (GLDS) {
+            const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void *)spre;
+            const int total = npre * NCp;
+            for (int it = wid; (it << 6) < total; it += nw) {
+                const int c = (it << 6) + lane;
+                const int q = (int)(((uint32_t)c * NCm) >> 20), ch = c - q * NCp;
+                if (c < total && ch < NC) {
+                    glds16(row_at((const T *)A.wsn + (int64_t)surv_base * A.ld_ws, (uint32_t)q, (uint32_t)A.ld_ws,
+                                  (uint32_t)(c_base + min(ch * VN, Dc - VN))), lds0 + ((uint32_t)it << 10));
+                }
+            }
+        } else
         if (active) for (int it = wid; (it << lr) < npre; it += nw) {
             const int q = min((it << lr) + g, npre - 1);
             const V16 x = ld_chunk<T>(row_at((const T *)A.wsn + (int64_t)surv_base * A.ld_ws, (uint32_t)q, (uint32_t)A.ld_ws, (uint32_t)goff));
@@ -445,7 +488,7 @@ __global__ __launch_bounds__(512, (sizeof(T) == 4 ? 6 : 4)) void tile_kernel(con
         if (j < nt) { if (!IDENT) srow[j] = m_row[s]; if (QM && INV) sdst[j] = m_pos[s]; }
     }
     PHASE_STAMP(1);
-    __syncthreads();                                                       // sync #1
+    sync_lds();                                                            // sync #1
     PHASE_STAMP(2);
 
     // inverse of the later stages / fused inverse: gather every slot's coefficient row now (survivor
@@ -454,7 +497,21 @@ __global__ __launch_bounds__(512, (sizeof(T) == 4 ? 6 : 4)) void tile_kernel(con
     // that three workgroups per CU leave, and hipcc then parks ONE row in scratch -- behind an s_waitcnt vmcnt(0),
     // i.e. a full HBM round trip in front of the other five loads: 0.267 -> 0.341 ms, whether the gather is issued in
     // front of P1 or behind it. This gather is the one exposed HBM round trip left in the step.
-    if (INV && !input_done) {
+    if constexpr (GLDS) {
+        const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void *)tile;
+        const int total = nt * NCp;
+        for (int it = wid; (it << 6) < total; it += nw) {
+            const int c = (it << 6) + lane;
+            const int jr = (int)(((uint32_t)c * NCm) >> 20), ch = c - jr * NCp;
+            if (c < total && ch < NC) {
+                const uint32_t go = (uint32_t)(c_base + min(ch * VN, Dc - VN));
+                const RawT *src;
+                if constexpr (QM) src = row_far((const RawT *)A.Q, (uint32_t)sdst[jr], (uint32_t)A.ldq, go);
+                else src = row_far((const RawT *)A.fin, (uint32_t)srow[jr], (uint32_t)A.ld_fin, go);
+                glds16(src, lds0 + ((uint32_t)it << 10));
+            }
+        }
+    } else if (INV && !input_done) {
         load_steps(lane);
         if (active) for (int it0 = wid; (it0 << lr) < nt; it0 += nw * TILE_IO_U) {
             RawChunk x[TILE_IO_U];
@@ -493,7 +550,7 @@ __global__ __launch_bounds__(512, (sizeof(T) == 4 ? 6 : 4)) void tile_kernel(con
         m_rank[s] = __popcll(bal & lt);
         if (lane == 0 && s * nw + wid < 32) scnt[s * nw + wid] = (uint32_t)__popcll(bal);
     }
-    __syncthreads();                                                       // sync #2
+    sync_lds();                                                            // sync #2
     PHASE_STAMP(3);
 
     // ---- P2. level offsets (wave 0); survivor destinations ----
@@ -520,8 +577,24 @@ __global__ __launch_bounds__(512, (sizeof(T) == 4 ? 6 : 4)) void tile_kernel(con
             }
         }
     }
-    __syncthreads();                                                       // sync #3
+    if constexpr (GLDS) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");     // sync #3: the gathered rows have landed
+    else __syncthreads();                                                  // sync #3
     PHASE_STAMP(4);
+    if constexpr (GLDS && QM) {
+        load_steps(lane);
+        // roots finalised here come straight from Q as well: dequantize them in place (no butterfly will)
+        if (A.last_stage && !A.root_buf && active) for (int it = wid; (it << lr) < nt; it += nw) {
+            const int j = (it << lr) + g;
+            if (j < nt && sflag[j] == 2) {
+                V16 *pr = (V16 *)&tile[__mul24(j, Dp) + coff];
+                const RawChunk raw = *(const RawChunk *)pr;
+                V16 x;
+#pragma unroll
+                for (int i = 0; i < VN; ++i) x.v[i] = (T)raw.v[i] * (T)my_step[i];          // encode_3dgs.py:261
+                *pr = x;
+            }
+        }
+    }
     // the rows loaded in P0b (forward, plain stage-0 inverse) or gathered after sync #1 (other inverses) land in the
     // tile now (they were in flight during P1 and P2; holding them across the float64 record arithmetic of P3a as
     // well would spill)
@@ -639,6 +712,13 @@ __global__ __launch_bounds__(512, (sizeof(T) == 4 ? 6 : 4)) void tile_kernel(con
                     }
 #pragma unroll
                     for (int u = 0; u < U; ++u) { x0[u] = *(const V16 *)&tile[ip[u]]; x1[u] = *(const V16 *)&tile[ij[u]]; }
+                    if constexpr (GLDS && QM) {           // the high-pass operand is still the quantized integer (encode_3dgs.py:261)
+#pragma unroll
+                        for (int u = 0; u < U; ++u) {
+#pragma unroll
+                            for (int i = 0; i < VN; ++i) x1[u].v[i] = (T)__float_as_int((float)x1[u].v[i]) * (T)my_step[i];
+                        }
+                    }
 #pragma unroll
                     for (int u = 0; u < U; ++u) {
                         V16 lo, hi;
