@@ -166,8 +166,10 @@ template <> struct __align__(16) MRec<float> { uint32_t po; uint32_t jo; float a
 template <> struct __align__(8) MRec<double> { uint32_t po; uint32_t jo; double a; double b; };
 
 constexpr int TILE_MAX_SLOTS = 2;      // slots per thread (template SLOTS = 1 or 2): R <= SLOTS * blockDim
-constexpr int TILE_IO_U = 6;           // row chunks in flight per lane in the load / gather phases
-constexpr int TILE_ROUND_U = 2;        // butterflies in flight per lane group in a round
+#ifndef RAHT_ROUND_U
+#define RAHT_ROUND_U 2
+#endif
+constexpr int TILE_ROUND_U = RAHT_ROUND_U;        // butterflies in flight per lane group in a round
 constexpr int TILE_PRE_ROWS = 12;      // survivor rows prefetched by the inverse before flags are known
 
 // Plan metadata of one tile, held in registers (slot j = tid + s * blockDim). The persistent tile
@@ -252,10 +254,12 @@ __device__ __forceinline__ P *row_far(P *base, uint32_t row, uint32_t ld, uint32
 // that LDS is being written, so it neither drains the load at the next LDS access it cannot tell apart from the
 // destination (every one, with one dynamic LDS block) nor counts it -- its own s_waitcnt vmcnt(n) are then merely
 // stricter than needed (the counter retires in order). The kernel waits for the data itself: tile_kernel, sync #3.
+template <bool STREAM = false>                          // STREAM: nontemporal (matrices touched once: C, T, Q)
 __device__ __forceinline__ void glds16(const void *g, uint32_t lds_base)
 {
     const uint32_t b = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_base);
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(g), "s"(b) : "memory");
+    if constexpr (STREAM) asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off nt" :: "v"(g), "s"(b) : "memory");
+    else asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(g), "s"(b) : "memory");
 }
 
 // IDENT = true is stage 0 (entries are the rows themselves: the HBM-heavy launch); IDENT = false
@@ -288,25 +292,25 @@ __global__ __launch_bounds__(512, (sizeof(T) == 4 ? 6 : 4)) void tile_kernel(con
     const int Dp = A.Dp;                                  // LDS row stride in elements
     const int lg = A.lg, lr = 6 - A.lg;                   // log2(lanes per row), log2(rows per wave instruction)
     const int NC = (Dc + VN - 1) / VN;                    // chunks per row
-    // Inverse kernels that GATHER their rows (T rows of the later stages, Q rows when fused): the addresses need the plan
-    // metadata, so the loads cannot be issued at tile start, and kept in registers across the metadata phases they spill
-    // (see LATE below). They go straight to LDS instead, lane-linear: chunk c = 64 * instruction + lane of the tile's
-    // nt * NCp chunk places sits at tile + 16 * c (an LDS row is NCp whole chunks; NCp > NC only in the last channel block of
-    // a chunked stage, whose rows end early: those lanes load nothing), in flight from sync #1 to sync #3. The fused
-    // inverse's integers are dequantized where they are consumed: in the butterfly that reads the row as its high-pass
-    // operand (every row finalised in a tile is read that way exactly once, before anything is written to it).
-#ifdef RAHT_NO_GLDS                                       // A/B build: the register path (make NO_GLDS=1)
-    constexpr bool GLDS = false;
-#else
-    constexpr bool GLDS = INV && !(IDENT && !QM);
-#endif
+    // Row loads go STRAIGHT to LDS (glds16), lane-linear: chunk c = 64 * instruction + lane of the tile's nt * NCp chunk
+    // places sits at tile + 16 * c (an LDS row is NCp whole chunks; NCp > NC only in the last channel block of a chunked
+    // stage, whose rows end early: those lanes load nothing). No register holds a row between HBM and LDS, so the loads
+    // stay in flight across the metadata phases for free (kept in registers they cost 24 VGPRs: the forward kernels sat at
+    // the 80-register limit of three workgroups per CU with it, the gathering inverses spilled and had to wait for their
+    // rows on the spot -- the one exposed HBM round trip of the round-1 step).
+    //   forward, plain inverse of stage 0: the input is one contiguous span (C / ws_k / T), issued at tile start (P0b);
+    //   other inverses: a GATHER (T rows of the later stages, Q rows when fused) whose addresses need the plan metadata,
+    //       issued after sync #1. The fused inverse's integers are dequantized where they are consumed: in the butterfly
+    //       that reads the row as its high-pass operand (every row finalised in a tile is read that way exactly once,
+    //       before anything is written to it);
+    //   the forward waits for its rows in front of the butterflies (sync #4), the inverse at sync #3 (P3b writes the
+    //   survivors' values from the stage above over what the gather put in their slots).
+    constexpr bool GATHER = INV && !(IDENT && !QM);
     const int NCp = Dp / VN;
     const uint32_t NCm = ((1u << 20) + (uint32_t)NCp - 1) / (uint32_t)NCp;   // c / NCp == (c * NCm) >> 20 for c < 2^15
     // workgroup barrier that leaves the LDS-direct loads in flight (__syncthreads() drains the vector memory counter)
-    auto sync_lds = [&]() {
-        if constexpr (GLDS) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        else __syncthreads();
-    };
+    auto sync_lds = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+    auto sync_landed = [&]() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
 
     // ---- LDS carve-up (must match tile_lds_bytes) ----
     size_t off = (size_t)R * Dp * sizeof(T);
@@ -341,8 +345,7 @@ __global__ __launch_bounds__(512, (sizeof(T) == 4 ? 6 : 4)) void tile_kernel(con
     };
     // quantization steps of this lane's channels (and their refined reciprocals: once per channel instead of once per
     // coefficient): fetched where they are used -- in front of the write-back (forward) or of the row gather
-    // (inverse) -- not at kernel start: eight registers that are NOT live while the forward keeps a tile's rows in
-    // flight across the metadata phases (LATE below), which is what lets the fused forward do that too
+    // (inverse) -- not at kernel start: eight registers less across the metadata phases
     float my_step[VN], my_rcp[VN];
     // (`ln` = the lane id from the tile loop's OPAQUE copy of the thread id: computed from tid0 the eight step-table
     // addresses are loop invariants that hipcc hoists to kernel start and spills -- and any scratch use at all cost the
@@ -381,106 +384,38 @@ __global__ __launch_bounds__(512, (sizeof(T) == 4 ? 6 : 4)) void tile_kernel(con
     }
     if (tid < 64) hist[tid] = 0;
 
-    // Predication. Every row loop below runs inside ONE `if (active)` region (lanes beyond the row's last
-    // chunk sit the whole loop out) and addresses rows past the end of the tile as its last row: those lanes
+    // Predication. Every LDS <-> global row loop below runs inside ONE `if (active)` region (lanes beyond the row's
+    // last chunk sit the whole loop out) and addresses rows past the end of the tile as its last row: those lanes
     // move the same bytes to the same place as the lane that owns the row, so no per-chunk exec-mask
     // juggling is needed (it was 4 scalar instructions and a branch per chunk; the kernel issues nearly
-    // as many scalar as vector instructions). A whole wave instruction past the end (the unrolled loads of
-    // the last step) rewrites the tile's last row with the bytes it already holds.
-    // dequantize (fused inverse) / pass through a raw chunk and drop it into its LDS row (jb: the wave
-    // instruction's first row, uniform)
-    auto put_row = [&](int jb, const RawChunk &raw) {
-        V16 x;
-#pragma unroll
-        for (int i = 0; i < VN; ++i) {
-            x.v[i] = (T)raw.v[i];
-            if constexpr (QM && INV) x.v[i] = x.v[i] * (T)my_step[i];                     // encode_3dgs.py:261
-        }
-        *(V16 *)&tile[__mul24(min(jb + g, nt - 1), Dp) + coff] = x;
-    };
+    // as many scalar as vector instructions).
 
     PHASE_STAMP(0);
+    // all chunks of `rows` rows, row jr's chunk ch from src(jr) + its channels, to the LDS rows at `dst`
+    auto load_rows = [&](auto stream, const T *dst, int rows, auto src) {
+        const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void *)dst;
+        const int total = rows * NCp;
+        for (int it = wid; (it << 6) < total; it += nw) {
+            const int c = (it << 6) + lane;
+            const int jr = (int)(((uint32_t)c * NCm) >> 20), ch = c - jr * NCp;
+            if (c < total && ch < NC)
+                glds16<decltype(stream)::value>(src(jr, (uint32_t)(c_base + min(ch * VN, Dc - VN))), lds0 + ((uint32_t)it << 10));
+        }
+    };
     // ---- P0b. row transfers whose addresses do not depend on the plan metadata ----
-    bool input_done = false;                  // tile already holds every slot's input
-    // forward kernels (80 VGPRs at three workgroups per CU: the fused one fits since its step table is fetched late;
-    // a spilled row would be a wait for HBM right behind its load: +6 % instead of -3 %)
-    // The inverse does the same with the rows it gathers (T / Q rows of the slots finalised here): issued as soon as
-    // their addresses are known, landing after sync #3 -- in the slots that are NOT survivors: those take their value
-    // from the stage above (P3b), and nothing may overwrite it afterwards.
-    // Only where it fits the 80 registers of three workgroups per CU: the plain stage-0 inverse (77). The fused inverse
-    // would spill 16 registers (measured: 0.267 -> 0.341 ms), the later-stage inverses 8.
-    constexpr bool LATE = (!INV || (IDENT && !QM)) && SLOTS == 1;     // (two slots per thread: no room either)
-    V16 x_late[TILE_IO_U];
-    int it_late = -1;
-    if (!INV || (IDENT && !QM)) {
+    if constexpr (!GATHER) {
         // forward: this stage's entries, entry order (C or ws_k); plain inverse of stage 0: T rows [e0, e0+nt)
         const uint32_t lds = (uint32_t)(INV ? A.ld_fin : A.ld_in);
         const T *src = (INV ? (const T *)A.fin : A.in) + e0 * (int64_t)lds;      // wave-uniform
-        if constexpr (!LATE) {
-            if (active) for (int it0 = wid; (it0 << lr) < nt; it0 += nw * TILE_IO_U) {
-                V16 x[TILE_IO_U];
-#pragma unroll
-                for (int u = 0; u < TILE_IO_U; ++u) {
-                    const int j = min(((it0 + u * nw) << lr) + g, nt - 1);
-                    x[u] = ld_chunk<T, IDENT>(row_at(src, (uint32_t)j, lds, (uint32_t)goff));   // stage 0: C (or T) itself; later stages: workspace
-                }
-#pragma unroll
-                for (int u = 0; u < TILE_IO_U; ++u) {
-                    const int j = min(((it0 + u * nw) << lr) + g, nt - 1);
-                    *(V16 *)&tile[__mul24(j, Dp) + coff] = x[u];
-                }
-            }
-        } else if (active) {
-            int it0 = wid;
-            // every load step but the last: into the tile at once
-            for (; ((it0 + nw * TILE_IO_U) << lr) < nt; it0 += nw * TILE_IO_U) {
-                V16 x[TILE_IO_U];
-#pragma unroll
-                for (int u = 0; u < TILE_IO_U; ++u) {
-                    const int j = min(((it0 + u * nw) << lr) + g, nt - 1);
-                    x[u] = ld_chunk<T, IDENT>(row_at(src, (uint32_t)j, lds, (uint32_t)goff));
-                }
-#pragma unroll
-                for (int u = 0; u < TILE_IO_U; ++u) {
-                    const int j = min(((it0 + u * nw) << lr) + g, nt - 1);
-                    *(V16 *)&tile[__mul24(j, Dp) + coff] = x[u];
-                }
-            }
-            // the last (usually the only) step: nothing reads the rows before the butterflies, so they stay
-            // in registers, in flight, while P1 and P2 work on the plan metadata (the wait for HBM was a
-            // fifth of the tile's time); they are dropped into the tile after sync #3
-            if ((it0 << lr) < nt) {
-#pragma unroll
-                for (int u = 0; u < TILE_IO_U; ++u) {
-                    const int j = min(((it0 + u * nw) << lr) + g, nt - 1);
-                    x_late[u] = ld_chunk<T, IDENT>(row_at(src, (uint32_t)j, lds, (uint32_t)goff));
-                }
-                it_late = it0;
-            }
-        }
-        input_done = true;
+        load_rows(std::integral_constant<bool, IDENT>(), tile, nt,                // stage 0: C (or T) itself, touched once
+                  [&](int jr, uint32_t go) { return row_at(src, (uint32_t)jr, lds, go); });
     }
     if (INV) {
         // survivors of this tile were produced by the stage above: one contiguous chunk of ws_{k+1}
         // (the top stage has no stage above it: its survivors are the roots, handled in P3b)
         const int npre = A.last_stage ? 0 : (int)min(surv_cnt, (uint32_t)TILE_PRE_ROWS);
-        if constexpr (GLDS) {
-            const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void *)spre;
-            const int total = npre * NCp;
-            for (int it = wid; (it << 6) < total; it += nw) {
-                const int c = (it << 6) + lane;
-                const int q = (int)(((uint32_t)c * NCm) >> 20), ch = c - q * NCp;
-                if (c < total && ch < NC) {
-                    glds16(row_at((const T *)A.wsn + (int64_t)surv_base * A.ld_ws, (uint32_t)q, (uint32_t)A.ld_ws,
-                                  (uint32_t)(c_base + min(ch * VN, Dc - VN))), lds0 + ((uint32_t)it << 10));
-                }
-            }
-        } else
-        if (active) for (int it = wid; (it << lr) < npre; it += nw) {
-            const int q = min((it << lr) + g, npre - 1);
-            const V16 x = ld_chunk<T>(row_at((const T *)A.wsn + (int64_t)surv_base * A.ld_ws, (uint32_t)q, (uint32_t)A.ld_ws, (uint32_t)goff));
-            *(V16 *)&spre[__mul24(q, Dp) + coff] = x;
-        }
+        load_rows(std::false_type(), spre, npre, [&](int q, uint32_t go) {
+            return row_at((const T *)A.wsn + (int64_t)surv_base * A.ld_ws, (uint32_t)q, (uint32_t)A.ld_ws, go); });
     }
 #pragma unroll
     for (int s = 0; s < SLOTS; ++s) {
@@ -491,39 +426,13 @@ __global__ __launch_bounds__(512, (sizeof(T) == 4 ? 6 : 4)) void tile_kernel(con
     sync_lds();                                                            // sync #1
     PHASE_STAMP(2);
 
-    // inverse of the later stages / fused inverse: gather every slot's coefficient row now (survivor
-    // slots get overwritten in P3b) -- the addresses need srow / sdst. The rows are consumed at once: keeping them in
-    // flight until sync #3 (as the forward kernels and the plain stage-0 inverse do) needs 4 registers more than the 80
-    // that three workgroups per CU leave, and hipcc then parks ONE row in scratch -- behind an s_waitcnt vmcnt(0),
-    // i.e. a full HBM round trip in front of the other five loads: 0.267 -> 0.341 ms, whether the gather is issued in
-    // front of P1 or behind it. This gather is the one exposed HBM round trip left in the step.
-    if constexpr (GLDS) {
-        const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void *)tile;
-        const int total = nt * NCp;
-        for (int it = wid; (it << 6) < total; it += nw) {
-            const int c = (it << 6) + lane;
-            const int jr = (int)(((uint32_t)c * NCm) >> 20), ch = c - jr * NCp;
-            if (c < total && ch < NC) {
-                const uint32_t go = (uint32_t)(c_base + min(ch * VN, Dc - VN));
-                const RawT *src;
-                if constexpr (QM) src = row_far((const RawT *)A.Q, (uint32_t)sdst[jr], (uint32_t)A.ldq, go);
-                else src = row_far((const RawT *)A.fin, (uint32_t)srow[jr], (uint32_t)A.ld_fin, go);
-                glds16(src, lds0 + ((uint32_t)it << 10));
-            }
-        }
-    } else if (INV && !input_done) {
-        load_steps(lane);
-        if (active) for (int it0 = wid; (it0 << lr) < nt; it0 += nw * TILE_IO_U) {
-            RawChunk x[TILE_IO_U];
-#pragma unroll
-            for (int u = 0; u < TILE_IO_U; ++u) {
-                const int j = min(((it0 + u * nw) << lr) + g, nt - 1);
-                if constexpr (QM) x[u] = ld_chunk<RawT, true>(row_far((const RawT *)A.Q, (uint32_t)sdst[j], (uint32_t)A.ldq, (uint32_t)goff));
-                else x[u] = ld_chunk<RawT, true>(row_far((const RawT *)A.fin, (uint32_t)srow[j], (uint32_t)A.ld_fin, (uint32_t)goff));
-            }
-#pragma unroll
-            for (int u = 0; u < TILE_IO_U; ++u) put_row((it0 + u * nw) << lr, x[u]);
-        }
+    // inverse of the later stages / fused inverse: gather every slot's coefficient row now (survivor slots get
+    // overwritten in P3b) -- the addresses need srow / sdst
+    if constexpr (GATHER) {
+        load_rows(std::true_type(), tile, nt, [&](int jr, uint32_t go) {
+            if constexpr (QM) return (const void *)row_far((const RawT *)A.Q, (uint32_t)sdst[jr], (uint32_t)A.ldq, go);
+            else return (const void *)row_far((const RawT *)A.fin, (uint32_t)srow[jr], (uint32_t)A.ld_fin, go);
+        });
     }
 
     // ---- P1. which slots merge inside this tile; level histogram; survivor ranks ----
@@ -577,10 +486,9 @@ __global__ __launch_bounds__(512, (sizeof(T) == 4 ? 6 : 4)) void tile_kernel(con
             }
         }
     }
-    if constexpr (GLDS) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");     // sync #3: the gathered rows have landed
-    else __syncthreads();                                                  // sync #3
+    if constexpr (INV) sync_landed(); else sync_lds();                     // sync #3 (inverse: its rows have landed)
     PHASE_STAMP(4);
-    if constexpr (GLDS && QM) {
+    if constexpr (INV && QM) {
         load_steps(lane);
         // roots finalised here come straight from Q as well: dequantize them in place (no butterfly will)
         if (A.last_stage && !A.root_buf && active) for (int it = wid; (it << lr) < nt; it += nw) {
@@ -592,23 +500,6 @@ __global__ __launch_bounds__(512, (sizeof(T) == 4 ? 6 : 4)) void tile_kernel(con
 #pragma unroll
                 for (int i = 0; i < VN; ++i) x.v[i] = (T)raw.v[i] * (T)my_step[i];          // encode_3dgs.py:261
                 *pr = x;
-            }
-        }
-    }
-    // the rows loaded in P0b (forward, plain stage-0 inverse) or gathered after sync #1 (other inverses) land in the
-    // tile now (they were in flight during P1 and P2; holding them across the float64 record arithmetic of P3a as
-    // well would spill)
-    if (LATE && it_late >= 0) {
-#pragma unroll
-        for (int u = 0; u < TILE_IO_U; ++u) {
-            const int j = min(((it_late + u * nw) << lr) + g, nt - 1);
-            if constexpr (!INV) {
-                *(V16 *)&tile[__mul24(j, Dp) + coff] = x_late[u];
-            } else {
-                // plain stage-0 inverse: not into survivor slots (flag 0: their value comes from the stage above, P3b) nor
-                // into roots that the caller's root buffer provides (flag 2 with a root buffer, P3b as well)
-                const int fl = sflag[j];
-                if (fl == 1 || (fl == 2 && !A.root_buf)) *(V16 *)&tile[__mul24(j, Dp) + coff] = x_late[u];
             }
         }
     }
@@ -670,7 +561,7 @@ __global__ __launch_bounds__(512, (sizeof(T) == 4 ? 6 : 4)) void tile_kernel(con
             *(V16 *)&tile[__mul24((int)ssurv[qc], Dp) + coff] = x;
         }
     }
-    __syncthreads();                                                       // sync #4
+    if constexpr (!INV) sync_landed(); else __syncthreads();               // sync #4 (forward: its rows have landed)
     PHASE_STAMP(5);
 
     // prefetch the next tile's plan metadata: the loads stay in flight during the butterflies
@@ -712,7 +603,7 @@ __global__ __launch_bounds__(512, (sizeof(T) == 4 ? 6 : 4)) void tile_kernel(con
                     }
 #pragma unroll
                     for (int u = 0; u < U; ++u) { x0[u] = *(const V16 *)&tile[ip[u]]; x1[u] = *(const V16 *)&tile[ij[u]]; }
-                    if constexpr (GLDS && QM) {           // the high-pass operand is still the quantized integer (encode_3dgs.py:261)
+                    if constexpr (INV && QM) {            // the high-pass operand is still the quantized integer (encode_3dgs.py:261)
 #pragma unroll
                         for (int u = 0; u < U; ++u) {
 #pragma unroll

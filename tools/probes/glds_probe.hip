@@ -13,9 +13,9 @@ __device__ __forceinline__ void glds16(const void *g, uint32_t lds_base)
 
 // every wave gathers 64 16-byte chunks: chunk c = 15 per row of 59 floats (row stride 59 floats = 236 bytes: only
 // dword-aligned), LDS rows of 60 floats, lane-linear; lanes with (c % 7 == 3) are masked off and must keep the fill value
-__global__ void probe(const float *src, float *dst, int nrows)
+__global__ void probe(const float *src, float *dst, int nrows, int lds_off)
 {
-    float *tile = (float *)smem;
+    float *tile = (float *)(smem + lds_off);          // (also beyond 64 KiB: M0 must carry the full LDS address)
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
     for (int i = threadIdx.x; i < nrows * 60; i += blockDim.x) tile[i] = -1.0f;
     __syncthreads();
@@ -42,10 +42,15 @@ int main()
     float *src, *dst;
     if (hipMalloc(&src, h.size() * 4) != hipSuccess || hipMalloc(&dst, nrows * 60 * 4) != hipSuccess) return 3;
     if (hipMemcpy(src, h.data(), h.size() * 4, hipMemcpyHostToDevice) != hipSuccess) return 3;
-    hipLaunchKernelGGL(probe, dim3(1), dim3(512), 48 * 1024, 0, src, dst, nrows);
+    int bad = 0;
+    if (hipFuncSetAttribute((const void *)probe, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return 3;
+    const int offs[3] = {0, 60 * 1024, 112 * 1024};
+    for (int t = 0; t < 3; ++t) {
+    hipMemset(dst, 0, nrows * 60 * 4);
+    hipLaunchKernelGGL(probe, dim3(1), dim3(512), offs[t] + 48 * 1024, 0, src, dst, nrows, offs[t]);
     std::vector<float> o((size_t)nrows * 60);
     if (hipMemcpy(o.data(), dst, o.size() * 4, hipMemcpyDeviceToHost) != hipSuccess) { printf("copy failed\n"); return 2; }
-    int bad = 0;
+    const int bad0 = bad;
     for (int c = 0; c < nrows * 15; ++c) {
         const int row = c / 15, ch = c % 15, goff = ch * 4 < 55 ? ch * 4 : 55;
         for (int i = 0; i < 4; ++i) {
@@ -54,6 +59,7 @@ int main()
             if (want != got) { if (bad < 10) printf("chunk %d elem %d: want %g got %g\n", c, i, want, got); ++bad; }
         }
     }
-    printf("glds probe: %d mismatches of %d\n", bad, nrows * 60);
+    printf("glds probe, tile at LDS byte %d: %d mismatches of %d\n", offs[t], bad - bad0, nrows * 60);
+    }
     return bad ? 1 : 0;
 }
