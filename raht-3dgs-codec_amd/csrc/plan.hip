@@ -650,14 +650,25 @@ __device__ __forceinline__ uint32_t block_sum_256(uint32_t v, uint32_t *red /* [
 }
 
 // wl / wr / lvl are ENTRY-ordered for this stage (stage 0: the plan arrays, entry = row)
-__global__ __launch_bounds__(SB_THREADS) void sched_count_kernel(const SchedState *__restrict__ S, int k, const uint32_t *__restrict__ rows,
+// n_first >= 0: this is the FIRST launch of the chain (stage 0 as a tile stage of n_first entries): nothing has
+// written the state yet -- block 0 does (the launches behind this one read it), every block takes n from the argument
+__device__ __forceinline__ void sched_state_init(SchedState *S, uint32_t n0, uint32_t kind0)
+{
+    uint32_t *w = (uint32_t *)S;
+    for (int i = threadIdx.x; i < SCHED_STATE_WORDS; i += blockDim.x) w[i] = 0;
+    __syncthreads();
+    if (threadIdx.x == 0) { S->n[0] = n0; S->kind[0] = kind0; }
+}
+
+__global__ __launch_bounds__(SB_THREADS) void sched_count_kernel(SchedState *__restrict__ S, int k, const uint32_t *__restrict__ rows,
                                                                  const int32_t *__restrict__ wl, const int32_t *__restrict__ wr,
                                                                  const uint8_t *__restrict__ lvl, int R, int64_t N, int top_level,
-                                                                 uint8_t *__restrict__ flags, uint32_t *__restrict__ blk_cnt)
+                                                                 uint8_t *__restrict__ flags, uint32_t *__restrict__ blk_cnt, int64_t n_first)
 {
     __shared__ uint32_t red[4];
-    if (S->kind[k] != SK_TILE) return;
-    const int64_t n = S->n[k];
+    if (n_first >= 0) { if (blockIdx.x == 0) sched_state_init(S, (uint32_t)n_first, SK_TILE); }
+    else if (S->kind[k] != SK_TILE) return;
+    const int64_t n = n_first >= 0 ? n_first : (int64_t)S->n[k];
     const int64_t base = (int64_t)blockIdx.x * SB_BLOCK + (int64_t)threadIdx.x * SB_ITEMS;
     if ((int64_t)blockIdx.x * SB_BLOCK >= n) return;
     uint32_t cnt = 0;
@@ -744,8 +755,8 @@ __global__ __launch_bounds__(SB_THREADS) void sched_emit_kernel(SchedState *__re
         const uint32_t total = block_base + block_tot;
         surv_off[(n + R - 1) / R] = total;
         S->n[k + 1] = total;
-        if (total > cap_next) S->trouble = 1;
-        if (total == n_roots) { S->finished = 1; S->last_stage = (uint32_t)k; S->last_is_top = 0; }   // only the roots are left
+        if (total > cap_next) S->trouble = 1;                                                     // (and the chain stops: kind[k + 1] stays SK_NONE)
+        else if (total == n_roots) { S->finished = 1; S->last_stage = (uint32_t)k; S->last_is_top = 0; }   // only the roots are left
         else if (total >= (uint32_t)n) S->trouble = 2;                                              // no progress
         else S->kind[k + 1] = (total <= Rf) ? SK_TOP : SK_TILE;
     }
@@ -754,18 +765,19 @@ __global__ __launch_bounds__(SB_THREADS) void sched_emit_kernel(SchedState *__re
 // The TOP stage in one workgroup: every butterfly still to do, resolved against the stage's entry list, bucketed by
 // level; root ranks; the level program (what build_top_stage does with a dozen launches and a read-back).
 constexpr int ST_THREADS = 1024;
-__global__ __launch_bounds__(ST_THREADS) void sched_top_kernel(SchedState *__restrict__ S, int k, const uint32_t *__restrict__ rows,
-                                                               const int32_t *__restrict__ p_wl, const int32_t *__restrict__ p_wr,
-                                                               const uint8_t *__restrict__ p_lvl, const int64_t *__restrict__ wsum,
-                                                               int top_level, uint32_t *__restrict__ t_pj, float *__restrict__ t_ab32,
-                                                               double *__restrict__ t_ab64, uint32_t *__restrict__ t_root,
-                                                               uint32_t *__restrict__ t_lev)
+struct SchedTopOut { uint32_t *t_pj; float *t_ab32; double *t_ab64; uint32_t *t_root; uint32_t *t_lev; };
+
+__device__ __forceinline__ void sched_top_body(SchedState *__restrict__ S, int k, int n, const uint32_t *__restrict__ rows,
+                                               const int32_t *__restrict__ p_wl, const int32_t *__restrict__ p_wr,
+                                               const uint8_t *__restrict__ p_lvl, const int64_t *__restrict__ wsum,
+                                               int top_level, const SchedTopOut &O)
 {
     __shared__ uint32_t s_rows[RAHT_TOP_MAX_ROWS];
     __shared__ uint32_t hist[64], cursor[64], wtot[ST_THREADS / 64];
     __shared__ uint32_t root_base;
-    if (S->kind[k] != SK_TOP) return;
-    const int n = (int)S->n[k];
+    uint32_t *__restrict__ t_pj = O.t_pj, *__restrict__ t_root = O.t_root, *__restrict__ t_lev = O.t_lev;
+    float *__restrict__ t_ab32 = O.t_ab32;
+    double *__restrict__ t_ab64 = O.t_ab64;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     if (tid < 64) hist[tid] = 0;
     if (tid == 0) root_base = 0;
@@ -851,6 +863,110 @@ __global__ __launch_bounds__(ST_THREADS) void sched_top_kernel(SchedState *__res
     }
 }
 
+// The END of the chain in ONE launch of one workgroup: from stage k0 on, every tile stage of at most `tail_max`
+// entries (flags, survivor scan, the next stage's entry list and this stage's per-tile survivor offsets: what
+// sched_count_kernel + sched_emit_kernel do for the large stages) and the TOP stage. On cfg3 that is stage 2
+// (7 013 entries) and the top stage (439): two launches of work instead of the eight (two of them empty) that the
+// launch-per-step chain enqueued -- back-to-back launches cost 4.6 us each even when they have nothing to do.
+struct SchedStageBufs {                         // buffers of stage k (entry-ordered copies; surv: its per-tile survivor offsets)
+    uint32_t *rows[SCHED_SPEC_MAX + 2]; int32_t *wl[SCHED_SPEC_MAX + 2], *wr[SCHED_SPEC_MAX + 2];
+    uint8_t *lvl[SCHED_SPEC_MAX + 2]; uint32_t *pos[SCHED_SPEC_MAX + 2], *surv[SCHED_SPEC_MAX + 2];
+    uint32_t cap[SCHED_SPEC_MAX + 2];
+};
+
+__global__ __launch_bounds__(ST_THREADS) void sched_tail_kernel(SchedState *S, int k_multi, int k_last, SchedStageBufs B, int R, uint32_t Rf,
+                                                                uint32_t n_roots, int64_t N, int top_level, uint32_t tail_max,
+                                                                const int32_t *__restrict__ p_wl, const int32_t *__restrict__ p_wr,
+                                                                const uint8_t *__restrict__ p_lvl, const uint32_t *__restrict__ p_inv,
+                                                                const int64_t *__restrict__ wsum, SchedTopOut O, int64_t n_first)
+{
+    __shared__ uint32_t wcnt[8 * (ST_THREADS / 64)], woff[8 * (ST_THREADS / 64) + 1];
+    __shared__ uint32_t s_state[2];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    if (n_first >= 0) { sched_state_init(S, (uint32_t)n_first, SK_TOP); __threadfence(); __syncthreads(); }   // (a tree that fits the top stage)
+    // stages 1 .. k_multi - 1 had the multi-workgroup launches if they were tile stages; one of them may have turned out
+    // to be the top stage already (a tree that shrank faster than expected)
+    for (int k = (k_multi == 0) ? 0 : 1; k <= k_last; ++k) {
+        if (tid == 0) { s_state[0] = __atomic_load_n(&S->kind[k], __ATOMIC_RELAXED); s_state[1] = __atomic_load_n(&S->n[k], __ATOMIC_RELAXED); }
+        __syncthreads();
+        const uint32_t kind = s_state[0], n = s_state[1];
+        __syncthreads();
+        if (kind == SK_TOP) {
+            sched_top_body(S, k, (int)n, B.rows[k], p_wl, p_wr, p_lvl, wsum, top_level, O);
+            return;
+        }
+        if (kind == SK_TILE && k < k_multi) continue;                       // done by its own launches
+        if (kind != SK_TILE || n > tail_max || n > B.cap[k] || k == k_last) return;   // nothing left / larger than expected: exact builder
+        const uint32_t *__restrict__ rows = B.rows[k];
+        const int32_t *__restrict__ wl = B.wl[k], *__restrict__ wr = B.wr[k];
+        const uint8_t *__restrict__ lvl = B.lvl[k];
+        uint32_t *__restrict__ surv_off = B.surv[k];
+        uint32_t *__restrict__ n_rows = B.rows[k + 1], *__restrict__ n_pos = B.pos[k + 1];
+        int32_t *__restrict__ n_wl = B.wl[k + 1], *__restrict__ n_wr = B.wr[k + 1];
+        uint8_t *__restrict__ n_lvl = B.lvl[k + 1];
+        const uint32_t cap_next = B.cap[k + 1];
+        uint32_t running = 0;                                               // survivors in front of this pass (uniform)
+        // TI x 1024 entries per pass (entry j = base + q * 1024 + tid): the loads of a pass are independent of each
+        // other, so a 7 013-entry stage is ONE round of dependent L2 round trips instead of seven
+        constexpr int TI = 8, NWV = ST_THREADS / 64;
+        for (uint32_t base = 0; base < n; base += ST_THREADS * TI) {
+            uint32_t r[TI];
+            uint64_t bal[TI];
+#pragma unroll
+            for (int q = 0; q < TI; ++q) {
+                const uint32_t j = base + (uint32_t)(q * ST_THREADS + tid);
+                bool surv = false;
+                r[q] = 0;
+                if (j < n) {
+                    const uint32_t j0 = j / (uint32_t)R * (uint32_t)R, j1 = j0 + (uint32_t)R;
+                    const int64_t start = (int64_t)rows[j0], end = (j1 < n) ? (int64_t)rows[j1] : N;
+                    r[q] = rows[j];
+                    const bool merged = (r[q] > 0) && ((int)lvl[j] < top_level) && ((int64_t)r[q] - wl[j] >= start) && ((int64_t)r[q] + wr[j] <= end);
+                    surv = !merged;
+                }
+                bal[q] = __ballot(surv);
+                if (lane == 0) wcnt[q * NWV + wid] = (uint32_t)__popcll(bal[q]);
+            }
+            __syncthreads();
+            if (wid == 0) {                                                 // exclusive offsets of the TI * 16 (q, wave) counts
+                const uint32_t c0 = wcnt[2 * lane], c1 = wcnt[2 * lane + 1];
+                uint32_t inc = c0 + c1;
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) { const uint32_t t = __shfl_up(inc, d, 64); if (lane >= d) inc += t; }
+                woff[2 * lane] = inc - c0 - c1;
+                woff[2 * lane + 1] = inc - c1;
+                if (lane == 63) woff[TI * NWV] = inc;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < TI; ++q) {
+                const uint32_t j = base + (uint32_t)(q * ST_THREADS + tid);
+                if (j < n) {
+                    const uint32_t pos = running + woff[q * NWV + wid] + (uint32_t)__popcll(bal[q] & (((uint64_t)1 << lane) - 1));
+                    if (j % (uint32_t)R == 0) surv_off[j / (uint32_t)R] = pos;     // first survivor of the tile
+                    if (((bal[q] >> lane) & 1) && pos < cap_next) {
+                        const uint32_t rr = r[q];
+                        n_rows[pos] = rr; n_wl[pos] = p_wl[rr]; n_wr[pos] = p_wr[rr]; n_lvl[pos] = p_lvl[rr]; n_pos[pos] = p_inv[rr];
+                    }
+                }
+            }
+            running += woff[TI * NWV];
+            __syncthreads();
+        }
+        if (tid == 0) {
+            const uint32_t total = running;
+            surv_off[(n + (uint32_t)R - 1) / (uint32_t)R] = total;
+            S->n[k + 1] = total;
+            if (total > cap_next) S->trouble = 1;                                                      // (and the chain stops)
+            else if (total == n_roots) { S->finished = 1; S->last_stage = (uint32_t)k; S->last_is_top = 0; }   // only the roots are left
+            else if (total >= n) S->trouble = 2;                                                       // no progress
+            else S->kind[k + 1] = (total <= Rf) ? SK_TOP : SK_TILE;
+        }
+        __threadfence();                                                     // the next stage reads what this one wrote
+        __syncthreads();
+    }
+}
+
 static int get_schedule_exact(raht_plan *plan, int R0, int R1, int Rf, hipStream_t s, Schedule **out);
 
 // -> RAHT_OK and *built = true when the schedule was built; *built = false: use the exact builder
@@ -858,25 +974,29 @@ static int build_schedule_fast(raht_plan *plan, int R0, int R1, int Rf, hipStrea
 {
     *built = false;
     const int64_t N = plan->N;
-    // how many stages to enqueue: sizes are unknown, assume a stage keeps at most 1/8 of its entries (measured 1/20
-    // at 184 rows per tile, 1/6 at 64); buffers hold 1/3 (+ slack). Too few stages enqueued -> exact builder.
+    // Sizes are unknown on the host. Stages expected to be large (a stage keeps ~1/20 of its entries at 184 rows per
+    // tile, ~1/6 at 64: assume 1/16 resp. 1/4) get the two multi-workgroup launches; from the first stage expected to
+    // be small on, ONE single-workgroup launch finishes the chain (sched_tail_kernel: up to TAIL_MAX entries per stage).
+    // Buffers hold 1/3 of the stage before (+ slack). A stage larger than expected at the tail, or a bound exceeded ->
+    // the state says so and the exact builder takes over.
+    constexpr uint32_t TAIL_MAX = 65536;
+    constexpr int KB = SCHED_SPEC_MAX;                    // stages with buffers: 0 .. KB
     int64_t cap[SCHED_SPEC_MAX + 2];
     cap[0] = N;
-    int KS = 0;                                           // tile stages enqueued: k = 0 .. KS - 1
-    {
+    for (int k = 0; k <= KB; ++k) cap[k + 1] = std::min<int64_t>(cap[k], cap[k] / 3 + 2048);
+    int KS = 0;                                           // stages given the multi-workgroup launches: k = 0 .. KS - 1
+    if (N > Rf) {
         double expect = (double)N;
-        while (KS < SCHED_SPEC_MAX && KS < plan->max_stages && expect > (double)Rf * 0.5) { ++KS; expect /= (R0 >= 128 && KS > 0 ? 8.0 : 4.0); }
-        for (int k = 0; k <= KS; ++k) cap[k + 1] = std::min<int64_t>(cap[k], cap[k] / 3 + 2048);
+        while (KS < KB - 1 && KS < plan->max_stages && (KS == 0 || expect > (double)TAIL_MAX * 0.5)) { ++KS; expect /= (R0 >= 128 ? 16.0 : 4.0); }
     }
-    if (N <= Rf) KS = 0;
     struct Bufs { uint32_t *rows = nullptr; int32_t *wl = nullptr, *wr = nullptr; uint8_t *lvl = nullptr; uint32_t *pos = nullptr; uint32_t *surv = nullptr; };
-    std::vector<Bufs> B((size_t)KS + 2);
+    std::vector<Bufs> B((size_t)KB + 2);
     uint32_t *t_pj = nullptr, *t_root = nullptr, *t_lev = nullptr;
     float *t_ab32 = nullptr;
     double *t_ab64 = nullptr;
     bool ok = true;
     auto take = [&](auto **ptr, size_t bytes) { if (ok && dev_malloc(ptr, std::max<size_t>(bytes, 16)) != hipSuccess) ok = false; };
-    for (int k = 0; k < KS; ++k) {
+    for (int k = 0; k < KB && N > Rf; ++k) {
         const int R = (k == 0) ? R0 : R1;
         take(&B[(size_t)k].surv, sizeof(uint32_t) * (size_t)(ceil_div(cap[k], R) + 1));
         Bufs &nx = B[(size_t)k + 1];
@@ -896,28 +1016,28 @@ static int build_schedule_fast(raht_plan *plan, int R0, int R1, int Rf, hipStrea
     SchedState *dS = scr.as<SchedState>();
     uint32_t *blk_cnt = (uint32_t *)(dS + 1);
     uint8_t *flags = (uint8_t *)(blk_cnt + nblk0);
-    SchedState h0;
-    memset(&h0, 0, sizeof(h0));
-    h0.n[0] = (uint32_t)N;
-    h0.kind[0] = (N <= Rf) ? SK_TOP : SK_TILE;
-    hipError_t e = hipMemcpyAsync(dS, &h0, sizeof(h0), hipMemcpyHostToDevice, s);     // pageable: copied before return
-    for (int k = 0; k <= KS && e == hipSuccess; ++k) {
+    SchedStageBufs SB;
+    for (int k = 0; k <= KB + 1 && k < SCHED_SPEC_MAX + 2; ++k) {
+        const Bufs &b = B[(size_t)k];
+        SB.rows[k] = b.rows; SB.wl[k] = b.wl; SB.wr[k] = b.wr; SB.lvl[k] = b.lvl; SB.pos[k] = b.pos; SB.surv[k] = b.surv;
+        SB.cap[k] = (uint32_t)cap[k];
+    }
+    const SchedTopOut TO = {t_pj, t_ab32, t_ab64, t_root, t_lev};
+    // the first launch of the chain also initialises the state (no upload, no memset: ~5 us each)
+    for (int k = 0; k < KS; ++k) {
         const Bufs &cur = B[(size_t)k];
-        // stage k as the TOP stage (k = 0 only when the whole tree fits; later stages decide on the device)
-        if (k > 0 || N <= Rf)
-            hipLaunchKernelGGL(sched_top_kernel, dim3(1), dim3(ST_THREADS), 0, s, dS, k, cur.rows, plan->wl, plan->wr, plan->lvl,
-                               plan->wsum, plan->top_level, t_pj, t_ab32, t_ab64, t_root, t_lev);
-        if (k == KS) break;
         const int R = (k == 0) ? R0 : R1;
         const unsigned gb = (unsigned)ceil_div(cap[k], SB_BLOCK);
         const Bufs &nx = B[(size_t)k + 1];
         hipLaunchKernelGGL(sched_count_kernel, dim3(gb), dim3(SB_THREADS), 0, s, dS, k, cur.rows, k ? cur.wl : plan->wl,
-                           k ? cur.wr : plan->wr, k ? cur.lvl : plan->lvl, R, N, plan->top_level, flags, blk_cnt);
+                           k ? cur.wr : plan->wr, k ? cur.lvl : plan->lvl, R, N, plan->top_level, flags, blk_cnt, k == 0 ? N : (int64_t)-1);
         hipLaunchKernelGGL(sched_emit_kernel, dim3(gb), dim3(SB_THREADS), 0, s, dS, k, cur.rows, flags, blk_cnt, R, (uint32_t)Rf,
                            (uint32_t)plan->n_roots, plan->wl, plan->wr, plan->lvl, plan->inv_order, nx.rows, nx.wl, nx.wr, nx.lvl,
                            nx.pos, (uint32_t)cap[k + 1], cur.surv);
-        e = hipGetLastError();
     }
+    hipLaunchKernelGGL(sched_tail_kernel, dim3(1), dim3(ST_THREADS), 0, s, dS, KS, KB, SB, R1, (uint32_t)Rf, (uint32_t)plan->n_roots, N,
+                       plan->top_level, TAIL_MAX, plan->wl, plan->wr, plan->lvl, plan->inv_order, plan->wsum, TO, KS == 0 ? N : (int64_t)-1);
+    hipError_t e = hipGetLastError();
     SchedState hs;
     int rc = RAHT_ERR_HIP;
     if (e == hipSuccess) {
@@ -1094,7 +1214,18 @@ int ensure_level_rows(raht_plan *p, hipStream_t s)
 }
 
 // ---- plan construction ---------------------------------------------------------------------------
-static int finish_plan(raht_plan *p, const int64_t *leaf_weights, hipStream_t s)
+// First launch of a plan build: the caller's sorted keys into the plan (keys_in == nullptr: they are there already), the
+// error word and the root list of an untruncated tree (row 0) initialised -- one launch instead of a device copy, an
+// 8-byte upload and a 4-byte memset (~5 us each on the stream)
+__global__ void plan_begin_kernel(const uint64_t *__restrict__ keys_in, uint64_t *__restrict__ keys, int64_t N, PlanErr *derr, uint32_t *root_rows)
+{
+    if (blockIdx.x == 0 && threadIdx.x == 0) { derr->code = 0; derr->row = 0xffffffffu; root_rows[0] = 0; }
+    if (!keys_in) return;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (int64_t)gridDim.x * blockDim.x)
+        keys[i] = __builtin_nontemporal_load(keys_in + i);
+}
+
+static int finish_plan(raht_plan *p, const int64_t *leaf_weights, hipStream_t s, const uint64_t *keys_in)
 {
     const int64_t N = p->N;
     const unsigned gb = (unsigned)ceil_div(N, 256);
@@ -1108,9 +1239,12 @@ static int finish_plan(raht_plan *p, const int64_t *leaf_weights, hipStream_t s)
     uint32_t *bhist = lhist + 64;
     uint32_t *gq = bhist + (size_t)(ORDER_BUCKETS + 64) * nblk, *gq_count = gq + (size_t)EXT_QCAP * nblk;
     uint8_t *bucket = (uint8_t *)(gq_count + nblk);
-    uint32_t init[2] = {0, 0xffffffffu};              // error word (pageable source: copied before the call returns)
     static_assert(sizeof(PlanErr) == 2 * sizeof(uint32_t), "PlanErr is read back as two words");
-    RAHT_HIP_CHECK(hipMemcpyAsync(derr, init, sizeof(init), hipMemcpyHostToDevice, s));
+    // top_level = 64 at creation: row 0 is the only row left carrying a low-pass value (compute_roots' first case)
+    p->n_roots = 1;
+    RAHT_HIP_CHECK(dev_malloc(&p->root_rows, sizeof(uint32_t)));
+    hipLaunchKernelGGL(plan_begin_kernel, dim3(keys_in ? (unsigned)std::min<int64_t>(ceil_div(N, 256), 4096) : 1u), dim3(256), 0, s,
+                       keys_in, p->keys, N, derr, p->root_rows);
     RAHT_HIP_CHECK(dev_malloc(&p->lvl, (size_t)N));
     RAHT_HIP_CHECK(dev_malloc(&p->wl, sizeof(int32_t) * (size_t)N));
     RAHT_HIP_CHECK(dev_malloc(&p->wr, sizeof(int32_t) * (size_t)N));
@@ -1147,7 +1281,6 @@ static int finish_plan(raht_plan *p, const int64_t *leaf_weights, hipStream_t s)
         RAHT_HIP_CHECK(hipMemcpy(p->wsum, ps.data(), sizeof(int64_t) * ((size_t)N + 1), hipMemcpyHostToDevice));
     }
     RAHT_HIP_CHECK(hipGetLastError());
-    RAHT_RET(compute_roots(p, s));                  // top_level = 64 at creation: row 0 alone, nothing to wait for
     // Build the default schedule now so that float32 transforms with D <= 64 never allocate.
     Schedule *sc = nullptr;
     const int R0 = pick_tile_rows(p, 4, 59);
@@ -1232,7 +1365,7 @@ int raht_plan_create(const void *V, int v_dtype, int64_t N, const double minV[3]
             set_error("coordinate out of [0, 2^%d) at row %u (reference RAHT_param.py:26-27 raises ValueError)", depth, he.row);
             return he.code;
         }
-        RAHT_RET(finish_plan(p, nullptr, s));
+        RAHT_RET(finish_plan(p, nullptr, s, nullptr));
         *out = h.release();
         return RAHT_OK;
     });
@@ -1253,8 +1386,7 @@ int raht_plan_create_from_keys(const uint64_t *keys_sorted, int64_t N, int nbits
         p->N = N;
         p->nbits = nbits;
         if (dev_malloc(&p->keys, sizeof(uint64_t) * (size_t)N) != hipSuccess) { set_error("hipMalloc keys"); return RAHT_ERR_NOMEM; }
-        RAHT_HIP_CHECK(hipMemcpyAsync(p->keys, keys_sorted, sizeof(uint64_t) * (size_t)N, hipMemcpyDeviceToDevice, s));
-        RAHT_RET(finish_plan(p, leaf_weights, s));
+        RAHT_RET(finish_plan(p, leaf_weights, s, keys_sorted));
         *out = h.release();
         return RAHT_OK;
     });
