@@ -3,6 +3,8 @@
 * the round-1 abort: an INVERSE transform whose last TILE stage has survivors (the roots)
   and therefore no stage above it (wsn == nullptr);
 * the level-engine fallback when a tile schedule is abandoned (raht_plan_set_max_stages);
+* the exits of the device-driven schedule chain (a stage larger than its buffer, a tree that reaches the top stage
+  early, many small stages inside the one tail launch);
 * schedules of several geometries on one plan (float32 then float64 then another D: the schedule cache grows
   while earlier schedules are still referenced);
 * plans on two devices in one process (skipped on a one-GPU box);
@@ -111,6 +113,56 @@ def test_abandoned_tile_schedule_falls_back_to_the_level_engine(rt, oracle):
     plan.set_max_stages(24)
     assert plan.stage_stats(4, 14)["valid"]
     assert torch.equal(plan.forward(Cd, want_w=False), T_tile)
+
+
+# ------------------------------------------------- the device-driven schedule chain and its exits
+@pytest.mark.parametrize("case", ["half_roots", "early_top", "many_small_stages"])
+def test_schedule_chain_exits(rt, case):
+    """The schedule is built by a chain of launches that never returns to the host (plan.hip: build_schedule_fast):
+    multi-workgroup stages, then ONE launch for every small stage and the top stage. Its exits must all end in a
+    correct transform:
+    * half_roots: a tree truncated so that half the rows are roots -- stage 0 keeps more entries than the buffer of
+      stage 1 holds (1/3 of the stage before): the chain must STOP there (it once went on and read past the buffer:
+      a GPU memory fault) and the exact builder takes over;
+    * early_top: tiles of 512 rows shrink a 30 000-row tree below the top stage's size one stage earlier than the
+      host expected when it enqueued the chain;
+    * many_small_stages: 64-row tiles, 64-entry top stage: two tile stages and the top stage run inside the one tail launch."""
+    import torch
+    from tests.numpy_ops import NumpyPlan
+    rng = np.random.default_rng({"half_roots": 1, "early_top": 2, "many_small_stages": 3}[case])
+    N, nbits, D = 30000, 30, 7
+    keys = np.unique(rng.integers(0, (1 << nbits) - 1, size=N + 64, dtype=np.int64))[:N]
+    top, geom = None, (0, 0, 0, 0)
+    if case == "half_roots":
+        ref_all = NumpyPlan(torch.from_numpy(keys.copy()), nbits)
+        lv = np.sort(np.asarray(ref_all.lvl)[1:])
+        top = int(lv[len(lv) // 2])                               # about half of the rows sit at or above this level
+    elif case == "early_top":
+        geom = (512, 512, 0, 4096)
+    else:
+        geom = (64, 64, 0, 64)
+    kt = torch.from_numpy(keys.copy())
+    ref = NumpyPlan(kt, nbits, top_level=top)
+    p = rt.RahtPlan.from_keys(kt.cuda(), nbits, top_level=top)
+    p.set_engine("tile", *geom)
+    st = p.stage_stats(4, D)
+    assert st["valid"]
+    if case == "half_roots":
+        assert 0.3 * N < p.n_roots < 0.7 * N
+    if case == "many_small_stages":
+        assert len(st["rows_per_stage"]) >= 4
+    assert np.array_equal(p.root_rows.cpu().numpy(), ref.root_rows.numpy())
+    C = rng.normal(size=(N, D))
+    Cd = torch.from_numpy(C).cuda()
+    roots = torch.empty((p.n_roots, D), dtype=Cd.dtype, device="cuda")
+    T = p.forward(Cd, want_w=False, roots=roots)
+    r_ref = torch.empty((ref.n_roots, D), dtype=torch.float64)
+    T_ref = ref.forward(torch.from_numpy(C), roots=r_ref).numpy()
+    scale = np.maximum(np.abs(T_ref).max(axis=0), 1e-300)
+    assert (np.abs(T.cpu().numpy() - T_ref).max(axis=0) / scale).max() <= 1e-12
+    assert (np.abs(roots.cpu().numpy() - r_ref.numpy()).max(axis=0) / scale).max() <= 1e-12
+    R = p.inverse(T, roots=roots)
+    assert (R - Cd).abs().max().item() <= 1e-11 * Cd.abs().max().item()
 
 
 # ----------------------------------------------------------- several schedules alive on one plan
