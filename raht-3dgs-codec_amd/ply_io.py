@@ -18,55 +18,71 @@ import numpy as np
 import torch
 
 
+_HEADER_LIMIT = 1 << 20          # bytes: a header that has not ended by then is not a PLY header
+
+
+def _parse_header(f):
+    """Reads up to and including `end_header`; returns the fields the codec needs as a dict:
+    format (str), vertices (int), float_props (int), voxel_size (float | None), vmin (3 floats | None)."""
+    blob = bytearray()
+    while not blob.endswith(b"end_header\n") and not blob.endswith(b"end_header\r\n"):
+        chunk = f.readline()
+        if not chunk or len(blob) > _HEADER_LIMIT:
+            raise ValueError("PLY header does not end")
+        blob += chunk
+    words = [ln.split() for ln in blob.decode("ascii").splitlines()]
+    hdr = {"format": "", "vertices": 0, "float_props": 0, "voxel_size": None, "vmin": None}
+    for w in words:
+        if len(w) >= 2 and w[0] == "format":
+            hdr["format"] = w[1]
+        elif w[:2] == ["element", "vertex"]:
+            hdr["vertices"] = int(w[2])
+        elif w[:2] == ["property", "float"]:
+            hdr["float_props"] += 1
+        elif w[:2] == ["comment", "voxel_size"]:
+            hdr["voxel_size"] = float(w[2])
+        elif w[:2] == ["comment", "vmin"]:
+            hdr["vmin"] = [float(x) for x in w[2:5]]
+    return hdr
+
+
 def read_compressed_3dgs_ply(filename):
+    """-> (V_int, attributes, voxel_size, vmin), or None with a warning when the file cannot be used (the reference's
+    contract, data_util.py:272-382)."""
     try:
         with open(filename, "rb") as f:
-            lines = []
-            while True:
-                line = f.readline().decode("ascii").strip()
-                lines.append(line)
-                if line == "end_header":
-                    break
-            n, binary, voxel_size, vmin, nprops = 0, False, None, None, 0
-            for line in lines:
-                if line.startswith("format"):
-                    binary = "binary" in line
-                elif line.startswith("element vertex"):
-                    n = int(line.split()[-1])
-                elif line.startswith("comment voxel_size"):
-                    voxel_size = float(line.split()[-1])
-                elif line.startswith("comment vmin"):
-                    p = line.split()
-                    vmin = torch.tensor([float(p[2]), float(p[3]), float(p[4])], dtype=torch.float32)
-                elif line.startswith("property float"):
-                    nprops += 1
-            if n == 0:
-                raise ValueError("Could not find vertex count in PLY header")
-            if not binary:
-                raise ValueError("ASCII format not supported for compressed 3DGS PLY. Use binary format.")
-            if voxel_size is None:
-                warnings.warn("Could not find voxel_size in PLY header comments")
-                voxel_size = 1.0
-            if vmin is None:
-                warnings.warn("Could not find vmin in PLY header comments")
-                vmin = torch.zeros(3, dtype=torch.float32)
-            if nprops < 15:
-                raise ValueError(f"unexpected vertex layout ({nprops} float properties)")
+            hdr = _parse_header(f)
+            n, nprops = hdr["vertices"], hdr["float_props"]
+            problems = {
+                "Could not find vertex count in PLY header": n == 0,
+                "ASCII format not supported for compressed 3DGS PLY. Use binary format.": not hdr["format"].startswith("binary"),
+                f"unexpected vertex layout ({nprops} float properties)": nprops < 15,
+            }
+            for msg, bad in problems.items():
+                if bad:
+                    raise ValueError(msg)
             data = np.fromfile(f, dtype="<f4", count=n * nprops).reshape(n, nprops)
-        ncol = nprops - 14                                   # 62 -> 48 SH coefficients
-        V_int = torch.from_numpy(data[:, 0:3].copy()).long()
-        colors = data[:, 6:6 + ncol]
-        opacity = data[:, 6 + ncol:7 + ncol]
-        scales = data[:, 7 + ncol:10 + ncol]
-        quats = data[:, 10 + ncol:14 + ncol]
-        attributes = torch.from_numpy(np.concatenate([quats, scales, opacity, colors], axis=1).astype(np.float32))
-        return V_int, attributes, voxel_size, vmin
     except FileNotFoundError:
         warnings.warn(f"File not found: {filename}")
         return None
     except Exception as e:                                    # same contract as the reference: warn, return None
         warnings.warn(f"Error reading compressed 3DGS PLY {filename}: {e}")
         return None
+    voxel_size, vmin = hdr["voxel_size"], hdr["vmin"]
+    if voxel_size is None:
+        warnings.warn("Could not find voxel_size in PLY header comments")
+        voxel_size = 1.0
+    if vmin is None:
+        warnings.warn("Could not find vmin in PLY header comments")
+        vmin = [0.0, 0.0, 0.0]
+    # vertex layout: x y z | nx ny nz | ncol colours | opacity | scale_0..2 | rot_0..3   (62 floats -> 48 colours)
+    ncol = nprops - 14
+    cols = {"xyz": slice(0, 3), "colors": slice(6, 6 + ncol), "opacity": slice(6 + ncol, 7 + ncol),
+            "scales": slice(7 + ncol, 10 + ncol), "quats": slice(10 + ncol, 14 + ncol)}
+    V_int = torch.from_numpy(data[:, cols["xyz"]].copy()).long()
+    attributes = torch.from_numpy(np.concatenate([data[:, cols[k]] for k in ("quats", "scales", "opacity", "colors")],
+                                                 axis=1).astype(np.float32))
+    return V_int, attributes, voxel_size, torch.tensor(vmin, dtype=torch.float32)
 
 
 def save_ply(filepath, means, quats, scales, opacities, colors, voxel_size=None, vmin=None):
