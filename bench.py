@@ -246,16 +246,22 @@ class SoloScene:
 
     def fwd_quant(self):
         vp = C.c_void_p
+        if self.f64:
+            self._lib.check(self.L.raht_fwd_quant_f64(self.plan._h, vp(self.Cd.data_ptr()), self.D, self.D, self.steps64, 1, vp(self.Q.data_ptr()), self.D, self.s_()))
+            return
         self._lib.check(self.L.raht_fwd_quant(self.plan._h, vp(self.Cd.data_ptr()), self.D, self.D, self.steps32, 1, vp(self.Q.data_ptr()), self.D, self.s_()))
 
     def dequant_inv(self):
         vp = C.c_void_p
+        if self.f64:
+            self._lib.check(self.L.raht_dequant_inv_f64(self.plan._h, vp(self.Q.data_ptr()), self.D, self.D, self.steps64, 1, vp(self.Crec.data_ptr()), self.D, self.s_()))
+            return
         self._lib.check(self.L.raht_dequant_inv(self.plan._h, vp(self.Q.data_ptr()), self.D, self.D, self.steps32, 1, vp(self.Crec.data_ptr()), self.D, self.s_()))
 
     def step_fn(self, no_quant, unfused):
         if no_quant:
             return lambda: (self.fwd(), self.inv(self.T))
-        if unfused or self.f64:
+        if unfused:
             return lambda: (self.fwd(), self.quant(), self.dequant(), self.inv(self.Td))
         return lambda: (self.fwd_quant(), self.dequant_inv())
 
@@ -581,15 +587,22 @@ def main():
         if not a.skip_legs and a.workload == "cfg3" and a.engine == "tile" and not a.unfused:
             kreps = 50
             s64 = SoloScene(R, L, _lib, kd, sc.Cd.double(), 3 * J, a, dev, dtype=torch.float64)
-            f_fi, f_q = s64.step_fn(True, False), s64.step_fn(False, False)
+            f_fi, f_q, f_u = s64.step_fn(True, False), s64.step_fn(False, False), s64.step_fn(False, True)
             for _ in range(10):
                 f_q()
-            t_fi, t_q = timed(f_fi, kreps), timed(f_q, kreps)
+            # fused float64 integers == two-call float64 integers, on the benched scene
+            s64.fwd_quant(); torch.cuda.synchronize(); Qf = s64.Q.clone()
+            s64.fwd(); s64.quant(); torch.cuda.synchronize()
+            assert torch.equal(Qf, s64.Q), "float64: fused != two-call"
+            del Qf
+            t_fi, t_q, t_u = timed(f_fi, kreps), timed(f_q, kreps), timed(f_u, 10)
             alg64 = 2 * (16.0 * N * D + 8.0 * N)
-            out["f64"] = {"what": "the reference's own precision (encode_3dgs.py:82-83): raht_fwd_f64 + raht_inv_f64; with_quant adds the float64 quantize/reorder and dequantize/un-reorder passes (not fused)",
+            out["f64"] = {"what": "the reference's own precision (encode_3dgs.py:82-83): raht_fwd_f64 + raht_inv_f64; with_quant = raht_fwd_quant_f64 + raht_dequant_inv_f64 (float64 quantizer fused into the float64 kernels), unfused = the four-pass sequence",
                           "fwd_inv_ms": round(t_fi, 4), "fwd_inv_MGs": round(N / (t_fi * 1e-3) / 1e6, 1), "alg_bytes_fwd_inv": alg64,
                           "frac_of_peak": round(alg64 / (t_fi * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                          "with_quant_ms": round(t_q, 4), "with_quant_MGs": round(N / (t_q * 1e-3) / 1e6, 1)}
+                          "with_quant_ms": round(t_q, 4), "with_quant_MGs": round(N / (t_q * 1e-3) / 1e6, 1),
+                          "with_quant_frac_of_peak": round((alg64 - 8.0 * N * D) / (t_q * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),      # C 8 B in, Q 4 B out, Q 4 B in, C 8 B out per coefficient
+                          "unfused_ms": round(t_u, 4)}
             del s64
             n2, J2, D2, seed2 = synth.CONFIGS["cfg2"]
             V2, keys2, C2 = synth.scene(n2, J2, D2, seed2)

@@ -193,9 +193,9 @@ int raht_dequant_inv(const raht_plan *plan, const int32_t *Q, int64_t ldq, int D
                      int n_steps, float *C, int64_t ldc, raht_stream_t stream);
 
 /* The same two at the reference's own precision (python/encode_3dgs.py:82-83: float64 coefficients are what
- * :204 quantizes): float64 transform + float64 quantizer with float64 steps, run as TWO passes through a
- * pooled N x D float64 temporary (not fused: this path exists for parity with the reference's arithmetic;
- * Q is bit-identical to floor(T64 / step + 0.5) of the float64 transform except at exact rounding ties). */
+ * :204 quantizes): the float64 tile kernels with the float64 quantizer (IEEE double division, float64 steps) in their
+ * write-back / row gather -- one pass, no N x D temporary. Q is bit-identical to raht_fwd_f64 + raht_quant_reorder_f64,
+ * i.e. to floor(T64 / step + 0.5) of the float64 transform. (Level engine / D < 2: the two-call sequence.) */
 int raht_fwd_quant_f64(const raht_plan *plan, const double *C, int64_t ldc, int D, const double *steps,
                        int n_steps, int32_t *Q, int64_t ldq, raht_stream_t stream);
 int raht_dequant_inv_f64(const raht_plan *plan, const int32_t *Q, int64_t ldq, int D, const double *steps,

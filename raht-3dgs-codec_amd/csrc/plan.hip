@@ -407,7 +407,7 @@ int pick_tile_rows(const raht_plan *plan, int elem_size, int Dc)
     // 59-channel float32 case (R = 192); see DESIGN.md for the sweep.
     const size_t budget = (size_t)42 * 1280;
     for (int R = 512; R >= 64; R -= 8)
-        if (tile_lds_bytes(R, elem_size, Dc, true, elem_size == 4) <= budget) return R;
+        if (tile_lds_bytes(R, elem_size, Dc, true, true) <= budget) return R;
     return 0;
 }
 
@@ -423,9 +423,9 @@ void pick_tail_geometry(const raht_plan *plan, int elem_size, int D, int stage0_
     if (plan->tail_chunk_override > 0) Dc = fit_chunk_channels(elem_size, D, std::min(plan->tail_chunk_override, std::min(D, 64)));
     if (plan->tail_rows_override > 0) {
         R = plan->tail_rows_override;
-        while (R > 64 && tile_lds_bytes(R, elem_size, Dc, false, elem_size == 4) > (size_t)128 * 1280) R -= 64;
+        while (R > 64 && tile_lds_bytes(R, elem_size, Dc, false, true) > (size_t)128 * 1280) R -= 64;
     } else {
-        while (R > 64 && tile_lds_bytes(R, elem_size, Dc, false, elem_size == 4) > (size_t)42 * 1280) R -= 8;
+        while (R > 64 && tile_lds_bytes(R, elem_size, Dc, false, true) > (size_t)42 * 1280) R -= 8;
     }
     *tail_rows = R;
     *tail_chunk = Dc;

@@ -141,7 +141,6 @@ __global__ __launch_bounds__(256) void dequant_rows_kernel(const int32_t *__rest
 
 // float64 (the reference's own precision, python/encode_3dgs.py:82-83,204): one lane per element, rows gathered
 // through the permutation as above. The division is the IEEE double division of the reference's CPU path.
-struct StepTable64 { int n; double v[MAX_STEP_CH]; };
 
 template <bool QUANT>
 __global__ __launch_bounds__(256) void reorder_f64_kernel(const void *__restrict__ src_, int64_t lds, int D,
@@ -155,7 +154,7 @@ __global__ __launch_bounds__(256) void reorder_f64_kernel(const void *__restrict
         const int64_t r = (int64_t)perm[k];
         for (int c = lane; c < D; c += 64) {
             const double st = steps.v[steps.n == 1 ? 0 : c];
-            if constexpr (QUANT) ((int32_t *)dst_)[k * ldd + c] = (int32_t)floor(((const double *)src_)[r * lds + c] / st + 0.5);   // :204, :210, :215
+            if constexpr (QUANT) ((int32_t *)dst_)[k * ldd + c] = quantize_one_f64(((const double *)src_)[r * lds + c], st);        // :204, :210, :215
             else ((double *)dst_)[k * ldd + c] = (double)((const int32_t *)src_)[r * lds + c] * st;                                // :261, :267-268
         }
     }
@@ -306,35 +305,6 @@ int raht_dequant_unreorder_f64(const raht_plan *p, const int32_t *Q, int64_t ldq
                        p->inv_order, p->N, st, (void *)T, ldt);
     RAHT_HIP_CHECK(hipGetLastError());
     return RAHT_OK;
-}
-
-/* Reference-precision counterparts of raht_fwd_quant / raht_dequant_inv: float64 transform + float64
- * quantizer, as TWO passes through a pooled N x D float64 temporary (not fused: the float64 path exists for
- * parity with the reference's arithmetic, python/encode_3dgs.py:82-83, the float32 path for speed). */
-int raht_fwd_quant_f64(const raht_plan *p, const double *C, int64_t ldc, int D, const double *steps, int n_steps,
-                       int32_t *Q, int64_t ldq, raht_stream_t stream)
-{
-    if (!p || !C || !Q || D < 1 || ldc < D || ldq < D) { set_error("raht_fwd_quant_f64: bad argument"); return RAHT_ERR_INVALID; }
-    RAHT_RET(check_plan_device(p, "raht_fwd_quant_f64"));
-    StepTable64 st;
-    RAHT_RET(fill_steps64(st, steps, n_steps, D));
-    Scratch tmp(sizeof(double) * (size_t)p->N * (size_t)D);
-    if (!tmp.ok()) return RAHT_ERR_NOMEM;
-    RAHT_RET(raht_fwd_f64(p, C, ldc, D, tmp.as<double>(), D, nullptr, stream));
-    return raht_quant_reorder_f64(p, tmp.as<double>(), D, D, steps, n_steps, Q, ldq, stream);
-}
-
-int raht_dequant_inv_f64(const raht_plan *p, const int32_t *Q, int64_t ldq, int D, const double *steps, int n_steps,
-                         double *C, int64_t ldc, raht_stream_t stream)
-{
-    if (!p || !C || !Q || D < 1 || ldc < D || ldq < D) { set_error("raht_dequant_inv_f64: bad argument"); return RAHT_ERR_INVALID; }
-    RAHT_RET(check_plan_device(p, "raht_dequant_inv_f64"));
-    StepTable64 st;
-    RAHT_RET(fill_steps64(st, steps, n_steps, D));
-    Scratch tmp(sizeof(double) * (size_t)p->N * (size_t)D);
-    if (!tmp.ok()) return RAHT_ERR_NOMEM;
-    RAHT_RET(raht_dequant_unreorder_f64(p, Q, ldq, D, steps, n_steps, tmp.as<double>(), D, stream));
-    return raht_inv_f64(p, tmp.as<double>(), D, D, C, ldc, stream);
 }
 
 int raht_quant_rows(const float *X, int64_t ldx, int64_t n, int D, const float *steps, int n_steps,

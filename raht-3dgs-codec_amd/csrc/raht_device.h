@@ -12,6 +12,11 @@ struct StepTable {
     float v[MAX_STEP_CH];
 };
 struct NoSteps { int n; int fast_div; };
+// float64 steps (the reference's own precision, python/encode_3dgs.py:82-83,204): always the IEEE double division
+struct StepTable64 { int n; double v[MAX_STEP_CH]; };
+template <typename T> struct StepsFor;
+template <> struct StepsFor<float> { typedef StepTable type; typedef float elem; };
+template <> struct StepsFor<double> { typedef StepTable64 type; typedef double elem; };
 
 
 // ---- row chunks: one lane moves 16 bytes (VN = 16 / sizeof(T) consecutive channels) of one row --------
@@ -63,6 +68,25 @@ __device__ __forceinline__ void st_chunk(E *__restrict__ p, const RegChunk<E> &x
     }
 }
 
+// VN quantized integers of one row chunk (float64 rows: 2 per 16-byte chunk), element-aligned in global memory
+template <int VN> struct __attribute__((packed, aligned(4))) IntPack { int32_t v[VN]; };
+template <int VN>
+__device__ __forceinline__ void ld_ints(const int32_t *__restrict__ p, int32_t (&v)[VN])
+{
+    const IntPack<VN> t = *(const IntPack<VN> *)p;
+#pragma unroll
+    for (int i = 0; i < VN; ++i) v[i] = t.v[i];
+}
+template <int VN>
+__device__ __forceinline__ void st_ints(int32_t *__restrict__ p, const int32_t (&v)[VN])
+{
+    IntPack<VN> t;
+#pragma unroll
+    for (int i = 0; i < VN; ++i) t.v[i] = v[i];
+    *(IntPack<VN> *)p = t;
+}
+__device__ __forceinline__ int32_t quantize_one_f64(double x, double step) { return (int32_t)floor(x / step + 0.5); }   // encode_3dgs.py:204
+
 __device__ __forceinline__ int32_t quantize_one(float x, float sp, float r, int fast_div)
 {
     float q;
@@ -88,6 +112,11 @@ __device__ __forceinline__ float refined_rcp(float sp)
 
 
 // StepTable from the caller's steps (host)
+inline void fill_step_table(StepTable64 &t, const double *steps, int n_steps)
+{
+    t.n = n_steps;
+    for (int c = 0; c < n_steps; ++c) t.v[c] = steps[c];
+}
 inline void fill_step_table(StepTable &t, const float *steps, int n_steps)
 {
     t.n = n_steps;

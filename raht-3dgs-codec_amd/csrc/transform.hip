@@ -276,14 +276,18 @@ __device__ __forceinline__ void glds16(const void *g, uint32_t lds_base)
 // rows need element alignment only. A butterfly is one ds_read_b128 per operand and lane.
 template <typename T, bool INV, bool IDENT, bool QM, int SLOTS>
 __global__ __launch_bounds__(512, (sizeof(T) == 4 ? 6 : 4)) void tile_kernel(const TileArgs<T> A,
-                                                   const typename std::conditional<QM, StepTable, NoSteps>::type ST)
+                                                   const typename std::conditional<QM, typename StepsFor<T>::type, NoSteps>::type ST)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     typedef RegChunk<T> V16;
     typedef typename std::conditional<QM, int32_t, T>::type RawT;       // element type of the inverse's input rows
     typedef RegChunk<RawT> RawChunk;
     constexpr int VN = 16 / sizeof(T);
-    static_assert(sizeof(RawT) == sizeof(T), "fused quantization is a float32 mode");
+    // float64 rows with fused quantization (the reference's own precision): a 16-byte chunk is 2 coefficients = 2
+    // integers, so Q rows do not have the tile's chunk layout -- the forward stores 8 bytes per lane, the inverse gathers
+    // 8 bytes per lane through registers and converts them on the way into LDS (no LDS-direct load, no lazy conversion)
+    constexpr bool QM64 = QM && sizeof(T) == 8;
+    typedef typename StepsFor<T>::elem StepT;
     const int R = A.R;
     const int tid0 = threadIdx.x;
     const int nthreads = blockDim.x, nw = nthreads >> 6;
@@ -346,7 +350,8 @@ __global__ __launch_bounds__(512, (sizeof(T) == 4 ? 6 : 4)) void tile_kernel(con
     // quantization steps of this lane's channels (and their refined reciprocals: once per channel instead of once per
     // coefficient): fetched where they are used -- in front of the write-back (forward) or of the row gather
     // (inverse) -- not at kernel start: eight registers less across the metadata phases
-    float my_step[VN], my_rcp[VN];
+    StepT my_step[VN];
+    float my_rcp[VN];
     // (`ln` = the lane id from the tile loop's OPAQUE copy of the thread id: computed from tid0 the eight step-table
     // addresses are loop invariants that hipcc hoists to kernel start and spills -- and any scratch use at all cost the
     // fused inverse 0.27 -> 0.35 ms)
@@ -357,7 +362,7 @@ __global__ __launch_bounds__(512, (sizeof(T) == 4 ? 6 : 4)) void tile_kernel(con
 #pragma unroll
             for (int i = 0; i < VN; ++i) {
                 my_step[i] = ST.v[ST.n == 1 ? 0 : g0 + i];
-                my_rcp[i] = refined_rcp(my_step[i]);
+                if constexpr (!QM64) my_rcp[i] = refined_rcp(my_step[i]);
             }
         }
     };
@@ -428,7 +433,26 @@ __global__ __launch_bounds__(512, (sizeof(T) == 4 ? 6 : 4)) void tile_kernel(con
 
     // inverse of the later stages / fused inverse: gather every slot's coefficient row now (survivor slots get
     // overwritten in P3b) -- the addresses need srow / sdst
-    if constexpr (GATHER) {
+    if constexpr (GATHER && QM64) {
+        load_steps(lane);
+        constexpr int GU = 4;                                 // rows in flight per lane
+        if (active) for (int it0 = wid; (it0 << lr) < nt; it0 += nw * GU) {
+            int32_t q[GU][VN];
+#pragma unroll
+            for (int u = 0; u < GU; ++u) {
+                const int j = min(((it0 + u * nw) << lr) + g, nt - 1);
+                ld_ints<VN>(row_far((const int32_t *)A.Q, (uint32_t)sdst[j], (uint32_t)A.ldq, (uint32_t)goff), q[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < GU; ++u) {
+                const int j = min(((it0 + u * nw) << lr) + g, nt - 1);
+                V16 x;
+#pragma unroll
+                for (int i = 0; i < VN; ++i) x.v[i] = (T)q[u][i] * (T)my_step[i];                 // encode_3dgs.py:261
+                *(V16 *)&tile[__mul24(j, Dp) + coff] = x;
+            }
+        }
+    } else if constexpr (GATHER) {
         load_rows(std::true_type(), tile, nt, [&](int jr, uint32_t go) {
             if constexpr (QM) return (const void *)row_far((const RawT *)A.Q, (uint32_t)sdst[jr], (uint32_t)A.ldq, go);
             else return (const void *)row_far((const RawT *)A.fin, (uint32_t)srow[jr], (uint32_t)A.ld_fin, go);
@@ -488,7 +512,7 @@ __global__ __launch_bounds__(512, (sizeof(T) == 4 ? 6 : 4)) void tile_kernel(con
     }
     if constexpr (INV) sync_landed(); else sync_lds();                     // sync #3 (inverse: its rows have landed)
     PHASE_STAMP(4);
-    if constexpr (INV && QM) {
+    if constexpr (INV && QM && !QM64) {
         load_steps(lane);
         // roots finalised here come straight from Q as well: dequantize them in place (no butterfly will)
         if (A.last_stage && !A.root_buf && active) for (int it = wid; (it << lr) < nt; it += nw) {
@@ -603,7 +627,7 @@ __global__ __launch_bounds__(512, (sizeof(T) == 4 ? 6 : 4)) void tile_kernel(con
                     }
 #pragma unroll
                     for (int u = 0; u < U; ++u) { x0[u] = *(const V16 *)&tile[ip[u]]; x1[u] = *(const V16 *)&tile[ij[u]]; }
-                    if constexpr (INV && QM) {            // the high-pass operand is still the quantized integer (encode_3dgs.py:261)
+                    if constexpr (INV && QM && !QM64) {   // the high-pass operand is still the quantized integer (encode_3dgs.py:261)
 #pragma unroll
                         for (int u = 0; u < U; ++u) {
 #pragma unroll
@@ -680,10 +704,17 @@ __global__ __launch_bounds__(512, (sizeof(T) == 4 ? 6 : 4)) void tile_kernel(con
                     const uint32_t dv = (uint32_t)sdst[jc];
                     asm volatile("" : "+v"(x.v[0]));          // keep the row read next to the flag read, not behind its branch
                     if (dv >> 31) {
-                        RegChunk<int32_t> qv;
+                        if constexpr (QM64) {
+                            int32_t qv[VN];
 #pragma unroll
-                        for (int i = 0; i < VN; ++i) qv.v[i] = quantize_one((float)x.v[i], my_step[i], my_rcp[i], decltype(fast_div)::value);
-                        st_chunk<int32_t, true>(row_far(A.Q, dv & 0x7fffffffu, (uint32_t)A.ldq, (uint32_t)goff), qv);
+                            for (int i = 0; i < VN; ++i) qv[i] = quantize_one_f64((double)x.v[i], (double)my_step[i]);
+                            st_ints<VN>(row_far(A.Q, dv & 0x7fffffffu, (uint32_t)A.ldq, (uint32_t)goff), qv);
+                        } else {
+                            RegChunk<int32_t> qv;
+#pragma unroll
+                            for (int i = 0; i < VN; ++i) qv.v[i] = quantize_one((float)x.v[i], (float)my_step[i], my_rcp[i], decltype(fast_div)::value);
+                            st_chunk<int32_t, true>(row_far(A.Q, dv & 0x7fffffffu, (uint32_t)A.ldq, (uint32_t)goff), qv);
+                        }
                     }
                 } else {
                     if (sflag[jc] != 0) {
@@ -693,7 +724,10 @@ __global__ __launch_bounds__(512, (sizeof(T) == 4 ? 6 : 4)) void tile_kernel(con
                 }
             }
         };
-        if constexpr (QM) {
+        if constexpr (QM64) {
+            load_steps(lane);
+            store_final(std::false_type());
+        } else if constexpr (QM) {
             load_steps(lane);
             if (ST.fast_div) store_final(std::true_type()); else store_final(std::false_type());
         } else {
@@ -741,8 +775,9 @@ struct TopArgs {
 
 template <typename T, bool INV, bool QM>
 __global__ __launch_bounds__(TOP_THREADS) void top_kernel(const TopArgs<T> A,
-                                                          const typename std::conditional<QM, StepTable, NoSteps>::type ST)
+                                                          const typename std::conditional<QM, typename StepsFor<T>::type, NoSteps>::type ST)
 {
+    constexpr bool QM64 = QM && sizeof(T) == 8;              // float64 rows, 2 quantized integers per 16-byte chunk
     extern __shared__ __align__(16) unsigned char smem[];
     typedef RegChunk<T> V16;
     constexpr int VN = 16 / sizeof(T);
@@ -762,14 +797,15 @@ __global__ __launch_bounds__(TOP_THREADS) void top_kernel(const TopArgs<T> A,
         s_ab[2 * i + 1] = A.ab[2 * (A.small_start + i) + 1];
     }
 
-    float my_step[VN], my_rcp[VN];
+    typename StepsFor<T>::elem my_step[VN];
+    float my_rcp[VN];
 #pragma unroll
-    for (int i = 0; i < VN; ++i) { my_step[i] = 1.0f; my_rcp[i] = 1.0f; }
+    for (int i = 0; i < VN; ++i) { my_step[i] = 1; my_rcp[i] = 1.0f; }
     if constexpr (QM) {
 #pragma unroll
         for (int i = 0; i < VN; ++i) {
             my_step[i] = ST.v[ST.n == 1 ? 0 : goff + i];
-            my_rcp[i] = refined_rcp(my_step[i]);
+            if constexpr (!QM64) my_rcp[i] = refined_rcp(my_step[i]);
         }
     }
 
@@ -792,12 +828,17 @@ __global__ __launch_bounds__(TOP_THREADS) void top_kernel(const TopArgs<T> A,
     }
     // ... and the entries themselves
     {
-        typedef typename std::conditional<QM && INV, int32_t, T>::type RawT;
+        typedef typename std::conditional<QM && INV && !QM64, int32_t, T>::type RawT;
         RegChunk<RawT> x[TOP_SLOTS];
 #pragma unroll
         for (int k = 0; k < TOP_SLOTS; ++k) {
             const int e = min(k * TOP_THREADS + tid, n - 1);
-            if constexpr (!INV) {
+            if constexpr (QM64 && INV) {
+                int32_t q[VN];
+                ld_ints<VN>(A.Q + (int64_t)m_dst[k] * A.ldq + goff, q);
+#pragma unroll
+                for (int i = 0; i < VN; ++i) x[k].v[i] = (T)q[i];
+            } else if constexpr (!INV) {
                 x[k] = ld_chunk<RawT>((const RawT *)A.in + (int64_t)(A.io_mapped ? m_dst[k] : (uint32_t)e) * A.ld_in + goff);
             } else if constexpr (QM) {
                 x[k] = ld_chunk<RawT>((const RawT *)A.Q + (int64_t)m_dst[k] * A.ldq + goff);
@@ -897,10 +938,17 @@ __global__ __launch_bounds__(TOP_THREADS) void top_kernel(const TopArgs<T> A,
             if (QM && to_buf) {
                 // roots are quantized by the caller's top stage
             } else if constexpr (QM) {
-                RegChunk<int32_t> qv;
+                if constexpr (QM64) {
+                    int32_t qv[VN];
 #pragma unroll
-                for (int i = 0; i < VN; ++i) qv.v[i] = quantize_one((float)v.v[i], my_step[i], my_rcp[i], ST.fast_div);
-                st_chunk<int32_t>(A.Q + (int64_t)m_dst[k] * A.ldq + goff, qv);
+                    for (int i = 0; i < VN; ++i) qv[i] = quantize_one_f64((double)v.v[i], (double)my_step[i]);
+                    st_ints<VN>(A.Q + (int64_t)m_dst[k] * A.ldq + goff, qv);
+                } else {
+                    RegChunk<int32_t> qv;
+#pragma unroll
+                    for (int i = 0; i < VN; ++i) qv.v[i] = quantize_one((float)v.v[i], (float)my_step[i], my_rcp[i], ST.fast_div);
+                    st_chunk<int32_t>(A.Q + (int64_t)m_dst[k] * A.ldq + goff, qv);
+                }
             } else {
                 st_chunk<T>(A.fin + (int64_t)m_dst[k] * A.ld_fin + goff, v);
             }
@@ -980,7 +1028,7 @@ struct XformIO {
     const T *src = nullptr; int64_t ld_src = 0;     // fwd: C             inv: T (unless quantized)
     T *dst = nullptr; int64_t ld_dst = 0;           // fwd: T (unless q)  inv: C
     int32_t *Q = nullptr; int64_t ldq = 0;          // fused quantization (fwd out / inv in)
-    const float *steps = nullptr; int n_steps = 0;
+    const typename StepsFor<T>::elem *steps = nullptr; int n_steps = 0;
 };
 
 template <typename T, bool INV, bool IDENT, bool QM, int SLOTS>
@@ -992,7 +1040,7 @@ static int launch_tile_one(const TileArgs<T> &A, const XformIO<T> &io, dim3 grid
         RAHT_HIP_CHECK(hipFuncSetAttribute((const void *)tile_kernel<T, INV, IDENT, QM, SLOTS>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     if constexpr (QM) {
-        StepTable st;
+        typename StepsFor<T>::type st;
         fill_step_table(st, io.steps, io.n_steps);
         hipLaunchKernelGGL((tile_kernel<T, INV, IDENT, true, SLOTS>), grid, dim3(threads), lds, s, A, st);
     } else {
@@ -1036,7 +1084,7 @@ static int launch_top_stage(const raht_plan *p, const Schedule &sc, int k, const
         RAHT_HIP_CHECK(hipFuncSetAttribute((const void *)top_kernel<T, INV, QM>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                            160 * 1024 - 1024));
     if constexpr (QM) {
-        StepTable stp;
+        typename StepsFor<T>::type stp;
         fill_step_table(stp, io.steps, io.n_steps);
         hipLaunchKernelGGL((top_kernel<T, INV, true>), grid, dim3(TOP_THREADS), lds, s, A, stp);
     } else {
@@ -1246,12 +1294,80 @@ static int run_transform(const raht_plan *cp, const T *src, int64_t ld_src, int 
     return rc;
 }
 
-static int check_steps(const float *steps, int n_steps, int D)
+template <typename S>
+static int check_steps(const S *steps, int n_steps, int D)
 {
     if (!steps || !(n_steps == 1 || n_steps == D)) { set_error("quant: n_steps must be 1 or D"); return RAHT_ERR_INVALID; }
     if (n_steps > MAX_STEP_CH) { set_error("quant: per-channel steps support D <= %d", MAX_STEP_CH); return RAHT_ERR_UNSUPPORTED; }
     for (int c = 0; c < n_steps; ++c)
-        if (!(steps[c] > 0.0f)) { set_error("quant: step[%d] must be > 0", c); return RAHT_ERR_INVALID; }
+        if (!(steps[c] > (S)0)) { set_error("quant: step[%d] must be > 0", c); return RAHT_ERR_INVALID; }
+    return RAHT_OK;
+}
+
+// the two-pass entry points (quant.hip), by element type: what the fused entry points fall back to
+static int quant_reorder_any(const raht_plan *p, const float *T, int64_t ldt, int D, const float *st, int n, int32_t *Q, int64_t ldq, raht_stream_t s)
+{ return raht_quant_reorder(p, T, ldt, D, st, n, Q, ldq, s); }
+static int quant_reorder_any(const raht_plan *p, const double *T, int64_t ldt, int D, const double *st, int n, int32_t *Q, int64_t ldq, raht_stream_t s)
+{ return raht_quant_reorder_f64(p, T, ldt, D, st, n, Q, ldq, s); }
+static int dequant_unreorder_any(const raht_plan *p, const int32_t *Q, int64_t ldq, int D, const float *st, int n, float *T, int64_t ldt, raht_stream_t s)
+{ return raht_dequant_unreorder(p, Q, ldq, D, st, n, T, ldt, s); }
+static int dequant_unreorder_any(const raht_plan *p, const int32_t *Q, int64_t ldq, int D, const double *st, int n, double *T, int64_t ldt, raht_stream_t s)
+{ return raht_dequant_unreorder_f64(p, Q, ldq, D, st, n, T, ldt, s); }
+
+/* Fused forward RAHT + quantize + reorder: Q[k, c] = floor(T[order[k], c] / step_c + 0.5) without
+ * ever materialising T (encode_3dgs.py:159,204,210,215 in one pass). */
+template <typename T>
+static int fwd_quant_impl(const raht_plan *cp, const T *C, int64_t ldc, int D, const T *steps, int n_steps,
+                          int32_t *Q, int64_t ldq, raht_stream_t stream)
+{
+    raht_plan *p = const_cast<raht_plan *>(cp);
+    hipStream_t s = (hipStream_t)stream;
+    if (!p || !C || !Q || D < 1 || ldc < D || ldq < D) { set_error("raht_fwd_quant: bad argument"); return RAHT_ERR_INVALID; }
+    RAHT_RET(check_plan_device(p, "raht_fwd_quant"));
+    if (p->row_map) { set_error("raht_fwd_quant: not available for a row-mapped plan"); return RAHT_ERR_UNSUPPORTED; }
+    RAHT_RET(check_steps(steps, n_steps, D));
+    Schedule *sc = nullptr;
+    int Dc = 0;
+    RAHT_RET(tile_setup<T>(p, D, std::max(ldc, ldq), s, &sc, &Dc));
+    if (!sc) {
+        // level engine (selected explicitly, or fallback for pathological key patterns): two passes
+        // through a pooled temporary (stream-ordered reuse; see Scratch in raht_common.h)
+        Scratch tmp(sizeof(T) * (size_t)p->N * (size_t)D);
+        if (!tmp.ok()) return RAHT_ERR_NOMEM;
+        RAHT_RET((run_level_engine<T, false>(p, C, ldc, tmp.as<T>(), D, D, s)));
+        return quant_reorder_any(p, tmp.as<T>(), D, D, steps, n_steps, Q, ldq, stream);
+    }
+    XformIO<T> io;
+    io.src = C; io.ld_src = ldc; io.Q = Q; io.ldq = ldq; io.steps = steps; io.n_steps = n_steps;
+    const int K = (int)sc->stages.size();
+    for (int k = 0; k < K; ++k) RAHT_RET((launch_tile_stage<T, false, true>(p, *sc, k, io, D, Dc, s)));
+    return RAHT_OK;
+}
+
+/* Fused un-reorder + dequantize + inverse RAHT (encode_3dgs.py:261,267-268,274 in one pass). */
+template <typename T>
+static int dequant_inv_impl(const raht_plan *cp, const int32_t *Q, int64_t ldq, int D, const T *steps, int n_steps,
+                            T *C, int64_t ldc, raht_stream_t stream)
+{
+    raht_plan *p = const_cast<raht_plan *>(cp);
+    hipStream_t s = (hipStream_t)stream;
+    if (!p || !C || !Q || D < 1 || ldc < D || ldq < D) { set_error("raht_dequant_inv: bad argument"); return RAHT_ERR_INVALID; }
+    RAHT_RET(check_plan_device(p, "raht_dequant_inv"));
+    if (p->row_map) { set_error("raht_dequant_inv: not available for a row-mapped plan"); return RAHT_ERR_UNSUPPORTED; }
+    RAHT_RET(check_steps(steps, n_steps, D));
+    Schedule *sc = nullptr;
+    int Dc = 0;
+    RAHT_RET(tile_setup<T>(p, D, std::max(ldc, ldq), s, &sc, &Dc));
+    if (!sc) {
+        Scratch tmp(sizeof(T) * (size_t)p->N * (size_t)D);
+        if (!tmp.ok()) return RAHT_ERR_NOMEM;
+        RAHT_RET(dequant_unreorder_any(p, Q, ldq, D, steps, n_steps, tmp.as<T>(), D, stream));
+        return run_level_engine<T, true>(p, tmp.as<T>(), D, C, ldc, D, s);
+    }
+    XformIO<T> io;
+    io.dst = C; io.ld_dst = ldc; io.Q = const_cast<int32_t *>(Q); io.ldq = ldq; io.steps = steps; io.n_steps = n_steps;
+    const int K = (int)sc->stages.size();
+    for (int k = K - 1; k >= 0; --k) RAHT_RET((launch_tile_stage<T, true, true>(p, *sc, k, io, D, Dc, s)));
     return RAHT_OK;
 }
 
@@ -1285,71 +1401,30 @@ int raht_inv_f64(const raht_plan *plan, const double *T, int64_t ldt, int D, dou
     return guarded("raht_inv_f64", [&]() { return run_transform<double, true>(plan, T, ldt, D, C, ldc, nullptr, (hipStream_t)stream); });
 }
 
-/* Fused forward RAHT + quantize + reorder: Q[k, c] = floor(T[order[k], c] / step_c + 0.5) without
- * ever materialising T (encode_3dgs.py:159,204,210,215 in one pass). */
-static int fwd_quant_impl(const raht_plan *cp, const float *C, int64_t ldc, int D, const float *steps, int n_steps,
-                          int32_t *Q, int64_t ldq, raht_stream_t stream)
-{
-    raht_plan *p = const_cast<raht_plan *>(cp);
-    hipStream_t s = (hipStream_t)stream;
-    if (!p || !C || !Q || D < 1 || ldc < D || ldq < D) { set_error("raht_fwd_quant: bad argument"); return RAHT_ERR_INVALID; }
-    RAHT_RET(check_plan_device(p, "raht_fwd_quant"));
-    if (p->row_map) { set_error("raht_fwd_quant: not available for a row-mapped plan"); return RAHT_ERR_UNSUPPORTED; }
-    RAHT_RET(check_steps(steps, n_steps, D));
-    Schedule *sc = nullptr;
-    int Dc = 0;
-    RAHT_RET(tile_setup<float>(p, D, std::max(ldc, ldq), s, &sc, &Dc));
-    if (!sc) {
-        // level engine (selected explicitly, or fallback for pathological key patterns): two passes
-        // through a pooled temporary (stream-ordered reuse; see Scratch in raht_common.h)
-        Scratch tmp(sizeof(float) * (size_t)p->N * (size_t)D);
-        if (!tmp.ok()) return RAHT_ERR_NOMEM;
-        RAHT_RET((run_level_engine<float, false>(p, C, ldc, tmp.as<float>(), D, D, s)));
-        return raht_quant_reorder(p, tmp.as<float>(), D, D, steps, n_steps, Q, ldq, stream);
-    }
-    XformIO<float> io;
-    io.src = C; io.ld_src = ldc; io.Q = Q; io.ldq = ldq; io.steps = steps; io.n_steps = n_steps;
-    const int K = (int)sc->stages.size();
-    for (int k = 0; k < K; ++k) RAHT_RET((launch_tile_stage<float, false, true>(p, *sc, k, io, D, Dc, s)));
-    return RAHT_OK;
-}
-
 int raht_fwd_quant(const raht_plan *plan, const float *C, int64_t ldc, int D, const float *steps, int n_steps,
                    int32_t *Q, int64_t ldq, raht_stream_t stream)
 {
-    return guarded("raht_fwd_quant", [&]() { return fwd_quant_impl(plan, C, ldc, D, steps, n_steps, Q, ldq, stream); });
+    return guarded("raht_fwd_quant", [&]() { return fwd_quant_impl<float>(plan, C, ldc, D, steps, n_steps, Q, ldq, stream); });
 }
 
-/* Fused un-reorder + dequantize + inverse RAHT (encode_3dgs.py:261,267-268,274 in one pass). */
-static int dequant_inv_impl(const raht_plan *cp, const int32_t *Q, int64_t ldq, int D, const float *steps, int n_steps,
-                            float *C, int64_t ldc, raht_stream_t stream)
+/* The same at the reference's own precision (float64 coefficients are what encode_3dgs.py:204 quantizes): the float64
+ * tile kernels with the float64 quantizer in their write-back. */
+int raht_fwd_quant_f64(const raht_plan *plan, const double *C, int64_t ldc, int D, const double *steps, int n_steps,
+                       int32_t *Q, int64_t ldq, raht_stream_t stream)
 {
-    raht_plan *p = const_cast<raht_plan *>(cp);
-    hipStream_t s = (hipStream_t)stream;
-    if (!p || !C || !Q || D < 1 || ldc < D || ldq < D) { set_error("raht_dequant_inv: bad argument"); return RAHT_ERR_INVALID; }
-    RAHT_RET(check_plan_device(p, "raht_dequant_inv"));
-    if (p->row_map) { set_error("raht_dequant_inv: not available for a row-mapped plan"); return RAHT_ERR_UNSUPPORTED; }
-    RAHT_RET(check_steps(steps, n_steps, D));
-    Schedule *sc = nullptr;
-    int Dc = 0;
-    RAHT_RET(tile_setup<float>(p, D, std::max(ldc, ldq), s, &sc, &Dc));
-    if (!sc) {
-        Scratch tmp(sizeof(float) * (size_t)p->N * (size_t)D);
-        if (!tmp.ok()) return RAHT_ERR_NOMEM;
-        RAHT_RET(raht_dequant_unreorder(p, Q, ldq, D, steps, n_steps, tmp.as<float>(), D, stream));
-        return run_level_engine<float, true>(p, tmp.as<float>(), D, C, ldc, D, s);
-    }
-    XformIO<float> io;
-    io.dst = C; io.ld_dst = ldc; io.Q = const_cast<int32_t *>(Q); io.ldq = ldq; io.steps = steps; io.n_steps = n_steps;
-    const int K = (int)sc->stages.size();
-    for (int k = K - 1; k >= 0; --k) RAHT_RET((launch_tile_stage<float, true, true>(p, *sc, k, io, D, Dc, s)));
-    return RAHT_OK;
+    return guarded("raht_fwd_quant_f64", [&]() { return fwd_quant_impl<double>(plan, C, ldc, D, steps, n_steps, Q, ldq, stream); });
 }
 
 int raht_dequant_inv(const raht_plan *plan, const int32_t *Q, int64_t ldq, int D, const float *steps, int n_steps,
                      float *C, int64_t ldc, raht_stream_t stream)
 {
-    return guarded("raht_dequant_inv", [&]() { return dequant_inv_impl(plan, Q, ldq, D, steps, n_steps, C, ldc, stream); });
+    return guarded("raht_dequant_inv", [&]() { return dequant_inv_impl<float>(plan, Q, ldq, D, steps, n_steps, C, ldc, stream); });
+}
+
+int raht_dequant_inv_f64(const raht_plan *plan, const int32_t *Q, int64_t ldq, int D, const double *steps, int n_steps,
+                         double *C, int64_t ldc, raht_stream_t stream)
+{
+    return guarded("raht_dequant_inv_f64", [&]() { return dequant_inv_impl<double>(plan, Q, ldq, D, steps, n_steps, C, ldc, stream); });
 }
 
 /* Pre-build the tile schedule and workspaces for (elem_size, D) so that later transform calls

@@ -296,7 +296,8 @@ class RahtPlan:
 
     def forward_quant(self, Cmat, steps, roots=None):
         """Forward RAHT + quantize + reorder -> int32 Q. float32 (default): ONE fused pass, T is never
-        materialised. float64 input: the reference's precision (encode_3dgs.py:82-83,204), two passes."""
+        materialised. float64 input: the same at the reference's precision (encode_3dgs.py:82-83,204): the float64 tile
+        kernels with the float64 quantizer in their write-back."""
         _need_cuda(Cmat, "C")
         if Cmat.dtype == torch.float64 and roots is None:
             X = Cmat if (Cmat.stride(1) == 1 and Cmat.stride(0) >= Cmat.shape[1]) else Cmat.contiguous()
@@ -319,8 +320,8 @@ class RahtPlan:
         return Q
 
     def dequant_inverse(self, Q, steps, roots=None, dtype=torch.float32):
-        """Un-reorder + dequantize + inverse RAHT -> C (float32: one fused pass; dtype=torch.float64: the
-        reference's precision, two passes)."""
+        """Un-reorder + dequantize + inverse RAHT -> C in ONE fused pass (dtype=torch.float64: at the reference's
+        precision)."""
         _need_cuda(Q, "Q")
         Q = Q.to(torch.int32).contiguous()
         D = Q.shape[1]

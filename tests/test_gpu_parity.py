@@ -223,6 +223,31 @@ def test_fused_quant_equals_two_call_sequence(rt, name, tile_rows, tail_rows, ta
         assert torch.equal(C1, C2)
 
 
+@pytest.mark.parametrize("tile_rows,tail_rows,tail_ch,final_rows", [(0, 0, 0, 0), (64, 64, 0, 64), (128, 64, 8, 64), (64, 256, 3, 0)])
+@pytest.mark.parametrize("name", ["n257_j3_d11", "n1000_j10_d14", "n1500_j12_d56", "n2000_j10_d59", "n3000_j18_d3", "early_root_j10", "n8_cube_j1"])
+def test_fused_quant_float64_equals_two_call_sequence(rt, name, tile_rows, tail_rows, tail_ch, final_rows):
+    """The same at the reference's precision: raht_fwd_quant_f64 (float64 tile kernels with the float64 quantizer in their
+    write-back) == raht_fwd_f64 + raht_quant_reorder_f64, raht_dequant_inv_f64 == dequant + raht_inv_f64, bit for bit --
+    and the integers are floor(T64 / step + 0.5) of the float64 coefficients (encode_3dgs.py:204,210,215)."""
+    import torch
+    g = load_golden(name)
+    p = _plan(rt, g, "tile", tile_rows, tail_rows, tail_ch, final_rows)
+    C = _dev(g["C"].astype(np.float64))
+    D = C.shape[1]
+    order = p.order_RAGFT.cpu().numpy()
+    for steps in (1.0, 0.37, [0.5 + 0.25 * c for c in range(D)]):
+        T, _ = p.forward(C)
+        assert T.dtype == torch.float64
+        Q2 = p.quant_reorder(T, steps)
+        Q1 = p.forward_quant(C, steps)
+        assert Q1.dtype == torch.int32 and torch.equal(Q1, Q2)
+        exp = np.floor(T.cpu().numpy()[order] / np.asarray(steps, np.float64) + 0.5).astype(np.int32)
+        assert np.array_equal(Q1.cpu().numpy(), exp)
+        C2 = p.inverse(p.dequant_unreorder(Q2, steps, dtype=torch.float64))
+        C1 = p.dequant_inverse(Q1, steps, dtype=torch.float64)
+        assert C1.dtype == torch.float64 and torch.equal(C1, C2)
+
+
 def test_fused_quant_strided_input(rt):
     import torch
     g = load_golden("n2000_j10_d59")
