@@ -596,6 +596,12 @@ def test_randomised_configurations(rt, seed):
         Q2 = p.quant_reorder(p.forward(Cd, want_w=False), steps)
         assert torch.equal(Q1, Q2)
         assert torch.equal(p.dequant_inverse(Q1, steps), p.inverse(p.dequant_unreorder(Q1, steps)))
+    if f64 and D <= 256:
+        steps = float(10 ** rng.uniform(-3, 0)) * float(np.abs(T_ref).max() + 1e-3) / 1000.0
+        Q1 = p.forward_quant(Cd, steps)                                        # float64 quantizer fused into the float64 kernels
+        Q2 = p.quant_reorder(p.forward(Cd, want_w=False), steps)
+        assert Q1.dtype == torch.int32 and torch.equal(Q1, Q2)
+        assert torch.equal(p.dequant_inverse(Q1, steps, dtype=torch.float64), p.inverse(p.dequant_unreorder(Q1, steps, dtype=torch.float64)))
 
 
 def test_fused_quantization_divides_exactly(rt):
