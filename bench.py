@@ -568,6 +568,9 @@ def main():
             vox_alg = 4.0 * N * ld * 2 + 24.0 * N * ((3 * J + 7) // 8)
             pre["voxelize"] = roof(wall(lambda: R.voxelize_pc_batched(PC, [0.0, 0.0, 0.0], float(2 ** J), J, device=dev, residuals=False, sorted_points=False)), vox_alg)
             pre["voxelize"]["points"], pre["voxelize"]["columns"] = N, ld
+            # ... and with the reference's secondary outputs (PCsorted, DeltaPC: voxelize_pc.py:103-111, 147-156): the cloud
+            # gathered once more, PCvox read per point, two N x ld matrices written
+            pre["voxelize_with_residuals"] = roof(wall(lambda: R.voxelize_pc_batched(PC, [0.0, 0.0, 0.0], float(2 ** J), J, device=dev)), vox_alg + 4.0 * N * ld * 4)
             out["prelude"] = pre
             del PC, xyz, ku, perm
 
