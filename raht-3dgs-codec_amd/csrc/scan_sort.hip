@@ -471,9 +471,7 @@ static int radix_pass_impl(const KeyT *keys_in, const uint32_t *vals_in, KeyT *k
 // every pass costs 68 us instead of 58 (512 runs of ~8 items per block write worse than 256 runs of 16; 58 KiB of LDS; a
 // 512 x blocks scan), so 30-bit keys, which need 4 passes either way, got slower: not kept either. A one-launch scan of the
 // digit-major histogram (workgroup per digit, digit totals by global atomics from the histogram kernel): 0.254 -> 0.360 ms --
-// ~1500 atomics on each of 256 hot words serialise in L2; the two-launch generic scan stays. So does it against a
-// one-launch scan whose LAST-ARRIVING block turns the 184 block totals into bases that the scatter adds itself: 0.255 ->
-// 0.272 ms (60 bit: 0.39 -> 0.43) -- the serial tail behind an arrival counter costs more than the 5 us launch it saves.)
+// ~1500 atomics on each of 256 hot words serialise in L2; the two-launch generic scan stays.)
 int radix_pass_u64(const uint64_t *keys_in, const uint32_t *vals_in, uint64_t *keys_out,
                    uint32_t *vals_out, int64_t n, int shift, int bits, hipStream_t s)
 {
