@@ -258,6 +258,27 @@ def test_fused_quant_strided_input(rt):
     assert torch.equal(p.forward_quant(big[:, :D], 0.01), p.forward_quant(_dev(g["C"]), 0.01))
 
 
+@pytest.mark.parametrize("geom", [(0, 0, 0, 0), (64, 64, 0, 64)])
+@pytest.mark.parametrize("dtype", ["f32", "f64"])
+def test_strided_rows_through_every_tile_kernel(rt, geom, dtype):
+    """Row stride > D on the input side of every direction (the tile kernels' LDS-direct loads take one global address per
+    lane: row * ld + channel): forward, inverse, fused forward -- same results as from contiguous matrices, bit for bit."""
+    import torch
+    g = load_golden("n2000_j10_d59")
+    p = _plan(rt, g, "tile", *geom)
+    td = torch.float32 if dtype == "f32" else torch.float64
+    C = _dev(g["C"]).to(td)
+    N, D = C.shape
+    wide = torch.full((N, D + 7), float("nan"), dtype=td, device="cuda")
+    wide[:, :D] = C
+    T = p.forward(C, want_w=False)
+    assert torch.equal(p.forward(wide[:, :D], want_w=False), T)
+    wideT = torch.full((N, D + 3), float("nan"), dtype=td, device="cuda")
+    wideT[:, :D] = T
+    assert torch.equal(p.inverse(wideT[:, :D]), p.inverse(T))
+    assert torch.equal(p.forward_quant(wide[:, :D], 0.02), p.forward_quant(C, 0.02))
+
+
 # ------------------------------------------------------------------------------------------- voxelizer
 @pytest.mark.parametrize("name", VOX)
 def test_voxelize(rt, name):
