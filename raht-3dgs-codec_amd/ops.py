@@ -299,10 +299,15 @@ class RahtPlan:
         materialised. float64 input: the same at the reference's precision (encode_3dgs.py:82-83,204): the float64 tile
         kernels with the float64 quantizer in their write-back."""
         _need_cuda(Cmat, "C")
-        if Cmat.dtype == torch.float64 and roots is None:
+        if Cmat.dtype == torch.float64:
             X = Cmat if (Cmat.stride(1) == 1 and Cmat.stride(0) >= Cmat.shape[1]) else Cmat.contiguous()
             Q = torch.empty((self.N, X.shape[1]), dtype=torch.int32, device=X.device)
-            return self._f64_quant_call(_lib.lib().raht_fwd_quant_f64, X, X.shape[1], steps, Q)
+            self._set_roots_buffer(roots, X.shape[1], torch.float64)
+            try:
+                return self._f64_quant_call(_lib.lib().raht_fwd_quant_f64, X, X.shape[1], steps, Q)
+            finally:
+                if roots is not None:
+                    self._set_roots_buffer(None, X.shape[1], torch.float64)
         X = Cmat.to(torch.float32)
         if X.stride(1) != 1 or X.stride(0) < X.shape[1]:
             X = X.contiguous()
@@ -325,9 +330,14 @@ class RahtPlan:
         _need_cuda(Q, "Q")
         Q = Q.to(torch.int32).contiguous()
         D = Q.shape[1]
-        if dtype == torch.float64 and roots is None:
+        if dtype == torch.float64:
             out = torch.empty((self.N, D), dtype=torch.float64, device=Q.device)
-            return self._f64_quant_call(_lib.lib().raht_dequant_inv_f64, Q, D, steps, out)
+            self._set_roots_buffer(roots, D, torch.float64)
+            try:
+                return self._f64_quant_call(_lib.lib().raht_dequant_inv_f64, Q, D, steps, out)
+            finally:
+                if roots is not None:
+                    self._set_roots_buffer(None, D, torch.float64)
         st = _steps(steps, D)
         out = torch.empty((self.N, D), dtype=torch.float32, device=Q.device)
         self._set_roots_buffer(roots, D, torch.float32)

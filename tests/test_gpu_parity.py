@@ -623,6 +623,13 @@ def test_randomised_configurations(rt, seed):
         Q2 = p.quant_reorder(p.forward(Cd, want_w=False), steps)
         assert Q1.dtype == torch.int32 and torch.equal(Q1, Q2)
         assert torch.equal(p.dequant_inverse(Q1, steps, dtype=torch.float64), p.inverse(p.dequant_unreorder(Q1, steps, dtype=torch.float64)))
+        # ... and with the roots travelling through a caller buffer (truncated trees: what a sharded scene does)
+        r1 = torch.empty((p.n_roots, D), dtype=torch.float64, device="cuda")
+        Q3 = p.forward_quant(Cd, steps, roots=r1)
+        assert torch.equal(r1, roots)                                           # the same float64 low-pass rows as the plain forward
+        R3 = p.dequant_inverse(Q3, steps, roots=r1, dtype=torch.float64)
+        # orthonormal inverse of coefficients that are off by at most half a step each (the roots not at all)
+        assert (R3 - Cd).abs().max().item() <= 1e-11 * max(Cd.abs().max().item(), 1e-30) + 0.5 * steps * np.sqrt(N) * 1.001
 
 
 def test_fused_quantization_divides_exactly(rt):
