@@ -53,7 +53,7 @@ def encode_frame(V_int, attributes, J, steps, frame=1, device="cuda:0", dtype=to
     _sync()
     t_prelude = time.time() - t0
     plan = plan_of(ListC)
-    use_fused = fused and dtype == torch.float32
+    use_fused = fused                     # float32 and float64 (the reference's precision) both have fused entry points
 
     Coeff, t_transform = None, 0.0
     if not use_fused:
@@ -105,7 +105,7 @@ def encode_frame(V_int, attributes, J, steps, frame=1, device="cuda:0", dtype=to
             qd = rlgr_mod.transpose_on_device(qd)
         if use_fused:
             t0 = time.time()
-            C_rec = plan.dequant_inverse(qd, step_arg)                              # :261 + :267-268 + :274
+            C_rec = plan.dequant_inverse(qd, step_arg, dtype=dtype)                 # :261 + :267-268 + :274
             _sync()
             r["iRAHT_time"], r["Dequant_time"], r["Coeff_reorder_dec_time"] = time.time() - t0, 0.0, 0.0
         else:
