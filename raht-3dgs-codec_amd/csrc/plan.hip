@@ -571,7 +571,7 @@ static int build_top_stage(raht_plan *plan, uint32_t *rows, int64_t n, hipStream
                            plan->inv_order, st.e_wl, st.e_wr, st.e_lvl, st.e_pos);
     }
     // scratch: pj | is_root | pos | perm | boff[65] | total | ab (double, 8-byte aligned first) | bucket
-    Scratch buf(sizeof(double) * 2 * (size_t)n + sizeof(uint32_t) * (4 * (size_t)n + 66) + (size_t)n);
+    Scratch buf(sizeof(double) * 2 * (size_t)n + sizeof(uint32_t) * (4 * (size_t)n + 66) + (size_t)n, s);
     if (!buf.ok()) return RAHT_ERR_NOMEM;
     double *ab = buf.as<double>();
     uint32_t *pj = (uint32_t *)(ab + 2 * n), *is_root = pj + n, *pos = is_root + n, *perm = pos + n, *boff = perm + n,
@@ -1007,7 +1007,7 @@ static int build_schedule_fast(raht_plan *plan, int R0, int R1, int Rf, hipStrea
     take(&t_pj, 4 * tm); take(&t_ab32, 8 * tm); take(&t_ab64, 16 * tm); take(&t_root, 4 * tm); take(&t_lev, 4 * 128);
     // scratch: state | per-block counts | flags
     const size_t nblk0 = (size_t)ceil_div(N, SB_BLOCK);
-    Scratch scr(sizeof(SchedState) + sizeof(uint32_t) * nblk0 + (size_t)N);
+    Scratch scr(sizeof(SchedState) + sizeof(uint32_t) * nblk0 + (size_t)N, s);
     auto release = [&]() {
         for (auto &b : B) { dev_free(b.rows); dev_free(b.wl); dev_free(b.wr); dev_free(b.lvl); dev_free(b.pos); dev_free(b.surv); }
         dev_free(t_pj); dev_free(t_ab32); dev_free(t_ab64); dev_free(t_root); dev_free(t_lev);
@@ -1104,7 +1104,7 @@ static int get_schedule_exact(raht_plan *plan, int R0, int R1, int Rf, hipStream
     sc.final_rows = Rf;
     sc.valid = true;
     const int64_t N = plan->N;
-    Scratch buf(sizeof(uint32_t) * (2 * (size_t)N + 1));
+    Scratch buf(sizeof(uint32_t) * (2 * (size_t)N + 1), s);
     if (!buf.ok()) return RAHT_ERR_NOMEM;
     uint32_t *flag = buf.as<uint32_t>(), *pos = flag + N, *dtotal = pos + N;
     uint32_t *rows = nullptr;      // rows of the current stage (nullptr = identity)
@@ -1189,7 +1189,7 @@ static int compute_roots(raht_plan *p, hipStream_t s)
         RAHT_HIP_CHECK(hipMemsetAsync(p->root_rows, 0, sizeof(uint32_t), s));
         return RAHT_OK;
     }
-    Scratch buf(sizeof(uint32_t) * 2 * (size_t)p->N);
+    Scratch buf(sizeof(uint32_t) * 2 * (size_t)p->N, s);
     if (!buf.ok()) return RAHT_ERR_NOMEM;
     uint32_t *flag = buf.as<uint32_t>(), *tmp = flag + p->N;
     hipLaunchKernelGGL(root_flag_kernel, dim3((unsigned)ceil_div(p->N, 256)), dim3(256), 0, s, p->lvl, p->N,
@@ -1232,7 +1232,7 @@ static int finish_plan(raht_plan *p, const int64_t *leaf_weights, hipStream_t s,
     const unsigned nblk = (unsigned)ceil_div(N, EXT_THREADS);
     // scratch: error word | level starts [64] | (order bucket + level) histograms / positions [(ORDER_BUCKETS + 64) x nblk]
     //          | search queue [EXT_QCAP x nblk] + counts [nblk] | bucket ids [N]
-    Scratch tmp(sizeof(PlanErr) + sizeof(uint32_t) * (64 + (size_t)(ORDER_BUCKETS + 64 + EXT_QCAP + 1) * nblk) + (size_t)N);
+    Scratch tmp(sizeof(PlanErr) + sizeof(uint32_t) * (64 + (size_t)(ORDER_BUCKETS + 64 + EXT_QCAP + 1) * nblk) + (size_t)N, s);
     if (!tmp.ok()) return RAHT_ERR_NOMEM;
     PlanErr *derr = tmp.as<PlanErr>();
     uint32_t *lhist = (uint32_t *)((char *)tmp.ptr() + sizeof(PlanErr));
@@ -1345,7 +1345,7 @@ int raht_plan_create(const void *V, int v_dtype, int64_t N, const double minV[3]
         p->N = N;
         p->nbits = 3 * depth;
         if (dev_malloc(&p->keys, sizeof(uint64_t) * (size_t)N) != hipSuccess) { set_error("hipMalloc keys"); return RAHT_ERR_NOMEM; }
-        Scratch errw(sizeof(PlanErr));
+        Scratch errw(sizeof(PlanErr), s);
         if (!errw.ok()) return RAHT_ERR_NOMEM;
         PlanErr *derr = errw.as<PlanErr>();
         PlanErr h0 = {0, 0xffffffffu};
@@ -1580,7 +1580,7 @@ int raht_plan_set_row_map(raht_plan *p, const int64_t *map_dev, int64_t n_matrix
     if (p->N > RAHT_TOP_MAX_ROWS) { set_error("raht_plan_set_row_map: plans of at most %d rows", RAHT_TOP_MAX_ROWS); return RAHT_ERR_UNSUPPORTED; }
     if (n_matrix_rows < p->N || n_matrix_rows >= ((int64_t)1 << 31)) { set_error("raht_plan_set_row_map: n_matrix_rows=%lld", (long long)n_matrix_rows); return RAHT_ERR_INVALID; }
     if (!p->row_map) RAHT_HIP_CHECK(dev_malloc(&p->row_map, sizeof(uint32_t) * (size_t)p->N));
-    Scratch errw(sizeof(PlanErr));
+    Scratch errw(sizeof(PlanErr), s);
     if (!errw.ok()) return RAHT_ERR_NOMEM;
     PlanErr h0 = {0, 0xffffffffu}, he;
     RAHT_HIP_CHECK(hipMemcpyAsync(errw.ptr(), &h0, sizeof(h0), hipMemcpyHostToDevice, s));
@@ -1634,8 +1634,9 @@ int raht_plan_stage_stats(raht_plan *p, int elem_size, int D, int *n_stages, int
 
 int raht_morton(const int64_t *V, int64_t N, int J, uint64_t *keys, raht_stream_t stream)
 {
-    if (!V || !keys || N < 0 || J < 1 || J > 21) { set_error("raht_morton: bad argument"); return RAHT_ERR_INVALID; }
+    if (N < 0 || J < 1 || J > 21) { set_error("raht_morton: bad argument"); return RAHT_ERR_INVALID; }
     if (N == 0) return RAHT_OK;
+    if (!V || !keys) { set_error("raht_morton: NULL argument"); return RAHT_ERR_INVALID; }
     hipLaunchKernelGGL(morton_i64_kernel, dim3((unsigned)ceil_div(N, 256)), dim3(256), 0,
                        (hipStream_t)stream, V, N, keys);
     RAHT_HIP_CHECK(hipGetLastError());

@@ -94,12 +94,15 @@ struct PerDeviceOnce {
 
 // Device scratch memory from a thread-local grow-only pool (one per device): plan / sort / voxelizer
 // temporaries are reused across calls instead of paying hipMalloc + hipFree (each a device
-// synchronisation) per use. Stream-ordered reuse is safe because every user of the pool runs its work on
-// the caller's stream in program order and the pool is per host thread. Blocks belong to the device that
-// was current when they were allocated and are only handed out while that device is current.
+// synchronisation) per use. A block is released when its Scratch object dies, i.e. possibly while the kernels
+// that use it are still queued on `stream`: reuse is STREAM-ORDERED. Every block remembers the stream of its
+// last user; handing it to work on ANOTHER stream (a caller that moves between streams on one host thread, e.g.
+// side streams around collectives) first waits for the device to drain -- rare, and the only way to be right
+// without an event per release. Blocks belong to the device that was current when they were allocated and are
+// only handed out while that device is current.
 class Scratch {
 public:
-    explicit Scratch(size_t bytes);
+    Scratch(size_t bytes, hipStream_t stream);
     ~Scratch();
     Scratch(const Scratch &) = delete;
     Scratch &operator=(const Scratch &) = delete;

@@ -14,10 +14,10 @@ namespace raht {
 // ------------------------------------------------------------------------------------------------
 // Scratch pool
 // ------------------------------------------------------------------------------------------------
-struct PoolBlock { void *p; size_t bytes; bool used; int device; };
+struct PoolBlock { void *p; size_t bytes; bool used; int device; hipStream_t last_stream; bool touched; };
 static thread_local std::vector<PoolBlock> g_pool;
 
-Scratch::Scratch(size_t bytes)
+Scratch::Scratch(size_t bytes, hipStream_t stream)
 {
     if (bytes == 0) bytes = 16;
     const int dev = current_device();
@@ -42,18 +42,23 @@ Scratch::Scratch(size_t bytes)
             (void)hipFree(g_pool[(size_t)victim].p);
             // a failed allocation leaves an EMPTY slot behind: erasing it would shift the slot indices that
             // live Scratch objects hold, and a later destructor would release somebody else's block
-            g_pool[(size_t)victim] = {nullptr, 0, false, dev};
+            g_pool[(size_t)victim] = {nullptr, 0, false, dev, nullptr, false};
             if (hipMalloc(&q, want) != hipSuccess) { (void)hipGetLastError(); set_error("scratch: out of device memory (%zu bytes)", want); return; }
-            g_pool[(size_t)victim] = {q, want, false, dev};
+            g_pool[(size_t)victim] = {q, want, false, dev, nullptr, false};
             best = victim;
         } else {
             if (hipMalloc(&q, want) != hipSuccess) { (void)hipGetLastError(); set_error("scratch: out of device memory (%zu bytes)", want); return; }
-            if (empty >= 0) { g_pool[(size_t)empty] = {q, want, false, dev}; best = empty; }
-            else { g_pool.push_back({q, want, false, dev}); best = (int)g_pool.size() - 1; }
+            if (empty >= 0) { g_pool[(size_t)empty] = {q, want, false, dev, nullptr, false}; best = empty; }
+            else { g_pool.push_back({q, want, false, dev, nullptr, false}); best = (int)g_pool.size() - 1; }
         }
     }
-    g_pool[(size_t)best].used = true;
-    p_ = g_pool[(size_t)best].p;
+    PoolBlock &blk = g_pool[(size_t)best];
+    // the block's previous user may still be running on another stream (see raht_common.h)
+    if (blk.touched && blk.last_stream != stream) (void)hipDeviceSynchronize();
+    blk.used = true;
+    blk.touched = true;
+    blk.last_stream = stream;
+    p_ = blk.p;
     slot_ = best;
 }
 
@@ -266,7 +271,7 @@ int exclusive_scan_u32(const uint32_t *in, uint32_t *out, int64_t n, uint32_t *t
     // workspace: nb + nb/2048 + ... entries, plus one word to keep in[n-1] (out may alias in)
     int64_t wsn = 1;
     for (int64_t m = ceil_div(n, SCAN_BLOCK); m > 1; m = ceil_div(m, SCAN_BLOCK)) wsn += m;
-    Scratch ws(sizeof(uint32_t) * (size_t)wsn);
+    Scratch ws(sizeof(uint32_t) * (size_t)wsn, s);
     if (!ws.ok()) return RAHT_ERR_NOMEM;
     const int64_t nb = ceil_div(n, SCAN_BLOCK);
     if (nb <= SCAN_FUSE_BLOCKS) {
@@ -431,7 +436,7 @@ static int radix_pass_impl(const KeyT *keys_in, const uint32_t *vals_in, KeyT *k
     if (bits < 1 || bits > 8) { set_error("radix pass: bits=%d", bits); return RAHT_ERR_INVALID; }
     const uint32_t nb = (uint32_t)ceil_div(n, RP_BLOCK);
     const uint32_t nd = 1u << bits;
-    Scratch gh(sizeof(uint32_t) * (size_t)nd * nb);
+    Scratch gh(sizeof(uint32_t) * (size_t)nd * nb, s);
     if (!gh.ok()) return RAHT_ERR_NOMEM;
     uint32_t *ghist = gh.as<uint32_t>();
     hipLaunchKernelGGL(radix_hist_kernel<KeyT>, dim3(nb), dim3(RP_THREADS), 0, s, keys_in, n, shift,
@@ -499,7 +504,7 @@ int compact_u32(const uint32_t *in, const uint32_t *flag, uint32_t *out, int64_t
 {
     *count_host = 0;
     if (n <= 0) return RAHT_OK;
-    Scratch pos(sizeof(uint32_t) * ((size_t)n + 1));
+    Scratch pos(sizeof(uint32_t) * ((size_t)n + 1), s);
     if (!pos.ok()) return RAHT_ERR_NOMEM;
     uint32_t *total = pos.as<uint32_t>() + n;
     int rc = exclusive_scan_u32(flag, pos.as<uint32_t>(), n, total, s);

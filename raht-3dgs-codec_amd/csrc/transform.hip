@@ -1332,7 +1332,7 @@ static int fwd_quant_impl(const raht_plan *cp, const T *C, int64_t ldc, int D, c
     if (!sc) {
         // level engine (selected explicitly, or fallback for pathological key patterns): two passes
         // through a pooled temporary (stream-ordered reuse; see Scratch in raht_common.h)
-        Scratch tmp(sizeof(T) * (size_t)p->N * (size_t)D);
+        Scratch tmp(sizeof(T) * (size_t)p->N * (size_t)D, s);
         if (!tmp.ok()) return RAHT_ERR_NOMEM;
         RAHT_RET((run_level_engine<T, false>(p, C, ldc, tmp.as<T>(), D, D, s)));
         return quant_reorder_any(p, tmp.as<T>(), D, D, steps, n_steps, Q, ldq, stream);
@@ -1359,7 +1359,7 @@ static int dequant_inv_impl(const raht_plan *cp, const int32_t *Q, int64_t ldq, 
     int Dc = 0;
     RAHT_RET(tile_setup<T>(p, D, std::max(ldc, ldq), s, &sc, &Dc));
     if (!sc) {
-        Scratch tmp(sizeof(T) * (size_t)p->N * (size_t)D);
+        Scratch tmp(sizeof(T) * (size_t)p->N * (size_t)D, s);
         if (!tmp.ok()) return RAHT_ERR_NOMEM;
         RAHT_RET(dequant_unreorder_any(p, Q, ldq, D, steps, n_steps, tmp.as<T>(), D, stream));
         return run_level_engine<T, true>(p, tmp.as<T>(), D, C, ldc, D, s);

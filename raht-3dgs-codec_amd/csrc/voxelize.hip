@@ -315,7 +315,7 @@ static int sort_keys_u32idx(const uint64_t *keys_in, int64_t N, int nbits, uint6
 {
     // LSD passes of 8 bits; ping-pong between two (key, index) buffers, last pass lands in *_out
     const int npass = std::max(1, (nbits + 7) / 8);
-    Scratch tmp(npass > 1 ? (sizeof(uint64_t) + sizeof(uint32_t)) * (size_t)N : 16);
+    Scratch tmp(npass > 1 ? (sizeof(uint64_t) + sizeof(uint32_t)) * (size_t)N : 16, s);
     if (!tmp.ok()) return RAHT_ERR_NOMEM;
     uint64_t *ktmp = tmp.as<uint64_t>();
     uint32_t *itmp = (uint32_t *)(ktmp + N);
@@ -343,11 +343,14 @@ extern "C" {
 int raht_sort_keys(const uint64_t *keys_in, int64_t N, int nbits, uint64_t *keys_out, int64_t *idx_out,
                    raht_stream_t stream)
 {
-    if (!keys_in || !keys_out || N < 0 || nbits < 1 || nbits > 64) { set_error("raht_sort_keys: bad argument"); return RAHT_ERR_INVALID; }
+    // an empty input is valid and needs no buffers (an empty device tensor's data pointer is NULL): ranks of a sharded scene
+    // may hold no points, and must reach the next collective like every other rank
+    if (N < 0 || nbits < 1 || nbits > 64) { set_error("raht_sort_keys: bad argument"); return RAHT_ERR_INVALID; }
     if (N == 0) return RAHT_OK;
+    if (!keys_in || !keys_out) { set_error("raht_sort_keys: NULL argument"); return RAHT_ERR_INVALID; }
     if (N >= ((int64_t)1 << 31)) { set_error("raht_sort_keys: N too large"); return RAHT_ERR_INVALID; }
     hipStream_t s = (hipStream_t)stream;
-    Scratch ib(sizeof(uint32_t) * (size_t)N);
+    Scratch ib(sizeof(uint32_t) * (size_t)N, s);
     if (!ib.ok()) return RAHT_ERR_NOMEM;
     uint32_t *idx32 = ib.as<uint32_t>();
     RAHT_RET(sort_keys_u32idx(keys_in, N, nbits, keys_out, idx32, s));
@@ -361,8 +364,9 @@ int raht_sort_keys(const uint64_t *keys_in, int64_t N, int nbits, uint64_t *keys
 int raht_voxel_keys(const float *PC, int64_t ldpc, int64_t N, const float vmin[3], double width, int J,
                     uint64_t *keys, raht_stream_t stream)
 {
-    if (!PC || !keys || !vmin || N < 0 || ldpc < 3 || J < 1 || J > 21 || !(width > 0)) { set_error("raht_voxel_keys: bad argument"); return RAHT_ERR_INVALID; }
-    if (N == 0) return RAHT_OK;
+    if (!vmin || N < 0 || ldpc < 3 || J < 1 || J > 21 || !(width > 0)) { set_error("raht_voxel_keys: bad argument"); return RAHT_ERR_INVALID; }
+    if (N == 0) return RAHT_OK;                              // empty rank of a sharded cloud: nothing to do, no buffers needed
+    if (!PC || !keys) { set_error("raht_voxel_keys: NULL argument"); return RAHT_ERR_INVALID; }
     const float vs = (float)(width / (double)((uint64_t)1 << J));        // voxelize_pc.py:97, as raht_voxelize
     hipLaunchKernelGGL(vox_keys_kernel, dim3((unsigned)ceil_div(N, 256 * 4)), dim3(256), 0, (hipStream_t)stream, PC, ldpc, N,
                        vmin[0], vmin[1], vmin[2], vs, J, keys);
@@ -380,7 +384,7 @@ int raht_voxelize_residuals(const float *PC, int64_t ldpc, int64_t N, int d, con
     }
     if (N >= ((int64_t)1 << 31)) { set_error("raht_voxelize_residuals: N too large"); return RAHT_ERR_INVALID; }
     hipStream_t s = (hipStream_t)stream;
-    Scratch buf(sizeof(uint32_t) * 2 * (size_t)N);
+    Scratch buf(sizeof(uint32_t) * 2 * (size_t)N, s);
     if (!buf.ok()) return RAHT_ERR_NOMEM;
     uint32_t *flag = buf.as<uint32_t>(), *pos = flag + N;
     hipLaunchKernelGGL(boundary_kernel, dim3((unsigned)ceil_div(N, 256)), dim3(256), 0, s, keys_sorted, N, flag);
@@ -412,7 +416,7 @@ int raht_voxelize(const float *PC, int64_t ldpc, int64_t N, int d, const float *
     double width = width_in;
     // ---- vmin / width (voxelize_pc.py:87-95) ----
     const int nb = (int)std::min<int64_t>(ceil_div(N, 256), 1024);
-    Scratch partb(sizeof(float) * 4 * (size_t)nb);
+    Scratch partb(sizeof(float) * 4 * (size_t)nb, s);
     if (!partb.ok()) return RAHT_ERR_NOMEM;
     float *part = partb.as<float>();
     float hp_buf[1024 * 4];                          // nb <= 1024 partial results (no host allocation: nothing can throw)
@@ -441,7 +445,7 @@ int raht_voxelize(const float *PC, int64_t ldpc, int64_t N, int d, const float *
     const float vs = (float)voxel_size;
 
     // ---- keys, sort ----
-    Scratch kb(sizeof(uint64_t) * 2 * (size_t)N), ib(sizeof(uint32_t) * 3 * (size_t)N);
+    Scratch kb(sizeof(uint64_t) * 2 * (size_t)N, s), ib(sizeof(uint32_t) * 3 * (size_t)N, s);
     if (!kb.ok() || !ib.ok()) return RAHT_ERR_NOMEM;
     uint64_t *keys = kb.as<uint64_t>();
     uint64_t *ks = keys_sorted ? keys_sorted : keys + N;

@@ -142,9 +142,16 @@ class ShardedRaht:
         self.N = int(keys_sorted.shape[0])
         dev = keys_sorted.device
         self.device = dev
-        # shard-local plan: butterflies at levels >= nbits - prefix_bits are left to the top stage
-        self.plan = self.ops.make_plan(keys_sorted, self.nbits, top_level=self.nbits - self.prefix_bits)
-        self.root_rows = self.plan.root_rows                    # first row of every local prefix node
+        self._ev = None                                         # collective timing (time_collectives)
+        if self.N > 0:
+            # shard-local plan: butterflies at levels >= nbits - prefix_bits are left to the top stage
+            self.plan = self.ops.make_plan(keys_sorted, self.nbits, top_level=self.nbits - self.prefix_bits)
+            self.root_rows = self.plan.root_rows                # first row of every local prefix node
+        else:
+            # a rank whose prefix range holds no point (balanced cuts of a very uneven scene, or fewer occupied prefixes
+            # than ranks): no local plan, no roots -- but it takes part in every collective like the others
+            self.plan = None
+            self.root_rows = torch.empty(0, dtype=torch.int64, device=dev)
         self.n_roots = int(self.root_rows.shape[0])
         pref = (keys_sorted[self.root_rows] >> (self.nbits - self.prefix_bits)).to(torch.int64)
         ends = torch.cat([self.root_rows[1:], torch.tensor([self.N], dtype=torch.int64, device=dev)])
@@ -152,6 +159,8 @@ class ShardedRaht:
         # ---- one-off exchange of the root directory: (prefix id, leaf count) per root, padded slots ----
         sizes = self._all_gather(torch.tensor([[self.n_roots]], dtype=torch.int64, device=dev)).reshape(-1)
         self.sizes = [int(x) for x in sizes.tolist()]
+        if max(self.sizes) == 0:
+            raise ValueError("ShardedRaht: the scene is empty on every rank")
         self.slot = max(self.sizes)                             # rows per rank in the gather buffers
         self.offset = sum(self.sizes[:self.rank])               # this rank's first entry in the top tree
         directory = torch.zeros((self.slot, 2), dtype=torch.int64, device=dev)
@@ -209,8 +218,32 @@ class ShardedRaht:
 
     def _root_positions(self):
         if self._root_pos is None:
-            self._root_pos = self.plan.inv_order[self.root_rows].contiguous()
+            self._root_pos = self.plan.inv_order[self.root_rows].contiguous() if self.plan is not None else self.root_rows
         return self._root_pos
+
+    # ---- timing of the two collectives of a step (bench.py) ---------------------------------------
+    def time_collectives(self, on):
+        """on: record an event pair on the current stream around each all-gather of the steps that follow."""
+        self._ev = {"fwd": [], "inv": []} if on else None
+
+    def collective_ms(self):
+        """-> (forward, inverse) mean milliseconds between the events recorded since time_collectives(True)."""
+        torch.cuda.synchronize(self.device)
+        out = []
+        for k in ("fwd", "inv"):
+            ev = self._ev[k]
+            out.append(sum(a.elapsed_time(b) for a, b in ev) / max(1, len(ev)))
+            ev.clear()
+        return tuple(out)
+
+    def _gather_roots(self, b, which):
+        if self._ev is None or not b["send"].is_cuda:
+            return self._all_gather(b["send"], out=b["recv"])
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        self._all_gather(b["send"], out=b["recv"])
+        e1.record()
+        self._ev[which].append((e0, e1))
 
     def gathered_bytes_per_step(self, D, elem=4):
         """bytes every rank receives per direction x 2 directions"""
@@ -218,39 +251,48 @@ class ShardedRaht:
 
     # ---- transforms ------------------------------------------------------------------------------
     def _top_forward(self, b):
-        self._all_gather(b["send"], out=b["recv"])
+        self._gather_roots(b, "fwd")
         self.top.forward(b["recv"], want_w=False, out=b["res"])
 
     def _top_inverse(self, b):
-        self._all_gather(b["send"], out=b["recv"])
+        self._gather_roots(b, "inv")
         self.top.inverse(b["recv"], out=b["res"])
 
+    # A rank without rows (self.plan is None) has nothing to transform but still enters both collectives: every
+    # method below reaches _top_forward / _top_inverse whatever N is.
     def forward(self, C):
         """-> T_local: every row holds its coefficient of the WHOLE scene's RAHT."""
         b = self._buffers(C.shape[1], C.dtype)
-        T = self.plan.forward(C, want_w=False, roots=b["send_roots"])
+        T = self.plan.forward(C, want_w=False, roots=b["send_roots"]) if self.plan is not None else torch.empty_like(C)
         self._top_forward(b)
-        self.ops.rows_scatter(b["mine"], self.root_rows, T)
+        if self.n_roots:
+            self.ops.rows_scatter(b["mine"], self.root_rows, T)
         return T
 
     def inverse(self, T):
         b = self._buffers(T.shape[1], T.dtype)
-        self.ops.rows_gather(T, self.root_rows, b["send_roots"])
+        if self.n_roots:
+            self.ops.rows_gather(T, self.root_rows, b["send_roots"])
         self._top_inverse(b)
-        return self.plan.inverse(T, roots=b["mine"])
+        return self.plan.inverse(T, roots=b["mine"]) if self.plan is not None else torch.empty_like(T)
 
     def forward_quant(self, C, step):
         """-> Q_local (int32, rank-local order_RAGFT order); the top coefficients are quantized too."""
         b = self._buffers(C.shape[1], self.qdt)
-        Q = self.plan.forward_quant(C, step, roots=b["send_roots"])
+        Q = (self.plan.forward_quant(C, step, roots=b["send_roots"]) if self.plan is not None
+             else torch.empty(C.shape, dtype=torch.int32, device=C.device))
         self._top_forward(b)
-        self.ops.quant_rows(b["mine"], step, self._root_positions(), Q)
+        if self.n_roots:
+            self.ops.quant_rows(b["mine"], step, self._root_positions(), Q)
         return Q
 
     def dequant_inverse(self, Q, step):
         b = self._buffers(Q.shape[1], self.qdt)
-        self.ops.dequant_rows(Q, step, self._root_positions(), b["send_roots"])
+        if self.n_roots:
+            self.ops.dequant_rows(Q, step, self._root_positions(), b["send_roots"])
         self._top_inverse(b)
+        if self.plan is None:
+            return torch.empty(Q.shape, dtype=self.qdt, device=Q.device)
         return self.plan.dequant_inverse(Q, step, roots=b["mine"])
 
     # ---- bench helpers -----------------------------------------------------------------------------
@@ -259,8 +301,28 @@ class ShardedRaht:
             return self.inverse(self.forward(C))
         return self.dequant_inverse(self.forward_quant(C, quant_step), quant_step)
 
+    def local_step(self, C, quant_step=None):
+        """The shard-local part of step() alone (bench.py: what is left of a step without the exchange): truncated
+        forward (+ quantize) and (dequantize +) inverse, roots through the send / result buffers, NO collective and
+        no top tree. Its output is not a transform of anything; it exists to be timed."""
+        if self.plan is None:
+            return None
+        dt = C.dtype if quant_step is None else self.qdt
+        b = self._buffers(C.shape[1], dt)
+        if quant_step is None:
+            return self.plan.inverse(self.plan.forward(C, want_w=False, roots=b["send_roots"]), roots=b["mine"])
+        return self.plan.dequant_inverse(self.plan.forward_quant(C, quant_step, roots=b["send_roots"]), quant_step, roots=b["mine"])
+
+    def top_only(self, D, dtype=torch.float32):
+        """The replicated top tree of both directions on whatever the buffers hold (bench.py: timed alone)."""
+        b = self._buffers(D, dtype)
+        self.top.forward(b["recv"], want_w=False, out=b["res"])
+        self.top.inverse(b["recv"], out=b["res"])
+
     def roundtrip_error(self, C):
         R = self.inverse(self.forward(C))
+        if self.N == 0:
+            return 0.0
         return float(((R - C).abs().max() / C.abs().max()).item())
 
     def _gather_var(self, x):
@@ -288,25 +350,28 @@ class ShardedRaht:
         mine = slice(n_before, n_before + self.N)
         T = self.forward(C)
         colmax = Tf.abs().amax(dim=0).clamp_min(1e-30)
-        rel = float(((T - Tf[mine]).abs().amax(dim=0) / colmax).max().item())
+        rel = float(((T - Tf[mine]).abs().amax(dim=0) / colmax).max().item()) if self.N else 0.0
         out = {"kind": "sharded == unsharded (whole scene gathered and transformed on every rank)", "rows_total": int(allk.shape[0]),
                "max_rel_err_T_vs_unsharded": rel, "ok": rel <= 4e-6}
         if quant_step is not None:
             Q = self.forward_quant(C, quant_step)
-            Tq = torch.empty_like(T)
-            Tq[self.plan.order_RAGFT] = Q.to(T.dtype) * quant_step
-            # dequantized integers sit within half a step (+ the coefficient error) of the unsharded coefficients
-            worst = float(((Tq - Tf[mine]).abs() - 4e-6 * colmax).max().item())
-            out["max_dequantized_distance_over_step"] = worst / quant_step
-            out["ok"] = out["ok"] and worst <= 0.5 * quant_step * 1.0001
             R = self.dequant_inverse(Q, quant_step)
-            out["quantized_roundtrip_max_err_over_step"] = float((R - C).abs().max().item()) / quant_step
+            if self.N:
+                Tq = torch.empty_like(T)
+                Tq[self.plan.order_RAGFT] = Q.to(T.dtype) * quant_step
+                # dequantized integers sit within half a step (+ the coefficient error) of the unsharded coefficients
+                worst = float(((Tq - Tf[mine]).abs() - 4e-6 * colmax).max().item())
+                out["max_dequantized_distance_over_step"] = worst / quant_step
+                out["ok"] = out["ok"] and worst <= 0.5 * quant_step * 1.0001
+                out["quantized_roundtrip_max_err_over_step"] = float((R - C).abs().max().item()) / quant_step
         if self.world > 1:
             flag = torch.tensor([[1 if out["ok"] else 0]], dtype=torch.int64, device=C.device)
             out["ok"] = bool(self._all_gather(flag).min().item() == 1)
         return out
 
     def plan_keys(self):
+        if self.plan is None:
+            return torch.empty(0, dtype=torch.int64, device=self.device)
         ks = getattr(self.plan, "keys_tensor", None)
         if ks is None:
             raise ValueError("pass keys_sorted")

@@ -39,6 +39,11 @@ def _cases():
     return {"cfg2": synth.CONFIGS["cfg2"], "cfg3": synth.CONFIGS["cfg3"], "cfg4_6M": (6_000_000, 12, 59, 11)}
 
 
+# measured attribute-channel mismatch rates at step 0.01 (GPUTEST r03): cfg3 7.9e-7; the SH0 scenes (cfg2) carry
+# O(1) coefficients in every channel, so their float32 error per step is larger
+_RATE_SLACK = {"cfg2": 8.0}
+
+
 def _col_stats(T32, T64):
     """per-column max / rms error of a float32 result against the float64 oracle, blockwise (bounded temporaries)"""
     N, D = T64.shape
@@ -116,14 +121,35 @@ def test_full_scene_matches_oracle(rt, oracle, name):
         a0 = 3 if D in (14, 59) else 0
         assert int((bad[1] >= a0).sum()) <= 1e-6 * Qo.size + 2, (name, step, int((bad[1] >= a0).sum()))
         del Q64
-        # float32 fused kernel against the float64 oracle: the bound the float32 coefficient error implies
+        # float32 fused kernel against the float64 oracle. SURVEY 8c: "mismatch rate <= 1e-6 and each mismatch = +-1" was
+        # sized on step-1 data; what float32 can deliver at ANY step is derived from its coefficient error:
+        #   (a) per element |dQ| <= 1 + (|T32 - T64| + 1.2e-7 |T64|) / step  (coefficient error + the float32 quotient's
+        #       rounding, both in units of the step; on the xyz columns |T| reaches 1e6, so |T| / step > 2^24 at step 0.01
+        #       and float32 integers cannot be exact there: include/raht.h tells callers to use raht_fwd_quant_f64 then);
+        #   (b) the NUMBER of differing integers: an integer differs when a rounding boundary falls between the two
+        #       quotients, which for a quotient spread over many integers happens with probability |T32 - T64| / step --
+        #       so the count must stay near sum(|dT|) / step. A rounding-mode or +0.5 mistake flips ~every integer.
         Q32 = plan.forward_quant(Cd, step).cpu().numpy()
-        lim = 1.0 + (np.abs(T32.astype(np.float64) - To) + 1.2e-7 * np.abs(To))[order] / step
+        dT = np.abs(T32.astype(np.float64) - To)[order]
+        lim = 1.0 + (dT + 1.2e-7 * np.abs(To)[order]) / step
         dq = np.abs(Q32.astype(np.int64) - Qo.astype(np.int64))
         assert np.all(dq <= lim), (name, step, int((dq > lim).sum()))
-        # attribute channels (not the xyz columns, whose coefficients reach 1e6): almost every integer equal
-        rate = float((dq[:, a0:] != 0).mean())
-        assert rate <= (2e-4 if step < 0.1 else 2e-6), (name, step, rate)
+        # attribute channels (not the xyz columns): mismatches are +-1, and as many as the coefficient error predicts
+        nz = dq[:, a0:] != 0
+        n_bad = int(nz.sum())
+        expected = float(dT[:, a0:].sum() / step)
+        rate = n_bad / nz.size
+        print(f"[fullsize] {name} step {step}: attribute-channel integer mismatches {n_bad} of {nz.size} (rate {rate:.3g}); "
+              f"sum|dT|/step predicts {expected:.1f}; xyz columns max |dQ| {int(dq[:, :a0].max()) if a0 else 0}")
+        assert np.all(dq[:, a0:] <= 1), (name, step, int(dq[:, a0:].max()))
+        assert n_bad <= 1.5 * expected + 6.0 * np.sqrt(expected) + 5, (name, step, n_bad, expected)
+        assert rate <= 2e-6 * max(1.0, 0.01 / step) * _RATE_SLACK.get(name, 1.0), (name, step, rate)
+        if a0:
+            # xyz columns: reported on their own, every element inside (a); at step 1 the coefficients' quotients stay
+            # below 2^24 and almost every integer agrees
+            xyz_rate = float((dq[:, :a0] != 0).mean())
+            assert step < 0.1 or xyz_rate <= 1e-3, (name, step, xyz_rate)
+        del dT, nz
         del lim, dq, Q32
         # ... and back, from the ORACLE's integers: dequantize + un-reorder + inverse (encode_3dgs.py:261,267-268,274)
         Cq = plan.dequant_inverse(_dev(Qo), step)

@@ -239,3 +239,111 @@ def test_rccl_one_rank_group_carries_the_gathers(rt):
     msg = q.get(timeout=600)
     p.join(timeout=120)
     assert msg == "ok", msg
+
+
+# ------------------------------------------------------------------ bench.py starts its own ranks
+def _run_bench(args, timeout=900):
+    """`python bench.py ...` as a PLAIN subprocess (no launcher around it), the way the driver starts the 1-GPU bench."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True, timeout=timeout, env=env, cwd=ROOT)
+    assert r.returncode == 0, f"bench.py {' '.join(args)} -> rc {r.returncode}\n{r.stdout[-2000:]}\n{r.stderr[-4000:]}"
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_gpus_2_spawns_its_own_ranks(rt):
+    """`python bench.py --gpus 2 ...` with no launcher: bench.py starts the two ranks itself (before it touches the GPU),
+    relays rank 0's line and the children's status. gloo, both ranks on this box's one GPU: a strong-scaling cut of a small
+    cfg5 scene; the line says how many ranks the collective backend saw and separates the exchange from the local work."""
+    out = _run_bench(["--gpus", "2", "--backend", "gloo", "--workload", "cfg5", "--rows", "400000", "--steps", "3", "--warmup", "1",
+                      "--settle-steps", "0"])
+    assert out["n_gpus"] == 2 and out["scaling"] == "strong" and out["value"] > 0
+    assert out["oracle_gate"]["ok"] and out["oracle_gate"]["rows_total"] > out["config"]["rows_per_gpu"]
+    mg = out["multi_gpu"]
+    assert mg["ranks"] == 2 and mg["collective_backend"] == "gloo" and mg["rccl_world"] is None
+    assert mg["collective_ms"]["forward_all_gather"] > 0 and mg["collective_ms"]["inverse_all_gather"] > 0
+    assert 0 < mg["local_step_ms"] and mg["gathered_bytes_per_step"] == out["config"]["gathered_bytes_per_step"] > 0
+    assert 0 < mg["roofline_stage0"]["fwd_frac"] < 1 and 0 < mg["roofline_stage0"]["inv_frac"] < 1
+
+
+def test_bench_one_rank_rccl_group(rt):
+    """The same path through RCCL, as far as one GPU goes: --sharded runs ShardedRaht in a one-rank NCCL group."""
+    out = _run_bench(["--gpus", "1", "--backend", "nccl", "--sharded", "--workload", "cfg5", "--rows", "400000", "--steps", "3", "--warmup", "1",
+                      "--settle-steps", "0"])
+    assert out["n_gpus"] == 1 and out["value"] > 0 and out["oracle_gate"]["ok"]
+    mg = out["multi_gpu"]
+    assert mg["rccl_world"] == 1 and mg["collective_backend"] == "nccl"
+    assert mg["collective_ms"]["forward_all_gather"] > 0
+
+
+def _empty_rank_main(rank, world, port, q):
+    """Three gloo ranks on the one GPU; the scene occupies prefixes [0, 300) only, so the last rank owns no row, and rank 1
+    starts the exchange with no point: HIP local ops with N = 0, every collective still entered by every rank."""
+    try:
+        sys.path.insert(0, ROOT)
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(0)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        import raht_3dgs_codec_amd as R
+        from raht_3dgs_codec_amd import sharded, synth
+        J, D = 8, 14
+        V, keys, C = synth.scene(40000, J, D, seed=5, prefix_range=(0, 300, 9))
+        pref = (keys >> np.uint64(3 * J - 9)).astype(np.int64)
+        per = 512 // world
+        lo, hi = rank * per, ((rank + 1) * per if rank < world - 1 else 512)
+        mine = np.nonzero((pref >= lo) & (pref < hi))[0]
+        assert (mine.size == 0) == (rank == world - 1)
+        kd = torch.from_numpy(keys[mine].view(np.int64).copy()).cuda()
+        Cd = torch.from_numpy(C[mine]).cuda()
+        sh = sharded.ShardedRaht(kd, 3 * J, prefix_bits=9)
+        full = R.RahtPlan.from_keys(torch.from_numpy(keys.view(np.int64).copy()).cuda(), 3 * J)
+        Tf = full.forward(torch.from_numpy(C).cuda(), want_w=False)
+        T = sh.forward(Cd)
+        if mine.size:
+            scale = Tf.abs().amax(dim=0)
+            assert bool(((T - Tf[mine[0]: mine[-1] + 1]).abs().amax(dim=0) <= 4e-6 * scale).all())
+        else:
+            assert sh.plan is None and tuple(T.shape) == (0, D)
+        Rr = sh.step(Cd, 0.01)
+        assert tuple(Rr.shape) == tuple(Cd.shape)
+        chk = sh.check_against_unsharded(Cd, 0.01, keys_sorted=kd)
+        assert chk["ok"], chk
+        # front end: rank 1 holds no point before the exchange
+        n = 30000
+        rng = np.random.default_rng(4)
+        P = (synth.blob_positions(n, seed=3, nblobs=10, sigma=0.05) * 5.0).astype(np.float32)
+        PC = np.concatenate([P, rng.standard_normal((n, 3)).astype(np.float32)], axis=1)
+        bounds = [0, n // 2, n // 2, n]
+        part = torch.from_numpy(PC[bounds[rank]:bounds[rank + 1]].copy()).cuda()
+        PCvox, vkeys, info = sharded.exchange_by_prefix(part, 7, prefix_bits=9)
+        cnt = torch.tensor([PCvox.shape[0]], dtype=torch.int64)
+        dist.all_reduce(cnt)
+        from oracle import oracle as orc
+        assert int(cnt.item()) == orc.voxelize(PC, 7)["Nvox"] and info["N_global"] == n
+        dist.barrier()
+        dist.destroy_process_group()
+        q.put((rank, "ok"))
+    except Exception:
+        q.put((rank, traceback.format_exc()))
+
+
+def test_rank_without_rows_on_the_gpu(rt):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    world = 3
+    procs = [ctx.Process(target=_empty_rank_main, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=600) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=120)
+    for rank, msg in res:
+        assert msg == "ok", f"rank {rank}:\n{msg}"

@@ -27,7 +27,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, J, n, D, q, balanced=False):
+def _worker(rank, world, port, J, n, D, q, balanced=False, prefix_range=None):
     try:
         sys.path.insert(0, ROOT)
         os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -37,7 +37,8 @@ def _worker(rank, world, port, J, n, D, q, balanced=False):
         from tests.numpy_ops import NumpyLocalOps
         from oracle import oracle as orc
 
-        V, keys, C = synth.scene(n, J, D, seed=77)            # the whole scene, same on every rank
+        # the whole scene, same on every rank (prefix_range: only part of the cube is occupied -> some ranks own no row)
+        V, keys, C = synth.scene(n, J, D, seed=77, prefix_range=prefix_range)
         nbits, pb = 3 * J, 9
         if balanced:
             # shards cut by the population-balanced helper (512-bin prefix histogram)
@@ -48,7 +49,7 @@ def _worker(rank, world, port, J, n, D, q, balanced=False):
             per = (1 << pb) // world
             lo, hi = rank * per, ((rank + 1) * per if rank < world - 1 else 1 << pb)
             mine = np.nonzero((pref >= lo) & (pref < hi))[0]
-        assert mine.size > 0 and np.all(np.diff(mine) == 1)
+        assert (mine.size > 0 or prefix_range is not None) and np.all(np.diff(mine) == 1)
         k_loc = torch.from_numpy(keys[mine].view(np.int64).copy())
         C_loc = torch.from_numpy(C[mine].astype(np.float64))
 
@@ -68,12 +69,17 @@ def _worker(rank, world, port, J, n, D, q, balanced=False):
         step = 0.05
         Q = sh.forward_quant(C_loc, step)
         Tq = torch.empty_like(T)
-        Tq[sh.plan.order_RAGFT] = Q.to(torch.float64) * step
-        ref = np.floor(To[mine] / step + 0.5) * step
-        bad = np.abs(Tq.numpy() - ref) > 1e-9
-        assert bad.mean() < 1e-4            # only rounding ties may differ
+        if mine.size:
+            Tq[sh.plan.order_RAGFT] = Q.to(torch.float64) * step
+            ref = np.floor(To[mine] / step + 0.5) * step
+            bad = np.abs(Tq.numpy() - ref) > 1e-9
+            assert bad.mean() < 1e-4            # only rounding ties may differ
+        else:
+            assert sh.plan is None and tuple(Q.shape) == (0, D) and tuple(T.shape) == (0, D)
         Rq = sh.dequant_inverse(Q, step)
-        assert float((Rq - C_loc).abs().max()) < 40 * step
+        assert mine.size == 0 or float((Rq - C_loc).abs().max()) < 40 * step
+        chk = sh.check_against_unsharded(C_loc, step, keys_sorted=k_loc)
+        assert chk["ok"], chk
         # orthonormal transform: global error energy == global quantization error energy
         e_loc = torch.tensor([float(((Rq - C_loc) ** 2).sum()), float(((Tq - T) ** 2).sum())], dtype=torch.float64)
         dist.all_reduce(e_loc)
@@ -101,7 +107,24 @@ def test_sharded_matches_unsharded_oracle(world, J, n, D, balanced):
         assert msg == "ok", f"rank {rank}:\n{msg}"
 
 
-def _worker_frontend(rank, world, port, J, n, d, q):
+@pytest.mark.parametrize("world,J,n,D,prefix_range", [(3, 6, 3000, 5, (0, 300, 9)), (2, 5, 1500, 3, (256, 512, 9)), (3, 6, 2000, 4, (200, 320, 9))])
+def test_rank_without_rows_still_joins_the_collectives(world, J, n, D, prefix_range):
+    """A prefix range that holds no point (uneven scenes; fewer occupied prefixes than ranks): that rank has no plan and
+    no roots but must enter every collective -- round 2 raised on it and left the other ranks blocked."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, J, n, D, q, False, prefix_range)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, msg in res:
+        assert msg == "ok", f"rank {rank}:\n{msg}"
+
+
+def _worker_frontend(rank, world, port, J, n, d, q, empty_rank=-1):
     """Un-partitioned input: every rank holds an arbitrary third / half of an unsorted cloud with duplicates.
     exchange_by_prefix + ShardedRaht must reproduce the single-process pipeline on the WHOLE cloud:
     oracle voxelizer (reference voxelize_pc.py:62-172) -> oracle RAHT."""
@@ -121,6 +144,9 @@ def _worker_frontend(rank, world, port, J, n, d, q):
         PC = np.concatenate([P, A], axis=1)
         # arbitrary, uneven parts in rank order (their concatenation is the whole cloud)
         bounds = [0] + sorted(rng.choice(np.arange(1, n), size=world - 1, replace=False).tolist()) + [n]
+        if empty_rank >= 0:                                           # one rank starts with no point at all
+            bounds[empty_rank + 1] = bounds[empty_rank]
+            bounds = sorted(bounds)
         mine = torch.from_numpy(PC[bounds[rank]:bounds[rank + 1]].copy())
 
         PCvox, keys, info = sharded.exchange_by_prefix(mine, J, prefix_bits=9, local_ops=NumpyLocalOps)
@@ -157,14 +183,14 @@ def _worker_frontend(rank, world, port, J, n, d, q):
         q.put((rank, traceback.format_exc()))
 
 
-@pytest.mark.parametrize("world,J,n,d", [(2, 6, 5000, 3), (3, 8, 7000, 5)])
-def test_unpartitioned_cloud_exchange_then_sharded_transform(world, J, n, d):
+@pytest.mark.parametrize("world,J,n,d,empty_rank", [(2, 6, 5000, 3, -1), (3, 8, 7000, 5, -1), (3, 6, 4000, 3, 1), (2, 6, 3000, 2, 0)])
+def test_unpartitioned_cloud_exchange_then_sharded_transform(world, J, n, d, empty_rank):
     """all-to-all bucket exchange by 9-bit Morton prefix + local radix sort / voxelizer, against the
     oracle's sort of the whole cloud (reference python/voxelize_pc.py:97-118)."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker_frontend, args=(r, world, port, J, n, d, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker_frontend, args=(r, world, port, J, n, d, q, empty_rank)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=240) for _ in range(world)]
