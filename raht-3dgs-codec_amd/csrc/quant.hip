@@ -310,11 +310,11 @@ int raht_dequant_unreorder_f64(const raht_plan *p, const int32_t *Q, int64_t ldq
 int raht_quant_rows(const float *X, int64_t ldx, int64_t n, int D, const float *steps, int n_steps,
                     const int64_t *pos, int32_t *Q, int64_t ldq, raht_stream_t stream)
 {
-    if (n < 0 || D < 1 || ldx < D || ldq < D) { set_error("raht_quant_rows: bad argument"); return RAHT_ERR_INVALID; }
+    if (n < 0 || D < 1) { set_error("raht_quant_rows: bad argument"); return RAHT_ERR_INVALID; }
     StepTable st;
     RAHT_RET(fill_steps(st, steps, n_steps, D));
-    if (n == 0) return RAHT_OK;                              // no rows: no buffers needed (empty device tensors are NULL)
-    if (!X || !Q) { set_error("raht_quant_rows: NULL argument"); return RAHT_ERR_INVALID; }
+    if (n == 0) return RAHT_OK;                              // no rows: no buffers needed (empty device tensors are NULL, their strides 0)
+    if (!X || !Q || ldx < D || ldq < D) { set_error("raht_quant_rows: bad argument"); return RAHT_ERR_INVALID; }
     const unsigned gb = (unsigned)std::min<int64_t>(ceil_div(n, 4), 4096);
     hipLaunchKernelGGL(quant_rows_kernel, dim3(gb), dim3(256), 0, (hipStream_t)stream, X, ldx, n, D, pos, st, Q, ldq);
     RAHT_HIP_CHECK(hipGetLastError());
@@ -324,11 +324,11 @@ int raht_quant_rows(const float *X, int64_t ldx, int64_t n, int D, const float *
 int raht_dequant_rows(const int32_t *Q, int64_t ldq, const int64_t *pos, int64_t n, int D, const float *steps,
                       int n_steps, float *X, int64_t ldx, raht_stream_t stream)
 {
-    if (n < 0 || D < 1 || ldx < D || ldq < D) { set_error("raht_dequant_rows: bad argument"); return RAHT_ERR_INVALID; }
+    if (n < 0 || D < 1) { set_error("raht_dequant_rows: bad argument"); return RAHT_ERR_INVALID; }
     StepTable st;
     RAHT_RET(fill_steps(st, steps, n_steps, D));
     if (n == 0) return RAHT_OK;
-    if (!X || !Q) { set_error("raht_dequant_rows: NULL argument"); return RAHT_ERR_INVALID; }
+    if (!X || !Q || ldx < D || ldq < D) { set_error("raht_dequant_rows: bad argument"); return RAHT_ERR_INVALID; }
     const unsigned gb = (unsigned)std::min<int64_t>(ceil_div(n, 4), 4096);
     hipLaunchKernelGGL(dequant_rows_kernel, dim3(gb), dim3(256), 0, (hipStream_t)stream, Q, ldq, pos, n, D, st, X, ldx);
     RAHT_HIP_CHECK(hipGetLastError());
@@ -338,9 +338,9 @@ int raht_dequant_rows(const int32_t *Q, int64_t ldq, const int64_t *pos, int64_t
 static int rows_move(bool scatter, const void *src, int64_t ld_src, const int64_t *pos, int64_t n, int D, int elem_size,
                      void *dst, int64_t ld_dst, raht_stream_t stream, const char *what)
 {
-    if (n < 0 || D < 1 || ld_src < D || ld_dst < D || (elem_size != 4 && elem_size != 8)) { set_error("%s: bad argument", what); return RAHT_ERR_INVALID; }
-    if (n == 0) return RAHT_OK;                              // no rows: no buffers needed (empty device tensors are NULL)
-    if (!src || !dst || !pos) { set_error("%s: NULL argument", what); return RAHT_ERR_INVALID; }
+    if (n < 0 || D < 1 || (elem_size != 4 && elem_size != 8)) { set_error("%s: bad argument", what); return RAHT_ERR_INVALID; }
+    if (n == 0) return RAHT_OK;                              // no rows: no buffers needed (empty device tensors are NULL, their strides 0)
+    if (!src || !dst || !pos || ld_src < D || ld_dst < D) { set_error("%s: bad argument", what); return RAHT_ERR_INVALID; }
     const int wpe = elem_size / 4;
     const unsigned gb = (unsigned)std::min<int64_t>(ceil_div(n, 4), 4096);
     if (scatter)

@@ -364,9 +364,10 @@ int raht_sort_keys(const uint64_t *keys_in, int64_t N, int nbits, uint64_t *keys
 int raht_voxel_keys(const float *PC, int64_t ldpc, int64_t N, const float vmin[3], double width, int J,
                     uint64_t *keys, raht_stream_t stream)
 {
-    if (!vmin || N < 0 || ldpc < 3 || J < 1 || J > 21 || !(width > 0)) { set_error("raht_voxel_keys: bad argument"); return RAHT_ERR_INVALID; }
-    if (N == 0) return RAHT_OK;                              // empty rank of a sharded cloud: nothing to do, no buffers needed
-    if (!PC || !keys) { set_error("raht_voxel_keys: NULL argument"); return RAHT_ERR_INVALID; }
+    if (!vmin || N < 0 || J < 1 || J > 21 || !(width > 0)) { set_error("raht_voxel_keys: bad argument"); return RAHT_ERR_INVALID; }
+    if (N == 0) return RAHT_OK;                              // empty rank of a sharded cloud: nothing to do; an empty tensor has
+                                                             // neither a data pointer nor meaningful strides
+    if (!PC || !keys || ldpc < 3) { set_error("raht_voxel_keys: bad argument"); return RAHT_ERR_INVALID; }
     const float vs = (float)(width / (double)((uint64_t)1 << J));        // voxelize_pc.py:97, as raht_voxelize
     hipLaunchKernelGGL(vox_keys_kernel, dim3((unsigned)ceil_div(N, 256 * 4)), dim3(256), 0, (hipStream_t)stream, PC, ldpc, N,
                        vmin[0], vmin[1], vmin[2], vs, J, keys);

@@ -403,6 +403,8 @@ def _steps64(steps, D):
 def quant_rows(X, steps, pos, Q):
     """Q[pos[i], :] = floor(X[i, :] / step + 0.5) in place (X float32 (n, D), pos int64 (n,), Q int32)."""
     _need_cuda(X, "X")
+    if X.shape[0] == 0:
+        return Q
     X = X.to(torch.float32).contiguous()
     n, D = X.shape
     st = _steps(steps, D)
@@ -434,6 +436,8 @@ def dequant_rows(Q, steps, pos, out=None):
 
 def _rows_move(fn, src, pos, dst):
     _need_cuda(src, "src")
+    if pos.shape[0] == 0:                     # nothing to move (an empty rank of a sharded scene); empty tensors have no strides to check
+        return dst
     if src.dtype != dst.dtype or src.dtype not in (torch.float32, torch.float64, torch.int32) or src.stride(1) != 1 or dst.stride(1) != 1:
         raise ValueError("rows: float32 / float64 / int32 matrices with contiguous rows of one dtype")
     if pos.dtype != torch.int64 or not pos.is_contiguous():
