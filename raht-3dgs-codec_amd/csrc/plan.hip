@@ -451,6 +451,7 @@ static void free_schedule(Schedule &sc)
         if (st.e_wl) dev_free(st.e_wl);
         if (st.e_wr) dev_free(st.e_wr);
         if (st.e_lvl) dev_free(st.e_lvl);
+        if (st.e_ht) dev_free(st.e_ht);
         if (st.e_pos) dev_free(st.e_pos);
         if (st.t_pj) dev_free(st.t_pj);
         if (st.t_ab32) dev_free(st.t_ab32);
@@ -496,6 +497,87 @@ __global__ void gather_meta_kernel(const uint32_t *__restrict__ rows, int64_t n,
     if (j >= n) return;
     const uint32_t r = rows[j];
     e_wl[j] = wl[r]; e_wr[j] = wr[r]; e_lvl[j] = lvl[r]; e_pos[j] = inv_order[r];
+}
+
+// ---- butterfly heights of a tile stage ------------------------------------------------------------
+// One wave per tile (R <= 1024 entries). The recurrence is the forward transform's own order: walk the binary levels
+// present in the tile upwards; a butterfly (partner p, own slot j) gets h = 1 + max(cur[p], cur[j]) and leaves it in
+// cur[p], the slot that carries the merged node on. Butterflies of one level touch disjoint slots. What "merged in this
+// tile" means is the tile kernel's own predicate (transform.hip, P1).
+constexpr int HT_MAX_ROWS = 1024;
+__global__ __launch_bounds__(64) void tile_heights_kernel(const uint32_t *__restrict__ rows, int64_t n, int R, int64_t N,
+                                                          const int32_t *__restrict__ wl, const int32_t *__restrict__ wr,
+                                                          const uint8_t *__restrict__ lvl, int top_level, uint8_t *__restrict__ ht)
+{
+    __shared__ uint32_t s_row[HT_MAX_ROWS];
+    __shared__ uint16_t s_part[HT_MAX_ROWS];
+    __shared__ uint8_t s_lv[HT_MAX_ROWS], s_cur[HT_MAX_ROWS], s_ht[HT_MAX_ROWS];
+    const int lane = threadIdx.x;
+    const int64_t e0 = (int64_t)blockIdx.x * R;
+    if (e0 >= n) return;
+    const int nt = (int)min((int64_t)R, n - e0);
+    const int64_t start_row = rows ? (int64_t)rows[e0] : e0;
+    const int64_t end_row = (e0 + R < n) ? (rows ? (int64_t)rows[e0 + R] : e0 + R) : N;
+    if (rows) for (int j = lane; j < nt; j += 64) s_row[j] = rows[e0 + j];
+    __syncthreads();
+    uint64_t mask = 0;
+    for (int j = lane; j < nt; j += 64) {
+        const int64_t r = rows ? (int64_t)s_row[j] : e0 + j;
+        const int l = (int)lvl[e0 + j];
+        const int32_t wlv = wl[e0 + j], wrv = wr[e0 + j];
+        const bool merged = (r > 0) && (l < top_level) && (r - wlv >= start_row) && (r + wrv <= end_row);
+        int p = 0;
+        if (merged) {
+            if (!rows) p = j - wlv;
+            else {                                          // the partner row r - wl is an entry of this tile
+                const uint32_t want = (uint32_t)(r - wlv);
+                int lo = 0, hi = j - 1;
+                while (lo < hi) { const int mid = (lo + hi) >> 1; if (s_row[mid] < want) lo = mid + 1; else hi = mid; }
+                p = lo;
+            }
+            mask |= (uint64_t)1 << l;
+        }
+        s_lv[j] = merged ? (uint8_t)l : (uint8_t)255;
+        s_part[j] = (uint16_t)p;
+        s_cur[j] = 0;
+        s_ht[j] = 0;
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)mask, d, 64), hi = (uint32_t)__shfl_xor((int)(uint32_t)(mask >> 32), d, 64);
+        mask |= (uint64_t)lo | ((uint64_t)hi << 32);
+    }
+    __syncthreads();
+    while (mask) {
+        const int l = __ffsll((unsigned long long)mask) - 1;
+        mask &= mask - 1;
+        for (int j = lane; j < nt; j += 64) {
+            if (s_lv[j] == (uint8_t)l) {
+                const int p = s_part[j];
+                const uint8_t h = (uint8_t)(1 + max((int)s_cur[p], (int)s_cur[j]));
+                s_ht[j] = h;
+                s_cur[p] = h;
+            }
+        }
+        __syncthreads();                                    // one wave: orders the LDS traffic of consecutive levels
+    }
+    for (int j = lane; j < nt; j += 64) ht[e0 + j] = s_ht[j];
+}
+
+// heights of every tile stage of a finished schedule (sizes are known on the host by now; enqueued, not waited for:
+// the transforms that read them run behind this on the same stream)
+static int launch_stage_heights(raht_plan *plan, Schedule &sc, hipStream_t s)
+{
+    for (size_t k = 0; k < sc.stages.size(); ++k) {
+        Stage &st = sc.stages[k];
+        if (st.is_top || st.n_entries < 1) continue;
+        if (st.tile_rows > HT_MAX_ROWS) { set_error("tile_rows %d: heights support at most %d rows per tile", st.tile_rows, HT_MAX_ROWS); return RAHT_ERR_UNSUPPORTED; }
+        if (!st.e_ht) RAHT_HIP_CHECK(dev_malloc(&st.e_ht, (size_t)st.n_entries));
+        hipLaunchKernelGGL(tile_heights_kernel, dim3((unsigned)st.n_tiles), dim3(64), 0, s, st.rows, st.n_entries, st.tile_rows, plan->N,
+                           st.rows ? st.e_wl : plan->wl, st.rows ? st.e_wr : plan->wr, st.rows ? st.e_lvl : plan->lvl, plan->top_level, st.e_ht);
+    }
+    RAHT_HIP_CHECK(hipGetLastError());
+    return RAHT_OK;
 }
 
 // ---- TOP stage: every butterfly still to do, resolved against the stage's entry list ----------------
@@ -1088,6 +1170,8 @@ int get_schedule(raht_plan *plan, int R0, int R1, int Rf, hipStream_t s, Schedul
         bool built = false;
         RAHT_RET(build_schedule_fast(plan, R0, R1, Rf, s, sc, &built));
         if (built) {
+            const int rch = launch_stage_heights(plan, sc, s);
+            if (rch != RAHT_OK) { free_schedule(sc); return rch; }
             plan->schedules.push_back(sc);
             *out = &plan->schedules.back();
             return RAHT_OK;
@@ -1166,6 +1250,10 @@ static int get_schedule_exact(raht_plan *plan, int R0, int R1, int Rf, hipStream
         free_schedule(sc);
         set_error("schedule build failed");
         return rc;
+    }
+    if (sc.valid) {
+        rc = launch_stage_heights(plan, sc, s);
+        if (rc != RAHT_OK) { free_schedule(sc); return rc; }
     }
     plan->schedules.push_back(sc);                   // std::deque: earlier schedules keep their addresses
     *out = &plan->schedules.back();

@@ -168,6 +168,13 @@ struct Stage {
     int32_t *e_wl = nullptr, *e_wr = nullptr;
     uint8_t *e_lvl = nullptr;
     uint32_t *e_pos = nullptr;
+    // tile stages (stage 0 included): HEIGHT of every entry's butterfly inside its tile's merge tree (1 = both children are
+    // single entries; 0 = the entry survives the tile). The tile kernels run their butterfly rounds by height, not by
+    // binary level: a butterfly's height is 1 + the larger height of its two children, so rounds by ascending height
+    // respect every dependency, butterflies of one height are independent, and a tile needs as many rounds as its tree
+    // is high (9.3 on average at 184 rows) instead of one per binary level present (13.9). Heights are < 64: levels
+    // strictly increase along a dependency chain.
+    uint8_t *e_ht = nullptr;
     // TOP stage (the last one, when at most `top_rows` entries are left): ONE launch of top_kernel
     // finishes the tree. A workgroup per 16-byte channel chunk keeps all entries in LDS and walks
     // the butterflies level by level from this precomputed list, sorted by level:

@@ -151,6 +151,7 @@ struct TileArgs {
                          // butterflies, 2 = skip merge resolution too (pure staged copy). The product build
                          // compiles TILE_DBG to the constant 0: its kernels carry no ablation branches.
     const uint8_t *lvl;
+    const uint8_t *ht;   // entry-ordered: height of the entry's butterfly inside its tile (Stage::e_ht); keys the rounds
     const int32_t *wl;
     const int32_t *wr;
     const int64_t *wsum;
@@ -178,7 +179,7 @@ constexpr int TILE_PRE_ROWS = 12;      // survivor rows prefetched by the invers
 template <int SLOTS>
 struct TileMeta {
     int32_t row[SLOTS], wl[SLOTS], wr[SLOTS], pos[SLOTS];
-    int lv[SLOTS];
+    int lv[SLOTS], ht[SLOTS];
     int64_t start_row, end_row;
     uint32_t surv_raw;                 // lane l holds surv_off[t + (l & 1)]: a lane-dependent load, so that hipcc
                                        // does not scalarise it on the spot (s_waitcnt + v_readfirstlane right
@@ -198,7 +199,7 @@ __device__ __forceinline__ void load_tile_meta(const TileArgs<T> &A, int64_t t, 
 #pragma unroll
     for (int s = 0; s < SLOTS; ++s) {
         const int j = tid + s * nthreads;
-        M.row[s] = 0; M.wl[s] = 0; M.wr[s] = 0; M.lv[s] = 0; M.pos[s] = 0;
+        M.row[s] = 0; M.wl[s] = 0; M.wr[s] = 0; M.lv[s] = 0; M.ht[s] = 0; M.pos[s] = 0;
         if (j < nt) {
             // A.wl / wr / lvl / inv_order are ENTRY-ordered for this stage (stage 0: entry = row,
             // the plan arrays themselves; later stages: per-stage gathered copies), so all five
@@ -208,6 +209,7 @@ __device__ __forceinline__ void load_tile_meta(const TileArgs<T> &A, int64_t t, 
             M.wl[s] = A.wl[e0 + j];
             M.wr[s] = A.wr[e0 + j];
             M.lv[s] = A.lvl[e0 + j];
+            M.ht[s] = A.ht[e0 + j];
             M.pos[s] = QM ? (int32_t)A.inv_order[e0 + j] : (int32_t)r;    // where the final coefficient lives
         }
     }
@@ -382,10 +384,10 @@ __global__ __launch_bounds__(512, (sizeof(T) == 4 ? 6 : 4)) void tile_kernel(con
     const uint32_t surv_base = (uint32_t)__builtin_amdgcn_readlane((int)M.surv_raw, 0);
     const uint32_t surv_cnt = (uint32_t)__builtin_amdgcn_readlane((int)M.surv_raw, 1) - surv_base;
     int32_t m_row[SLOTS], m_wl[SLOTS], m_wr[SLOTS], m_pos[SLOTS];
-    int m_lv[SLOTS];
+    int m_lv[SLOTS], m_ht[SLOTS];
 #pragma unroll
     for (int s = 0; s < SLOTS; ++s) {
-        m_row[s] = M.row[s]; m_wl[s] = M.wl[s]; m_wr[s] = M.wr[s]; m_pos[s] = M.pos[s]; m_lv[s] = M.lv[s];
+        m_row[s] = M.row[s]; m_wl[s] = M.wl[s]; m_wr[s] = M.wr[s]; m_pos[s] = M.pos[s]; m_lv[s] = M.lv[s]; m_ht[s] = M.ht[s] & 63;
     }
     if (tid < 64) hist[tid] = 0;
 
@@ -476,7 +478,7 @@ __global__ __launch_bounds__(512, (sizeof(T) == 4 ? 6 : 4)) void tile_kernel(con
             // fused forward: bit 31 of the row's place in Q says "final here" (roots of a truncated tree are
             // quantized by the caller's top stage): the write-back needs ONE LDS word per row
             if (QM && !INV) sdst[j] = m_pos[s] | ((m_merged[s] || (A.last_stage && !A.root_buf)) ? (int32_t)0x80000000 : 0);
-            if (m_merged[s]) atomicAdd(&hist[m_lv[s]], 1u);
+            if (m_merged[s]) atomicAdd(&hist[m_ht[s]], 1u);            // rounds are keyed by HEIGHT (raht_common.h, Stage::e_ht)
         }
         if (j < nt && (TILE_DBG(A) & 2)) { sflag[j] = 1; if (QM && !INV) sdst[j] = m_pos[s] | (int32_t)0x80000000; }
         const uint64_t bal = __ballot(surv);
@@ -555,7 +557,7 @@ __global__ __launch_bounds__(512, (sizeof(T) == 4 ? 6 : 4)) void tile_kernel(con
             rec.jo = (uint32_t)__mul24((int)j, Dp);
             rec.a = (T)sqrt(w0 / den);                    // RAHT.py:321-322
             rec.b = (T)sqrt(w1 / den);
-            const uint32_t pos = atomicAdd(&cursor[m_lv[s]], 1u);
+            const uint32_t pos = atomicAdd(&cursor[m_ht[s]], 1u);
             mrec[pos] = rec;
         }
     }
@@ -1135,6 +1137,8 @@ static int launch_stage_impl(const raht_plan *p, const Schedule &sc, int k, cons
     A.wsum = p->wsum;
     if (st.rows) { A.lvl = st.e_lvl; A.wl = st.e_wl; A.wr = st.e_wr; A.inv_order = st.e_pos; }
     else { A.lvl = p->lvl; A.wl = p->wl; A.wr = p->wr; A.inv_order = p->inv_order; }
+    static const bool rounds_by_level = getenv("RAHT_ROUNDS_BY_LEVEL") != nullptr;    // A/B knob: one round per binary level present (rounds 1-2)
+    A.ht = rounds_by_level ? A.lvl : st.e_ht;
     A.Q = io.Q; A.ldq = io.ldq;
     A.top_level = p->top_level; A.root_buf = (T *)p->root_buf;
     A.dbg = dbg;
@@ -1156,7 +1160,7 @@ static int launch_stage_impl(const raht_plan *p, const Schedule &sc, int k, cons
     // tile stage has no stage above it (wsn == nullptr): its survivors are the roots.
     {
         const char *bad = nullptr;
-        if (!A.lvl || !A.wl || !A.wr) bad = "plan arrays";
+        if (!A.lvl || !A.wl || !A.wr || !A.ht) bad = "plan arrays";
         else if (!A.last_stage && (!A.wsn || !A.surv_off)) bad = "survivor workspace of a non-final stage";
         else if (k >= 1 && !ws_k) bad = "stage workspace";
         else if (QM && (!A.Q || !A.inv_order)) bad = "Q / inv_order";
