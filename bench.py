@@ -690,6 +690,20 @@ def main():
                   "roundtrip_abs_err": ob["err"]}
             if ob["s_one"]:
                 cb["single_core_value"] = round(N / ob["s_one"] / 1e6, 4)
+            # the reference's OWN CPU path (RAHT2_optimized + inverse_RAHT_optimized, float64, torch CPU) on this same scene:
+            # a constant measured in the build container by tools/time_reference_cpu.py -- the reference cannot travel here
+            rp = os.path.join(ROOT, "profiles", "reference_cpu.json")
+            if os.path.exists(rp):
+                try:
+                    rj = json.load(open(rp))
+                    row = rj["configs"].get(a.workload)
+                    if row and row["rows"] == N and row["channels"] == D:
+                        cb["reference_torch_cpu"] = {"value": row["M_Gaussians_per_s"], "unit": "M-Gaussians/s", "cores": rj["threads"], "kind": "reference",
+                                                     "fwd_s": row["RAHT_s"], "inv_s": row["iRAHT_s"], "RAHT_param_s": row["RAHT_param_s"],
+                                                     "provenance": f"constant: tools/time_reference_cpu.py in the build container ({rj['cpu']}, {rj['threads']} threads, torch {rj['torch']}, "
+                                                                   f"float64, median of {rj['repeats']}, {rj['date']}); python/RAHT.py:252-336 + python/iRAHT.py:40-114 imported unchanged"}
+                except Exception:
+                    pass
             out["cpu_baseline"] = cb
 
         # ---- extra legs on the same box: reference precision (float64), and cfg2 ----
@@ -713,19 +727,59 @@ def main():
                           "with_quant_frac_of_peak": round((alg64 - 8.0 * N * D) / (t_q * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),      # C 8 B in, Q 4 B out, Q 4 B in, C 8 B out per coefficient
                           "unfused_ms": round(t_u, 4)}
             del s64
+            def small_leg(name, n2, J2, D2, seed2, what):
+                """the same fused step on a smaller scene (latency-bound regime: few rounds of tiles, the tail stages are a
+                third of the step)"""
+                V2, keys2, C2 = synth.scene(n2, J2, D2, seed2)
+                s2 = SoloScene(R, L, _lib, torch.from_numpy(keys2.view(np.int64)).to(dev), torch.from_numpy(C2).to(dev), 3 * J2, a, dev)
+                f2 = s2.step_fn(a.no_quant, False)
+                for _ in range(64):
+                    f2()
+                t2 = timed(f2, 200)
+                alg2 = 2 * (8.0 * s2.N * D2 + 8.0 * s2.N)
+                leg = {"workload": f"{name}: {s2.N} Gaussians, J={J2}, {D2} channels, same step{what}", "ms_per_step": round(t2, 4),
+                       "value": round(s2.N / (t2 * 1e-3) / 1e6, 1), "unit": "M-Gaussians/s", "alg_bytes_fwd_inv": alg2,
+                       "frac_of_peak": round(alg2 / (t2 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                       "active_rows_per_stage": s2.plan.stage_stats(4, D2)["rows_per_stage"]}
+                del s2
+                return leg
             n2, J2, D2, seed2 = synth.CONFIGS["cfg2"]
-            V2, keys2, C2 = synth.scene(n2, J2, D2, seed2)
-            s2 = SoloScene(R, L, _lib, torch.from_numpy(keys2.view(np.int64)).to(dev), torch.from_numpy(C2).to(dev), 3 * J2, a, dev)
-            f2 = s2.step_fn(a.no_quant, False)
-            for _ in range(64):
-                f2()
-            t2 = timed(f2, 200)
-            alg2 = 2 * (8.0 * s2.N * D2 + 8.0 * s2.N)
-            out["cfg2"] = {"workload": f"cfg2: {s2.N} Gaussians, J={J2}, {D2} channels, same step", "ms_per_step": round(t2, 4),
-                           "value": round(s2.N / (t2 * 1e-3) / 1e6, 1), "unit": "M-Gaussians/s", "alg_bytes_fwd_inv": alg2,
-                           "frac_of_peak": round(alg2 / (t2 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                           "active_rows_per_stage": s2.plan.stage_stats(4, D2)["rows_per_stage"]}
-            del s2
+            out["cfg2"] = small_leg("cfg2", n2, J2, D2, seed2, "")
+            # the shape the reference's driver actually runs (python/encode_3dgs.py:20-33: J = 10, one frame of ~1 M voxels,
+            # 56 attribute channels; 59 with the xyz columns of PCvox)
+            out["reference_shape"] = {"what": "python/encode_3dgs.py:20-33: J = 10, ~1 M voxels per frame, 56 attribute channels (59 with xyz)",
+                                      "d56": small_leg("ref56", 1_000_000, 10, 56, 1, ""), "d59": small_leg("ref59", 1_000_000, 10, 59, 1, "")}
+            # a BATCH of such frames (BASELINE configs[3] is a batch of scenes; so is a dynamic sequence): one call per frame
+            # against raht_fwd_quant_batch + raht_dequant_inv_batch (stage k of all frames in one launch)
+            from raht_3dgs_codec_amd import ops as _ops
+            nb, Db = 8, 56
+            plans_b, Cs_b = [], []
+            for i in range(nb):
+                Vb, kb, Cb = synth.scene(1_000_000, 10, Db, 20 + i)
+                plans_b.append(R.RahtPlan.from_keys(torch.from_numpy(kb.view(np.int64)).to(dev), 30))
+                Cs_b.append(torch.from_numpy(Cb).to(dev))
+            rows_b = sum(p.N for p in plans_b)
+
+            def looped():
+                for p, c in zip(plans_b, Cs_b):
+                    p.dequant_inverse(p.forward_quant(c, a.quant_step), a.quant_step)
+
+            def batched():
+                _ops.dequant_inverse_batch(plans_b, _ops.forward_quant_batch(plans_b, Cs_b, a.quant_step), a.quant_step)
+            Qb = _ops.forward_quant_batch(plans_b, Cs_b, a.quant_step)
+            assert all(torch.equal(q, p.forward_quant(c, a.quant_step)) for q, p, c in zip(Qb, plans_b, Cs_b)), "batch != single-scene calls"
+            del Qb
+            for _ in range(10):
+                looped(); batched()
+            t_l, t_b = timed(looped, 50), timed(batched, 50)
+            alg_b = 2 * (8.0 * rows_b * Db + 8.0 * rows_b)
+            out["batch"] = {"workload": f"{nb} frames of the reference's shape ({rows_b} Gaussians in all, J=10, {Db} channels), same step per frame",
+                            "one_call_per_frame_ms": round(t_l, 4), "batched_ms": round(t_b, 4),
+                            "batched_value": round(rows_b / (t_b * 1e-3) / 1e6, 1), "one_call_per_frame_value": round(rows_b / (t_l * 1e-3) / 1e6, 1), "unit": "M-Gaussians/s",
+                            "batched_frac_of_peak": round(alg_b / (t_b * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                            "one_call_per_frame_frac_of_peak": round(alg_b / (t_l * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                            "bit_identical_to_single_scene_calls": True}
+            del plans_b, Cs_b
     if rank == 0:
         print(json.dumps(out))
     if dist is not None:

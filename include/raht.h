@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define RAHT_VERSION 200
+#define RAHT_VERSION 300
 
 enum raht_status {
     RAHT_OK = 0,
@@ -186,7 +186,16 @@ int raht_inv_f64(const raht_plan *plan, const double *T, int64_t ldt, int D, dou
 /* Fused variants for the float32 tile engine: the coefficient matrix T is never materialised.
  *   raht_fwd_quant   = raht_fwd + raht_quant_reorder      (encode_3dgs.py:159,204,210,215)
  *   raht_dequant_inv = raht_dequant_unreorder + raht_inv  (encode_3dgs.py:261,267-268,274)
- * Same results as the two-call sequences (identical float32 arithmetic). */
+ * Same results as the two-call sequences (identical float32 arithmetic).
+ *
+ * PRECISION OF THE float32 INTEGERS (against the reference's float64 floor(T / step + 0.5)). A float32 coefficient carries
+ * ~1e-7 of its own magnitude in error, so an integer differs from the reference's when a rounding boundary falls inside
+ * |dT| / step: on unit-range attribute channels that is +-1 in about 1e-8 (step 1) to 1e-6 (step 0.01) of the integers
+ * (measured and bounded in tests/test_gpu_fullsize.py). The quotient itself has 24 significant bits: a channel whose
+ * coefficients reach |T| / step >= 2^23 -- the xyz columns of a 59-channel frame at steps below ~0.1: |T| is ~1e6 there --
+ * cannot be integer-exact in float32 (differences of tens of units at step 0.01). Callers that need the reference's integers
+ * on such channels use raht_fwd_quant_f64 / raht_dequant_inv_f64 (same kernels in float64, Q bit-identical to the
+ * float64 two-call sequence) or a per-channel step table with coarser steps on those channels. */
 int raht_fwd_quant(const raht_plan *plan, const float *C, int64_t ldc, int D, const float *steps,
                    int n_steps, int32_t *Q, int64_t ldq, raht_stream_t stream);
 int raht_dequant_inv(const raht_plan *plan, const int32_t *Q, int64_t ldq, int D, const float *steps,
@@ -200,6 +209,25 @@ int raht_fwd_quant_f64(const raht_plan *plan, const double *C, int64_t ldc, int 
                        int n_steps, int32_t *Q, int64_t ldq, raht_stream_t stream);
 int raht_dequant_inv_f64(const raht_plan *plan, const int32_t *Q, int64_t ldq, int D, const double *steps,
                          int n_steps, double *C, int64_t ldc, raht_stream_t stream);
+
+/* SEVERAL SCENES IN ONE SET OF LAUNCHES (BASELINE configs[3] is a batch of scenes; the frames of a dynamic sequence are
+ * one too). Scene i = (plans[i], C[i] / Q[i] with row strides ldc[i] / ldq[i]); all scenes share D and the step table.
+ * Stage k of every scene runs in ONE tile-kernel launch (a workgroup finds its scene from its index) and the top stages in
+ * one launch with blockIdx.y = scene: a frame of ~1 M Gaussians on its own fills the 768 workgroup slots of the chip two
+ * and a half times and then spends a third of its step in three latency-bound tail launches; in a batch the partial rounds
+ * of the scenes fill each other and all tails are one launch per stage. Results are BIT-IDENTICAL to n calls of the
+ * single-scene entry points (same kernels, same tiles: tests/test_gpu_parity.py::test_batch_*). Any n >= 1 (launches carry
+ * up to 8 scenes each); float32 tile engine -- scenes that need the level engine (D < 4, strides > 2^18, pathological key
+ * patterns) or a row map run through their single-scene entry point inside the same call. Plans must be distinct objects
+ * (a plan owns its workspaces) on the current device. Arrays of pointers / strides are HOST arrays. */
+int raht_fwd_batch(int n, raht_plan *const *plans, const float *const *C, const int64_t *ldc, int D,
+                   float *const *T, const int64_t *ldt, raht_stream_t stream);
+int raht_inv_batch(int n, raht_plan *const *plans, const float *const *T, const int64_t *ldt, int D,
+                   float *const *C, const int64_t *ldc, raht_stream_t stream);
+int raht_fwd_quant_batch(int n, raht_plan *const *plans, const float *const *C, const int64_t *ldc, int D,
+                         const float *steps, int n_steps, int32_t *const *Q, const int64_t *ldq, raht_stream_t stream);
+int raht_dequant_inv_batch(int n, raht_plan *const *plans, const int32_t *const *Q, const int64_t *ldq, int D,
+                           const float *steps, int n_steps, float *const *C, const int64_t *ldc, raht_stream_t stream);
 
 /* Pre-build the tile schedule and the per-stage workspaces for (elem_size in {4, 8}, D). The
  * first transform with a new (element type, D) does this implicitly (allocating and synchronising

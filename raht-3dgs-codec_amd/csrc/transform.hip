@@ -27,6 +27,7 @@
 #include <algorithm>
 #include <cstdlib>
 #include <type_traits>
+#include <vector>
 
 namespace raht {
 
@@ -276,9 +277,12 @@ __device__ __forceinline__ void glds16(const void *g, uint32_t lds_base)
 // instruction moves 64 / G rows (59 float channels: 15 chunks, G = 16, 4 rows). LDS rows are padded
 // to Dp = Dc rounded up to VN so that every chunk is a 16-byte-aligned ds_read/write_b128; global
 // rows need element alignment only. A butterfly is one ds_read_b128 per operand and lane.
+//
+// tile_body is the kernel; tile_kernel runs it for ONE scene (workgroup b takes tiles b, b + gridDim.x, ...), tile_kernel_batch
+// for several scenes in one launch (workgroup b takes ONE tile of the scene whose tile range holds b).
 template <typename T, bool INV, bool IDENT, bool QM, int SLOTS>
-__global__ __launch_bounds__(512, (sizeof(T) == 4 ? 6 : 4)) void tile_kernel(const TileArgs<T> A,
-                                                   const typename std::conditional<QM, typename StepsFor<T>::type, NoSteps>::type ST)
+__device__ __forceinline__ void tile_body(const TileArgs<T> &A, const typename std::conditional<QM, typename StepsFor<T>::type, NoSteps>::type &ST,
+                                          const int64_t first_tile, const int64_t tile_stride, const int chunk_y)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     typedef RegChunk<T> V16;
@@ -293,7 +297,7 @@ __global__ __launch_bounds__(512, (sizeof(T) == 4 ? 6 : 4)) void tile_kernel(con
     const int R = A.R;
     const int tid0 = threadIdx.x;
     const int nthreads = blockDim.x, nw = nthreads >> 6;
-    const int c_base = blockIdx.y * A.Dc;
+    const int c_base = chunk_y * A.Dc;
     const int Dc = min(A.Dc, A.D - c_base);
     const int Dp = A.Dp;                                  // LDS row stride in elements
     const int lg = A.lg, lr = 6 - A.lg;                   // log2(lanes per row), log2(rows per wave instruction)
@@ -369,8 +373,8 @@ __global__ __launch_bounds__(512, (sizeof(T) == 4 ? 6 : 4)) void tile_kernel(con
         }
     };
 
-    if ((int64_t)blockIdx.x < n_tiles) load_tile_meta<T, IDENT, QM, SLOTS>(A, blockIdx.x, tid0, nthreads, M);
-    for (int64_t tile_id = blockIdx.x; tile_id < n_tiles; tile_id += gridDim.x) {
+    if (first_tile < n_tiles) load_tile_meta<T, IDENT, QM, SLOTS>(A, first_tile, tid0, nthreads, M);
+    for (int64_t tile_id = first_tile; tile_id < n_tiles; tile_id += tile_stride) {
     // Re-derive the lane-dependent indices every iteration from an opaque copy of the thread id:
     // otherwise the compiler hoists dozens of lane-dependent addresses out of this long loop body
     // and spills them (register budget: 80 VGPRs for three workgroups per CU).
@@ -591,7 +595,7 @@ __global__ __launch_bounds__(512, (sizeof(T) == 4 ? 6 : 4)) void tile_kernel(con
     PHASE_STAMP(5);
 
     // prefetch the next tile's plan metadata: the loads stay in flight during the butterflies
-    if (tile_id + gridDim.x < n_tiles) load_tile_meta<T, IDENT, QM, SLOTS>(A, tile_id + gridDim.x, tid, nthreads, M);
+    if (tile_id + tile_stride < n_tiles) load_tile_meta<T, IDENT, QM, SLOTS>(A, tile_id + tile_stride, tid, nthreads, M);
 
     // ---- P4. butterflies, one round per level present; a lane group handles one butterfly ----
     {
@@ -742,6 +746,36 @@ __global__ __launch_bounds__(512, (sizeof(T) == 4 ? 6 : 4)) void tile_kernel(con
     }                             // persistent tile loop
 }
 
+template <typename T, bool INV, bool IDENT, bool QM, int SLOTS>
+__global__ __launch_bounds__(512, (sizeof(T) == 4 ? 6 : 4)) void tile_kernel(const TileArgs<T> A,
+                                                   const typename std::conditional<QM, typename StepsFor<T>::type, NoSteps>::type ST)
+{
+    tile_body<T, INV, IDENT, QM, SLOTS>(A, ST, (int64_t)blockIdx.x, (int64_t)gridDim.x, (int)blockIdx.y);
+}
+
+// Several scenes, one launch (raht_*_batch): the same stage of up to TILE_BATCH_MAX scenes. first_tile[s] = number of tiles of the
+// scenes before s; a workgroup finds its scene with a handful of scalar compares and runs ONE tile of it. A frame of ~1 M
+// Gaussians fills the chip's 768 workgroup slots two and a half times and then waits ~20 us for its tail stages (a third of
+// its step); batched, the partial rounds of different scenes fill each other and ALL tails are one launch per stage.
+constexpr int TILE_BATCH_MAX = 8;
+template <typename T>
+struct TileBatch {
+    TileArgs<T> a[TILE_BATCH_MAX];
+    uint32_t first_tile[TILE_BATCH_MAX + 1];
+    int n;
+};
+
+template <typename T, bool INV, bool IDENT, bool QM, int SLOTS>
+__global__ __launch_bounds__(512, (sizeof(T) == 4 ? 6 : 4)) void tile_kernel_batch(const TileBatch<T> B,
+                                                   const typename std::conditional<QM, typename StepsFor<T>::type, NoSteps>::type ST)
+{
+    int s = 0;
+#pragma unroll
+    for (int q = 1; q < TILE_BATCH_MAX; ++q) s += (q < B.n && blockIdx.x >= B.first_tile[q]) ? 1 : 0;
+    const int64_t t = (int64_t)(blockIdx.x - B.first_tile[s]);
+    tile_body<T, INV, IDENT, QM, SLOTS>(B.a[s], ST, t, (int64_t)1 << 40, (int)blockIdx.y);
+}
+
 // ------------------------------------------------------------------------------------------------
 // TOP stage: the last <= RAHT_TOP_MAX_ROWS entries of the tree in ONE launch.
 //
@@ -776,8 +810,8 @@ struct TopArgs {
 };
 
 template <typename T, bool INV, bool QM>
-__global__ __launch_bounds__(TOP_THREADS) void top_kernel(const TopArgs<T> A,
-                                                          const typename std::conditional<QM, typename StepsFor<T>::type, NoSteps>::type ST)
+__device__ __forceinline__ void top_body(const TopArgs<T> &A, const typename std::conditional<QM, typename StepsFor<T>::type, NoSteps>::type &ST,
+                                         const int chunk)
 {
     constexpr bool QM64 = QM && sizeof(T) == 8;              // float64 rows, 2 quantized integers per 16-byte chunk
     extern __shared__ __align__(16) unsigned char smem[];
@@ -786,7 +820,7 @@ __global__ __launch_bounds__(TOP_THREADS) void top_kernel(const TopArgs<T> A,
     V16 *tile = (V16 *)smem;
     __shared__ uint32_t s_lev[2 * 64];
     const int tid = threadIdx.x;
-    const int goff = min((int)blockIdx.x * VN, A.D - VN);          // last chunk: the 16 bytes that end the row
+    const int goff = min(chunk * VN, A.D - VN);                    // last chunk: the 16 bytes that end the row
     const int n = A.n, nm = A.n_merges;
     if (tid < 2 * A.nlev) s_lev[tid] = A.lev[tid];
     // records of the chained levels, staged in LDS behind the entries
@@ -958,6 +992,24 @@ __global__ __launch_bounds__(TOP_THREADS) void top_kernel(const TopArgs<T> A,
     }
 }
 
+template <typename T, bool INV, bool QM>
+__global__ __launch_bounds__(TOP_THREADS) void top_kernel(const TopArgs<T> A,
+                                                          const typename std::conditional<QM, typename StepsFor<T>::type, NoSteps>::type ST)
+{
+    top_body<T, INV, QM>(A, ST, (int)blockIdx.x);
+}
+
+// the top stages of several scenes in one launch (raht_*_batch): blockIdx.y = scene
+template <typename T>
+struct TopBatch { TopArgs<T> a[TILE_BATCH_MAX]; };
+
+template <typename T, bool INV, bool QM>
+__global__ __launch_bounds__(TOP_THREADS) void top_kernel_batch(const TopBatch<T> B,
+                                                                const typename std::conditional<QM, typename StepsFor<T>::type, NoSteps>::type ST)
+{
+    top_body<T, INV, QM>(B.a[blockIdx.y], ST, (int)blockIdx.x);
+}
+
 // node weights of RAHT.py:325-328: after its own butterfly a right sibling carries w0 + w1 and is
 // never touched again; row 0 ends with the total weight.
 template <typename T>
@@ -1033,14 +1085,35 @@ struct XformIO {
     const typename StepsFor<T>::elem *steps = nullptr; int n_steps = 0;
 };
 
+// ---- host side of the tile / top launches: "prepare" fills and validates the kernel arguments of one (scene, stage),
+// "launch" enqueues one scene's stage, "launch_*_batch" the same stage of several scenes in one launch ----
+struct TileGeom {
+    int64_t n_tiles = 0;
+    unsigned grid_x = 0, nchunks = 0;
+    int threads = 0;
+    size_t lds = 0;
+    bool one = true, ident = true;
+    bool same_shape(const TileGeom &o) const { return nchunks == o.nchunks && threads == o.threads && lds == o.lds && one == o.one && ident == o.ident; }
+};
+
 template <typename T, bool INV, bool IDENT, bool QM, int SLOTS>
-static int launch_tile_one(const TileArgs<T> &A, const XformIO<T> &io, dim3 grid, int threads, size_t lds, hipStream_t s)
+static int tile_kernel_attr()
 {
     // > 64 KiB of dynamic LDS must be allowed per function AND per device
-    static PerDeviceOnce attr;
+    static PerDeviceOnce attr, attr_b;
     if (attr.first(current_device()))
         RAHT_HIP_CHECK(hipFuncSetAttribute((const void *)tile_kernel<T, INV, IDENT, QM, SLOTS>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    if (attr_b.first(current_device()))
+        RAHT_HIP_CHECK(hipFuncSetAttribute((const void *)tile_kernel_batch<T, INV, IDENT, QM, SLOTS>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    return RAHT_OK;
+}
+
+template <typename T, bool INV, bool IDENT, bool QM, int SLOTS>
+static int launch_tile_one(const TileArgs<T> &A, const XformIO<T> &io, dim3 grid, int threads, size_t lds, hipStream_t s)
+{
+    RAHT_RET((tile_kernel_attr<T, INV, IDENT, QM, SLOTS>()));
     if constexpr (QM) {
         typename StepsFor<T>::type st;
         fill_step_table(st, io.steps, io.n_steps);
@@ -1053,12 +1126,26 @@ static int launch_tile_one(const TileArgs<T> &A, const XformIO<T> &io, dim3 grid
     return RAHT_OK;
 }
 
+template <typename T, bool INV, bool IDENT, bool QM, int SLOTS>
+static int launch_tile_batch_one(const TileBatch<T> &B, const XformIO<T> &io, dim3 grid, int threads, size_t lds, hipStream_t s)
+{
+    RAHT_RET((tile_kernel_attr<T, INV, IDENT, QM, SLOTS>()));
+    if constexpr (QM) {
+        typename StepsFor<T>::type st;
+        fill_step_table(st, io.steps, io.n_steps);
+        hipLaunchKernelGGL((tile_kernel_batch<T, INV, IDENT, true, SLOTS>), grid, dim3(threads), lds, s, B, st);
+    } else {
+        NoSteps ns{0, 0};
+        hipLaunchKernelGGL((tile_kernel_batch<T, INV, IDENT, false, SLOTS>), grid, dim3(threads), lds, s, B, ns);
+    }
+    RAHT_HIP_CHECK(hipGetLastError());
+    return RAHT_OK;
+}
+
 template <typename T, bool INV, bool QM>
-static int launch_top_stage(const raht_plan *p, const Schedule &sc, int k, const XformIO<T> &io, int D, hipStream_t s)
+static int prepare_top_stage(const raht_plan *p, const Schedule &sc, int k, const XformIO<T> &io, int D, TopArgs<T> &A, size_t &lds)
 {
     const Stage &st = sc.stages[(size_t)k];
-    constexpr int VN = 16 / (int)sizeof(T);
-    TopArgs<T> A;
     T *ws_k = (k >= 1) ? (T *)st.ws : nullptr;
     A.in = nullptr; A.ld_in = 0; A.out = nullptr; A.ld_out = 0;
     if (!INV) { A.in = (k == 0) ? io.src : ws_k; A.ld_in = (k == 0) ? io.ld_src : D; A.fin = io.dst; A.ld_fin = io.ld_dst; }
@@ -1078,13 +1165,24 @@ static int launch_top_stage(const raht_plan *p, const Schedule &sc, int k, const
     A.root_buf = (T *)p->root_buf;
     A.n = (int)st.n_entries; A.n_merges = (int)st.n_merges; A.D = D;
     A.lev = st.t_lev; A.nlev = st.t_nlev; A.nbig = st.t_nbig; A.small_start = st.t_small_start;
-    const dim3 grid((unsigned)((D + VN - 1) / VN));
     const size_t n_small = st.n_merges - st.t_small_start;
-    const size_t lds = (size_t)st.n_entries * 16 + ((n_small + 3) & ~(size_t)3) * 4 + n_small * 2 * sizeof(T);   // + 512 B static
+    lds = (size_t)st.n_entries * 16 + ((n_small + 3) & ~(size_t)3) * 4 + n_small * 2 * sizeof(T);   // + 512 B static
     static PerDeviceOnce attr;
-    if (attr.first(current_device()))
-        RAHT_HIP_CHECK(hipFuncSetAttribute((const void *)top_kernel<T, INV, QM>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           160 * 1024 - 1024));
+    if (attr.first(current_device())) {
+        RAHT_HIP_CHECK(hipFuncSetAttribute((const void *)top_kernel<T, INV, QM>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
+        RAHT_HIP_CHECK(hipFuncSetAttribute((const void *)top_kernel_batch<T, INV, QM>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
+    }
+    return RAHT_OK;
+}
+
+template <typename T, bool INV, bool QM>
+static int launch_top_stage(const raht_plan *p, const Schedule &sc, int k, const XformIO<T> &io, int D, hipStream_t s)
+{
+    constexpr int VN = 16 / (int)sizeof(T);
+    TopArgs<T> A;
+    size_t lds = 0;
+    RAHT_RET((prepare_top_stage<T, INV, QM>(p, sc, k, io, D, A, lds)));
+    const dim3 grid((unsigned)((D + VN - 1) / VN));
     if constexpr (QM) {
         typename StepsFor<T>::type stp;
         fill_step_table(stp, io.steps, io.n_steps);
@@ -1097,36 +1195,39 @@ static int launch_top_stage(const raht_plan *p, const Schedule &sc, int k, const
     return RAHT_OK;
 }
 
+// the top stages of scenes idx[0..m): one launch, blockIdx.y = scene (io.steps: the batch shares one step table)
 template <typename T, bool INV, bool QM>
-static int launch_stage_impl(const raht_plan *p, const Schedule &sc, int k, const XformIO<T> &io, int D, int Dc0,
-                             hipStream_t s, int dbg);
-
-template <typename T, bool INV, bool QM>
-static int launch_tile_stage(const raht_plan *p, const Schedule &sc, int k, const XformIO<T> &io, int D, int Dc0,
-                             hipStream_t s, int dbg = 0)
+static int launch_top_batch(int m, const TopArgs<T> *As, const size_t *ldss, const XformIO<T> &io, int D, hipStream_t s)
 {
-    if (k == 0 && p->ev_before && dbg == 0) {          // profiling: bracket the stage-0 launch of a real transform
-        RAHT_HIP_CHECK(hipEventRecord(p->ev_before, s));
-        const int rc = launch_stage_impl<T, INV, QM>(p, sc, k, io, D, Dc0, s, dbg);
-        RAHT_HIP_CHECK(hipEventRecord(p->ev_after, s));
-        return rc;
+    constexpr int VN = 16 / (int)sizeof(T);
+    TopBatch<T> B;
+    size_t lds = 0;
+    for (int i = 0; i < m; ++i) { B.a[i] = As[i]; lds = std::max(lds, ldss[i]); }
+    for (int i = m; i < TILE_BATCH_MAX; ++i) B.a[i] = As[0];
+    const dim3 grid((unsigned)((D + VN - 1) / VN), (unsigned)m);
+    if constexpr (QM) {
+        typename StepsFor<T>::type stp;
+        fill_step_table(stp, io.steps, io.n_steps);
+        hipLaunchKernelGGL((top_kernel_batch<T, INV, true>), grid, dim3(TOP_THREADS), lds, s, B, stp);
+    } else {
+        NoSteps ns{0, 0};
+        hipLaunchKernelGGL((top_kernel_batch<T, INV, false>), grid, dim3(TOP_THREADS), lds, s, B, ns);
     }
-    return launch_stage_impl<T, INV, QM>(p, sc, k, io, D, Dc0, s, dbg);
+    RAHT_HIP_CHECK(hipGetLastError());
+    return RAHT_OK;
 }
 
 template <typename T, bool INV, bool QM>
-static int launch_stage_impl(const raht_plan *p, const Schedule &sc, int k, const XformIO<T> &io, int D, int Dc0,
-                             hipStream_t s, int dbg)
+static int prepare_tile_stage(const raht_plan *p, const Schedule &sc, int k, const XformIO<T> &io, int D, int Dc0, int dbg,
+                              TileArgs<T> &A, TileGeom &G)
 {
     const Stage &st = sc.stages[(size_t)k];
-    if (st.is_top) return launch_top_stage<T, INV, QM>(p, sc, k, io, D, s);
     int Dc = Dc0;
     if (k >= 1) {                                    // later stages: large tiles, channel chunks
         int r1 = 0, rf = 0;
         pick_tail_geometry(p, (int)sizeof(T), D, sc.tile_rows, &r1, &Dc, &rf);
     }
     const int K = (int)sc.stages.size();
-    TileArgs<T> A;
     A.rows = st.rows; A.surv_off = st.surv_off; A.n_entries = st.n_entries; A.N = p->N; A.R = st.tile_rows;
     A.D = D; A.Dc = Dc;
     constexpr int VN = 16 / (int)sizeof(T);
@@ -1169,27 +1270,81 @@ static int launch_stage_impl(const raht_plan *p, const Schedule &sc, int k, cons
         else if (st.tile_rows < 1 || (int64_t)st.tile_rows * std::max<int64_t>(std::max(A.ld_in, A.ld_out), A.ld_fin) * (int64_t)sizeof(T) >= ((int64_t)1 << 32)) bad = "tile geometry (32-bit row offsets)";
         if (bad) { set_error("tile stage %d (%s): missing %s", k, INV ? "inverse" : "forward", bad); return RAHT_ERR_INVALID; }
     }
-    const int nchunks = (D + Dc - 1) / Dc;
-    const size_t lds = tile_lds_bytes(st.tile_rows, (int)sizeof(T), Dc, st.rows == nullptr, QM);
-    const int threads = (k == 0) ? tile_threads() : tail_threads();
-    if (st.tile_rows > TILE_MAX_SLOTS * threads) {
-        set_error("tile_rows %d too large for %d threads", st.tile_rows, threads);
+    G.nchunks = (unsigned)((D + Dc - 1) / Dc);
+    G.lds = tile_lds_bytes(st.tile_rows, (int)sizeof(T), Dc, st.rows == nullptr, QM);
+    G.threads = (k == 0) ? tile_threads() : tail_threads();
+    if (st.tile_rows > TILE_MAX_SLOTS * G.threads) {
+        set_error("tile_rows %d too large for %d threads", st.tile_rows, G.threads);
         return RAHT_ERR_UNSUPPORTED;
     }
     // persistent workgroups: as many as the chip keeps resident (LDS granules of 1280 B, 32 waves
     // per CU), each walking tiles blockIdx.x, blockIdx.x + gridDim.x, ...
-    const int per_cu = std::max(1, std::min((int)(128 / ((lds + 1279) / 1280)), 32 / (threads / 64)));
+    const int per_cu = std::max(1, std::min((int)(128 / ((G.lds + 1279) / 1280)), 32 / (G.threads / 64)));
     const int64_t resident = (int64_t)per_cu * device_cus();
     const int pm = persist_mode();
-    const int64_t gx = pm == 1 ? std::min<int64_t>(st.n_tiles, std::max<int64_t>(1, resident / nchunks))
+    const int64_t gx = pm == 1 ? std::min<int64_t>(st.n_tiles, std::max<int64_t>(1, resident / G.nchunks))
                      : pm >= 2 ? ceil_div(st.n_tiles, (int64_t)pm) : st.n_tiles;
-    const dim3 grid((unsigned)gx, (unsigned)nchunks);
-    const bool one = st.tile_rows <= threads;
-    if (st.rows == nullptr)
-        return one ? launch_tile_one<T, INV, true, QM, 1>(A, io, grid, threads, lds, s)
-                   : launch_tile_one<T, INV, true, QM, 2>(A, io, grid, threads, lds, s);
-    return one ? launch_tile_one<T, INV, false, QM, 1>(A, io, grid, threads, lds, s)
-               : launch_tile_one<T, INV, false, QM, 2>(A, io, grid, threads, lds, s);
+    G.n_tiles = st.n_tiles;
+    G.grid_x = (unsigned)gx;
+    G.one = st.tile_rows <= G.threads;
+    G.ident = st.rows == nullptr;
+    return RAHT_OK;
+}
+
+template <typename T, bool INV, bool QM>
+static int launch_stage_impl(const raht_plan *p, const Schedule &sc, int k, const XformIO<T> &io, int D, int Dc0,
+                             hipStream_t s, int dbg);
+
+template <typename T, bool INV, bool QM>
+static int launch_tile_stage(const raht_plan *p, const Schedule &sc, int k, const XformIO<T> &io, int D, int Dc0,
+                             hipStream_t s, int dbg = 0)
+{
+    if (k == 0 && p->ev_before && dbg == 0) {          // profiling: bracket the stage-0 launch of a real transform
+        RAHT_HIP_CHECK(hipEventRecord(p->ev_before, s));
+        const int rc = launch_stage_impl<T, INV, QM>(p, sc, k, io, D, Dc0, s, dbg);
+        RAHT_HIP_CHECK(hipEventRecord(p->ev_after, s));
+        return rc;
+    }
+    return launch_stage_impl<T, INV, QM>(p, sc, k, io, D, Dc0, s, dbg);
+}
+
+template <typename T, bool INV, bool QM>
+static int launch_stage_impl(const raht_plan *p, const Schedule &sc, int k, const XformIO<T> &io, int D, int Dc0,
+                             hipStream_t s, int dbg)
+{
+    const Stage &st = sc.stages[(size_t)k];
+    if (st.is_top) return launch_top_stage<T, INV, QM>(p, sc, k, io, D, s);
+    TileArgs<T> A;
+    TileGeom G;
+    RAHT_RET((prepare_tile_stage<T, INV, QM>(p, sc, k, io, D, Dc0, dbg, A, G)));
+    const dim3 grid(G.grid_x, G.nchunks);
+    if (G.ident)
+        return G.one ? launch_tile_one<T, INV, true, QM, 1>(A, io, grid, G.threads, G.lds, s)
+                     : launch_tile_one<T, INV, true, QM, 2>(A, io, grid, G.threads, G.lds, s);
+    return G.one ? launch_tile_one<T, INV, false, QM, 1>(A, io, grid, G.threads, G.lds, s)
+                 : launch_tile_one<T, INV, false, QM, 2>(A, io, grid, G.threads, G.lds, s);
+}
+
+// the same tile stage of m <= TILE_BATCH_MAX scenes (equal launch shape) in one launch, one tile per workgroup
+template <typename T, bool INV, bool QM>
+static int launch_tile_batch(int m, const TileArgs<T> *As, const TileGeom *Gs, const XformIO<T> &io, hipStream_t s)
+{
+    TileBatch<T> B;
+    B.n = m;
+    uint32_t tot = 0;
+    for (int i = 0; i < TILE_BATCH_MAX; ++i) {
+        B.a[i] = As[i < m ? i : 0];
+        B.first_tile[i] = tot;
+        if (i < m) tot += (uint32_t)Gs[i].n_tiles;
+    }
+    B.first_tile[TILE_BATCH_MAX] = tot;
+    const TileGeom &G = Gs[0];
+    const dim3 grid(tot, G.nchunks);
+    if (G.ident)
+        return G.one ? launch_tile_batch_one<T, INV, true, QM, 1>(B, io, grid, G.threads, G.lds, s)
+                     : launch_tile_batch_one<T, INV, true, QM, 2>(B, io, grid, G.threads, G.lds, s);
+    return G.one ? launch_tile_batch_one<T, INV, false, QM, 1>(B, io, grid, G.threads, G.lds, s)
+                 : launch_tile_batch_one<T, INV, false, QM, 2>(B, io, grid, G.threads, G.lds, s);
 }
 
 template <typename T>
@@ -1375,6 +1530,91 @@ static int dequant_inv_impl(const raht_plan *cp, const int32_t *Q, int64_t ldq, 
     return RAHT_OK;
 }
 
+// ---- several scenes, one set of launches (raht_*_batch) ----------------------------------------------
+// Round r of the forward direction runs stage r of every scene that has one (inverse: the stages from the top of the
+// deepest schedule downwards, a scene joining when its own top stage comes up); within a round the tile stages of equal
+// launch shape go out TILE_BATCH_MAX scenes per launch, the top stages likewise with blockIdx.y = scene. Scenes without a
+// tile schedule run through the single-scene path.
+template <typename T, bool INV, bool QM>
+static int run_batch(int n, raht_plan *const *plans, const XformIO<T> *ios, int D, hipStream_t s, const char *what)
+{
+    if (n < 1 || !plans || !ios) { set_error("%s: bad argument", what); return RAHT_ERR_INVALID; }
+    std::vector<Schedule *> scs((size_t)n, nullptr);
+    std::vector<int> Dcs((size_t)n, 0);
+    int maxK = 0;
+    for (int i = 0; i < n; ++i) {
+        raht_plan *p = plans[i];
+        const XformIO<T> &io = ios[i];
+        if (!p) { set_error("%s: NULL plan (scene %d)", what, i); return RAHT_ERR_INVALID; }
+        for (int j = 0; j < i; ++j) if (plans[j] == p) { set_error("%s: scenes %d and %d share a plan (a plan owns its workspaces)", what, j, i); return RAHT_ERR_INVALID; }
+        RAHT_RET(check_plan_device(p, what));
+        const int64_t ld_a = INV ? (QM ? io.ldq : io.ld_src) : io.ld_src, ld_b = INV ? io.ld_dst : (QM ? io.ldq : io.ld_dst);
+        const void *pa = INV ? (QM ? (const void *)io.Q : (const void *)io.src) : (const void *)io.src;
+        const void *pb = INV ? (const void *)io.dst : (QM ? (const void *)io.Q : (const void *)io.dst);
+        if (!pa || !pb || D < 1 || ld_a < D || ld_b < D) { set_error("%s: bad matrix argument (scene %d)", what, i); return RAHT_ERR_INVALID; }
+        if (p->row_map) continue;                              // single-scene path (one mapped top stage)
+        RAHT_RET(tile_setup<T>(p, D, std::max(ld_a, ld_b), s, &scs[(size_t)i], &Dcs[(size_t)i]));
+        if (scs[(size_t)i]) maxK = std::max(maxK, (int)scs[(size_t)i]->stages.size());
+    }
+    // scenes outside the tile engine: their own entry point, in place in the stream
+    for (int i = 0; i < n; ++i) {
+        if (scs[(size_t)i]) continue;
+        const XformIO<T> &io = ios[i];
+        int rc;
+        if constexpr (QM && !INV) rc = fwd_quant_impl<T>(plans[i], io.src, io.ld_src, D, io.steps, io.n_steps, io.Q, io.ldq, (raht_stream_t)s);
+        else if constexpr (QM && INV) rc = dequant_inv_impl<T>(plans[i], io.Q, io.ldq, D, io.steps, io.n_steps, io.dst, io.ld_dst, (raht_stream_t)s);
+        else rc = run_transform<T, INV>(plans[i], io.src, io.ld_src, D, io.dst, io.ld_dst, nullptr, s);
+        RAHT_RET(rc);
+    }
+    for (int r = 0; r < maxK; ++r) {
+        int idx_tile[TILE_BATCH_MAX], idx_top[TILE_BATCH_MAX], n_tile = 0, n_top = 0;
+        TileArgs<T> At[TILE_BATCH_MAX];
+        TileGeom Gt[TILE_BATCH_MAX];
+        TopArgs<T> Ap[TILE_BATCH_MAX];
+        size_t Lp[TILE_BATCH_MAX];
+        auto flush_tile = [&]() -> int {
+            if (n_tile == 0) return RAHT_OK;
+            int rc;
+            if (n_tile == 1) {
+                const int i = idx_tile[0];
+                rc = launch_stage_impl<T, INV, QM>(plans[i], *scs[(size_t)i], INV ? maxK - 1 - r : r, ios[i], D, Dcs[(size_t)i], s, 0);
+            } else {
+                rc = launch_tile_batch<T, INV, QM>(n_tile, At, Gt, ios[idx_tile[0]], s);
+            }
+            n_tile = 0;
+            return rc;
+        };
+        auto flush_top = [&]() -> int {
+            if (n_top == 0) return RAHT_OK;
+            const int rc = launch_top_batch<T, INV, QM>(n_top, Ap, Lp, ios[idx_top[0]], D, s);
+            n_top = 0;
+            return rc;
+        };
+        for (int i = 0; i < n; ++i) {
+            Schedule *sc = scs[(size_t)i];
+            if (!sc) continue;
+            const int K = (int)sc->stages.size();
+            const int k = INV ? maxK - 1 - r : r;
+            if (k < 0 || k >= K) continue;
+            if (sc->stages[(size_t)k].is_top) {
+                RAHT_RET((prepare_top_stage<T, INV, QM>(plans[i], *sc, k, ios[i], D, Ap[n_top], Lp[n_top])));
+                idx_top[n_top++] = i;
+                if (n_top == TILE_BATCH_MAX) RAHT_RET(flush_top());
+            } else {
+                TileArgs<T> A;
+                TileGeom G;
+                RAHT_RET((prepare_tile_stage<T, INV, QM>(plans[i], *sc, k, ios[i], D, Dcs[(size_t)i], 0, A, G)));
+                if (n_tile > 0 && !G.same_shape(Gt[0])) RAHT_RET(flush_tile());     // another launch shape: its own launch
+                At[n_tile] = A; Gt[n_tile] = G; idx_tile[n_tile++] = i;
+                if (n_tile == TILE_BATCH_MAX) RAHT_RET(flush_tile());
+            }
+        }
+        RAHT_RET(flush_tile());
+        RAHT_RET(flush_top());
+    }
+    return RAHT_OK;
+}
+
 }  // namespace raht
 
 using namespace raht;
@@ -1493,6 +1733,58 @@ static int debug_run_stage_impl(const raht_plan *cp, int inverse, int stage, con
     return launch_tile_stage<float, false, true>(p, *sc, stage, io, D, Dc, s, ablate);
 }
 
+
+int raht_fwd_batch(int n, raht_plan *const *plans, const float *const *C, const int64_t *ldc, int D,
+                   float *const *T, const int64_t *ldt, raht_stream_t stream)
+{
+    return guarded("raht_fwd_batch", [&]() -> int {
+        if (n < 1 || !plans || !C || !ldc || !T || !ldt) { set_error("raht_fwd_batch: bad argument"); return RAHT_ERR_INVALID; }
+        std::vector<XformIO<float>> ios((size_t)n);
+        for (int i = 0; i < n; ++i) { ios[(size_t)i].src = C[i]; ios[(size_t)i].ld_src = ldc[i]; ios[(size_t)i].dst = T[i]; ios[(size_t)i].ld_dst = ldt[i]; }
+        return run_batch<float, false, false>(n, plans, ios.data(), D, (hipStream_t)stream, "raht_fwd_batch");
+    });
+}
+
+int raht_inv_batch(int n, raht_plan *const *plans, const float *const *T, const int64_t *ldt, int D,
+                   float *const *C, const int64_t *ldc, raht_stream_t stream)
+{
+    return guarded("raht_inv_batch", [&]() -> int {
+        if (n < 1 || !plans || !C || !ldc || !T || !ldt) { set_error("raht_inv_batch: bad argument"); return RAHT_ERR_INVALID; }
+        std::vector<XformIO<float>> ios((size_t)n);
+        for (int i = 0; i < n; ++i) { ios[(size_t)i].src = T[i]; ios[(size_t)i].ld_src = ldt[i]; ios[(size_t)i].dst = C[i]; ios[(size_t)i].ld_dst = ldc[i]; }
+        return run_batch<float, true, false>(n, plans, ios.data(), D, (hipStream_t)stream, "raht_inv_batch");
+    });
+}
+
+int raht_fwd_quant_batch(int n, raht_plan *const *plans, const float *const *C, const int64_t *ldc, int D,
+                         const float *steps, int n_steps, int32_t *const *Q, const int64_t *ldq, raht_stream_t stream)
+{
+    return guarded("raht_fwd_quant_batch", [&]() -> int {
+        if (n < 1 || !plans || !C || !ldc || !Q || !ldq) { set_error("raht_fwd_quant_batch: bad argument"); return RAHT_ERR_INVALID; }
+        RAHT_RET(check_steps(steps, n_steps, D));
+        std::vector<XformIO<float>> ios((size_t)n);
+        for (int i = 0; i < n; ++i) {
+            XformIO<float> &io = ios[(size_t)i];
+            io.src = C[i]; io.ld_src = ldc[i]; io.Q = Q[i]; io.ldq = ldq[i]; io.steps = steps; io.n_steps = n_steps;
+        }
+        return run_batch<float, false, true>(n, plans, ios.data(), D, (hipStream_t)stream, "raht_fwd_quant_batch");
+    });
+}
+
+int raht_dequant_inv_batch(int n, raht_plan *const *plans, const int32_t *const *Q, const int64_t *ldq, int D,
+                           const float *steps, int n_steps, float *const *C, const int64_t *ldc, raht_stream_t stream)
+{
+    return guarded("raht_dequant_inv_batch", [&]() -> int {
+        if (n < 1 || !plans || !C || !ldc || !Q || !ldq) { set_error("raht_dequant_inv_batch: bad argument"); return RAHT_ERR_INVALID; }
+        RAHT_RET(check_steps(steps, n_steps, D));
+        std::vector<XformIO<float>> ios((size_t)n);
+        for (int i = 0; i < n; ++i) {
+            XformIO<float> &io = ios[(size_t)i];
+            io.dst = C[i]; io.ld_dst = ldc[i]; io.Q = const_cast<int32_t *>(Q[i]); io.ldq = ldq[i]; io.steps = steps; io.n_steps = n_steps;
+        }
+        return run_batch<float, true, true>(n, plans, ios.data(), D, (hipStream_t)stream, "raht_dequant_inv_batch");
+    });
+}
 
 int raht_debug_run_stage(const raht_plan *plan, int inverse, int stage, const float *mat, int64_t ld_mat, int D,
                          float *mat2, int64_t ld_mat2, int32_t *Q, int64_t ldq, float step, int ablate,

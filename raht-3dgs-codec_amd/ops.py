@@ -400,6 +400,72 @@ def _steps64(steps, D):
     return (C.c_double * len(steps))(*steps)
 
 
+# ---------------------------------------------------------------------------------------------------
+# several scenes in one set of launches (include/raht.h: raht_*_batch)
+# ---------------------------------------------------------------------------------------------------
+def _batch_arrays(plans, mats, dtype, name):
+    n = len(plans)
+    if n < 1 or len(mats) != n:
+        raise ValueError("batch: one matrix per plan")
+    D = int(mats[0].shape[1])
+    ms = []
+    for p, m in zip(plans, mats):
+        _need_cuda(m, name)
+        if m.dim() != 2 or m.shape[0] != p.N or m.shape[1] != D:
+            raise ValueError(f"batch: expected ({p.N}, {D}) matrices, got {tuple(m.shape)}")
+        if m.dtype != dtype:
+            m = m.to(dtype)
+        if m.stride(1) != 1 or m.stride(0) < D:
+            m = m.contiguous()
+        ms.append(m)
+    hp = (C.c_void_p * n)(*[p._h for p in plans])
+    mp = (C.c_void_p * n)(*[m.data_ptr() for m in ms])
+    ld = (C.c_int64 * n)(*[m.stride(0) for m in ms])
+    return n, D, ms, hp, mp, ld
+
+
+def _batch_out(plans, D, dtype, device):
+    outs = [torch.empty((p.N, D), dtype=dtype, device=device) for p in plans]
+    return outs, (C.c_void_p * len(outs))(*[o.data_ptr() for o in outs]), (C.c_int64 * len(outs))(*[D] * len(outs))
+
+
+def forward_batch(plans, Cs):
+    """[T_i] = forward RAHT of every scene (plans[i], Cs[i]) in one set of launches; float32."""
+    n, D, ms, hp, mp, ld = _batch_arrays(plans, Cs, torch.float32, "C")
+    outs, op, old = _batch_out(plans, D, torch.float32, ms[0].device)
+    with torch.cuda.device(ms[0].device):
+        check(_lib.lib().raht_fwd_batch(n, hp, mp, ld, D, op, old, _stream()))
+    return outs
+
+
+def inverse_batch(plans, Ts):
+    n, D, ms, hp, mp, ld = _batch_arrays(plans, Ts, torch.float32, "T")
+    outs, op, old = _batch_out(plans, D, torch.float32, ms[0].device)
+    with torch.cuda.device(ms[0].device):
+        check(_lib.lib().raht_inv_batch(n, hp, mp, ld, D, op, old, _stream()))
+    return outs
+
+
+def forward_quant_batch(plans, Cs, steps):
+    """[Q_i] = forward RAHT + quantize + reorder of every scene in one set of launches (bit-identical to
+    plans[i].forward_quant(Cs[i], steps))."""
+    n, D, ms, hp, mp, ld = _batch_arrays(plans, Cs, torch.float32, "C")
+    st = _steps(steps, D)
+    outs, op, old = _batch_out(plans, D, torch.int32, ms[0].device)
+    with torch.cuda.device(ms[0].device):
+        check(_lib.lib().raht_fwd_quant_batch(n, hp, mp, ld, D, st, len(st), op, old, _stream()))
+    return outs
+
+
+def dequant_inverse_batch(plans, Qs, steps):
+    n, D, ms, hp, mp, ld = _batch_arrays(plans, Qs, torch.int32, "Q")
+    st = _steps(steps, D)
+    outs, op, old = _batch_out(plans, D, torch.float32, ms[0].device)
+    with torch.cuda.device(ms[0].device):
+        check(_lib.lib().raht_dequant_inv_batch(n, hp, mp, ld, D, st, len(st), op, old, _stream()))
+    return outs
+
+
 def quant_rows(X, steps, pos, Q):
     """Q[pos[i], :] = floor(X[i, :] / step + 0.5) in place (X float32 (n, D), pos int64 (n,), Q int32)."""
     _need_cuda(X, "X")

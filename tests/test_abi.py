@@ -37,7 +37,7 @@ def test_python_binding_covers_the_header(L):
 
 
 def test_version_and_error_string(L):
-    assert L.raht_version() == 200
+    assert L.raht_version() == 300
     assert isinstance(L.raht_last_error(), bytes)
     # argument validation happens before any HIP call, so it is safe without a GPU
     out = ctypes.c_void_p()

@@ -855,3 +855,73 @@ def test_very_wide_row_stride_takes_the_level_engine(rt):
     assert int((Q0 != Q1).sum()) <= 2                      # two engines: a rounding tie may fall either way
     C1 = p.dequant_inverse(Q1, 0.5)
     assert float((C1 - _dev(g["C"])).abs().max()) < 40 * 0.5
+
+
+# ------------------------------------------------------------------ several scenes in one set of launches
+def _batch_scenes(R, sizes, D, seed0=50):
+    import torch
+    from raht_3dgs_codec_amd import synth
+    plans, Cs = [], []
+    for i, (n, J) in enumerate(sizes):
+        V, keys, C = synth.scene(n, J, D, seed=seed0 + i)
+        plans.append(R.RahtPlan.from_keys(torch.from_numpy(keys.view(np.int64)).cuda(), 3 * J))
+        Cs.append(torch.from_numpy(C).cuda())
+    return plans, Cs
+
+
+@pytest.mark.parametrize("D", [59, 14, 56])
+@pytest.mark.parametrize("sizes", [
+    [(40000, 10), (300, 6), (150000, 11), (5000, 9)],                       # 3 stages, one top stage, 4 stages, 2 stages
+    [(20000 + 3000 * i, 10) for i in range(11)],                            # more scenes than one launch carries
+    [(70000, 12)],                                                          # a batch of one
+])
+def test_batch_equals_single_scene_calls_bit_for_bit(rt, D, sizes):
+    """raht_*_batch (stage k of every scene in ONE launch, top stages with blockIdx.y = scene) against n calls of the
+    single-scene entry points: the same kernels on the same tiles, so every output is bit-identical."""
+    import torch
+    from raht_3dgs_codec_amd import ops
+    plans, Cs = _batch_scenes(rt, sizes, D)
+    step = 0.02
+    Tb = ops.forward_batch(plans, Cs)
+    Qb = ops.forward_quant_batch(plans, Cs, step)
+    for p, C, T, Q in zip(plans, Cs, Tb, Qb):
+        assert torch.equal(T, p.forward(C, want_w=False))
+        assert torch.equal(Q, p.forward_quant(C, step))
+    Cb = ops.inverse_batch(plans, Tb)
+    Cq = ops.dequant_inverse_batch(plans, Qb, step)
+    for p, C, T, Q, c1, c2 in zip(plans, Cs, Tb, Qb, Cb, Cq):
+        assert torch.equal(c1, p.inverse(T))
+        assert torch.equal(c2, p.dequant_inverse(Q, step))
+        assert (c1 - C).abs().max().item() <= 1e-5 * C.abs().max().item()
+    # per-channel steps travel with the batch as well
+    steps = [0.01 * (1 + (c % 5)) for c in range(D)]
+    Qs = ops.forward_quant_batch(plans, Cs, steps)
+    for p, C, Q in zip(plans, Cs, Qs):
+        assert torch.equal(Q, p.forward_quant(C, steps))
+
+
+def test_batch_mixes_engines_and_geometries(rt):
+    """Scenes outside the tile engine (level engine selected; D below one 16-byte chunk) and scenes with another tile
+    geometry run inside the same call: the level-engine scenes through their own entry point, the others in launches of
+    their own shape."""
+    import torch
+    from raht_3dgs_codec_amd import ops
+    plans, Cs = _batch_scenes(rt, [(30000, 10), (30000, 10), (30000, 10), (30000, 10)], 14, seed0=70)
+    plans[1].set_engine("level")
+    plans[2].set_engine("tile", 64, 64, 0, 64)
+    ref = [p.forward_quant(C, 0.05) for p, C in zip(plans, Cs)]
+    out = ops.forward_quant_batch(plans, Cs, 0.05)
+    for a, b in zip(out, ref):
+        assert torch.equal(a, b)
+    back = ops.dequant_inverse_batch(plans, out, 0.05)
+    for p, Q, c in zip(plans, out, back):
+        assert torch.equal(c, p.dequant_inverse(Q, 0.05))
+    # D = 3 float32: rows shorter than one chunk -> every scene on the level engine
+    p3, C3 = _batch_scenes(rt, [(5000, 8), (900, 7)], 3, seed0=80)
+    for T, p, C in zip(ops.forward_batch(p3, C3), p3, C3):
+        assert torch.equal(T, p.forward(C, want_w=False))
+    # errors: a plan twice in one batch, mismatched D
+    with pytest.raises(rt.RahtError):
+        ops.forward_batch([plans[0], plans[0]], [Cs[0], Cs[0]])
+    with pytest.raises(ValueError):
+        ops.forward_batch([plans[0], p3[0]], [Cs[0], C3[0]])
