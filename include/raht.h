@@ -93,6 +93,11 @@ int raht_plan_create(const void *V, int v_dtype, int64_t N, const double minV[3]
  * when rows are themselves roots of already-transformed subtrees (multi-GPU top levels). */
 int raht_plan_create_from_keys(const uint64_t *keys_sorted, int64_t N, int nbits,
                                const int64_t *leaf_weights, raht_stream_t stream, raht_plan **out);
+/* The same without the 8 N-byte copy of the keys: the plan reads the CALLER's array for as long as it lives (the
+ * caller keeps `keys_sorted` allocated and unchanged until raht_plan_destroy). What a per-frame pipeline wants: the
+ * voxelizer's sorted key buffer outlives the frame's plan anyway. */
+int raht_plan_create_from_keys_borrowed(const uint64_t *keys_sorted, int64_t N, int nbits,
+                                        const int64_t *leaf_weights, raht_stream_t stream, raht_plan **out);
 
 /* Truncated trees (Morton-prefix sharded scenes): butterflies at binary levels >= top_level are
  * NOT performed by this plan's transforms; the rows that still carry a low-pass value afterwards
@@ -375,6 +380,9 @@ int raht_rlgr_decode_channels(const uint8_t *bufs, int64_t cap_per_channel, cons
                               int64_t chan_stride, int nthreads);
 int raht_transpose_i32(const int32_t *in, int64_t ld_in, int64_t rows, int64_t cols, int32_t *out,
                        int64_t ld_out, raht_stream_t stream);
+/* Host: are two contiguous int32 arrays equal? *first_diff = index of the first difference or -1. Threaded (the drivers'
+ * round-trip assertion, python/encode_3dgs.py:242-245, on 10^8 symbols). */
+int raht_i32_equal(const int32_t *a, const int32_t *b, int64_t n, int nthreads, int64_t *first_diff);
 
 #ifdef __cplusplus
 }

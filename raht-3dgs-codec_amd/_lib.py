@@ -18,7 +18,7 @@ ENGINE_TILE, ENGINE_LEVEL = 0, 1
 
 # every symbol include/raht.h declares (checked by tests/test_abi.py)
 EXPORTS = [
-    "raht_last_error", "raht_version", "raht_plan_create", "raht_plan_create_from_keys",
+    "raht_last_error", "raht_version", "raht_plan_create", "raht_plan_create_from_keys", "raht_plan_create_from_keys_borrowed",
     "raht_plan_destroy", "raht_plan_set_top_level", "raht_plan_roots", "raht_plan_set_root_buffer", "raht_plan_size", "raht_plan_nbits", "raht_plan_set_engine", "raht_plan_set_tail_tile", "raht_release_cached_memory", "raht_quant_rows", "raht_dequant_rows",
     "raht_plan_levels", "raht_plan_export_level", "raht_plan_order", "raht_plan_arrays",
     "raht_plan_copy_array", "raht_plan_stage_stats", "raht_fwd", "raht_fwd_f64", "raht_inv", "raht_inv_f64", "raht_debug_run_stage", "raht_plan_set_stage0_events", "raht_fwd_quant", "raht_dequant_inv", "raht_plan_prepare",
@@ -26,7 +26,7 @@ EXPORTS = [
     "raht_voxel_keys", "raht_voxelize_residuals", "raht_plan_set_row_map", "raht_rows_gather", "raht_rows_scatter",
     "raht_plan_set_max_stages", "raht_quant_reorder_f64", "raht_dequant_unreorder_f64", "raht_fwd_quant_f64", "raht_dequant_inv_f64",
     "raht_fwd_batch", "raht_inv_batch", "raht_fwd_quant_batch", "raht_dequant_inv_batch",
-    "raht_rlgr_bound", "raht_rlgr_encode", "raht_rlgr_decode", "raht_rlgr_encode_channels", "raht_rlgr_decode_channels", "raht_transpose_i32", "raht_merge_clusters",
+    "raht_rlgr_bound", "raht_rlgr_encode", "raht_rlgr_decode", "raht_rlgr_encode_channels", "raht_rlgr_decode_channels", "raht_transpose_i32", "raht_i32_equal", "raht_merge_clusters",
 ]
 
 
@@ -69,6 +69,7 @@ def lib():
     L.raht_last_error.restype = C.c_char_p
     L.raht_plan_create.argtypes = [vp, i32, i64, C.POINTER(dbl), dbl, i32, vp, C.POINTER(vp)]
     L.raht_plan_create_from_keys.argtypes = [vp, i64, i32, vp, vp, C.POINTER(vp)]
+    L.raht_plan_create_from_keys_borrowed.argtypes = [vp, i64, i32, vp, vp, C.POINTER(vp)]
     L.raht_plan_destroy.argtypes = [vp]
     L.raht_plan_set_top_level.argtypes = [vp, i32, vp]
     L.raht_plan_roots.argtypes = [vp, C.POINTER(i64), vp, vp]
@@ -122,6 +123,7 @@ def lib():
     L.raht_rlgr_decode_channels.argtypes = [vp, i64, vp, i64, i32, i32, vp, i64, i64, i32]
     L.raht_merge_clusters.argtypes = [vp, vp, i64, vp, vp, vp, vp, vp, i32, i32, vp, vp, vp, vp, vp, vp]
     L.raht_transpose_i32.argtypes = [vp, i64, i64, i64, vp, i64, vp]
+    L.raht_i32_equal.argtypes = [vp, vp, i64, i32, C.POINTER(i64)]
     _lib = L
     return L
 

@@ -172,7 +172,8 @@ __global__ void __launch_bounds__(EXT_THREADS) level_extent_kernel(const uint64_
     __shared__ uint8_t s_lvl[EXT_THREADS];
     __shared__ uint32_t n_queued;
     __shared__ uint32_t s_lh[64];
-    if (threadIdx.x == 0) n_queued = 0;
+    __shared__ uint32_t s_present[2];
+    if (threadIdx.x == 0) { n_queued = 0; s_present[0] = 0; s_present[1] = 0; }
     if (threadIdx.x < 64) s_lh[threadIdx.x] = 0;
     __syncthreads();
     const int64_t b0 = (int64_t)blockIdx.x * EXT_THREADS;
@@ -196,9 +197,23 @@ __global__ void __launch_bounds__(EXT_THREADS) level_extent_kernel(const uint64_
         order_bucket[i] = (i == 0) ? 0 : (uint8_t)(1 + (20 - l / 3));
     }
     const bool searching = valid && i != 0;
-    // one word per (level, wave), and the level histogram (one LDS atomic per wave and level present)
-    const int top = min(max(nbits, 1), 63);          // levels are < nbits
-    for (int t = 0; t < top; ++t) {
+    // Which levels occur in this BLOCK at all: a row only ever reads the words of its own level, so only those columns
+    // are needed -- typically a dozen of the up to 63 (the kernel was bound by the two wave-wide compares per level and
+    // wave: 36 levels on cfg3). Wave-wide OR of 1 << l by butterfly shuffles, one LDS atomic per wave.
+    {
+        uint32_t plo = (l < 32) ? (1u << l) : 0u, phi = (l >= 32 && l < 64) ? (1u << (l - 32)) : 0u;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) { plo |= (uint32_t)__shfl_xor((int)plo, d, 64); phi |= (uint32_t)__shfl_xor((int)phi, d, 64); }
+        if (lane == 0) { if (plo) atomicOr(&s_present[0], plo); if (phi) atomicOr(&s_present[1], phi); }
+    }
+    __syncthreads();
+    // one word per (level present, wave), and the level histogram (one LDS atomic per wave and level present)
+    uint64_t present = (uint64_t)s_present[0] | ((uint64_t)s_present[1] << 32);
+    if (nbits < 64) present &= ((uint64_t)1 << max(nbits, 1)) - 1;    // levels are < nbits (out-of-range keys are reported, not indexed)
+    present &= ~((uint64_t)1 << 63);
+    while (present) {
+        const int t = __ffsll((unsigned long long)present) - 1;
+        present &= present - 1;
         const uint64_t ge = __ballot(l >= t);
         const uint32_t eq = (uint32_t)__popcll(__ballot(l == t));
         if (lane == 0) {
@@ -499,83 +514,130 @@ __global__ void gather_meta_kernel(const uint32_t *__restrict__ rows, int64_t n,
     e_wl[j] = wl[r]; e_wr[j] = wr[r]; e_lvl[j] = lvl[r]; e_pos[j] = inv_order[r];
 }
 
-// ---- butterfly heights of a tile stage ------------------------------------------------------------
-// One wave per tile (R <= 1024 entries). The recurrence is the forward transform's own order: walk the binary levels
-// present in the tile upwards; a butterfly (partner p, own slot j) gets h = 1 + max(cur[p], cur[j]) and leaves it in
-// cur[p], the slot that carries the merged node on. Butterflies of one level touch disjoint slots. What "merged in this
-// tile" means is the tile kernel's own predicate (transform.hip, P1).
-constexpr int HT_MAX_ROWS = 1024;
-__global__ __launch_bounds__(64) void tile_heights_kernel(const uint32_t *__restrict__ rows, int64_t n, int R, int64_t N,
-                                                          const int32_t *__restrict__ wl, const int32_t *__restrict__ wr,
-                                                          const uint8_t *__restrict__ lvl, int top_level, uint8_t *__restrict__ ht)
+// ---- butterfly heights of the tile stages -----------------------------------------------------------
+// One wave per tile, every tile stage of a schedule in ONE launch. The recurrence is the forward transform's own order:
+// walk the binary levels present in the tile upwards; a butterfly (partner slot p, own slot j) gets h = 1 + max(cur[p],
+// cur[j]) and leaves it in cur[p], the slot that carries the merged node on. Butterflies of one level touch disjoint slots,
+// so a level is: every lane reads the two values of its (<= SPL) butterflies, then writes them -- two LDS round trips. A
+// lane keeps its slots' level / partner / height in registers; LDS holds one byte per slot (and the row ids of a later
+// stage, for the partner search). What "merged in this tile" means is the tile kernel's own predicate (transform.hip, P1).
+constexpr int HT_MAX_ROWS = 1024, HT_MAX_STAGES = 8;
+struct HeightStage {
+    const uint32_t *rows; const int32_t *wl, *wr; const uint8_t *lvl; uint8_t *ht;
+    int64_t n; int R; uint32_t first_tile;
+};
+struct HeightArgs { HeightStage st[HT_MAX_STAGES]; int n_stages; uint32_t n_tiles; int64_t N; int top_level; };
+
+template <int SPL>
+__global__ __launch_bounds__(64) void tile_heights_kernel(const HeightArgs H)
 {
-    __shared__ uint32_t s_row[HT_MAX_ROWS];
-    __shared__ uint16_t s_part[HT_MAX_ROWS];
-    __shared__ uint8_t s_lv[HT_MAX_ROWS], s_cur[HT_MAX_ROWS], s_ht[HT_MAX_ROWS];
+    extern __shared__ __align__(16) unsigned char ht_smem[];
+    int k = 0;
+#pragma unroll
+    for (int q = 1; q < HT_MAX_STAGES; ++q) k += (q < H.n_stages && blockIdx.x >= H.st[q].first_tile) ? 1 : 0;
+    const HeightStage &S = H.st[k];
+    const int R = S.R;
     const int lane = threadIdx.x;
-    const int64_t e0 = (int64_t)blockIdx.x * R;
-    if (e0 >= n) return;
-    const int nt = (int)min((int64_t)R, n - e0);
+    const int64_t e0 = (int64_t)(blockIdx.x - S.first_tile) * R;
+    if (e0 >= S.n) return;
+    const uint32_t *__restrict__ rows = S.rows;
+    const int nt = (int)min((int64_t)R, S.n - e0);
+    uint8_t *s_cur = ht_smem;                                   // [R]
+    uint32_t *s_row = (uint32_t *)(ht_smem + ((R + 15) & ~15)); // [R], later stages only
     const int64_t start_row = rows ? (int64_t)rows[e0] : e0;
-    const int64_t end_row = (e0 + R < n) ? (rows ? (int64_t)rows[e0 + R] : e0 + R) : N;
-    if (rows) for (int j = lane; j < nt; j += 64) s_row[j] = rows[e0 + j];
+    const int64_t end_row = (e0 + R < S.n) ? (rows ? (int64_t)rows[e0 + R] : e0 + R) : H.N;
+    int lv[SPL], part[SPL];
+    int32_t wlv[SPL], wrv[SPL];
+    int64_t r[SPL];
+#pragma unroll
+    for (int s = 0; s < SPL; ++s) {                          // all loads first: one round trip
+        const int j = lane + s * 64;
+        lv[s] = 255; wlv[s] = 0; wrv[s] = 0; r[s] = 0;
+        if (j < nt) {
+            r[s] = rows ? (int64_t)rows[e0 + j] : e0 + j;
+            lv[s] = (int)S.lvl[e0 + j]; wlv[s] = S.wl[e0 + j]; wrv[s] = S.wr[e0 + j];
+        }
+    }
+    if (rows) {
+#pragma unroll
+        for (int s = 0; s < SPL; ++s) { const int j = lane + s * 64; if (j < nt) s_row[j] = (uint32_t)r[s]; }
+    }
+#pragma unroll
+    for (int s = 0; s < SPL; ++s) { const int j = lane + s * 64; if (j < nt) s_cur[j] = 0; }
     __syncthreads();
     uint64_t mask = 0;
-    for (int j = lane; j < nt; j += 64) {
-        const int64_t r = rows ? (int64_t)s_row[j] : e0 + j;
-        const int l = (int)lvl[e0 + j];
-        const int32_t wlv = wl[e0 + j], wrv = wr[e0 + j];
-        const bool merged = (r > 0) && (l < top_level) && (r - wlv >= start_row) && (r + wrv <= end_row);
-        int p = 0;
+#pragma unroll
+    for (int s = 0; s < SPL; ++s) {
+        const int j = lane + s * 64;
+        const bool merged = (j < nt) && (r[s] > 0) && (lv[s] < H.top_level) && (r[s] - wlv[s] >= start_row) && (r[s] + wrv[s] <= end_row);
+        part[s] = 0;
         if (merged) {
-            if (!rows) p = j - wlv;
+            if (!rows) part[s] = j - wlv[s];
             else {                                          // the partner row r - wl is an entry of this tile
-                const uint32_t want = (uint32_t)(r - wlv);
+                const uint32_t want = (uint32_t)(r[s] - wlv[s]);
                 int lo = 0, hi = j - 1;
                 while (lo < hi) { const int mid = (lo + hi) >> 1; if (s_row[mid] < want) lo = mid + 1; else hi = mid; }
-                p = lo;
+                part[s] = lo;
             }
-            mask |= (uint64_t)1 << l;
+            mask |= (uint64_t)1 << lv[s];
+        } else {
+            lv[s] = 255;
         }
-        s_lv[j] = merged ? (uint8_t)l : (uint8_t)255;
-        s_part[j] = (uint16_t)p;
-        s_cur[j] = 0;
-        s_ht[j] = 0;
     }
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) {
         const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)mask, d, 64), hi = (uint32_t)__shfl_xor((int)(uint32_t)(mask >> 32), d, 64);
         mask |= (uint64_t)lo | ((uint64_t)hi << 32);
     }
-    __syncthreads();
+    int ht[SPL];
+#pragma unroll
+    for (int s = 0; s < SPL; ++s) ht[s] = 0;
     while (mask) {
         const int l = __ffsll((unsigned long long)mask) - 1;
         mask &= mask - 1;
-        for (int j = lane; j < nt; j += 64) {
-            if (s_lv[j] == (uint8_t)l) {
-                const int p = s_part[j];
-                const uint8_t h = (uint8_t)(1 + max((int)s_cur[p], (int)s_cur[j]));
-                s_ht[j] = h;
-                s_cur[p] = h;
-            }
+        int h[SPL];
+#pragma unroll
+        for (int s = 0; s < SPL; ++s) {
+            h[s] = 0;
+            if (lv[s] == l) h[s] = 1 + max((int)s_cur[part[s]], (int)s_cur[lane + s * 64]);
         }
+#pragma unroll
+        for (int s = 0; s < SPL; ++s)
+            if (lv[s] == l) { ht[s] = h[s]; s_cur[part[s]] = (uint8_t)h[s]; }
         __syncthreads();                                    // one wave: orders the LDS traffic of consecutive levels
     }
-    for (int j = lane; j < nt; j += 64) ht[e0 + j] = s_ht[j];
+#pragma unroll
+    for (int s = 0; s < SPL; ++s) { const int j = lane + s * 64; if (j < nt) S.ht[e0 + j] = (uint8_t)ht[s]; }
 }
 
-// heights of every tile stage of a finished schedule (sizes are known on the host by now; enqueued, not waited for:
-// the transforms that read them run behind this on the same stream)
+// heights of every tile stage of a finished schedule: one launch (sizes are known on the host by now; enqueued, not
+// waited for: the transforms that read them run behind this on the same stream)
 static int launch_stage_heights(raht_plan *plan, Schedule &sc, hipStream_t s)
 {
+    HeightArgs H;
+    H.n_stages = 0; H.n_tiles = 0; H.N = plan->N; H.top_level = plan->top_level;
+    int maxR = 0;
+    bool any_rows = false;
     for (size_t k = 0; k < sc.stages.size(); ++k) {
         Stage &st = sc.stages[k];
         if (st.is_top || st.n_entries < 1) continue;
-        if (st.tile_rows > HT_MAX_ROWS) { set_error("tile_rows %d: heights support at most %d rows per tile", st.tile_rows, HT_MAX_ROWS); return RAHT_ERR_UNSUPPORTED; }
+        if (st.tile_rows > HT_MAX_ROWS || H.n_stages >= HT_MAX_STAGES) { set_error("tile heights: %d rows per tile / %d tile stages not supported", st.tile_rows, (int)sc.stages.size()); return RAHT_ERR_UNSUPPORTED; }
         if (!st.e_ht) RAHT_HIP_CHECK(dev_malloc(&st.e_ht, (size_t)st.n_entries));
-        hipLaunchKernelGGL(tile_heights_kernel, dim3((unsigned)st.n_tiles), dim3(64), 0, s, st.rows, st.n_entries, st.tile_rows, plan->N,
-                           st.rows ? st.e_wl : plan->wl, st.rows ? st.e_wr : plan->wr, st.rows ? st.e_lvl : plan->lvl, plan->top_level, st.e_ht);
+        HeightStage &h = H.st[H.n_stages++];
+        h.rows = st.rows; h.wl = st.rows ? st.e_wl : plan->wl; h.wr = st.rows ? st.e_wr : plan->wr; h.lvl = st.rows ? st.e_lvl : plan->lvl;
+        h.ht = st.e_ht; h.n = st.n_entries; h.R = st.tile_rows; h.first_tile = H.n_tiles;
+        H.n_tiles += (uint32_t)st.n_tiles;
+        maxR = std::max(maxR, st.tile_rows);
+        any_rows = any_rows || st.rows != nullptr;
     }
+    if (H.n_stages == 0) return RAHT_OK;
+    for (int q = H.n_stages; q < HT_MAX_STAGES; ++q) H.st[q] = H.st[0];
+    const size_t lds = (size_t)((maxR + 15) & ~15) + (any_rows ? (size_t)maxR * 4 : 0);
+    const int spl = (maxR + 63) / 64;
+    if (spl <= 3) hipLaunchKernelGGL(tile_heights_kernel<3>, dim3(H.n_tiles), dim3(64), lds, s, H);
+    else if (spl <= 4) hipLaunchKernelGGL(tile_heights_kernel<4>, dim3(H.n_tiles), dim3(64), lds, s, H);
+    else if (spl <= 8) hipLaunchKernelGGL(tile_heights_kernel<8>, dim3(H.n_tiles), dim3(64), lds, s, H);
+    else hipLaunchKernelGGL(tile_heights_kernel<16>, dim3(H.n_tiles), dim3(64), lds, s, H);
     RAHT_HIP_CHECK(hipGetLastError());
     return RAHT_OK;
 }
@@ -1459,25 +1521,41 @@ int raht_plan_create(const void *V, int v_dtype, int64_t N, const double minV[3]
     });
 }
 
-int raht_plan_create_from_keys(const uint64_t *keys_sorted, int64_t N, int nbits,
-                               const int64_t *leaf_weights, raht_stream_t stream, raht_plan **out)
+static int plan_from_keys_impl(const uint64_t *keys_sorted, int64_t N, int nbits, const int64_t *leaf_weights, bool borrow,
+                               raht_stream_t stream, raht_plan **out, const char *what)
 {
-    if (!keys_sorted || !out) { set_error("raht_plan_create_from_keys: NULL argument"); return RAHT_ERR_INVALID; }
-    if (N < 1 || N >= ((int64_t)1 << 31)) { set_error("raht_plan_create_from_keys: N=%lld out of range", (long long)N); return RAHT_ERR_INVALID; }
-    if (nbits < 1 || nbits > 63) { set_error("raht_plan_create_from_keys: nbits=%d (1..63)", nbits); return RAHT_ERR_INVALID; }
+    if (!keys_sorted || !out) { set_error("%s: NULL argument", what); return RAHT_ERR_INVALID; }
+    if (N < 1 || N >= ((int64_t)1 << 31)) { set_error("%s: N=%lld out of range", what, (long long)N); return RAHT_ERR_INVALID; }
+    if (nbits < 1 || nbits > 63) { set_error("%s: nbits=%d (1..63)", what, nbits); return RAHT_ERR_INVALID; }
     hipStream_t s = (hipStream_t)stream;
-    return guarded("raht_plan_create_from_keys", [&]() -> int {
+    return guarded(what, [&]() -> int {
         PlanHolder h;
         h.p = new raht_plan();
         raht_plan *p = h.p;
         p->device = current_device();
         p->N = N;
         p->nbits = nbits;
-        if (dev_malloc(&p->keys, sizeof(uint64_t) * (size_t)N) != hipSuccess) { set_error("hipMalloc keys"); return RAHT_ERR_NOMEM; }
-        RAHT_RET(finish_plan(p, leaf_weights, s, keys_sorted));
+        if (borrow) {
+            // the caller's array IS the plan's key array (no 8 N-byte copy): it must stay alive and unchanged as long as the plan
+            p->keys = const_cast<uint64_t *>(keys_sorted);
+            p->keys_borrowed = true;
+        } else if (dev_malloc(&p->keys, sizeof(uint64_t) * (size_t)N) != hipSuccess) { set_error("hipMalloc keys"); return RAHT_ERR_NOMEM; }
+        RAHT_RET(finish_plan(p, leaf_weights, s, borrow ? nullptr : keys_sorted));
         *out = h.release();
         return RAHT_OK;
     });
+}
+
+int raht_plan_create_from_keys(const uint64_t *keys_sorted, int64_t N, int nbits,
+                               const int64_t *leaf_weights, raht_stream_t stream, raht_plan **out)
+{
+    return plan_from_keys_impl(keys_sorted, N, nbits, leaf_weights, false, stream, out, "raht_plan_create_from_keys");
+}
+
+int raht_plan_create_from_keys_borrowed(const uint64_t *keys_sorted, int64_t N, int nbits,
+                                        const int64_t *leaf_weights, raht_stream_t stream, raht_plan **out)
+{
+    return plan_from_keys_impl(keys_sorted, N, nbits, leaf_weights, true, stream, out, "raht_plan_create_from_keys_borrowed");
 }
 
 int raht_plan_destroy(raht_plan *p)
@@ -1490,7 +1568,7 @@ int raht_plan_destroy(raht_plan *p)
     // enqueued on any stream may still be using them (hipFree used to imply the same wait)
     (void)hipDeviceSynchronize();
     for (auto &sc : p->schedules) free_schedule(sc);
-    if (p->keys) dev_free(p->keys);
+    if (p->keys && !p->keys_borrowed) dev_free(p->keys);
     if (p->lvl) dev_free(p->lvl);
     if (p->wl) dev_free(p->wl);
     if (p->wr) dev_free(p->wr);

@@ -210,6 +210,7 @@ struct raht_plan {
     int nbits = 0;
     int max_level = -1;          // highest binary level with a pair (-1 when N == 1)
     uint64_t *keys = nullptr;    // device, sorted Morton keys
+    bool keys_borrowed = false;  // keys is the CALLER's array (raht_plan_create_from_keys_borrowed): never freed here
     uint8_t *lvl = nullptr;      // device, 255 for row 0
     int32_t *wl = nullptr;       // device
     int32_t *wr = nullptr;       // device

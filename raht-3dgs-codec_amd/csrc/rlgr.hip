@@ -14,6 +14,9 @@
 
 #include <algorithm>
 #include <atomic>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
 #include <thread>
 #include <vector>
 
@@ -322,9 +325,39 @@ static void transpose_from_channels(const int32_t *T, int64_t N, int D, int32_t 
     raht::rlgr::run_pool(nthreads, work);
 }
 
+// CPUs this process may actually use: the cgroup's CPU quota (containers: 16 CPUs on the one-GPU MI355X box although 256 are
+// visible -- 56 coder threads there run in bursts and get throttled: 24 ... 105 ms per pass instead of a steady 65) and the
+// affinity mask, not just the number of hardware threads.
+static int usable_cpus()
+{
+    static int n = 0;
+    if (n) return n;
+    int v = (int)std::max(1u, std::thread::hardware_concurrency());
+    if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {          // cgroup v2: "<quota> <period>" or "max <period>"
+        char q[32] = "";
+        long long period = 0;
+        if (fscanf(f, "%31s %lld", q, &period) == 2 && strcmp(q, "max") != 0 && period > 0) {
+            const long long quota = atoll(q);
+            if (quota > 0) v = std::min<long long>(v, std::max<long long>(1, (quota + period - 1) / period));
+        }
+        fclose(f);
+    } else if (FILE *g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {   // cgroup v1
+        long long quota = -1, period = 0;
+        if (fscanf(g, "%lld", &quota) == 1 && quota > 0) {
+            if (FILE *h = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) {
+                if (fscanf(h, "%lld", &period) == 1 && period > 0) v = std::min<long long>(v, std::max<long long>(1, (quota + period - 1) / period));
+                fclose(h);
+            }
+        }
+        fclose(g);
+    }
+    n = std::max(1, v);
+    return n;
+}
+
 static int resolve_threads(int nthreads, int D)
 {
-    if (nthreads <= 0) nthreads = (int)std::max(1u, std::thread::hardware_concurrency());
+    if (nthreads <= 0) nthreads = usable_cpus();
     return std::max(1, std::min(nthreads, std::max(D, 1)));
 }
 }}  // namespace raht::rlgr
@@ -380,6 +413,33 @@ int raht_rlgr_decode_channels(const uint8_t *bufs, int64_t cap_per_channel, cons
             rlgr::decode(bufs + (int64_t)c * cap_per_channel, nbytes[c], N, flag_signed, dst + (int64_t)c * cs, ss);
         });
         if (via_tmp) rlgr::transpose_from_channels(tmp.data(), N, D, Q, sym_stride, nt);
+        return RAHT_OK;
+    });
+}
+
+
+/* Are two contiguous int32 arrays equal? (the drivers' round-trip assertion, python/encode_3dgs.py:242-245, on 10^8 symbols:
+ * numpy's single-threaded array_equal costs more than coding them.) *first_diff = index of the first difference, or -1. */
+int raht_i32_equal(const int32_t *a, const int32_t *b, int64_t n, int nthreads, int64_t *first_diff)
+{
+    if ((!a || !b) && n > 0) { set_error("raht_i32_equal: NULL argument"); return RAHT_ERR_INVALID; }
+    if (n < 0 || !first_diff) { set_error("raht_i32_equal: bad argument"); return RAHT_ERR_INVALID; }
+    return raht::guarded("raht_i32_equal", [&]() -> int {
+        const int64_t B = (int64_t)1 << 20;
+        const int64_t nblk = (n + B - 1) / B;
+        const int nt = (int)std::max<int64_t>(1, std::min<int64_t>(resolve_threads(nthreads, 1 << 20), nblk));
+        std::atomic<int64_t> next(0), first(INT64_MAX);
+        auto work = [&]() {
+            for (int64_t blk = next++; blk < nblk; blk = next++) {
+                const int64_t i0 = blk * B, i1 = std::min(n, i0 + B);
+                if (i0 >= first.load(std::memory_order_relaxed)) continue;
+                if (memcmp(a + i0, b + i0, (size_t)(i1 - i0) * 4) == 0) continue;
+                for (int64_t i = i0; i < i1; ++i)
+                    if (a[i] != b[i]) { int64_t cur = first.load(); while (i < cur && !first.compare_exchange_weak(cur, i)) {} break; }
+            }
+        };
+        raht::rlgr::run_pool(nt, work);
+        *first_diff = first.load() == INT64_MAX ? -1 : first.load();
         return RAHT_OK;
     });
 }

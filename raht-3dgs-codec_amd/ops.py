@@ -95,7 +95,9 @@ class RahtPlan:
         return RahtPlan(h, V.device)
 
     @staticmethod
-    def from_keys(keys_sorted, nbits, leaf_weights=None, top_level=None):
+    def from_keys(keys_sorted, nbits, leaf_weights=None, top_level=None, borrow=False):
+        """borrow=True: the plan reads `keys_sorted` in place instead of copying it (the plan keeps a reference to the
+        tensor; the caller must not modify it while the plan lives)."""
         _need_cuda(keys_sorted, "keys_sorted")
         k = keys_sorted.contiguous()
         if k.dtype not in (torch.int64, torch.uint64):
@@ -105,11 +107,13 @@ class RahtPlan:
             _need_cuda(leaf_weights, "leaf_weights")
             lw = leaf_weights.to(torch.int64).contiguous()
         h = C.c_void_p()
+        fn = _lib.lib().raht_plan_create_from_keys_borrowed if borrow else _lib.lib().raht_plan_create_from_keys
         with torch.cuda.device(k.device):
-            check(_lib.lib().raht_plan_create_from_keys(C.c_void_p(k.data_ptr()), k.shape[0], int(nbits),
-                                                        C.c_void_p(lw.data_ptr()) if lw is not None else None,
-                                                        _stream(), C.byref(h)))
+            check(fn(C.c_void_p(k.data_ptr()), k.shape[0], int(nbits),
+                     C.c_void_p(lw.data_ptr()) if lw is not None else None, _stream(), C.byref(h)))
         p = RahtPlan(h, k.device)
+        if borrow:
+            p._keys_ref = k                   # keeps the borrowed array alive as long as the plan
         if top_level is not None:
             p.set_top_level(top_level)
         return p

@@ -39,9 +39,16 @@ def _psnr(a, b):
 
 
 def encode_frame(V_int, attributes, J, steps, frame=1, device="cuda:0", dtype=torch.float32, fused=True,
-                 nthreads=0, channel_major=True):
+                 nthreads=0, channel_major=True, overlap=False):
     """One frame through the whole pipeline. Returns a list of dict rows (one per step) with the CSV
-    columns plus ``size_bytes`` and ``C_rec`` (last step) for inspection."""
+    columns plus ``size_bytes`` and ``C_rec`` (last step) for inspection, and the stages the reference's CSV has no
+    column for (``Transpose_time``, ``D2H_time``, ``H2D_time``, ``PSNR_time``, ``Step_wall_time``).
+
+    overlap=True (fused path): the steps are software-pipelined -- while the host threads entropy-code step s, the GPU
+    already transforms / quantizes / copies step s + 1 and decodes step s - 1 (the reference serialises all of it,
+    python/encode_3dgs.py:199-275). Same rows, same bytes; ``Step_wall_time`` is then the pipeline's period."""
+    if overlap and fused:
+        return _encode_frame_overlapped(V_int, attributes, J, steps, frame, device, dtype, nthreads)
     N = V_int.shape[0]
     C = attributes.to(dtype=dtype).contiguous().to(device)
     _sync()
@@ -63,6 +70,7 @@ def encode_frame(V_int, attributes, J, steps, frame=1, device="cuda:0", dtype=to
         t_transform = time.time() - t0
 
     rows = []
+    coder = None
     for step in steps:
         # a scalar step (the drivers' colorStep entries) or one step per channel (per_attribute_steps below)
         per_channel = not isinstance(step, (int, float))
@@ -74,6 +82,7 @@ def encode_frame(V_int, attributes, J, steps, frame=1, device="cuda:0", dtype=to
             step_t, step_arg = step, float(step)
         r = dict(Frame=frame, Quantization_Step="per_attribute" if per_channel else step)
         step = step_t
+        t_step0 = time.time()
         # ---------------- encoder ----------------
         if use_fused:
             t0 = time.time()
@@ -91,18 +100,45 @@ def encode_frame(V_int, attributes, J, steps, frame=1, device="cuda:0", dtype=to
             r["Coeff_reorder_enc_time"] = time.time() - t0
             r["RAHT_transform_time"] = t_transform
         # device -> host, channel-major so that the entropy coder reads contiguous channels
+        t0 = time.time()
         q_dev = rlgr_mod.transpose_on_device(coeff_reordered) if channel_major else coeff_reordered
+        _sync()
+        r["Transpose_time"] = time.time() - t0
+        t0 = time.time()
         q_cpu = rlgr_mod.to_host(q_dev)                                             # :215-217 (pinned staging)
-        streams, t_enc = rlgr_mod.encode_channels(q_cpu, 1, nthreads=nthreads, channel_major=channel_major)   # :229-234
-        size_bytes = sum(int(s.shape[0]) for s in streams)                          # :247
-        r["Entropy_enc_time"] = t_enc
-        # ---------------- decoder ----------------
-        q_back, t_dec = rlgr_mod.decode_channels(streams, N, 1, nthreads=nthreads, channel_major=channel_major)   # :237-245
-        assert np.array_equal(q_back, q_cpu), "RLGR roundtrip failed"               # :242-245
-        r["Entropy_dec_time"] = t_dec
-        qd = torch.from_numpy(q_back).to(device)
+        r["D2H_time"] = time.time() - t0
         if channel_major:
+            # all D channels on the host threads, streams in one arena, decoded straight into a page-locked upload buffer
+            if coder is None:
+                coder = rlgr_mod.ChannelCoder(N, q_cpu.shape[0], 1, nthreads)
+            r["Entropy_enc_time"] = coder.encode(q_cpu)                             # :229-234
+            size_bytes = coder.size_bytes                                           # :247
+            up = rlgr_mod.pinned_like(q_cpu.shape, torch.int32, "up")
+            q_back = up.numpy()
+            r["Entropy_dec_time"] = coder.decode(q_back)                            # :237-241
+            t0 = time.time()
+            assert rlgr_mod.arrays_equal(q_back, q_cpu, nthreads), "RLGR roundtrip failed"   # :242-245
+            r["Roundtrip_check_time"] = time.time() - t0
+            t0 = time.time()
+            qd = up.to(device, non_blocking=True)
+            _sync()
+            r["H2D_time"] = time.time() - t0
+        else:
+            streams, t_enc = rlgr_mod.encode_channels(q_cpu, 1, nthreads=nthreads, channel_major=channel_major)   # :229-234
+            size_bytes = sum(int(s.shape[0]) for s in streams)                          # :247
+            r["Entropy_enc_time"] = t_enc
+            q_back, t_dec = rlgr_mod.decode_channels(streams, N, 1, nthreads=nthreads, channel_major=channel_major)   # :237-245
+            assert np.array_equal(q_back, q_cpu), "RLGR roundtrip failed"               # :242-245
+            r["Entropy_dec_time"] = t_dec
+            t0 = time.time()
+            qd = torch.from_numpy(q_back).to(device)
+            _sync()
+            r["H2D_time"] = time.time() - t0
+        if channel_major:
+            t0 = time.time()
             qd = rlgr_mod.transpose_on_device(qd)
+            _sync()
+            r["Transpose_time"] += time.time() - t0
         if use_fused:
             t0 = time.time()
             C_rec = plan.dequant_inverse(qd, step_arg, dtype=dtype)                 # :261 + :267-268 + :274
@@ -128,13 +164,121 @@ def encode_frame(V_int, attributes, J, steps, frame=1, device="cuda:0", dtype=to
         r["Pipeline_time"] = t_prelude + r["Total_enc_time"] + r["Total_dec_time"]
         r["Rate_bpp"] = size_bytes * 8 / N                                          # :403
         r["size_bytes"] = size_bytes
-        r["PSNR_all"] = _psnr(C, C_rec)
-        r["PSNR_quats"] = _psnr(C[:, 0:4], C_rec[:, 0:4])
-        r["PSNR_scales"] = _psnr(C[:, 4:7], C_rec[:, 4:7])
-        r["PSNR_opacity"] = _psnr(C[:, 7], C_rec[:, 7])
-        r["PSNR_colors"] = _psnr(C[:, 8:], C_rec[:, 8:])
+        t0 = time.time()
+        _psnr_columns(r, C, C_rec)
+        r["PSNR_time"] = time.time() - t0
+        r["Step_wall_time"] = time.time() - t_step0
         r["C_rec"] = C_rec
         rows.append(r)
+    return rows
+
+
+def _psnr_columns(r, C, C_rec):
+    r["PSNR_all"] = _psnr(C, C_rec)                                                 # encode_3dgs.py:298-310
+    r["PSNR_quats"] = _psnr(C[:, 0:4], C_rec[:, 0:4])
+    r["PSNR_scales"] = _psnr(C[:, 4:7], C_rec[:, 4:7])
+    r["PSNR_opacity"] = _psnr(C[:, 7], C_rec[:, 7])
+    r["PSNR_colors"] = _psnr(C[:, 8:], C_rec[:, 8:])
+
+
+def _encode_frame_overlapped(V_int, attributes, J, steps, frame, device, dtype, nthreads):
+    """The same frame, software-pipelined over the quantization steps (encode_frame, overlap=True).
+
+    GPU (this thread):   step s: forward RAHT + quantize + reorder (fused) -> channel-major transpose -> device-to-host copy into
+                         a page-locked buffer on a copy stream;   step s - 1 (once its bytes are back): host-to-device copy ->
+                         transpose -> dequantize + un-reorder + inverse RAHT (fused) -> PSNR
+    host (worker thread; the coder itself runs the channels on all cores): entropy-code step s, decode it again, check the
+                         round trip (encode_3dgs.py:229-245), hand the decoded integers back in a second page-locked buffer
+    Two buffers per direction: step s + 2 may only reuse what step s has finished with, which the order of this loop
+    guarantees. What the reference runs back to back per step -- GPU stages, copies, coder -- costs max(host, GPU) here."""
+    from concurrent.futures import ThreadPoolExecutor
+    N = V_int.shape[0]
+    dev = torch.device(device)
+    C = attributes.to(dtype=dtype).contiguous().to(dev)
+    _sync()
+    V = V_int.to(dtype=torch.float64).to(dev)
+    origin = torch.tensor([0, 0, 0], dtype=V.dtype, device=dev)
+    t0 = time.time()
+    ListC, FlagsC, weightsC, order_RAGFT = RAHT_param_reorder_fast(V, origin, 2 ** J, J)
+    _sync()
+    t_prelude = time.time() - t0
+    plan = plan_of(ListC)
+    D = C.shape[1]
+    pin_dn = [torch.empty((D, N), dtype=torch.int32, pin_memory=True) for _ in range(2)]
+    pin_up = [torch.empty((D, N), dtype=torch.int32, pin_memory=True) for _ in range(2)]
+    copy_stream = torch.cuda.Stream(device=dev)
+    main = torch.cuda.current_stream(dev)
+    steps = list(steps)
+    n = len(steps)
+
+    def step_args(step):
+        if isinstance(step, (int, float)):
+            return float(step), step
+        lst = [float(x) for x in (step.tolist() if hasattr(step, "tolist") else step)]
+        return lst, "per_attribute"
+
+    coder = rlgr_mod.ChannelCoder(N, D, 1, nthreads)
+
+    def host_job(i, ev_dn):
+        ev_dn.synchronize()                                   # step i's integers have arrived
+        q_cpu = pin_dn[i % 2].numpy()
+        t_enc = coder.encode(q_cpu)
+        size_bytes = coder.size_bytes
+        q_back = pin_up[i % 2].numpy()
+        t_dec = coder.decode(q_back)                          # straight into the page-locked upload buffer
+        assert rlgr_mod.arrays_equal(q_back, q_cpu, nthreads), "RLGR roundtrip failed"   # encode_3dgs.py:242-245
+        return size_bytes, t_enc, t_dec, time.time()
+
+    rows = [None] * n
+    jobs = [None] * n
+    t_enc_gpu = [0.0] * n
+    t_mark = time.time()
+    with ThreadPoolExecutor(max_workers=1) as pool:
+        for i in range(n + 1):
+            if i < n:
+                sa, _ = step_args(steps[i])
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(main)
+                q_dev = rlgr_mod.transpose_on_device(plan.forward_quant(C, sa))
+                e1.record(main)
+                copy_stream.wait_stream(main)
+                with torch.cuda.stream(copy_stream):
+                    pin_dn[i % 2].copy_(q_dev, non_blocking=True)
+                    q_dev.record_stream(copy_stream)
+                    ev = torch.cuda.Event()
+                    ev.record(copy_stream)
+                jobs[i] = pool.submit(host_job, i, ev)
+                t_enc_gpu[i] = (e0, e1)
+            if i >= 1:
+                k = i - 1
+                size_bytes, t_enc, t_dec, t_done = jobs[k].result()
+                sa, label = step_args(steps[k])
+                r = dict(Frame=frame, Quantization_Step=label if label == "per_attribute" else steps[k])
+                f0, f1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                t0 = time.time()
+                qd = pin_up[k % 2].to(dev, non_blocking=True)
+                f0.record(main)
+                C_rec = plan.dequant_inverse(rlgr_mod.transpose_on_device(qd), sa, dtype=dtype)
+                f1.record(main)
+                _psnr_columns(r, C, C_rec)                    # (synchronises: .item())
+                t_gpu_dec = time.time() - t0
+                e0, e1 = t_enc_gpu[k]
+                r["RAHT_transform_time"] = e0.elapsed_time(e1) * 1e-3          # forward + quantize + reorder + transpose (GPU time)
+                r["iRAHT_time"] = f0.elapsed_time(f1) * 1e-3
+                r["Quant_time"] = r["Coeff_reorder_enc_time"] = r["Dequant_time"] = r["Coeff_reorder_dec_time"] = 0.0
+                r["Entropy_enc_time"], r["Entropy_dec_time"] = t_enc, t_dec
+                r["RAHT_prelude_time"] = t_prelude
+                r["Total_enc_time"] = r["RAHT_transform_time"] + r["Entropy_enc_time"]
+                r["Total_dec_time"] = r["Entropy_dec_time"] + r["iRAHT_time"]
+                now = time.time()
+                r["Step_wall_time"] = now - t_mark             # the pipeline's period: what a step costs end to end here
+                t_mark = now
+                r["Pipeline_time"] = t_prelude + r["Step_wall_time"]
+                r["GPU_decode_side_time"] = t_gpu_dec
+                r["Rate_bpp"] = size_bytes * 8 / N
+                r["size_bytes"] = size_bytes
+                r["C_rec"] = C_rec
+                rows[k] = r
     return rows
 
 

@@ -14,6 +14,8 @@ import time
 
 import numpy as np
 
+_STAGING = {}
+
 from . import _lib
 from ._lib import check
 
@@ -110,6 +112,66 @@ def decode_channels(streams, N, flag_signed=1, nthreads=0, channel_major=False):
     return Q, time.perf_counter() - t0
 
 
+class ChannelCoder:
+    """All channels of a frame through the host coder WITHOUT per-call glue: one arena for the D streams, kept across
+    calls (worst case 13 bytes per symbol: virtual memory -- only what a stream really takes is ever touched), streams
+    handed out as views, decoding straight from the arena into a caller-supplied (e.g. page-locked) array, and a threaded
+    round-trip check. On the MI355X box the coder itself takes ~25 ms per direction for 3 M x 56 symbols; the per-call
+    numpy allocations / copies / array_equal of encode_channels + decode_channels were another 110 ms."""
+
+    def __init__(self, N, D, flag_signed=1, nthreads=0):
+        self.N, self.D, self.flag, self.nthreads = int(N), int(D), int(flag_signed), int(nthreads)
+        self.cap = int(_lib.lib().raht_rlgr_bound(self.N))
+        self.arena = np.empty((self.D, self.cap), np.uint8)
+        self.nb = np.zeros(self.D, np.int64)
+
+    def encode(self, Qcm):
+        """Qcm: (D, N) int32, channel-major contiguous -> seconds; streams in self.arena / self.nb"""
+        if Qcm.dtype != np.int32 or Qcm.shape != (self.D, self.N) or not Qcm.flags.c_contiguous:
+            raise ValueError("ChannelCoder.encode: expected a contiguous (D, N) int32 array")
+        t0 = time.perf_counter()
+        check(_lib.lib().raht_rlgr_encode_channels(Qcm.ctypes.data_as(C.c_void_p), self.N, self.D, 1, self.N, self.flag,
+                                                   self.arena.ctypes.data_as(C.c_void_p), self.cap, self.nb.ctypes.data_as(C.c_void_p), self.nthreads))
+        return time.perf_counter() - t0
+
+    @property
+    def size_bytes(self):
+        return int(self.nb.sum())
+
+    def streams(self):
+        return [self.arena[c, : self.nb[c]] for c in range(self.D)]
+
+    def decode(self, out):
+        """-> seconds; out: (D, N) int32 contiguous (filled)"""
+        if out.dtype != np.int32 or out.shape != (self.D, self.N) or not out.flags.c_contiguous:
+            raise ValueError("ChannelCoder.decode: expected a contiguous (D, N) int32 array")
+        t0 = time.perf_counter()
+        check(_lib.lib().raht_rlgr_decode_channels(self.arena.ctypes.data_as(C.c_void_p), self.cap, self.nb.ctypes.data_as(C.c_void_p), self.N, self.D,
+                                                   self.flag, out.ctypes.data_as(C.c_void_p), 1, self.N, self.nthreads))
+        return time.perf_counter() - t0
+
+
+def arrays_equal(a, b, nthreads=0):
+    """threaded equality of two contiguous int32 arrays (the drivers' round-trip assertion, encode_3dgs.py:242-245)"""
+    a, b = np.asarray(a), np.asarray(b)
+    if a.shape != b.shape or a.dtype != np.int32 or b.dtype != np.int32 or not a.flags.c_contiguous or not b.flags.c_contiguous:
+        return bool(np.array_equal(a, b))
+    first = C.c_int64()
+    check(_lib.lib().raht_i32_equal(a.ctypes.data_as(C.c_void_p), b.ctypes.data_as(C.c_void_p), a.size, int(nthreads), C.byref(first)))
+    return first.value < 0
+
+
+def pinned_like(shape, dtype, key):
+    """a cached page-locked host tensor of at least this size (the codec's staging buffers), viewed as `shape`"""
+    import torch
+    n = int(np.prod(shape))
+    buf = _STAGING.get(key)
+    if buf is None or buf.numel() < n or buf.dtype != dtype:
+        buf = torch.empty(max(n, 1), dtype=dtype, pin_memory=True)
+        _STAGING[key] = buf
+    return buf[:n].view(shape)
+
+
 def transpose_on_device(Q):
     """(rows, cols) int32 CUDA tensor -> (cols, rows) contiguous, with the HIP LDS-tile transpose
     (row-major N x D quantized coefficients -> channel-major D x N for the entropy stage, or back)."""
@@ -122,9 +184,6 @@ def transpose_on_device(Q):
         check(_lib.lib().raht_transpose_i32(C.c_void_p(Q.data_ptr()), Q.stride(0), rows, cols, C.c_void_p(out.data_ptr()),
                                             rows, C.c_void_p(torch.cuda.current_stream().cuda_stream)))
     return out
-
-
-_STAGING = {}
 
 
 def to_host(t):

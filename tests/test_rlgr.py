@@ -155,3 +155,31 @@ def test_random_streams_round_trip_and_match_the_reference_build_when_present():
             assert bytes(bytearray(m.get_buffer())) == streams[0].tobytes()
             checked += 1
     assert ref is None or checked == 300
+
+
+def test_channel_coder_keeps_one_arena_and_checks_round_trips():
+    """ChannelCoder (the pipeline's glue-free path): same bytes as encode_channels, decode into a caller's array, threaded
+    equality with the position of the first difference."""
+    from raht_3dgs_codec_amd import rlgr
+    rng = np.random.default_rng(5)
+    N, D = 50000, 7
+    Q = np.rint(rng.laplace(0, 3.0, size=(D, N))).astype(np.int32)
+    Q[3] = 0
+    cc = rlgr.ChannelCoder(N, D, 1, nthreads=3)
+    for rep in range(2):                                      # the arena is reused
+        cc.encode(Q)
+        ref, _ = rlgr.encode_channels(Q, 1, nthreads=2, channel_major=True)
+        assert [bytes(s) for s in cc.streams()] == [bytes(s) for s in ref]
+        assert cc.size_bytes == sum(len(s) for s in ref)
+        out = np.empty_like(Q)
+        cc.decode(out)
+        assert rlgr.arrays_equal(out, Q, 4)
+        if rep == 0:
+            Q = Q[:, ::-1].copy()
+    out[5, 1234] += 1
+    assert not rlgr.arrays_equal(out, Q, 4)
+    import ctypes as C
+    from raht_3dgs_codec_amd import _lib
+    first = C.c_int64()
+    _lib.check(_lib.lib().raht_i32_equal(out.ctypes.data_as(C.c_void_p), Q.ctypes.data_as(C.c_void_p), out.size, 3, C.byref(first)))
+    assert first.value == 5 * N + 1234
