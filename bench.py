@@ -719,13 +719,14 @@ def main():
             assert torch.equal(Qf, s64.Q), "float64: fused != two-call"
             del Qf
             t_fi, t_q, t_u = timed(f_fi, kreps), timed(f_q, kreps), timed(f_u, 10)
+            t_qf, t_qi = timed(s64.fwd_quant, kreps), timed(s64.dequant_inv, kreps)
             alg64 = 2 * (16.0 * N * D + 8.0 * N)
             out["f64"] = {"what": "the reference's own precision (encode_3dgs.py:82-83): raht_fwd_f64 + raht_inv_f64; with_quant = raht_fwd_quant_f64 + raht_dequant_inv_f64 (float64 quantizer fused into the float64 kernels), unfused = the four-pass sequence",
                           "fwd_inv_ms": round(t_fi, 4), "fwd_inv_MGs": round(N / (t_fi * 1e-3) / 1e6, 1), "alg_bytes_fwd_inv": alg64,
                           "frac_of_peak": round(alg64 / (t_fi * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                           "with_quant_ms": round(t_q, 4), "with_quant_MGs": round(N / (t_q * 1e-3) / 1e6, 1),
                           "with_quant_frac_of_peak": round((alg64 - 8.0 * N * D) / (t_q * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),      # C 8 B in, Q 4 B out, Q 4 B in, C 8 B out per coefficient
-                          "unfused_ms": round(t_u, 4)}
+                          "fwd_quant_ms": round(t_qf, 4), "dequant_inv_ms": round(t_qi, 4), "unfused_ms": round(t_u, 4)}
             del s64
             def small_leg(name, n2, J2, D2, seed2, what):
                 """the same fused step on a smaller scene (latency-bound regime: few rounds of tiles, the tail stages are a

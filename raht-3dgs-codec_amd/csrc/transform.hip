@@ -440,22 +440,41 @@ __device__ __forceinline__ void tile_body(const TileArgs<T> &A, const typename s
     // inverse of the later stages / fused inverse: gather every slot's coefficient row now (survivor slots get
     // overwritten in P3b) -- the addresses need srow / sdst
     if constexpr (GATHER && QM64) {
-        load_steps(lane);
-        constexpr int GU = 4;                                 // rows in flight per lane
-        if (active) for (int it0 = wid; (it0 << lr) < nt; it0 += nw * GU) {
-            int32_t q[GU][VN];
-#pragma unroll
-            for (int u = 0; u < GU; ++u) {
-                const int j = min(((it0 + u * nw) << lr) + g, nt - 1);
-                ld_ints<VN>(row_far((const int32_t *)A.Q, (uint32_t)sdst[j], (uint32_t)A.ldq, (uint32_t)goff), q[u]);
+        if (Dc >= 4) {
+            // float64 rows, int32 coefficients: the integer rows go STRAIGHT to LDS as well (round 3; rounds 1-2 gathered
+            // them through registers and waited for them on the spot) -- packed, NCi 16-byte chunks per row, at the start
+            // of the tile (they take half the room of the float64 rows they will become), lane-linear like load_rows.
+            // They are converted after they have landed (P2b below). Chunk ch of a row holds its integers
+            // [min(4 ch, Dc - 4), + 4): the last chunk is the 16 bytes that END the row.
+            const int NCi = (Dc + 3) >> 2;
+            const uint32_t NCim = ((1u << 20) + (uint32_t)NCi - 1) / (uint32_t)NCi;
+            const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void *)tile;
+            const int total = nt * NCi;
+            for (int it = wid; (it << 6) < total; it += nw) {
+                const int c = (it << 6) + lane;
+                const int jr = (int)(((uint32_t)c * NCim) >> 20), ch = c - jr * NCi;
+                if (c < total)
+                    glds16<true>(row_far((const int32_t *)A.Q, (uint32_t)sdst[jr], (uint32_t)A.ldq, (uint32_t)(c_base + min(ch * 4, Dc - 4))), lds0 + ((uint32_t)it << 10));
             }
+        } else {
+            // rows of fewer than four integers: through registers
+            load_steps(lane);
+            constexpr int GU = 4;                                 // rows in flight per lane
+            if (active) for (int it0 = wid; (it0 << lr) < nt; it0 += nw * GU) {
+                int32_t q[GU][VN];
 #pragma unroll
-            for (int u = 0; u < GU; ++u) {
-                const int j = min(((it0 + u * nw) << lr) + g, nt - 1);
-                V16 x;
+                for (int u = 0; u < GU; ++u) {
+                    const int j = min(((it0 + u * nw) << lr) + g, nt - 1);
+                    ld_ints<VN>(row_far((const int32_t *)A.Q, (uint32_t)sdst[j], (uint32_t)A.ldq, (uint32_t)goff), q[u]);
+                }
 #pragma unroll
-                for (int i = 0; i < VN; ++i) x.v[i] = (T)q[u][i] * (T)my_step[i];                 // encode_3dgs.py:261
-                *(V16 *)&tile[__mul24(j, Dp) + coff] = x;
+                for (int u = 0; u < GU; ++u) {
+                    const int j = min(((it0 + u * nw) << lr) + g, nt - 1);
+                    V16 x;
+#pragma unroll
+                    for (int i = 0; i < VN; ++i) x.v[i] = (T)q[u][i] * (T)my_step[i];                 // encode_3dgs.py:261
+                    *(V16 *)&tile[__mul24(j, Dp) + coff] = x;
+                }
             }
         }
     } else if constexpr (GATHER) {
@@ -518,6 +537,48 @@ __device__ __forceinline__ void tile_body(const TileArgs<T> &A, const typename s
     }
     if constexpr (INV) sync_landed(); else sync_lds();                     // sync #3 (inverse: its rows have landed)
     PHASE_STAMP(4);
+    if constexpr (INV && QM64) {
+        // ---- P2b. the packed integer rows -> float64 coefficients in their rows' slots (encode_3dgs.py:261) ----
+        // The integers of row j sit inside the slots of rows j / 2 (they take half the room), so within a round every
+        // lane READS its integers before anyone writes (a barrier in between), and rounds walk the rows downwards: writing
+        // row r only overwrites the integers of rows 2 r and 2 r + 1, which are behind us. Survivor slots are left alone
+        // (P3b fills them). Usually one round: 88 rows x 30 chunks on 512 lanes = 6 tasks per lane.
+        if (Dc >= 4) {
+            load_steps(lane);
+            constexpr int CU = 8;
+            const int NCi = (Dc + 3) >> 2;
+            const int rows_per_k = nw << lr;
+            const int K = (nt + rows_per_k - 1) / rows_per_k;
+            const int32_t *stg = (const int32_t *)tile;
+            const int e0 = min(coff, Dc - VN);                    // this lane's two channels inside the channel block
+            const int last0 = 4 * (NCi - 1), shift = 4 * NCi - Dc;
+            const int p0 = e0 >= last0 ? e0 + shift : e0, p1 = e0 + 1 >= last0 ? e0 + 1 + shift : e0 + 1;
+            for (int k1 = K; k1 > 0; k1 -= CU) {
+                const int k0 = max(k1 - CU, 0);
+                int32_t q0[CU], q1[CU];
+#pragma unroll
+                for (int u = 0; u < CU; ++u) {
+                    const int k = k0 + u;
+                    const int j = min(((wid + k * nw) << lr) + g, nt - 1);
+                    q0[u] = 0; q1[u] = 0;
+                    if (k < k1) { q0[u] = stg[__mul24(j, NCi * 4) + p0]; q1[u] = stg[__mul24(j, NCi * 4) + p1]; }
+                }
+                sync_lds();
+#pragma unroll
+                for (int u = 0; u < CU; ++u) {
+                    const int k = k0 + u;
+                    const int jj = ((wid + k * nw) << lr) + g;
+                    if (k < k1 && active && jj < nt && sflag[jj] != 0) {
+                        V16 x;
+                        x.v[0] = (T)q0[u] * (T)my_step[0];
+                        x.v[1] = (T)q1[u] * (T)my_step[1];
+                        *(V16 *)&tile[__mul24(jj, Dp) + coff] = x;
+                    }
+                }
+                if (k0 > 0) sync_lds();
+            }
+        }
+    }
     if constexpr (INV && QM && !QM64) {
         load_steps(lane);
         // roots finalised here come straight from Q as well: dequantize them in place (no butterfly will)
