@@ -78,6 +78,9 @@ def parse():
     ap.add_argument("--sharded", action="store_true",
                     help="--gpus 1 only: run the Morton-prefix sharded path (ShardedRaht) in a ONE-rank process group of --backend, "
                          "collectives included -- what a one-GPU box can show of the multi-GPU step")
+    ap.add_argument("--direct", action="store_true",
+                    help="--gpus > 1 / --sharded: the two all-gathers of a step as direct writes into the peers' buffers over hipIpc "
+                         "(raht_xchg_*, one launch per direction) instead of the collective backend's all_gather_into_tensor")
     ap.add_argument("--unfused", action="store_true", help="quantize / dequantize as separate passes")
     ap.add_argument("--ablate", type=int, default=0, help="kernel-timing experiment for the roofline probe only (0 = real kernel; needs a make ABLATE=1 library)")
     return ap.parse_args()
@@ -265,7 +268,10 @@ def sharded_report(a, sh, Cd, qs, dist, world, rank, dev, L, _lib):
         dist.all_reduce(v, op=dist.ReduceOp.MAX)
         vals = v.cpu()
     t_f, t_i, t_loc, t_top, tfm, tim = [float(x) for x in vals.tolist()]
-    rep = {"rccl_world": dist.get_world_size() if a.backend == "nccl" else None,
+    rep = {"exchange": "direct writes into the peers' gather buffers (raht_xchg_gather over hipIpc), one launch per direction" if a.direct
+                       else "all_gather_into_tensor of the collective backend",
+           "exchange_status": sh.exchange_status() if a.direct else None,
+           "rccl_world": dist.get_world_size() if a.backend == "nccl" else None,
            "collective_backend": dist.get_backend(), "ranks": dist.get_world_size(),
            "collective_ms": {"forward_all_gather": round(t_f, 4), "inverse_all_gather": round(t_i, 4),
                              "timed": "events on the compute stream around all_gather_into_tensor, mean over %d steps, max over ranks" % reps},
@@ -509,7 +515,7 @@ def main():
             del Q2
     else:
         from raht_3dgs_codec_amd import sharded
-        sh = sharded.ShardedRaht(kd, 3 * J, prefix_bits=9, force_collectives=True)
+        sh = sharded.ShardedRaht(kd, 3 * J, prefix_bits=9, force_collectives=True, direct=a.direct)
         qs = None if a.no_quant else a.quant_step
 
         def step():
@@ -677,6 +683,10 @@ def main():
             # ... and with the reference's secondary outputs (PCsorted, DeltaPC: voxelize_pc.py:103-111, 147-156): the cloud
             # gathered once more, PCvox read per point, two N x ld matrices written
             pre["voxelize_with_residuals"] = roof(wall(lambda: R.voxelize_pc_batched(PC, [0.0, 0.0, 0.0], float(2 ** J), J, device=dev)), vox_alg + 4.0 * N * ld * 4)
+            # the per-frame prelude of a dynamic sequence in one call: voxelize, then the plan straight from the voxelizer's
+            # sorted voxel keys (borrowed, not copied)
+            pre["voxelize_plan"] = roof(wall(lambda: R.voxelize_plan(PC, [0.0, 0.0, 0.0], float(2 ** J), J, device=dev)), vox_alg + 17.0 * N)
+            pre["plan_from_sorted_keys_borrowed"] = roof(wall(lambda: R.RahtPlan.from_keys(kd, 3 * J, borrow=True)), 9.0 * N + 8.0 * N)
             out["prelude"] = pre
             del PC, xyz, ku, perm
 
@@ -784,6 +794,8 @@ def main():
     if rank == 0:
         print(json.dumps(out))
     if dist is not None:
+        if not solo:
+            sh.close()
         dist.destroy_process_group()
 
 

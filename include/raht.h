@@ -380,6 +380,30 @@ int raht_rlgr_decode_channels(const uint8_t *bufs, int64_t cap_per_channel, cons
                               int64_t chan_stride, int nthreads);
 int raht_transpose_i32(const int32_t *in, int64_t ld_in, int64_t rows, int64_t cols, int32_t *out,
                        int64_t ld_out, raht_stream_t stream);
+/* ------------------------------------------------------------------------------------------------
+ * DIRECT all-gather for Morton-prefix sharded scenes (one process per GPU; SURVEY.md 5 / 8e: "a direct all-gather -- each
+ * GPU writes its <= 15 KB slice to its 7 peers over the 7 point-to-point links -- beats a ring"). Opt-in alternative to
+ * the RCCL all_gather_into_tensor of raht_3dgs_codec_amd.sharded (ShardedRaht(direct=True)); the reference has no
+ * multi-GPU path at all.
+ *   raht_xchg_alloc   : this rank's exchange block (fine-grained device memory: 2 x world x slot_bytes of data, double
+ *                       buffered, + flags) and its 64-byte hipIpc handle, which the caller sends to the peers (once)
+ *   raht_xchg_open    : map a peer's block from its handle;  raht_xchg_close / raht_xchg_free: undo
+ *   raht_xchg_gather  : ONE launch (one workgroup per peer): write `send` into slot `rank` of buffer (seq & 1) of every
+ *                       peer's block, raise the peer's flag, wait until every peer's slot has landed here. seq = 1, 2, 3, ...
+ *                       identical on all ranks. Waits are bounded (20 s): a missing peer ends in status 1, not a hung GPU.
+ *   raht_xchg_buffer  : device address of buffer (seq & 1): world slots of slot_bytes, slot r = rank r's rows
+ *   raht_xchg_status  : (synchronises the stream) 0 = fine, 1 = a wait timed out
+ * slot_bytes: a multiple of 16; world <= 8. */
+int raht_xchg_bytes(int world, int64_t slot_bytes, int64_t *total);
+int raht_xchg_alloc(int world, int64_t slot_bytes, void **base, void *handle64);
+int raht_xchg_open(const void *handle64, void **base);
+int raht_xchg_close(void *base);
+int raht_xchg_free(void *base);
+int raht_xchg_gather(const void *send, int64_t slot_bytes, void *const *peers, int rank, int world, uint32_t seq,
+                     raht_stream_t stream);
+int raht_xchg_buffer(void *base, int world, int64_t slot_bytes, uint32_t seq, void **buf);
+int raht_xchg_status(void *base, int world, int64_t slot_bytes, raht_stream_t stream, int *status);
+
 /* Host: are two contiguous int32 arrays equal? *first_diff = index of the first difference or -1. Threaded (the drivers'
  * round-trip assertion, python/encode_3dgs.py:242-245, on 10^8 symbols). */
 int raht_i32_equal(const int32_t *a, const int32_t *b, int64_t n, int nthreads, int64_t *first_diff);

@@ -685,3 +685,17 @@ def voxelize_pc_batched(PC, vmin=None, width=None, J=10, device="cuda", residual
     info = {"Nvox": nv, "voxel_size": vs_out.value, "vmin": vmin_t, "width": w_out.value, "N": N,
             "sort_idx": idx, "keys_sorted": keys}
     return PCvox, PCsorted, voxel_indices, DeltaPC, info
+
+
+@torch.no_grad()
+def voxelize_plan(PC, vmin=None, width=None, J=10, device="cuda"):
+    """Unsorted cloud -> (PCvox, plan, info): the voxelizer's own sorted voxel keys go STRAIGHT into the RAHT plan
+    (reference: voxelize_pc_batched, python/voxelize_pc.py:62-172, then -- one script later, through a PLY file --
+    RAHT_param_reorder_fast on the voxel coordinates, python/RAHT_param.py:190-279, which re-derives the same Morton keys).
+    No key recomputation, no key copy (the plan borrows the key tensor and keeps it alive), one plan build per frame.
+    PCvox[:, 3:] is the attribute matrix in the plan's row order."""
+    PCvox, _, vidx, _, info = voxelize_pc_batched(PC, vmin, width, J, device=device, residuals=False, sorted_points=False)
+    vkeys = info["keys_sorted"][vidx]                     # first point of every voxel: sorted, unique
+    plan = RahtPlan.from_keys(vkeys, 3 * int(J), borrow=True)
+    info = dict(info, voxel_keys=vkeys, voxel_indices=vidx)
+    return PCvox, plan, info

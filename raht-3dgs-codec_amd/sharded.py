@@ -124,13 +124,26 @@ class HipLocalOps:
         return PCvox, info["keys_sorted"][vidx], vidx, info
 
 
+class _DeviceArray:
+    """a raw device pointer as something torch.as_tensor can wrap without copying (__cuda_array_interface__)"""
+
+    def __init__(self, ptr, shape, typestr):
+        self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": typestr, "data": (int(ptr), False), "version": 2}
+
+
 class ShardedRaht:
-    def __init__(self, keys_sorted, nbits, prefix_bits=9, group=None, local_ops=None, force_collectives=False):
+    def __init__(self, keys_sorted, nbits, prefix_bits=9, group=None, local_ops=None, force_collectives=False, direct=False):
         """keys_sorted: this rank's sorted, unique Morton keys (int64 tensor). Ranks must own disjoint,
         increasing ranges of the top ``prefix_bits`` bits (rank 0 the lowest prefixes).
-        force_collectives: issue the all-gathers even in a one-rank group (exercises the RCCL path on one GPU)."""
+        force_collectives: issue the all-gathers even in a one-rank group (exercises the RCCL path on one GPU).
+        direct: the two all-gathers of a step as DIRECT writes into the peers' gather buffers (include/raht.h, raht_xchg_*:
+        one launch per direction, every rank writes its <= 15 KB slot to each peer over its own xGMI link and raises a flag;
+        SURVEY.md 5 / 8e) instead of RCCL's all_gather_into_tensor. Opt-in; the process group is still used once per
+        (D, dtype) to exchange the hipIpc handles. Call close() (collective) before dropping the object."""
         self.ops = local_ops or HipLocalOps
         self.force = bool(force_collectives)
+        self.direct = bool(direct)
+        self._xchg_bases = []
         self.qdt = getattr(self.ops, "quant_dtype", torch.float32)
         self.dist = _dist()
         self.group = group
@@ -161,7 +174,7 @@ class ShardedRaht:
         self.sizes = [int(x) for x in sizes.tolist()]
         if max(self.sizes) == 0:
             raise ValueError("ShardedRaht: the scene is empty on every rank")
-        self.slot = max(self.sizes)                             # rows per rank in the gather buffers
+        self.slot = (max(self.sizes) + 3) // 4 * 4              # rows per rank in the gather buffers (whole 16-byte units per slot)
         self.offset = sum(self.sizes[:self.rank])               # this rank's first entry in the top tree
         directory = torch.zeros((self.slot, 2), dtype=torch.int64, device=dev)
         directory[: self.n_roots, 0] = pref
@@ -213,6 +226,8 @@ class ShardedRaht:
             res = mk(self.gather_rows)
             lo = self.rank * self.slot
             b = dict(send=send, send_roots=send[: self.n_roots], recv=recv, res=res, mine=res[lo: lo + self.n_roots])
+            if self.direct and self.dist is not None and send.is_cuda and (self.world > 1 or self.force):
+                b["xchg"] = self._open_exchange(send, D, dtype)
             self._bufs[key] = b
         return b
 
@@ -236,12 +251,93 @@ class ShardedRaht:
             ev.clear()
         return tuple(out)
 
+    # ---- direct exchange (raht_xchg_*): blocks, handles, gathers -----------------------------------
+    def _open_exchange(self, send, D, dtype):
+        """COLLECTIVE, once per (D, dtype): allocate this rank's exchange block, swap the hipIpc handles through the process
+        group, map the peers' blocks. -> dict(base, peers (C array), slot_bytes, seq, views of the two gather buffers)"""
+        import ctypes as C
+        from . import _lib
+        L = _lib.lib()
+        slot_bytes = int(send.numel() * send.element_size())
+        base, handle = C.c_void_p(), (C.c_ubyte * 64)()
+        with torch.cuda.device(self.device):
+            _lib.check(L.raht_xchg_alloc(self.world, slot_bytes, C.byref(base), handle))
+        handles = [None] * self.world
+        self.dist.all_gather_object(handles, bytes(handle), group=self.group)
+        peers = (C.c_void_p * self.world)()
+        for r in range(self.world):
+            if r == self.rank:
+                peers[r] = base.value
+            else:
+                hb, pb = (C.c_ubyte * 64).from_buffer_copy(handles[r]), C.c_void_p()
+                with torch.cuda.device(self.device):
+                    _lib.check(L.raht_xchg_open(hb, C.byref(pb)))
+                peers[r] = pb.value
+        typestr = {torch.float32: "<f4", torch.float64: "<f8"}[dtype]
+        views = []
+        for par in (0, 1):
+            p = C.c_void_p()
+            _lib.check(L.raht_xchg_buffer(base, self.world, slot_bytes, par, C.byref(p)))
+            views.append(torch.as_tensor(_DeviceArray(p.value, (self.gather_rows, D), typestr), device=self.device))
+        self.dist.barrier(group=self.group)                    # nobody writes into a block that is not mapped yet
+        self._xchg_bases.append(base)
+        return dict(base=base, peers=peers, slot_bytes=slot_bytes, seq=0, views=views)
+
+    def _direct_gather(self, b):
+        import ctypes as C
+        from . import _lib
+        x = b["xchg"]
+        x["seq"] += 1
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.lib().raht_xchg_gather(C.c_void_p(b["send"].data_ptr()), x["slot_bytes"], x["peers"], self.rank, self.world,
+                                                   x["seq"] & 0xffffffff, C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)))
+        b["recv"] = x["views"][x["seq"] & 1]
+
+    def exchange_status(self):
+        """(synchronises) 0 = every direct gather so far met all of its peers; 1 = a wait timed out"""
+        import ctypes as C
+        from . import _lib
+        worst = 0
+        for b in self._bufs.values():
+            x = b.get("xchg")
+            if x is None:
+                continue
+            st = C.c_int()
+            with torch.cuda.device(self.device):
+                _lib.check(_lib.lib().raht_xchg_status(x["base"], self.world, x["slot_bytes"], C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream), C.byref(st)))
+            worst = max(worst, st.value)
+        return worst
+
+    def close(self):
+        """COLLECTIVE: unmap the peers' exchange blocks and free this rank's (direct=True). A block must outlive every peer's
+        last write into it, hence the barriers; nothing to do for the RCCL path."""
+        from . import _lib
+        if not any("xchg" in b for b in self._bufs.values()):
+            return
+        torch.cuda.synchronize(self.device)
+        self.dist.barrier(group=self.group)
+        for b in self._bufs.values():
+            x = b.pop("xchg", None)
+            if x is None:
+                continue
+            b["recv"] = None
+            for r in range(self.world):
+                if r != self.rank:
+                    _lib.check(_lib.lib().raht_xchg_close(x["peers"][r]))
+        self.dist.barrier(group=self.group)
+        self._bufs.clear()                                     # the views of the blocks go with them
+        # (the blocks themselves: freed when every rank has unmapped them)
+        for base in self._xchg_bases:
+            _lib.check(_lib.lib().raht_xchg_free(base))
+        self._xchg_bases = []
+
     def _gather_roots(self, b, which):
+        gather = (lambda: self._direct_gather(b)) if "xchg" in b else (lambda: self._all_gather(b["send"], out=b["recv"]))
         if self._ev is None or not b["send"].is_cuda:
-            return self._all_gather(b["send"], out=b["recv"])
+            return gather()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        self._all_gather(b["send"], out=b["recv"])
+        gather()
         e1.record()
         self._ev[which].append((e0, e1))
 
@@ -339,7 +435,8 @@ class ShardedRaht:
     def check_against_unsharded(self, C, quant_step=None, keys_sorted=None):
         """Correctness gate for a multi-rank run (not on the timed path): gather the whole scene, transform it
         UNSHARDED on this rank, and compare this rank's rows with what the sharded path produced.
-        float32: |dT| <= 4e-6 * column max (the top levels are evaluated in another order); integers: the same
+        float32: |dT| <= 4e-6 * column max (two float32 transforms, each within SURVEY 8c's 2e-6 of the float64 one: triangle
+        inequality; measured 0.0 -- the replicated top tree performs the same butterflies on the same operands); integers: the same
         coefficient-error bound as bench.py's oracle gate."""
         keys = self.plan_keys() if keys_sorted is None else keys_sorted
         allk = self._gather_var(keys.reshape(-1, 1).to(torch.int64)).reshape(-1).contiguous()

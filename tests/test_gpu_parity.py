@@ -605,6 +605,10 @@ def test_randomised_configurations(rt, seed):
     r_ref = torch.empty((ref.n_roots, D), dtype=torch.float64)
     T_ref = ref.forward(torch.from_numpy(Cd.cpu().numpy().astype(np.float64)), roots=r_ref).numpy()
     scale = np.maximum(np.abs(T_ref).max(axis=0), 1e-300)
+    # float32 bar, derived: a coefficient passes through <= nbits butterflies, each rounding it by <= 2.5 eps32 (a, b rounded
+    # once, two products, one sum) of the running magnitude: worst case 2.5 * 6e-8 * 63 = 9.4e-6 of the column maximum, a
+    # random walk ~sqrt(63) * 1.5e-7 = 1.2e-6. SURVEY 8c's 2e-6 is the bar for 3DGS-like scenes (tests/test_gpu_fullsize.py:
+    # measured 1.7e-7); these adversarial draws (weighted leaves, truncated trees, 3-row tiles) get 3e-6, inside the worst case.
     tol = 1e-12 if f64 else 3e-6
     err = np.abs(T.cpu().numpy().astype(np.float64) - T_ref).max(axis=0) / scale
     assert err.max() <= tol, (seed, N, D, nbits, top, geo, float(err.max()))
@@ -692,6 +696,8 @@ def test_top_stage_thresholds(rt, N, D, top_rows):
     p.set_engine("tile", 0, 0, 0, top_rows)
     st = p.stage_stats(4, D)
     assert st["valid"]
+    # float32: tile engine against LEVEL engine, both float32 -- each within 2e-6 of the float64 transform, so
+    # within 4e-6 of each other by the triangle inequality; 3e-6 asserted
     for dt, tol in ((torch.float32, 3e-6), (torch.float64, 1e-12)):
         C = torch.from_numpy(rng.normal(size=(N, D))).to(dt).cuda()
         T, w = p.forward(C)
@@ -723,7 +729,7 @@ def test_plan_memory_cache_survives_churn(rt):
         assert (p.inverse(T) - C).abs().max().item() <= 2e-5 * C.abs().max().item()
         p.set_engine("level")
         Tl, _ = p.forward(C)
-        assert (T - Tl).abs().max().item() <= 3e-6 * Tl.abs().max().item()
+        assert (T - Tl).abs().max().item() <= 3e-6 * Tl.abs().max().item()      # two float32 engines: <= 2 x 2e-6 (triangle inequality)
         del p
         if it == 2:
             _lib.check(_lib.lib().raht_release_cached_memory())
@@ -925,3 +931,26 @@ def test_batch_mixes_engines_and_geometries(rt):
         ops.forward_batch([plans[0], plans[0]], [Cs[0], Cs[0]])
     with pytest.raises(ValueError):
         ops.forward_batch([plans[0], p3[0]], [Cs[0], C3[0]])
+
+
+def test_voxelize_plan_feeds_the_plan_from_the_voxelizers_keys(rt, oracle):
+    """ops.voxelize_plan: unsorted cloud -> PCvox + plan in one call; the plan built from the (borrowed) voxel keys is the
+    plan RAHT_param_reorder_fast builds from the voxel coordinates (order_RAGFT, transform bit for bit)."""
+    import torch
+    rng = np.random.default_rng(77)
+    n, d, J = 60000, 11, 9
+    P = (rng.random((n, 3)) * 5.0 - 1.0).astype(np.float32)
+    P[::6] = P[1::6][: P[::6].shape[0]]
+    PC = np.concatenate([P, rng.standard_normal((n, d)).astype(np.float32)], axis=1)
+    PCvox, plan, info = rt.voxelize_plan(torch.from_numpy(PC).cuda(), None, None, J)
+    ref = oracle.voxelize(PC, J)
+    assert plan.N == ref["Nvox"] and np.array_equal(PCvox.cpu().numpy(), ref["PCvox"])
+    V = PCvox[:, :3].double()
+    ListC, _, _, order = rt.raht_fn["RAHT_param"](V, torch.zeros(3, dtype=torch.float64, device="cuda"), 2 ** J, J)
+    assert torch.equal(order, plan.order_RAGFT)
+    C = PCvox[:, 3:].contiguous()
+    T0, _ = rt.raht_fn["RAHT"](C, ListC, None, None)
+    assert torch.equal(plan.forward(C, want_w=False), T0)
+    del info, PCvox            # the plan keeps the borrowed key tensor alive
+    torch.cuda.empty_cache()
+    assert torch.equal(plan.inverse(T0), rt.plan_of(ListC).inverse(T0))

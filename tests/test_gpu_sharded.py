@@ -347,3 +347,67 @@ def test_rank_without_rows_on_the_gpu(rt):
         p.join(timeout=120)
     for rank, msg in res:
         assert msg == "ok", f"rank {rank}:\n{msg}"
+
+
+# ------------------------------------------------------------------ direct exchange (raht_xchg_*)
+def _direct_main(rank, world, port, q):
+    """ranks share the one GPU; gloo carries the hipIpc handles once, the gathers themselves are direct writes + flags"""
+    try:
+        sys.path.insert(0, ROOT)
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(0)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        from raht_3dgs_codec_amd import sharded, synth
+        J, D = 10, 59
+        per = 512 // world
+        V, keys, C = synth.scene(60000 + 7000 * rank, J, D, seed=31 + rank, prefix_range=(rank * per, (rank + 1) * per, 9))
+        kd = torch.from_numpy(keys.view(np.int64).copy()).cuda()
+        Cd = torch.from_numpy(C).cuda()
+        ref = sharded.ShardedRaht(kd, 3 * J, prefix_bits=9)                    # gloo all-gathers (host staged)
+        drc = sharded.ShardedRaht(kd, 3 * J, prefix_bits=9, direct=True, force_collectives=True)
+        T0, Q0 = ref.forward(Cd), ref.forward_quant(Cd, 0.01)
+        for it in range(5):                                                    # both buffer parities, several times
+            assert torch.equal(drc.forward(Cd), T0), it
+            assert torch.equal(drc.forward_quant(Cd, 0.01), Q0), it
+        assert torch.equal(drc.inverse(T0), ref.inverse(T0))
+        assert torch.equal(drc.dequant_inverse(Q0, 0.01), ref.dequant_inverse(Q0, 0.01))
+        T64 = drc.forward(Cd.double())                                         # another (D, dtype): another exchange block
+        assert torch.equal(T64, ref.forward(Cd.double()))
+        chk = drc.check_against_unsharded(Cd, 0.01, keys_sorted=kd)
+        assert chk["ok"], chk
+        assert drc.exchange_status() == 0
+        drc.close()
+        dist.barrier()
+        dist.destroy_process_group()
+        q.put((rank, "ok"))
+    except Exception:
+        q.put((rank, traceback.format_exc()))
+
+
+@pytest.mark.parametrize("world", [1, 2, 3])
+def test_direct_exchange_equals_the_collective(rt, world):
+    """ShardedRaht(direct=True): every rank writes its root slot into each peer's gather buffer (hipIpc-mapped fine-grained
+    device memory) and raises a flag -- one launch per direction -- instead of all_gather_into_tensor. Bit-identical results;
+    here the 'peers' are processes sharing this box's one GPU (IPC to the same device), on xGMI they are the other GPUs."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_direct_main, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=600) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=120)
+    for rank, msg in res:
+        assert msg == "ok", f"rank {rank}:\n{msg}"
+
+
+def test_bench_direct_exchange(rt):
+    out = _run_bench(["--gpus", "2", "--backend", "gloo", "--direct", "--workload", "cfg5", "--rows", "400000", "--steps", "3", "--warmup", "1",
+                      "--settle-steps", "0"])
+    assert out["oracle_gate"]["ok"] and out["multi_gpu"]["exchange"].startswith("direct") and out["multi_gpu"]["exchange_status"] == 0
+    assert out["multi_gpu"]["collective_ms"]["forward_all_gather"] > 0
