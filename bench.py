@@ -419,6 +419,11 @@ def main():
     a = parse()
     if "WORLD_SIZE" not in os.environ and a.gpus > 1:
         sys.exit(self_launch(a))
+    # stdout carries ONE line, the JSON record. Libraries write banners there too (RCCL: "RCCL version : ...", gloo:
+    # "[Gloo] Rank 0 is connected to ..."): file descriptor 1 points at stderr until the record is written.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -792,7 +797,8 @@ def main():
                             "bit_identical_to_single_scene_calls": True}
             del plans_b, Cs_b
     if rank == 0:
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if dist is not None:
         if not solo:
             sh.close()

@@ -447,10 +447,12 @@ void pick_tail_geometry(const raht_plan *plan, int elem_size, int D, int stage0_
     // The top of the tree is latency-bound: once at most this many entries are left, ONE launch
     // (top_kernel: a workgroup per 16-byte channel chunk, all entries in LDS, 16 bytes per entry)
     // finishes the tree. 8192 entries = 128 KiB of the CU's 160 KiB.
-    // Default 4096: above that, one workgroup per chunk touching EVERY entry's row (one 128-byte line per
-    // 16 useful bytes, on ceil(D / 4) CUs only) costs more than a tile stage spread over the chip
-    // (cfg3: 7013 entries in the top stage 41 us, as a tile stage + a 439-entry top stage 15 + 10 us).
-    int Rf = 4096;
+    // Default 1536 (rounds 1-2: 4096): one workgroup per chunk touching EVERY entry's row (one 128-byte line per
+    // 16 useful bytes, on ceil(D / 4) CUs only) costs 6 us + 7.8 ns per entry (439 entries 9.4 us, 2310 entries 24 us,
+    // 7013 entries 41 us), a tile stage 11 us and leaves 1/18 of its entries: above ~1500 entries one more tile stage
+    // is cheaper. The reference's own shape (J = 10, ~1 M voxels x 56) leaves 2310 entries after two tile stages:
+    // 0.239 -> 0.225 ms per fused step with the third tile stage (r03 sweep, tools/sweep_tail2.sh).
+    int Rf = 1536;
     if (plan->final_rows_override > 0) Rf = std::min(plan->final_rows_override, RAHT_TOP_MAX_ROWS);
     *final_rows = Rf;
 }

@@ -190,7 +190,7 @@ class ShardedRaht:
         # padded gather buffer: entry e of the tree lives in buffer row vidx[e] ----
         self.top = self.ops.make_plan(allpref, self.prefix_bits, leaf_weights=allcnt)
         self.gather_rows = self.world * self.slot
-        if self.world > 1:
+        if self.gather_rows != int(allpref.numel()):          # padded slots: entry e of the tree lives in buffer row vidx[e]
             self.top.set_row_map(vidx, self.gather_rows)
         self._bufs = {}
         self._root_pos = None
