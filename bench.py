@@ -78,6 +78,9 @@ def parse():
     ap.add_argument("--sharded", action="store_true",
                     help="--gpus 1 only: run the Morton-prefix sharded path (ShardedRaht) in a ONE-rank process group of --backend, "
                          "collectives included -- what a one-GPU box can show of the multi-GPU step")
+    ap.add_argument("--batch-scenes", type=int, default=0,
+                    help="--workload cfg4 --gpus 1: BASELINE configs[3] on ONE GPU -- this many of its 8 scenes (1-6 M Gaussians each) as a batch "
+                         "(raht_fwd_quant_batch + raht_dequant_inv_batch: stage k of all scenes in one launch) against one call per scene")
     ap.add_argument("--direct", action="store_true",
                     help="--gpus > 1 / --sharded: the two all-gathers of a step as direct writes into the peers' buffers over hipIpc "
                          "(raht_xchg_*, one launch per direction) instead of the collective backend's all_gather_into_tensor")
@@ -415,6 +418,57 @@ def self_launch(a):
     return subprocess.run(cmd, env=env).returncode
 
 
+def cfg4_batch_main(a, R, synth, dev, real_stdout):
+    """BASELINE configs[3] when there is ONE GPU: its scenes (1-6 M Gaussians, 59 channels, seeds 10 ...) as a batch on it."""
+    from raht_3dgs_codec_amd import ops
+    n_draws, J, D, seed = synth.CONFIGS["cfg4"]
+    K = min(a.batch_scenes, len(synth.CFG4_DRAWS))
+    plans, Cs = [], []
+    for i in range(K):
+        V, keys, Ch = synth.scene(synth.CFG4_DRAWS[i], J, D, seed + i)
+        plans.append(R.RahtPlan.from_keys(torch.from_numpy(keys.view(np.int64)).to(dev), 3 * J))
+        Cs.append(torch.from_numpy(Ch).to(dev))
+        del V, keys, Ch
+    rows = sum(p.N for p in plans)
+    qs = a.quant_step
+
+    def batched():
+        return ops.dequant_inverse_batch(plans, ops.forward_quant_batch(plans, Cs, qs), qs)
+
+    def looped():
+        return [p.dequant_inverse(p.forward_quant(c, qs), qs) for p, c in zip(plans, Cs)]
+    # gate: the batch is bit-identical to one call per scene (whose kernels the oracle checks scene by scene in the default
+    # run and in tests/test_gpu_fullsize.py), and every scene survives the float32 round trip
+    Qb = ops.forward_quant_batch(plans, Cs, qs)
+    assert all(torch.equal(q, p.forward_quant(c, qs)) for q, p, c in zip(Qb, plans, Cs)), "batch != single-scene calls"
+    Rb = ops.inverse_batch(plans, ops.forward_batch(plans, Cs))
+    rt = max(float(((r - c).abs().max() / c.abs().max()).item()) for r, c in zip(Rb, Cs))
+    assert rt <= 1e-5, f"round trip error {rt}"
+    del Qb, Rb
+    settle = a.settle_steps if a.settle_steps >= 0 else max(0, 64 - a.warmup)
+    for _ in range(settle + a.warmup):
+        batched()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        batched()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    t_loop = timed(looped, min(a.steps, 20))
+    alg = 2 * (8.0 * rows * D + 8.0 * rows)
+    out = {"metric": "M-Gaussians/s fwd+inv RAHT, 59-ch SH3 3DGS", "value": round(rows / (dt / a.steps) / 1e6, 2), "unit": "M-Gaussians/s", "n_gpus": 1,
+           "steps": a.steps, "warmup": a.warmup, "settle_steps": settle, "ms_per_step": round(dt / a.steps * 1e3, 4), "higher_is_better": True,
+           "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": f"cfg4 on ONE GPU: {K} scenes of {[p.N for p in plans]} Gaussians (J={J}, {D} channels) as a batch, "
+                                  "fwd RAHT + quantize/reorder + dequantize/un-reorder + inv RAHT per scene, stage k of all scenes in one launch",
+                      "rows_total": rows, "channels": D, "depth_J": J, "parallelism": "1 GPU, batched launches", "roundtrip_rel_err": rt},
+           "oracle_gate": {"kind": "batch == one call per scene (bit for bit) + round trip; the single-scene kernels are oracle-checked on whole scenes in the default run"},
+           "path_hbm": {"alg_bytes_fwd_inv": alg, "whole_step_frac_of_peak": round(alg / (dt / a.steps) / 1e9 / HBM_PEAK_GBS, 4)},
+           "one_call_per_scene_ms": round(t_loop, 4), "one_call_per_scene_value": round(rows / (t_loop * 1e-3) / 1e6, 2)}
+    sys.stdout.flush()
+    os.write(real_stdout, (json.dumps(out) + "\n").encode())
+
+
 def main():
     a = parse()
     if "WORLD_SIZE" not in os.environ and a.gpus > 1:
@@ -449,6 +503,8 @@ def main():
     from raht_3dgs_codec_amd import _lib, synth
     L = _lib.lib()                                     # fails loudly if the HIP library is missing
 
+    if a.workload == "cfg4" and world == 1 and a.batch_scenes > 0:
+        return cfg4_batch_main(a, R, synth, dev, real_stdout)
     n_draws, J, D, seed = synth.CONFIGS[a.workload]
     if a.rows > 0:
         n_draws = a.rows

@@ -668,6 +668,8 @@ __device__ __forceinline__ void tile_body(const TileArgs<T> &A, const typename s
         const int loff_v = (int)loff[lane], hist_v = (int)hist[lane];
         uint64_t mask = __ballot(hist_v > 0);            // levels present in this tile
         if (TILE_DBG(A) & 1) mask = 0;
+        MRec<T> pre[TILE_ROUND_U];                       // records of the next wide round's first pass, fetched ahead
+        bool have_pre = false;
         while (mask) {
             const int l = INV ? (63 - __clzll((long long)mask)) : (__ffsll((long long)mask) - 1);
             mask &= ~(1ull << l);
@@ -678,57 +680,85 @@ __device__ __forceinline__ void tile_body(const TileArgs<T> &A, const typename s
             // juggling in the chain. Only a WHOLE wave instruction past the end must be skipped (a second
             // application by another instruction would not be harmless): a scalar branch. Most levels of a
             // tile hold fewer butterflies than one pass of the workgroup covers: those take U = 1.
-            auto pass = [&](auto UC) {
+            // fetch: the butterfly records of one pass (U per lane group); apply: the butterflies themselves
+            auto fetch = [&](auto UC, uint32_t base_, uint32_t cnt_, uint32_t mb, MRec<T> *r) {
                 constexpr int U = decltype(UC)::value;
-                for (uint32_t mb = (uint32_t)(wid << lr); mb < cnt; mb += stride * U) {
-                    uint32_t ip[U], ij[U];
-                    T ca[U], cb[U];
-                    V16 x0[U], x1[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) r[u] = mrec[base_ + min(mb + u * stride + g, cnt_ - 1)];
+            };
+            auto apply = [&](auto UC, uint32_t mb, const MRec<T> *r) {
+                constexpr int U = decltype(UC)::value;
+                uint32_t ip[U], ij[U];
+                V16 x0[U], x1[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) { ip[u] = r[u].po + coff; ij[u] = r[u].jo + coff; }
+#pragma unroll
+                for (int u = 0; u < U; ++u) { x0[u] = *(const V16 *)&tile[ip[u]]; x1[u] = *(const V16 *)&tile[ij[u]]; }
+                if constexpr (INV && QM && !QM64) {   // the high-pass operand is still the quantized integer (encode_3dgs.py:261)
 #pragma unroll
                     for (int u = 0; u < U; ++u) {
-                        const uint32_t m = min(mb + u * stride + g, cnt - 1);
-                        const MRec<T> rec = mrec[base + m];
-                        ip[u] = rec.po + coff;
-                        ij[u] = rec.jo + coff;
-                        ca[u] = rec.a; cb[u] = rec.b;
-                    }
 #pragma unroll
-                    for (int u = 0; u < U; ++u) { x0[u] = *(const V16 *)&tile[ip[u]]; x1[u] = *(const V16 *)&tile[ij[u]]; }
-                    if constexpr (INV && QM && !QM64) {   // the high-pass operand is still the quantized integer (encode_3dgs.py:261)
-#pragma unroll
-                        for (int u = 0; u < U; ++u) {
-#pragma unroll
-                            for (int i = 0; i < VN; ++i) x1[u].v[i] = (T)__float_as_int((float)x1[u].v[i]) * (T)my_step[i];
-                        }
-                    }
-#pragma unroll
-                    for (int u = 0; u < U; ++u) {
-                        V16 lo, hi;
-#pragma unroll
-                        for (int i = 0; i < VN; ++i) {
-                            if (!INV) {                       // RAHT.py:331-332
-                                lo.v[i] = ca[u] * x0[u].v[i] + cb[u] * x1[u].v[i];
-                                hi.v[i] = ca[u] * x1[u].v[i] - cb[u] * x0[u].v[i];
-                            } else {                          // iRAHT.py:108-109
-                                lo.v[i] = ca[u] * x0[u].v[i] - cb[u] * x1[u].v[i];
-                                hi.v[i] = cb[u] * x0[u].v[i] + ca[u] * x1[u].v[i];
-                            }
-                        }
-                        if (u == 0 || mb + u * stride < cnt) { *(V16 *)&tile[ip[u]] = lo; *(V16 *)&tile[ij[u]] = hi; }
+                        for (int i = 0; i < VN; ++i) x1[u].v[i] = (T)__float_as_int((float)x1[u].v[i]) * (T)my_step[i];
                     }
                 }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const T ca = r[u].a, cb = r[u].b;
+                    V16 lo, hi;
+#pragma unroll
+                    for (int i = 0; i < VN; ++i) {
+                        if (!INV) {                       // RAHT.py:331-332
+                            lo.v[i] = ca * x0[u].v[i] + cb * x1[u].v[i];
+                            hi.v[i] = ca * x1[u].v[i] - cb * x0[u].v[i];
+                        } else {                          // iRAHT.py:108-109
+                            lo.v[i] = ca * x0[u].v[i] - cb * x1[u].v[i];
+                            hi.v[i] = cb * x0[u].v[i] + ca * x1[u].v[i];
+                        }
+                    }
+                    if (u == 0 || mb + u * stride < cnt) { *(V16 *)&tile[ip[u]] = lo; *(V16 *)&tile[ij[u]] = hi; }
+                }
+            };
+            // pre_loaded: the records of this round's first pass were fetched before the barrier in front of it
+            auto pass = [&](auto UC, bool pre_loaded) {
+                constexpr int U = decltype(UC)::value;
+                uint32_t mb = (uint32_t)(wid << lr);
+                MRec<T> r[U];
+                if (pre_loaded && mb < cnt) {
+#pragma unroll
+                    for (int u = 0; u < U; ++u) r[u] = pre[u];
+                    apply(UC, mb, r);
+                    mb += stride * U;
+                }
+                for (; mb < cnt; mb += stride * U) { fetch(UC, base, cnt, mb, r); apply(UC, mb, r); }
             };
             if (cnt <= (1u << lr)) {
                 // a level that fits ONE wave instruction (most levels of a tile): wave 0 takes it
                 // alone. A wave's LDS operations execute in order, so a run of such levels needs no
                 // workgroup barrier in between -- the rounds are a latency chain, and a 512-thread
                 // barrier per level was most of it.
-                if (wid == 0) pass(std::integral_constant<int, 1>());
+                if (wid == 0) pass(std::integral_constant<int, 1>(), false);
                 chained = true;
+                have_pre = false;
             } else {
                 if (chained) { __syncthreads(); chained = false; }
-                if (cnt <= stride) pass(std::integral_constant<int, 1>());
-                else pass(std::integral_constant<int, TILE_ROUND_U>());
+                if (cnt <= stride) pass(std::integral_constant<int, 1>(), have_pre);
+                else pass(std::integral_constant<int, TILE_ROUND_U>(), have_pre);
+                have_pre = false;
+#ifdef RAHT_REC_PREFETCH
+                // (measured, off: -DRAHT_REC_PREFETCH) the NEXT wide round's first records fetched while the waves gather at the
+                // barrier -- they are read-only during P4, and behind the barrier they are one more LDS round trip in every
+                // round's chain. 0.594 -> 0.608 ms on the fused step (tools/ab_swap.sh, round 3): eight more live registers and
+                // one more LDS access per wave in front of every barrier cost more than the round trip saves
+                if (mask) {
+                    const int l2 = INV ? (63 - __clzll((long long)mask)) : (__ffsll((long long)mask) - 1);
+                    const uint32_t base2 = (uint32_t)__builtin_amdgcn_readlane(loff_v, l2), cnt2 = (uint32_t)__builtin_amdgcn_readlane(hist_v, l2);
+                    if (cnt2 > (1u << lr) && (uint32_t)(wid << lr) < cnt2) {
+                        if (cnt2 <= stride) fetch(std::integral_constant<int, 1>(), base2, cnt2, (uint32_t)(wid << lr), pre);
+                        else fetch(std::integral_constant<int, TILE_ROUND_U>(), base2, cnt2, (uint32_t)(wid << lr), pre);
+                        have_pre = true;
+                    }
+                }
+#endif
                 __syncthreads();
             }
         }
