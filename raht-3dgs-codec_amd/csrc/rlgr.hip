@@ -245,14 +245,33 @@ static void run_pool(int nthreads, W &work)
     for (auto &t : pool) t.join();
 }
 
+// Channels are handed out most expensive first (cost[c]: any monotone proxy of the channel's coding time, or NULL): 56
+// channels on 16 threads are 3.5 rounds, and a frame's channels differ by 10 x in bit rate -- with the long ones last, the
+// pass ended on a few threads coding the xyz / DC-heavy channels alone.
 template <typename F>
-static void parallel_channels(int D, int nthreads, F fn)
+static void parallel_channels(int D, int nthreads, F fn, const double *cost = nullptr)
 {
     nthreads = std::min(nthreads, D);
     if (nthreads <= 1) { for (int c = 0; c < D; ++c) fn(c); return; }
+    std::vector<int> order((size_t)D);
+    for (int c = 0; c < D; ++c) order[(size_t)c] = c;
+    if (cost) std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return cost[a] > cost[b]; });
     std::atomic<int> next(0);
-    auto work = [&]() { for (int c = next++; c < D; c = next++) fn(c); };
+    auto work = [&]() { for (int i = next++; i < D; i = next++) fn(order[(size_t)i]); };
     run_pool(nthreads, work);
+}
+
+// proxy for a channel's bit rate from ~2048 evenly spaced symbols: sum of 1 + log2(1 + |q|)
+static double sampled_cost(const int32_t *q, int64_t N, int64_t stride)
+{
+    const int64_t step = std::max<int64_t>(1, N / 2048);
+    double c = 0;
+    for (int64_t i = 0; i < N; i += step) {
+        const int64_t v = q[i * stride];
+        const uint64_t a = (uint64_t)(v < 0 ? -v : v) + 1;
+        c += 1 + (63 - __builtin_clzll(a));
+    }
+    return c;
 }
 
 }  // namespace rlgr
@@ -383,10 +402,12 @@ int raht_rlgr_encode_channels(const int32_t *Q, int64_t N, int D, int64_t sym_st
             src = tmp.data(); ss = 1; cs = N;
         }
         std::atomic<int> bad(0);
+        std::vector<double> cost((size_t)D);
+        for (int c = 0; c < D; ++c) cost[(size_t)c] = rlgr::sampled_cost(src + (int64_t)c * cs, N, ss);
         rlgr::parallel_channels(D, nt, [&](int c) {
             const int64_t r = rlgr::encode(src + (int64_t)c * cs, N, ss, flag_signed, out + (int64_t)c * cap_per_channel, cap_per_channel);
             if (r < 0) { bad = 1; nbytes[c] = -1; } else nbytes[c] = r;
-        });
+        }, cost.data());
         if (bad) { set_error("raht_rlgr_encode_channels: cap_per_channel too small (use raht_rlgr_bound)"); return RAHT_ERR_NOMEM; }
         return RAHT_OK;
     });
@@ -409,9 +430,11 @@ int raht_rlgr_decode_channels(const uint8_t *bufs, int64_t cap_per_channel, cons
         int64_t ss = sym_stride, cs = chan_stride;
         const bool via_tmp = (sym_stride != 1 && chan_stride == 1 && D > 1 && N > 4096);
         if (via_tmp) { tmp.resize((size_t)N * (size_t)D); dst = tmp.data(); ss = 1; cs = N; }
+        std::vector<double> cost((size_t)D);
+        for (int c = 0; c < D; ++c) cost[(size_t)c] = (double)nbytes[c];          // a channel's decoding time follows its bytes
         rlgr::parallel_channels(D, nt, [&](int c) {
             rlgr::decode(bufs + (int64_t)c * cap_per_channel, nbytes[c], N, flag_signed, dst + (int64_t)c * cs, ss);
-        });
+        }, cost.data());
         if (via_tmp) rlgr::transpose_from_channels(tmp.data(), N, D, Q, sym_stride, nt);
         return RAHT_OK;
     });
