@@ -404,6 +404,24 @@ int raht_xchg_gather(const void *send, int64_t slot_bytes, void *const *peers, i
 int raht_xchg_buffer(void *base, int world, int64_t slot_bytes, uint32_t seq, void **buf);
 int raht_xchg_status(void *base, int world, int64_t slot_bytes, raht_stream_t stream, int *status);
 
+/* ------------------------------------------------------------------------------------------------
+ * The RLGR stage ON THE GPU, segmented (csrc/rlgr_seg.hip; SURVEY.md 8f-1 "GPU-segmented"). Every channel is cut into
+ * segments of seg_len symbols, every segment is an independent RLGR stream -- byte-identical to what the reference's
+ * membuf::rlgrWrite (python/PyRLGR/src/libs/rlgr/membuf.cpp:340-423) emits for that slice of the channel, so any RLGR decoder
+ * reads it -- and one lane codes one segment. The container (lengths + offsets + concatenated streams, 4-byte slots) is this
+ * library's own: the reference codes a channel as ONE stream (raht_rlgr_encode_channels does exactly that, on the host).
+ *   Q        : DEVICE int32, channel-major: symbol n of channel c at Q[c * chan_stride + n] (raht_transpose_i32's output)
+ *   seg_bytes: DEVICE uint32[D * nseg], nseg = ceil(N / seg_len): exact stream length of segment c * nseg + s
+ *   seg_off  : DEVICE uint32[D * nseg + 1]: its offset in `out` (slots padded to 4 bytes); the last entry = bytes used
+ *   out      : DEVICE, 4-byte aligned, cap bytes. RAHT_ERR_NOMEM (and *total_bytes = what is needed) when cap is too small.
+ * raht_rlgr_seg_encode synchronises the stream (it returns the size); raht_rlgr_seg_decode does not. */
+int raht_rlgr_seg_encode(const int32_t *Q, int64_t N, int D, int64_t chan_stride, int seg_len, int flag_signed,
+                         uint32_t *seg_bytes, uint32_t *seg_off, uint8_t *out, int64_t cap, int64_t *total_bytes,
+                         raht_stream_t stream);
+int raht_rlgr_seg_decode(const uint8_t *in, int64_t in_bytes, const uint32_t *seg_off, const uint32_t *seg_bytes, int64_t N,
+                         int D, int seg_len, int flag_signed, int32_t *Q, int64_t chan_stride, uint32_t *bad_dev,
+                         raht_stream_t stream);
+
 /* Host: are two contiguous int32 arrays equal? *first_diff = index of the first difference or -1. Threaded (the drivers'
  * round-trip assertion, python/encode_3dgs.py:242-245, on 10^8 symbols). */
 int raht_i32_equal(const int32_t *a, const int32_t *b, int64_t n, int nthreads, int64_t *first_diff);

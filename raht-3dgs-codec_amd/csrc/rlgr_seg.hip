@@ -1,0 +1,325 @@
+// rlgr_seg.hip -- the RLGR entropy stage ON THE GPU, segmented (second half: "GPU-segmented").
+//
+// The reference's coder (python/PyRLGR/src/libs/rlgr/membuf.cpp:258-423, parameters membuf.h:18-22) is one sequential
+// adaptive stream per channel: ~3 M symbols that each depend on the state all earlier ones left. csrc/rlgr.hip runs the 56
+// channels of a frame on the host threads, byte-exact, and that is what bounds a frame end to end (round 3: 65 ms per pass
+// on 16 CPUs next to 0.6 ms of transforms, plus 12 ms of PCIe each way for the raw integers). Here every channel is cut
+// into SEGMENTS of `seg_len` symbols and every segment is its own RLGR stream -- the coder's state starts afresh (k_P = 0,
+// k_RP = 2 L), the stream is padded to a byte boundary and, in the container, to a 4-byte boundary. One lane codes one
+// segment; 3 M x 56 symbols at 4096 per segment are 41 k independent streams = 656 waves.
+//
+// What "parity" means here: segment (c, s) is BYTE-IDENTICAL to what the reference's membuf::rlgrWrite produces for the
+// slice Q[c, s * seg_len : (s + 1) * seg_len] -- tests compare every segment with the host coder of rlgr.hip (itself pinned
+// byte for byte by reference-built streams, tests/test_rlgr.py), so any RLGR decoder reads a segment. The CONTAINER (sizes
+// table + concatenated segments) is this repo's: the reference has no segmented format. Cost of the restarts: the coder
+// re-adapts within a few dozen symbols; tests / DESIGN.md quote the measured size difference.
+#include "raht_common.h"
+
+namespace raht {
+namespace rlgr_seg {
+
+constexpr uint32_t L = 4, U0 = 3, D0 = 1, U1 = 2, D1 = 1;
+
+// MSB-first bit writer, same byte stream as membuf::write / flush (and as BitWriter of rlgr.hip): < 32 bits pending after
+// every put, whole 32-bit words leave big-endian. WRITE = false only counts. `out` is 4-byte aligned.
+template <bool WRITE>
+struct DevBitWriter {
+    uint32_t *out32;
+    uint32_t size = 0;       // bytes
+    uint64_t acc = 0;
+    int nbits = 0;
+
+    __device__ __forceinline__ void put(uint64_t v, int bits)      // bits <= 32, v < 2^bits
+    {
+        acc = (acc << bits) | v;
+        nbits += bits;
+        if (nbits >= 32) {
+            nbits -= 32;
+            if (WRITE) out32[size >> 2] = __builtin_bswap32((uint32_t)(acc >> nbits));
+            size += 4;
+        }
+    }
+    __device__ __forceinline__ void put_wide(uint64_t v, int bits)
+    {
+        if (bits > 32) { put((bits == 64) ? (v >> 32) : ((v >> 32) & ((1ull << (bits - 32)) - 1)), bits - 32); put(v & 0xffffffffull, 32); }
+        else put(bits ? (v & ((1ull << bits) - 1)) : 0, bits);
+    }
+    __device__ __forceinline__ void golomb_rice(uint64_t u, int k)  // membuf.cpp:242-256
+    {
+        const uint64_t p = u >> k;
+        if (p < 32) {
+            if (p + 1 + (uint64_t)k <= 32) put((((1ull << (p + 1)) - 2) << k) | (k ? (u & ((1ull << k) - 1)) : 0), (int)p + 1 + k);
+            else { put((1ull << (p + 1)) - 2, (int)p + 1); put(k ? (u & ((1ull << k) - 1)) : 0, k); }
+        } else {
+            put(0xffffffffull, 32);
+            put(u & 0xffffffffull, 32);
+        }
+    }
+    __device__ __forceinline__ void close()                         // membuf.cpp:47-58
+    {
+        if (nbits & 7) put(0, 8 - (nbits & 7));
+        if (nbits > 0) {                                            // 1..3 whole bytes left: the last, partial word (zero filled)
+            const uint32_t word = (uint32_t)(acc << (32 - nbits));
+            if (WRITE) out32[size >> 2] = __builtin_bswap32(word);
+            size += (uint32_t)(nbits >> 3);
+            nbits = 0;
+        }
+    }
+};
+
+__device__ __forceinline__ uint64_t s2u(int64_t v) { return v < 0 ? (((uint64_t)(-v)) << 1) - 1 : ((uint64_t)v) << 1; }
+__device__ __forceinline__ int64_t u2s(uint64_t v) { const int64_t d = (int64_t)(v >> 1); return (v & 1) ? -d - 1 : d; }
+
+#define RLGS_ADAPT_KRP(p)                                            \
+    do {                                                             \
+        if (p) { k_RP += (p) - 1; if (k_RP > 32 * L) k_RP = 32 * L; } \
+        else { k_RP = (k_RP < 2) ? 0 : k_RP - 2; }                   \
+    } while (0)
+
+// membuf.cpp:340-423 on one segment
+template <bool WRITE>
+__device__ __forceinline__ uint32_t encode_segment(const int32_t *__restrict__ seq, int n, int flag_signed, uint32_t *out32)
+{
+    DevBitWriter<WRITE> w;
+    w.out32 = out32;
+    uint64_t u = 0, k_P = 0, k_RP = 2 * L, m = 0, k = 0;
+    int32_t nxt = n > 0 ? seq[0] : 0;
+    for (int i = 0; i < n; ++i) {
+        const int64_t v = nxt;
+        if (i + 1 < n) nxt = seq[i + 1];                             // one symbol ahead: the load is off the dependent chain
+        u = flag_signed ? s2u(v) : (uint64_t)(uint32_t)v;
+        k = k_P / L;
+        const uint64_t k_R = k_RP / L;
+        if (k) {                                                    // run mode
+            if (u) {
+                --u;
+                w.put(0, 1);
+                w.put_wide(m, (int)k);
+                w.golomb_rice(u, (int)k_R);
+                const uint64_t p = u >> k_R;
+                RLGS_ADAPT_KRP(p);
+                k_P = (k_P < D1) ? 0 : k_P - D1;
+                m = 0;
+            } else if (++m == (1ull << k)) {
+                w.put(1, 1);
+                k_P += U1;
+                m = 0;
+            }
+        } else {                                                    // no-run mode
+            w.golomb_rice(u, (int)k_R);
+            const uint64_t p = u >> k_R;
+            RLGS_ADAPT_KRP(p);
+            if (u) k_P = (k_P < D0) ? 0 : k_P - D0;
+            else k_P += U0;
+            m = 0;
+        }
+    }
+    if (n > 0 && k && !u) {                                         // membuf.cpp:410-413: flush the open run
+        w.put(0, 1);
+        w.put_wide(m, (int)(k_P / L));
+    }
+    w.close();
+    return w.size;
+}
+
+// MSB-first bit reader over a 4-byte aligned segment of `size` bytes; bits past the end read as zeros
+struct DevBitReader {
+    const uint32_t *in32;
+    uint32_t size, pos = 0;      // bytes; pos is a multiple of 4 (whole words are consumed, the last one zero-extended)
+    uint64_t acc = 0;
+    int nbits = 0;
+
+    __device__ __forceinline__ void fill()                           // afterwards nbits > 32 unless the stream ended
+    {
+        if (nbits <= 32 && pos < size) {
+            uint32_t w = __builtin_bswap32(in32[pos >> 2]);
+            const uint32_t left = size - pos;
+            int got = 32;
+            if (left < 4) { got = (int)left * 8; w >>= (32 - got); }   // the last, partial word: only its bytes count
+            acc = (acc << got) | w;
+            nbits += got;
+            pos += 4;
+        }
+    }
+    __device__ __forceinline__ uint32_t bit()
+    {
+        if (!nbits) { fill(); if (!nbits) return 0; }
+        --nbits;
+        return (uint32_t)((acc >> nbits) & 1u);
+    }
+    __device__ __forceinline__ uint64_t get(int bits)                 // bits <= 32
+    {
+        if (!bits) return 0;
+        if (nbits < bits) fill();
+        if (nbits < bits) { const int miss = bits - nbits; acc <<= miss; nbits += miss; }   // zero padding
+        nbits -= bits;
+        return (acc >> nbits) & ((1ull << bits) - 1);
+    }
+    __device__ __forceinline__ uint64_t get_wide(int bits)
+    {
+        if (bits > 32) { const uint64_t hi = get(bits - 32) << 32; return hi + get(32); }
+        return get(bits);
+    }
+    __device__ __forceinline__ uint64_t golomb_rice(int k)            // membuf.cpp:228-240
+    {
+        if (nbits < 33) fill();
+        uint64_t p;
+        if (nbits >= 33) {
+            const uint64_t top = acc << (64 - nbits);
+            p = (uint64_t)__builtin_clzll(~top | (1ull << 30));      // leading ones, at most 33 counted
+            if (p >= 32) { nbits -= 32; return get(32); }
+            nbits -= (int)p + 1;
+        } else {
+            p = 0;
+            while (bit()) { if (++p >= 32) return get(32); }
+        }
+        return (p << k) + get(k);
+    }
+};
+
+__device__ __forceinline__ void decode_segment(const uint32_t *in32, uint32_t nbytes, int n, int flag_signed, int32_t *__restrict__ seq)
+{
+    DevBitReader r;
+    r.in32 = in32; r.size = nbytes;
+    uint64_t k_P = 0, k_RP = 2 * L;
+    int i = 0;
+    while (i < n) {                                                  // membuf.cpp:270-331
+        uint64_t k = k_P / L;
+        const uint64_t k_R = k_RP / L;
+        if (k) {
+            uint64_t m = 0;
+            while (r.bit()) {
+                m += 1ull << k;
+                k_P += U1;
+                k = k_P / L;
+                if (m > (uint64_t)n) break;                          // corrupt stream guard
+            }
+            m += r.get_wide((int)k);
+            while (m-- && i < n) seq[i++] = 0;
+            if (i >= n) break;
+            const uint64_t u = r.golomb_rice((int)k_R);
+            seq[i++] = (int32_t)(flag_signed ? u2s(u + 1) : (int64_t)(u + 1));
+            const uint64_t p = u >> k_R;
+            RLGS_ADAPT_KRP(p);
+            k_P = (k_P < D1) ? 0 : k_P - D1;
+        } else {
+            const uint64_t u = r.golomb_rice((int)k_R);
+            seq[i++] = (int32_t)(flag_signed ? u2s(u) : (int64_t)u);
+            const uint64_t p = u >> k_R;
+            RLGS_ADAPT_KRP(p);
+            if (u) k_P = (k_P < D0) ? 0 : k_P - D0;
+            else k_P += U0;
+        }
+    }
+}
+
+// segment g = c * nseg + s  <->  symbols [s * S, min(N, (s + 1) * S)) of channel c
+template <bool WRITE>
+__global__ __launch_bounds__(64) void seg_encode_kernel(const int32_t *__restrict__ Q, int64_t N, int D, int64_t chan_stride, int S, int nseg,
+                                                        int flag_signed, uint32_t *__restrict__ seg_bytes, const uint32_t *__restrict__ seg_off,
+                                                        uint8_t *__restrict__ out, uint64_t cap, uint32_t *__restrict__ overflow)
+{
+    const int64_t g = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    if (g >= (int64_t)D * nseg) return;
+    const int c = (int)(g / nseg), s = (int)(g - (int64_t)c * nseg);
+    const int64_t i0 = (int64_t)s * S;
+    const int n = (int)min((int64_t)S, N - i0);
+    const int32_t *seq = Q + (int64_t)c * chan_stride + i0;
+    if (!WRITE) {
+        seg_bytes[g] = encode_segment<false>(seq, n, flag_signed, nullptr);
+    } else {
+        const uint64_t off = seg_off[g];                              // 4-byte aligned
+        const uint32_t need = (seg_bytes[g] + 3u) & ~3u;
+        if (off + need > cap) { atomicOr(overflow, 1u); return; }
+        (void)encode_segment<true>(seq, n, flag_signed, (uint32_t *)(out + off));
+    }
+}
+
+// padded size of every segment (its slot in the container): the input of the offset scan
+__global__ void seg_pad_kernel(const uint32_t *__restrict__ seg_bytes, int64_t n, uint32_t *__restrict__ padded)
+{
+    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g < n) padded[g] = (seg_bytes[g] + 3u) & ~3u;
+}
+
+__global__ __launch_bounds__(64) void seg_decode_kernel(const uint8_t *__restrict__ in, uint64_t in_bytes, const uint32_t *__restrict__ seg_off,
+                                                        const uint32_t *__restrict__ seg_bytes, int64_t N, int D, int S, int nseg, int flag_signed,
+                                                        int32_t *__restrict__ Q, int64_t chan_stride, uint32_t *__restrict__ bad)
+{
+    const int64_t g = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    if (g >= (int64_t)D * nseg) return;
+    const int c = (int)(g / nseg), s = (int)(g - (int64_t)c * nseg);
+    const int64_t i0 = (int64_t)s * S;
+    const int n = (int)min((int64_t)S, N - i0);
+    // the tables come off the wire: a segment never reaches outside the buffer (its last word is read whole: 4-byte slots)
+    const uint64_t off = seg_off[g];
+    uint32_t nb = seg_bytes[g];
+    if ((off & 3) || off > in_bytes || (uint64_t)((nb + 3u) & ~3u) > in_bytes - off) { nb = 0; if (bad) atomicOr(bad, 1u); }
+    decode_segment((const uint32_t *)(in + (nb ? off : 0)), nb, n, flag_signed, Q + (int64_t)c * chan_stride + i0);
+}
+
+}  // namespace rlgr_seg
+}  // namespace raht
+
+using namespace raht;
+
+extern "C" {
+
+/* Segmented RLGR on the device. Q: DEVICE int32, channel-major (symbol n of channel c at Q[c * chan_stride + n], what
+ * raht_transpose_i32 produces); seg_len symbols per segment (>= 64), nseg = ceil(N / seg_len) segments per channel.
+ * Outputs (DEVICE): seg_bytes[D * nseg] = exact byte length of every segment's stream, seg_off[D * nseg + 1] = its offset in
+ * `out` (segments are laid out in order, each padded to 4 bytes; seg_off[last] = bytes used), out[cap] = the streams.
+ * *total_bytes (HOST) = bytes used. RAHT_ERR_NOMEM when cap is too small (nothing useful in out; 4 N D + 64 D nseg bytes
+ * always suffice for data a raw int32 dump would not beat, raht_rlgr_bound(seg_len) * D * nseg for anything). Synchronises. */
+int raht_rlgr_seg_encode(const int32_t *Q, int64_t N, int D, int64_t chan_stride, int seg_len, int flag_signed, uint32_t *seg_bytes,
+                         uint32_t *seg_off, uint8_t *out, int64_t cap, int64_t *total_bytes, raht_stream_t stream)
+{
+    if (!Q || !seg_bytes || !seg_off || !out || !total_bytes || N < 1 || D < 1 || chan_stride < N || seg_len < 64 || cap < 16 || ((uintptr_t)out & 3)) {
+        set_error("raht_rlgr_seg_encode: bad argument");
+        return RAHT_ERR_INVALID;
+    }
+    const int64_t nseg = ceil_div(N, seg_len), G = nseg * D;
+    if (nseg >= ((int64_t)1 << 31) || G >= ((int64_t)1 << 31)) { set_error("raht_rlgr_seg_encode: too many segments"); return RAHT_ERR_INVALID; }
+    hipStream_t s = (hipStream_t)stream;
+    return guarded("raht_rlgr_seg_encode", [&]() -> int {
+        Scratch tmp(sizeof(uint32_t) * ((size_t)G + 2), s);
+        if (!tmp.ok()) return RAHT_ERR_NOMEM;
+        uint32_t *padded = tmp.as<uint32_t>(), *flags = padded + G;          // flags[0] = overflow, flags[1] = total
+        RAHT_HIP_CHECK(hipMemsetAsync(flags, 0, 8, s));
+        const unsigned gb = (unsigned)ceil_div(G, 64);
+        hipLaunchKernelGGL(rlgr_seg::seg_encode_kernel<false>, dim3(gb), dim3(64), 0, s, Q, N, D, chan_stride, seg_len, (int)nseg, flag_signed,
+                           seg_bytes, (const uint32_t *)nullptr, (uint8_t *)nullptr, (uint64_t)0, flags);
+        hipLaunchKernelGGL(rlgr_seg::seg_pad_kernel, dim3((unsigned)ceil_div(G, 256)), dim3(256), 0, s, seg_bytes, G, padded);
+        RAHT_RET(exclusive_scan_u32(padded, seg_off, G, flags + 1, s));       // (32-bit offsets: containers below 4 GiB)
+        RAHT_HIP_CHECK(hipMemcpyAsync(seg_off + G, flags + 1, 4, hipMemcpyDeviceToDevice, s));
+        hipLaunchKernelGGL(rlgr_seg::seg_encode_kernel<true>, dim3(gb), dim3(64), 0, s, Q, N, D, chan_stride, seg_len, (int)nseg, flag_signed,
+                           seg_bytes, seg_off, out, (uint64_t)cap, flags);
+        RAHT_HIP_CHECK(hipGetLastError());
+        uint32_t back[2] = {0, 0};
+        RAHT_RET(read_back_u32(back, flags, 2, nullptr, nullptr, 0, s));
+        *total_bytes = (int64_t)back[1];
+        if (back[0] || (int64_t)back[1] > cap) { set_error("raht_rlgr_seg_encode: %u bytes needed, cap = %lld", back[1], (long long)cap); return RAHT_ERR_NOMEM; }
+        return RAHT_OK;
+    });
+}
+
+/* The inverse: streams `in` (DEVICE, 4-byte aligned, in_bytes long -- a multiple of 4) with their offsets / lengths (DEVICE, as
+ * raht_rlgr_seg_encode wrote them) -> Q (DEVICE, channel-major). Does not synchronise. The tables come off the wire: a
+ * segment whose offset / length reaches outside `in` decodes as an empty stream (zeros) and sets *bad_dev (DEVICE uint32,
+ * may be NULL) instead of reading there. */
+int raht_rlgr_seg_decode(const uint8_t *in, int64_t in_bytes, const uint32_t *seg_off, const uint32_t *seg_bytes, int64_t N, int D, int seg_len,
+                         int flag_signed, int32_t *Q, int64_t chan_stride, uint32_t *bad_dev, raht_stream_t stream)
+{
+    if (!in || in_bytes < 0 || (in_bytes & 3) || !seg_off || !seg_bytes || !Q || N < 1 || D < 1 || chan_stride < N || seg_len < 64 || ((uintptr_t)in & 3)) {
+        set_error("raht_rlgr_seg_decode: bad argument");
+        return RAHT_ERR_INVALID;
+    }
+    const int64_t nseg = ceil_div(N, seg_len), G = nseg * D;
+    if (G >= ((int64_t)1 << 31)) { set_error("raht_rlgr_seg_decode: too many segments"); return RAHT_ERR_INVALID; }
+    hipLaunchKernelGGL(rlgr_seg::seg_decode_kernel, dim3((unsigned)ceil_div(G, 64)), dim3(64), 0, (hipStream_t)stream, in, (uint64_t)in_bytes, seg_off, seg_bytes, N, D,
+                       seg_len, (int)nseg, flag_signed, Q, chan_stride, bad_dev);
+    RAHT_HIP_CHECK(hipGetLastError());
+    return RAHT_OK;
+}
+
+}  // extern "C"

@@ -39,7 +39,7 @@ def _psnr(a, b):
 
 
 def encode_frame(V_int, attributes, J, steps, frame=1, device="cuda:0", dtype=torch.float32, fused=True,
-                 nthreads=0, channel_major=True, overlap=False):
+                 nthreads=0, channel_major=True, overlap=False, entropy="host", seg_len=4096):
     """One frame through the whole pipeline. Returns a list of dict rows (one per step) with the CSV
     columns plus ``size_bytes`` and ``C_rec`` (last step) for inspection, and the stages the reference's CSV has no
     column for (``Transpose_time``, ``D2H_time``, ``H2D_time``, ``PSNR_time``, ``Step_wall_time``).
@@ -47,6 +47,14 @@ def encode_frame(V_int, attributes, J, steps, frame=1, device="cuda:0", dtype=to
     overlap=True (fused path): the steps are software-pipelined -- while the host threads entropy-code step s, the GPU
     already transforms / quantizes / copies step s + 1 and decodes step s - 1 (the reference serialises all of it,
     python/encode_3dgs.py:199-275). Same rows, same bytes; ``Step_wall_time`` is then the pipeline's period."""
+    """
+    entropy="gpu": the RLGR stage on the device, segmented (rlgr.SegmentedCoder: every ``seg_len`` symbols of a channel an
+    independent stream, byte-identical to the reference coder's output for that slice): the integers never leave the GPU, only
+    the container's bytes do (``D2H_time``). Rates then count the container (streams + 4 bytes per segment)."""
+    if entropy == "gpu":
+        if not fused:
+            raise ValueError("entropy='gpu' goes with the fused path")
+        return _encode_frame_gpu_entropy(V_int, attributes, J, steps, frame, device, dtype, seg_len)
     if overlap and fused:
         return _encode_frame_overlapped(V_int, attributes, J, steps, frame, device, dtype, nthreads)
     N = V_int.shape[0]
@@ -163,6 +171,75 @@ def encode_frame(V_int, attributes, J, steps, frame=1, device="cuda:0", dtype=to
         r["Total_dec_time"] = r["Entropy_dec_time"] + r["Dequant_time"] + r["Coeff_reorder_dec_time"] + r["iRAHT_time"]
         r["Pipeline_time"] = t_prelude + r["Total_enc_time"] + r["Total_dec_time"]
         r["Rate_bpp"] = size_bytes * 8 / N                                          # :403
+        r["size_bytes"] = size_bytes
+        t0 = time.time()
+        _psnr_columns(r, C, C_rec)
+        r["PSNR_time"] = time.time() - t0
+        r["Step_wall_time"] = time.time() - t_step0
+        r["C_rec"] = C_rec
+        rows.append(r)
+    return rows
+
+
+def _encode_frame_gpu_entropy(V_int, attributes, J, steps, frame, device, dtype, seg_len):
+    """encode_frame with the entropy stage on the device (entropy="gpu"): forward RAHT + quantize + reorder -> channel-major
+    transpose -> segmented RLGR encode (device) -> [container bytes to the host: the codec's output] -> segmented RLGR decode
+    (device) -> round-trip check (device) -> transpose -> dequantize + un-reorder + inverse RAHT -> PSNR."""
+    N = V_int.shape[0]
+    dev = torch.device(device)
+    C = attributes.to(dtype=dtype).contiguous().to(dev)
+    _sync()
+    V = V_int.to(dtype=torch.float64).to(dev)
+    origin = torch.tensor([0, 0, 0], dtype=V.dtype, device=dev)
+    t0 = time.time()
+    ListC, FlagsC, weightsC, order_RAGFT = RAHT_param_reorder_fast(V, origin, 2 ** J, J)
+    _sync()
+    t_prelude = time.time() - t0
+    plan = plan_of(ListC)
+    coder = rlgr_mod.SegmentedCoder(N, C.shape[1], seg_len, 1, dev)
+    rows = []
+    for step in steps:
+        per_channel = not isinstance(step, (int, float))
+        step_arg = [float(x) for x in (step.tolist() if hasattr(step, "tolist") else step)] if per_channel else float(step)
+        r = dict(Frame=frame, Quantization_Step="per_attribute" if per_channel else step)
+        t_step0 = time.time()
+        t0 = time.time()
+        coeff_reordered = plan.forward_quant(C, step_arg)
+        _sync()
+        r["RAHT_transform_time"], r["Quant_time"], r["Coeff_reorder_enc_time"] = time.time() - t0, 0.0, 0.0
+        t0 = time.time()
+        q_dev = rlgr_mod.transpose_on_device(coeff_reordered)
+        _sync()
+        r["Transpose_time"] = time.time() - t0
+        t0 = time.time()
+        coder.encode(q_dev)                                   # (returns the size: synchronises)
+        r["Entropy_enc_time"] = time.time() - t0
+        t0 = time.time()
+        hdr, lens, payload = coder.container_parts()          # what goes on the wire (header, length table, streams): page-locked D2H
+        r["D2H_time"] = time.time() - t0
+        size_bytes = len(hdr) + lens.nbytes + payload.nbytes
+        assert size_bytes == coder.size_bytes
+        t0 = time.time()
+        q_back = coder.decode()
+        _sync()
+        r["Entropy_dec_time"] = time.time() - t0
+        t0 = time.time()
+        assert torch.equal(q_back, q_dev) and int(coder.bad.item()) == 0, "RLGR roundtrip failed"    # encode_3dgs.py:242-245
+        r["Roundtrip_check_time"] = time.time() - t0
+        r["H2D_time"] = 0.0
+        t0 = time.time()
+        qd = rlgr_mod.transpose_on_device(q_back)
+        _sync()
+        r["Transpose_time"] += time.time() - t0
+        t0 = time.time()
+        C_rec = plan.dequant_inverse(qd, step_arg, dtype=dtype)
+        _sync()
+        r["iRAHT_time"], r["Dequant_time"], r["Coeff_reorder_dec_time"] = time.time() - t0, 0.0, 0.0
+        r["RAHT_prelude_time"] = t_prelude
+        r["Total_enc_time"] = r["RAHT_transform_time"] + r["Entropy_enc_time"]
+        r["Total_dec_time"] = r["Entropy_dec_time"] + r["iRAHT_time"]
+        r["Pipeline_time"] = t_prelude + r["Total_enc_time"] + r["Total_dec_time"]
+        r["Rate_bpp"] = size_bytes * 8 / N
         r["size_bytes"] = size_bytes
         t0 = time.time()
         _psnr_columns(r, C, C_rec)

@@ -172,6 +172,105 @@ def pinned_like(shape, dtype, key):
     return buf[:n].view(shape)
 
 
+class SegmentedCoder:
+    """The RLGR stage on the GPU (include/raht.h: raht_rlgr_seg_*): every channel in segments of ``seg_len`` symbols, every
+    segment an independent RLGR stream -- byte-identical to the reference coder's output for that slice -- one lane per
+    segment. ``encode`` takes the channel-major (D, N) int32 device tensor (``transpose_on_device`` of the quantized
+    coefficients) and leaves the streams on the device; ``container()`` is what goes on the wire; ``decode`` rebuilds the
+    (D, N) tensor on the device. Nothing but the compressed bytes ever crosses PCIe."""
+    MAGIC = b"RLGS0001"
+
+    def __init__(self, N, D, seg_len=4096, flag_signed=1, device="cuda"):
+        import torch
+        self.N, self.D, self.S, self.flag = int(N), int(D), int(seg_len), int(flag_signed)
+        self.nseg = (self.N + self.S - 1) // self.S
+        self.G = self.nseg * self.D
+        self.device = torch.device(device)
+        self.seg_bytes = torch.empty(self.G, dtype=torch.int32, device=self.device)
+        self.seg_off = torch.empty(self.G + 1, dtype=torch.int32, device=self.device)
+        self.cap = 4 * self.N * self.D + 64 * self.G           # what a raw dump would take, + slack; grown on demand
+        self.out = torch.empty(self.cap, dtype=torch.uint8, device=self.device)
+        self.bad = torch.zeros(1, dtype=torch.int32, device=self.device)
+        self.total = 0
+
+    def _stream(self):
+        import torch
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def encode(self, Qcm):
+        """Qcm: (D, N) int32 CUDA tensor, rows contiguous -> total container payload bytes (synchronises: it returns a size)"""
+        import torch
+        if not Qcm.is_cuda or Qcm.dtype != torch.int32 or tuple(Qcm.shape) != (self.D, self.N) or Qcm.stride(1) != 1:
+            raise ValueError("SegmentedCoder.encode: expected a (D, N) int32 CUDA tensor with contiguous channels")
+        tot = C.c_int64()
+        for attempt in (0, 1):
+            with torch.cuda.device(self.device):
+                rc = _lib.lib().raht_rlgr_seg_encode(C.c_void_p(Qcm.data_ptr()), self.N, self.D, Qcm.stride(0), self.S, self.flag,
+                                                     C.c_void_p(self.seg_bytes.data_ptr()), C.c_void_p(self.seg_off.data_ptr()),
+                                                     C.c_void_p(self.out.data_ptr()), self.cap, C.byref(tot), self._stream())
+            if rc == _lib.RAHT_OK or attempt == 1 or tot.value <= self.cap:
+                check(rc)
+                break
+            self.cap = int(tot.value) + 64                    # incompressible data: the exact size is known now
+            self.out = torch.empty(self.cap, dtype=torch.uint8, device=self.device)
+        self.total = int(tot.value)
+        return self.total
+
+    @property
+    def size_bytes(self):
+        """bytes of the container: header + length table + streams"""
+        return len(self.MAGIC) + 5 * 8 + 4 * self.G + self.total
+
+    def container_parts(self):
+        """-> (header bytes, uint32 lengths (G,), payload uint8 (total,)): the container without joining it. The payload comes down
+        through the cached page-locked staging buffer (57 GB/s) and aliases it until the next ``to_host`` of a uint8 tensor."""
+        hdr = self.MAGIC + np.array([self.N, self.D, self.S, self.flag, self.total], np.int64).tobytes()
+        lens = to_host(self.seg_bytes).view(np.uint32).copy()
+        return hdr, lens, to_host(self.out[: self.total])
+
+    def container(self):
+        """-> bytes: magic | N, D, seg_len, flag, payload bytes (int64 each) | uint32 length of every segment | the streams, each in
+        a 4-byte slot. Only the compressed bytes come down from the device."""
+        hdr, lens, payload = self.container_parts()
+        return hdr + lens.tobytes() + payload.tobytes()
+
+    @classmethod
+    def from_container(cls, blob, device="cuda"):
+        import torch
+        m = len(cls.MAGIC)
+        if blob[:m] != cls.MAGIC:
+            raise ValueError("not a segmented RLGR container")
+        N, D, S, flag, total = [int(x) for x in np.frombuffer(blob, np.int64, 5, m)]
+        sc = cls(N, D, S, flag, device)
+        lens = np.frombuffer(blob, np.uint32, sc.G, m + 40).astype(np.int64)
+        if total % 4 or total > len(blob) - (m + 40 + 4 * sc.G) or int(((lens + 3) // 4 * 4).sum()) != total:
+            raise ValueError("segmented RLGR container: inconsistent length table")
+        off = np.concatenate([[0], np.cumsum((lens + 3) // 4 * 4)])
+        sc.seg_bytes.copy_(torch.from_numpy(lens.astype(np.int32)))
+        sc.seg_off.copy_(torch.from_numpy(off.astype(np.int64).astype(np.int32)))
+        if total > sc.cap:
+            sc.cap, sc.out = total, torch.empty(total, dtype=torch.uint8, device=sc.device)
+        sc.out[:total].copy_(torch.from_numpy(np.frombuffer(blob, np.uint8, total, m + 40 + 4 * sc.G).copy()))
+        sc.total = total
+        return sc
+
+    def decode(self, out=None):
+        """-> (D, N) int32 CUDA tensor (enqueued on the current stream; no synchronisation)"""
+        import torch
+        Q = torch.empty((self.D, self.N), dtype=torch.int32, device=self.device) if out is None else out
+        with torch.cuda.device(self.device):
+            check(_lib.lib().raht_rlgr_seg_decode(C.c_void_p(self.out.data_ptr()), (self.total + 3) // 4 * 4, C.c_void_p(self.seg_off.data_ptr()),
+                                                  C.c_void_p(self.seg_bytes.data_ptr()), self.N, self.D, self.S, self.flag,
+                                                  C.c_void_p(Q.data_ptr()), Q.stride(0), C.c_void_p(self.bad.data_ptr()), self._stream()))
+        return Q
+
+    def segment(self, c, s):
+        """the bytes of segment s of channel c (host copy; tests)"""
+        g = c * self.nseg + s
+        off, nb = int(self.seg_off[g].item()), int(self.seg_bytes[g].item())
+        return self.out[off: off + nb].cpu().numpy()
+
+
 def transpose_on_device(Q):
     """(rows, cols) int32 CUDA tensor -> (cols, rows) contiguous, with the HIP LDS-tile transpose
     (row-major N x D quantized coefficients -> channel-major D x N for the entropy stage, or back)."""

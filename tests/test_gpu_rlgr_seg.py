@@ -1,0 +1,120 @@
+"""The RLGR stage on the GPU, segmented (csrc/rlgr_seg.hip; SURVEY.md 8f-1 "GPU-segmented"): every segment must be
+byte-identical to the host coder's stream for the same slice -- and the host coder is pinned byte for byte by streams built with
+the reference's own PyRLGR (tests/test_rlgr.py) -- so that any RLGR decoder reads a segment."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _cases():
+    rng = np.random.default_rng(11)
+    lap = lambda n, b: np.rint(rng.laplace(0, b, size=n)).astype(np.int64)          # noqa: E731
+    N = 70000
+    chans = [lap(N, 0.3), lap(N, 3.0), lap(N, 200.0), np.zeros(N, np.int64),                          # sparse / dense / wide / all zero
+             rng.integers(-2 ** 31, 2 ** 31 - 1, size=N),                                             # escapes: |u| >= 2^32 >> k
+             np.where(rng.random(N) < 0.001, lap(N, 50.0), 0),                                        # long zero runs
+             np.concatenate([np.zeros(N // 2, np.int64), lap(N - N // 2, 20.0)]),                     # a run across segment borders
+             np.arange(N) % 7 - 3]
+    return np.stack(chans).astype(np.int32)
+
+
+@pytest.mark.parametrize("seg_len", [64, 1000, 4096, 100000])
+def test_every_segment_is_the_host_coders_stream(seg_len):
+    import torch
+    from raht_3dgs_codec_amd import rlgr
+    Q = _cases()
+    D, N = Q.shape
+    sc = rlgr.SegmentedCoder(N, D, seg_len)
+    Qd = torch.from_numpy(Q).cuda()
+    total = sc.encode(Qd)
+    lens = sc.seg_bytes.cpu().numpy()
+    offs = sc.seg_off.cpu().numpy()
+    assert offs[0] == 0 and offs[-1] == total and np.all(np.diff(offs) == (lens + 3) // 4 * 4)
+    blob = sc.out[:total].cpu().numpy()
+    for c in range(D):
+        for s in range(sc.nseg):
+            sl = Q[c, s * seg_len: (s + 1) * seg_len]
+            m = rlgr.membuf()
+            m.rlgrWrite(sl, 1)                                                      # host coder == reference coder (tests/test_rlgr.py)
+            ref = m.get_array()
+            g = c * sc.nseg + s
+            assert lens[g] == ref.shape[0], (c, s, lens[g], ref.shape[0])
+            assert np.array_equal(blob[offs[g]: offs[g] + lens[g]], ref), (c, s)
+            pad = blob[offs[g] + lens[g]: offs[g + 1]]
+            assert not pad.any()
+    # GPU decode of the GPU streams
+    back = sc.decode()
+    assert torch.equal(back, Qd) and int(sc.bad.item()) == 0
+    # ... and of a container that went over the wire
+    sc2 = rlgr.SegmentedCoder.from_container(sc.container())
+    assert torch.equal(sc2.decode(), Qd)
+    assert sc.size_bytes == len(sc.container())
+    # host decoder on GPU-made segments (any RLGR decoder reads a segment)
+    for c, s in ((0, 0), (4, sc.nseg - 1), (6, sc.nseg // 2)):
+        n = min(seg_len, N - s * seg_len)
+        _, vals = rlgr.membuf(sc.segment(c, s)).rlgrRead(n, 1)
+        assert np.array_equal(np.asarray(vals, dtype=np.int64), Q[c, s * seg_len: s * seg_len + n].astype(np.int64))
+
+
+def test_unsigned_flag_and_strided_channels():
+    import torch
+    from raht_3dgs_codec_amd import rlgr
+    rng = np.random.default_rng(3)
+    N, D = 9000, 5
+    big = torch.from_numpy(rng.integers(0, 40, size=(D, N + 37)).astype(np.int32)).cuda()
+    Qv = big[:, :N]                                             # channel stride N + 37
+    sc = rlgr.SegmentedCoder(N, D, 512, flag_signed=0)
+    sc.encode(Qv)
+    for c in (0, 3):
+        m = rlgr.membuf(); m.rlgrWrite(Qv[c, :512].cpu().numpy(), 0)
+        assert np.array_equal(sc.segment(c, 0), m.get_array())
+    out = torch.full((D, N + 5), -7, dtype=torch.int32, device="cuda")
+    sc.decode(out=out[:, :N])
+    assert torch.equal(out[:, :N], Qv) and bool((out[:, N:] == -7).all())
+
+
+def test_incompressible_data_grows_the_buffer_and_corrupt_tables_do_not_fault():
+    import torch
+    from raht_3dgs_codec_amd import rlgr
+    rng = np.random.default_rng(9)
+    N, D = 20000, 3
+    Q = torch.from_numpy(rng.integers(-2 ** 31, 2 ** 31 - 1, size=(D, N)).astype(np.int32)).cuda()
+    sc = rlgr.SegmentedCoder(N, D, 1024)
+    total = sc.encode(Q)                                         # ~8 bytes per symbol: more than the raw-dump estimate
+    assert total > 4 * N * D and sc.cap >= total
+    assert torch.equal(sc.decode(), Q)
+    # offsets / lengths pointing outside the buffer: those segments decode as empty streams, the flag is raised, nothing faults
+    sc.seg_off[5] = 2 ** 31 - 4
+    sc.seg_bytes[7] = 2 ** 31 - 1
+    out = sc.decode()
+    torch.cuda.synchronize()
+    assert int(sc.bad.item()) == 1
+    nseg = sc.nseg
+    ok = torch.ones(D * nseg, dtype=torch.bool)
+    ok[5] = ok[7] = False
+    got = out.view(D, -1)
+    for g in np.nonzero(ok.numpy())[0][:40]:
+        c, s = divmod(int(g), nseg)
+        assert torch.equal(got[c, s * 1024: (s + 1) * 1024], Q[c, s * 1024: (s + 1) * 1024])
+
+
+def test_cost_of_restarting_the_coder_per_segment():
+    """The state restarts in every segment: what that costs in bytes against ONE stream per channel (the reference's format), on
+    quantized RAHT coefficients of a 3DGS-like frame."""
+    import torch
+    import raht_3dgs_codec_amd as R
+    from raht_3dgs_codec_amd import rlgr, synth
+    V, keys, C = synth.scene(300000, 10, 56, seed=4)
+    plan = R.RahtPlan.from_keys(torch.from_numpy(keys.view(np.int64)).cuda(), 30)
+    for step in (0.02, 0.2):
+        Qcm = rlgr.transpose_on_device(plan.forward_quant(torch.from_numpy(C).cuda(), step))
+        streams, _ = rlgr.encode_channels(rlgr.to_host(Qcm), 1, channel_major=True)
+        one = sum(int(s.shape[0]) for s in streams)
+        for S, bar in ((4096, 1.02), (1024, 1.06)):
+            sc = rlgr.SegmentedCoder(Qcm.shape[1], Qcm.shape[0], S)
+            sc.encode(Qcm)
+            ratio = sc.size_bytes / one
+            print(f"[rlgr_seg] step {step} seg_len {S}: {sc.size_bytes} bytes against {one} as one stream per channel: x{ratio:.4f}")
+            assert ratio <= bar, (step, S, ratio)
+            assert torch.equal(sc.decode(), Qcm)

@@ -25,17 +25,20 @@ ap.add_argument("--D", type=int, default=56)
 ap.add_argument("--out", default="gpurun_out/e2e")
 ap.add_argument("--overlap", type=int, default=0)
 ap.add_argument("--threads", type=int, default=0)
+ap.add_argument("--entropy", default="host", choices=["host", "gpu"])
+ap.add_argument("--seg-len", type=int, default=4096)
 ap.add_argument("--steps", default="0.01,0.04,0.08,0.12,0.16,0.20,0.24,0.32,0.64")
 a = ap.parse_args()
 os.makedirs(a.out, exist_ok=True)
 V, keys, C = synth.scene(a.rows, a.J, a.D, seed=2)
 steps = [float(x) for x in a.steps.split(",")]
 Vt, Ct = torch.from_numpy(V), torch.from_numpy(C)
-pipeline.encode_frame(Vt, Ct, a.J, steps[:1], frame=0, nthreads=a.threads, overlap=bool(a.overlap))         # warm-up (encode_3dgs.py:88-118)
+kw = dict(nthreads=a.threads, overlap=bool(a.overlap), entropy=a.entropy, seg_len=a.seg_len)
+pipeline.encode_frame(Vt, Ct, a.J, steps[:1], frame=0, **kw)         # warm-up (encode_3dgs.py:88-118)
 t0 = time.time()
-rows = pipeline.encode_frame(Vt, Ct, a.J, steps, frame=1, nthreads=a.threads, overlap=bool(a.overlap))
+rows = pipeline.encode_frame(Vt, Ct, a.J, steps, frame=1, **kw)
 wall = time.time() - t0
-tag = "overlap" if a.overlap else "sequential"
+tag = "gpu_entropy" if a.entropy == "gpu" else ("overlap" if a.overlap else "sequential")
 with open(os.path.join(a.out, f"runtime_3dgs_{tag}.csv"), "w") as f:
     f.write(pipeline.CSV_HEADER + "\n" + "\n".join(pipeline.format_row(r) for r in rows) + "\n")
 extra = []
@@ -45,7 +48,7 @@ for r in rows:
 summary = {"rows": int(V.shape[0]), "channels": a.D, "J": a.J, "steps": steps, "mode": tag, "host_threads": a.threads or os.cpu_count(),
            "wall_s_all_steps": round(wall, 4), "wall_s_per_step": round(wall / len(steps), 4), "per_step": extra}
 json.dump(summary, open(os.path.join(a.out, f"e2e_{tag}.json"), "w"), indent=1)
-keys_ = ["RAHT_transform_time", "Transpose_time", "D2H_time", "Entropy_enc_time", "Entropy_dec_time", "H2D_time", "iRAHT_time", "PSNR_time", "Step_wall_time"]
+keys_ = ["RAHT_transform_time", "Transpose_time", "D2H_time", "Entropy_enc_time", "Entropy_dec_time", "Roundtrip_check_time", "H2D_time", "iRAHT_time", "PSNR_time", "Step_wall_time"]
 print(tag, "rows", V.shape[0], "x", a.D, "wall per step %.4f s" % (wall / len(steps)))
 for k in keys_:
     vals = [r.get(k, 0.0) for r in rows]
