@@ -852,6 +852,30 @@ def main():
                             "one_call_per_frame_frac_of_peak": round(alg_b / (t_l * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                             "bit_identical_to_single_scene_calls": True}
             del plans_b, Cs_b
+            # ---- the whole codec step on a frame of the headline size (tools/e2e_frame.py runs all nine steps): transform +
+            # quantize + entropy stage + decode back, with the byte-exact RLGR coder on the host threads (the reference's format:
+            # one stream per channel) and with the segmented RLGR coder on the GPU (every segment byte-identical to the
+            # reference coder's stream for its slice; own container)
+            from raht_3dgs_codec_amd import pipeline as _pl
+            Vf, kf, Cf = synth.scene(3_000_000, 12, 56, 2)
+            Vt, Ct = torch.from_numpy(Vf), torch.from_numpy(Cf)
+            fsteps = [0.04, 0.2]
+            _pl.encode_frame(Vt, Ct, 12, fsteps[:1], frame=0, entropy="gpu")
+            rg = _pl.encode_frame(Vt, Ct, 12, fsteps, entropy="gpu")
+            rh = _pl.encode_frame(Vt, Ct, 12, fsteps, entropy="host")
+            assert all(torch.equal(x["C_rec"], y["C_rec"]) for x, y in zip(rg, rh)), "GPU entropy stage reconstructs differently"
+
+            def ms(rows_, k):
+                return round(float(np.mean([r[k] for r in rows_])) * 1e3, 3)
+            out["frame_codec"] = {"workload": f"one voxelized frame, {Vf.shape[0]} Gaussians x 56 channels (J=12), steps {fsteps}: per step forward RAHT + quantize + "
+                                              "RLGR encode + RLGR decode + round-trip check + dequantize + inverse RAHT + 5 PSNR columns",
+                                  "gpu_entropy": {"step_ms": ms(rg, "Step_wall_time"), "rlgr_encode_ms": ms(rg, "Entropy_enc_time"), "rlgr_decode_ms": ms(rg, "Entropy_dec_time"),
+                                                  "container_to_host_ms": ms(rg, "D2H_time"), "bytes": [r["size_bytes"] for r in rg], "segment_symbols": 2048},
+                                  "host_entropy": {"step_ms": ms(rh, "Step_wall_time"), "rlgr_encode_ms": ms(rh, "Entropy_enc_time"), "rlgr_decode_ms": ms(rh, "Entropy_dec_time"),
+                                                   "integers_to_host_ms": ms(rh, "D2H_time"), "integers_to_device_ms": ms(rh, "H2D_time"), "bytes": [r["size_bytes"] for r in rh],
+                                                   "threads": "the container's CPU quota"},
+                                  "same_reconstruction": True}
+            del rg, rh, Vt, Ct
     if rank == 0:
         sys.stdout.flush()
         os.write(real_stdout, (json.dumps(out) + "\n").encode())

@@ -39,20 +39,22 @@ struct DevBitWriter {
             size += 4;
         }
     }
-    __device__ __forceinline__ void put_wide(uint64_t v, int bits)
+    __device__ __forceinline__ void put_wide(uint32_t v, int bits)   // the run length m in k bits (k <= 32 inside a segment)
     {
-        if (bits > 32) { put((bits == 64) ? (v >> 32) : ((v >> 32) & ((1ull << (bits - 32)) - 1)), bits - 32); put(v & 0xffffffffull, 32); }
-        else put(bits ? (v & ((1ull << bits) - 1)) : 0, bits);
+        if (bits > 32) { put(0, bits - 32); put(v, 32); }
+        else put(bits == 32 ? v : (bits ? (v & ((1u << bits) - 1u)) : 0u), bits);
     }
-    __device__ __forceinline__ void golomb_rice(uint64_t u, int k)  // membuf.cpp:242-256
+    __device__ __forceinline__ void golomb_rice(uint32_t u, int k)  // membuf.cpp:242-256; k <= 32
     {
-        const uint64_t p = u >> k;
+        const uint32_t p = (k < 32) ? (u >> k) : 0u;
+        const uint32_t rem = (k >= 32) ? u : (u & ((1u << k) - 1u));
         if (p < 32) {
-            if (p + 1 + (uint64_t)k <= 32) put((((1ull << (p + 1)) - 2) << k) | (k ? (u & ((1ull << k) - 1)) : 0), (int)p + 1 + k);
-            else { put((1ull << (p + 1)) - 2, (int)p + 1); put(k ? (u & ((1ull << k) - 1)) : 0, k); }
+            const uint32_t pre = (uint32_t)((1ull << (p + 1)) - 2);               // p ones and a zero
+            if (p + 1 + (uint32_t)k <= 32) put(((uint64_t)pre << k) | rem, (int)p + 1 + k);
+            else { put(pre, (int)p + 1); put(rem, k); }
         } else {
-            put(0xffffffffull, 32);
-            put(u & 0xffffffffull, 32);
+            put(0xffffffffull, 32);                                               // escape: 32 ones, then 32 raw bits
+            put(u, 32);
         }
     }
     __device__ __forceinline__ void close()                         // membuf.cpp:47-58
@@ -76,39 +78,65 @@ __device__ __forceinline__ int64_t u2s(uint64_t v) { const int64_t d = (int64_t)
         else { k_RP = (k_RP < 2) ? 0 : k_RP - 2; }                   \
     } while (0)
 
+// (p - 1 may not fit 32 bits together with k_RP: saturate first)
+#define RLGS_ADAPT_KRP32(p)                                                              \
+    do {                                                                                 \
+        if (p) { k_RP = ((p) > 32 * L) ? 32 * L : min(k_RP + (p) - 1, 32 * L); }         \
+        else { k_RP = (k_RP < 2) ? 0 : k_RP - 2; }                                       \
+    } while (0)
+
 // membuf.cpp:340-423 on one segment
-template <bool WRITE>
+// VEC: the segment starts on a 16-byte boundary -- symbols are fetched four at a time (a lane walks its own segment, so a
+// wave's loads touch 64 different lines either way: 16-byte loads make it a quarter as many instructions and lookups)
+// What bounds this coder is instruction issue, one wave per SIMD at most: ~170 instructions per symbol (both modes' paths
+// are walked by a wave whose lanes disagree), 2.6 waves per SIMD at 1024 symbols per segment, 0.64 at 4096 -- the time per pass is
+// that of ONE wave walking its segments: proportional to seg_len above ~1500. Staging the symbols / the output through LDS in
+// blocks of 64 (to take the loads and stores off each other's wait counter) changed nothing for the encoder and made the
+// decoder slower (round 3): memory is not what a lane waits for.
+template <bool WRITE, bool VEC>
 __device__ __forceinline__ uint32_t encode_segment(const int32_t *__restrict__ seq, int n, int flag_signed, uint32_t *out32)
 {
     DevBitWriter<WRITE> w;
     w.out32 = out32;
-    uint64_t u = 0, k_P = 0, k_RP = 2 * L, m = 0, k = 0;
-    int32_t nxt = n > 0 ? seq[0] : 0;
+    // 32-bit state: u = s2u(int32) < 2^32; inside a segment of n < 2^31 symbols the run counter m and the run exponent
+    // k (<= log2 n + 1) stay far below 32 bits; k_RP is capped at 32 L. (The host coder carries them in 64 bits because one
+    // stream may hold 2^32 symbols and more; 64-bit integer arithmetic is several instructions per operation here.)
+    uint32_t u = 0, k_P = 0, k_RP = 2 * L, m = 0, k = 0;
+    int32_t nxt = (!VEC && n > 0) ? seq[0] : 0;
+    int4 cur4 = make_int4(0, 0, 0, 0), nxt4 = make_int4(0, 0, 0, 0);
+    if (VEC && n > 0) nxt4 = *(const int4 *)seq;                     // (whole groups of four are readable: see the kernel)
     for (int i = 0; i < n; ++i) {
-        const int64_t v = nxt;
-        if (i + 1 < n) nxt = seq[i + 1];                             // one symbol ahead: the load is off the dependent chain
-        u = flag_signed ? s2u(v) : (uint64_t)(uint32_t)v;
+        int32_t v;
+        if (VEC) {
+            if ((i & 3) == 0) { cur4 = nxt4; if (i + 4 < n) nxt4 = *(const int4 *)(seq + i + 4); }    // one group ahead
+            const int q = i & 3;
+            v = q == 0 ? cur4.x : q == 1 ? cur4.y : q == 2 ? cur4.z : cur4.w;
+        } else {
+            v = nxt;
+            if (i + 1 < n) nxt = seq[i + 1];                         // one symbol ahead: the load is off the dependent chain
+        }
+        u = flag_signed ? (v < 0 ? ((uint32_t)(-(int64_t)v) << 1) - 1u : (uint32_t)v << 1) : (uint32_t)v;     // _s2u, membuf.cpp:4-13
         k = k_P / L;
-        const uint64_t k_R = k_RP / L;
+        const uint32_t k_R = k_RP / L;
         if (k) {                                                    // run mode
             if (u) {
                 --u;
                 w.put(0, 1);
                 w.put_wide(m, (int)k);
                 w.golomb_rice(u, (int)k_R);
-                const uint64_t p = u >> k_R;
-                RLGS_ADAPT_KRP(p);
+                const uint32_t p = (k_R < 32) ? (u >> k_R) : 0u;      // (k_R reaches 32 after an escape: a 32-bit shift by 32 is not 0)
+                RLGS_ADAPT_KRP32(p);
                 k_P = (k_P < D1) ? 0 : k_P - D1;
                 m = 0;
-            } else if (++m == (1ull << k)) {
+            } else if (++m == ((k < 32) ? (1u << k) : 0u)) {         // (k >= 32 needs 2^32 zeros in one segment: never)
                 w.put(1, 1);
                 k_P += U1;
                 m = 0;
             }
         } else {                                                    // no-run mode
             w.golomb_rice(u, (int)k_R);
-            const uint64_t p = u >> k_R;
-            RLGS_ADAPT_KRP(p);
+            const uint32_t p = (k_R < 32) ? (u >> k_R) : 0u;      // (k_R reaches 32 after an escape: a 32-bit shift by 32 is not 0)
+            RLGS_ADAPT_KRP32(p);
             if (u) k_P = (k_P < D0) ? 0 : k_P - D0;
             else k_P += U0;
             m = 0;
@@ -129,10 +157,11 @@ struct DevBitReader {
     uint64_t acc = 0;
     int nbits = 0;
 
+    __device__ __forceinline__ uint32_t word(uint32_t w) { return in32[w]; }
     __device__ __forceinline__ void fill()                           // afterwards nbits > 32 unless the stream ended
     {
         if (nbits <= 32 && pos < size) {
-            uint32_t w = __builtin_bswap32(in32[pos >> 2]);
+            uint32_t w = __builtin_bswap32(word(pos >> 2));
             const uint32_t left = size - pos;
             int got = 32;
             if (left < 4) { got = (int)left * 8; w >>= (32 - got); }   // the last, partial word: only its bytes count
@@ -177,12 +206,25 @@ struct DevBitReader {
     }
 };
 
+// VEC: the segment starts on a 16-byte boundary: symbols leave four at a time
+template <bool VEC>
 __device__ __forceinline__ void decode_segment(const uint32_t *in32, uint32_t nbytes, int n, int flag_signed, int32_t *__restrict__ seq)
 {
     DevBitReader r;
     r.in32 = in32; r.size = nbytes;
     uint64_t k_P = 0, k_RP = 2 * L;
     int i = 0;
+    int4 buf = make_int4(0, 0, 0, 0);
+    auto emit = [&](int32_t v) {
+        if (VEC) {
+            const int q = i & 3;
+            if (q == 0) buf.x = v; else if (q == 1) buf.y = v; else if (q == 2) buf.z = v; else buf.w = v;
+            ++i;
+            if ((i & 3) == 0) *(int4 *)(seq + i - 4) = buf;
+        } else {
+            seq[i++] = v;
+        }
+    };
     while (i < n) {                                                  // membuf.cpp:270-331
         uint64_t k = k_P / L;
         const uint64_t k_R = k_RP / L;
@@ -195,21 +237,27 @@ __device__ __forceinline__ void decode_segment(const uint32_t *in32, uint32_t nb
                 if (m > (uint64_t)n) break;                          // corrupt stream guard
             }
             m += r.get_wide((int)k);
-            while (m-- && i < n) seq[i++] = 0;
+            while (m-- && i < n) emit(0);
             if (i >= n) break;
             const uint64_t u = r.golomb_rice((int)k_R);
-            seq[i++] = (int32_t)(flag_signed ? u2s(u + 1) : (int64_t)(u + 1));
+            emit((int32_t)(flag_signed ? u2s(u + 1) : (int64_t)(u + 1)));
             const uint64_t p = u >> k_R;
             RLGS_ADAPT_KRP(p);
             k_P = (k_P < D1) ? 0 : k_P - D1;
         } else {
             const uint64_t u = r.golomb_rice((int)k_R);
-            seq[i++] = (int32_t)(flag_signed ? u2s(u) : (int64_t)u);
+            emit((int32_t)(flag_signed ? u2s(u) : (int64_t)u));
             const uint64_t p = u >> k_R;
             RLGS_ADAPT_KRP(p);
             if (u) k_P = (k_P < D0) ? 0 : k_P - D0;
             else k_P += U0;
         }
+    }
+    if (VEC && (i & 3)) {                                            // the last, partial group (n not a multiple of four)
+        const int b = i & ~3;
+        seq[b] = buf.x;
+        if ((i & 3) > 1) seq[b + 1] = buf.y;
+        if ((i & 3) > 2) seq[b + 2] = buf.z;
     }
 }
 
@@ -225,13 +273,16 @@ __global__ __launch_bounds__(64) void seg_encode_kernel(const int32_t *__restric
     const int64_t i0 = (int64_t)s * S;
     const int n = (int)min((int64_t)S, N - i0);
     const int32_t *seq = Q + (int64_t)c * chan_stride + i0;
+    // 16-byte loads: segment starts aligned and a whole group of four readable behind the last symbol (wave-uniform choice)
+    const bool vec = ((((uintptr_t)Q) & 15) == 0) && ((chan_stride & 3) == 0) && ((S & 3) == 0) && ((N & 3) == 0 || chan_stride >= ((N + 3) & ~(int64_t)3));
     if (!WRITE) {
-        seg_bytes[g] = encode_segment<false>(seq, n, flag_signed, nullptr);
+        seg_bytes[g] = vec ? encode_segment<false, true>(seq, n, flag_signed, nullptr) : encode_segment<false, false>(seq, n, flag_signed, nullptr);
     } else {
         const uint64_t off = seg_off[g];                              // 4-byte aligned
         const uint32_t need = (seg_bytes[g] + 3u) & ~3u;
         if (off + need > cap) { atomicOr(overflow, 1u); return; }
-        (void)encode_segment<true>(seq, n, flag_signed, (uint32_t *)(out + off));
+        if (vec) (void)encode_segment<true, true>(seq, n, flag_signed, (uint32_t *)(out + off));
+        else (void)encode_segment<true, false>(seq, n, flag_signed, (uint32_t *)(out + off));
     }
 }
 
@@ -255,7 +306,11 @@ __global__ __launch_bounds__(64) void seg_decode_kernel(const uint8_t *__restric
     const uint64_t off = seg_off[g];
     uint32_t nb = seg_bytes[g];
     if ((off & 3) || off > in_bytes || (uint64_t)((nb + 3u) & ~3u) > in_bytes - off) { nb = 0; if (bad) atomicOr(bad, 1u); }
-    decode_segment((const uint32_t *)(in + (nb ? off : 0)), nb, n, flag_signed, Q + (int64_t)c * chan_stride + i0);
+    // (16-byte stores of four buffered symbols measured SLOWER than one 4-byte store per symbol -- 4.2 against 3.0 ms for 3 M x 56
+    // at 2048 per segment: the component selects cost more instructions than the stores save; kept behind this switch)
+    const bool vec = false && ((((uintptr_t)Q) & 15) == 0) && ((chan_stride & 3) == 0) && ((S & 3) == 0);
+    if (vec) decode_segment<true>((const uint32_t *)(in + (nb ? off : 0)), nb, n, flag_signed, Q + (int64_t)c * chan_stride + i0);
+    else decode_segment<false>((const uint32_t *)(in + (nb ? off : 0)), nb, n, flag_signed, Q + (int64_t)c * chan_stride + i0);
 }
 
 }  // namespace rlgr_seg

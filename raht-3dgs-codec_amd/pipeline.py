@@ -39,7 +39,7 @@ def _psnr(a, b):
 
 
 def encode_frame(V_int, attributes, J, steps, frame=1, device="cuda:0", dtype=torch.float32, fused=True,
-                 nthreads=0, channel_major=True, overlap=False, entropy="host", seg_len=4096):
+                 nthreads=0, channel_major=True, overlap=False, entropy="host", seg_len=2048):
     """One frame through the whole pipeline. Returns a list of dict rows (one per step) with the CSV
     columns plus ``size_bytes`` and ``C_rec`` (last step) for inspection, and the stages the reference's CSV has no
     column for (``Transpose_time``, ``D2H_time``, ``H2D_time``, ``PSNR_time``, ``Step_wall_time``).

@@ -180,7 +180,7 @@ class SegmentedCoder:
     (D, N) tensor on the device. Nothing but the compressed bytes ever crosses PCIe."""
     MAGIC = b"RLGS0001"
 
-    def __init__(self, N, D, seg_len=4096, flag_signed=1, device="cuda"):
+    def __init__(self, N, D, seg_len=2048, flag_signed=1, device="cuda"):
         import torch
         self.N, self.D, self.S, self.flag = int(N), int(D), int(seg_len), int(flag_signed)
         self.nseg = (self.N + self.S - 1) // self.S

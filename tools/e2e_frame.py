@@ -26,7 +26,7 @@ ap.add_argument("--out", default="gpurun_out/e2e")
 ap.add_argument("--overlap", type=int, default=0)
 ap.add_argument("--threads", type=int, default=0)
 ap.add_argument("--entropy", default="host", choices=["host", "gpu"])
-ap.add_argument("--seg-len", type=int, default=4096)
+ap.add_argument("--seg-len", type=int, default=2048)
 ap.add_argument("--steps", default="0.01,0.04,0.08,0.12,0.16,0.20,0.24,0.32,0.64")
 a = ap.parse_args()
 os.makedirs(a.out, exist_ok=True)
