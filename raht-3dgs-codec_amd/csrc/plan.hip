@@ -469,6 +469,7 @@ static void free_schedule(Schedule &sc)
         if (st.e_wr) dev_free(st.e_wr);
         if (st.e_lvl) dev_free(st.e_lvl);
         if (st.e_ht) dev_free(st.e_ht);
+        if (st.arrive) dev_free(st.arrive);
         if (st.e_pos) dev_free(st.e_pos);
         if (st.t_pj) dev_free(st.t_pj);
         if (st.t_ab32) dev_free(st.t_ab32);

@@ -175,6 +175,9 @@ struct Stage {
     // is high (9.3 on average at 184 rows) instead of one per binary level present (13.9). Heights are < 64: levels
     // strictly increase along a dependency chain.
     uint8_t *e_ht = nullptr;
+    // forward chaining of the later tile stages (transform.hip, tile_kernel_chain): entries of this stage that have arrived
+    // from the stage below, per tile; all zero between launches (the workgroup that completes a tile resets its counter)
+    uint32_t *arrive = nullptr;
     // TOP stage (the last one, when at most `top_rows` entries are left): ONE launch of top_kernel
     // finishes the tree. A workgroup per 16-byte channel chunk keeps all entries in LDS and walks
     // the butterflies level by level from this precomputed list, sorted by level:

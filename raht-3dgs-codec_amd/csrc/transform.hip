@@ -844,6 +844,76 @@ __global__ __launch_bounds__(512, (sizeof(T) == 4 ? 6 : 4)) void tile_kernel(con
     tile_body<T, INV, IDENT, QM, SLOTS>(A, ST, (int64_t)blockIdx.x, (int64_t)gridDim.x, (int)blockIdx.y);
 }
 
+// FORWARD CHAINING of the later tile stages (round 3). Stage k + 1's tile P can run as soon as the tiles of stage k that
+// feed it are done, and those are a handful of CONSECUTIVE tiles. So stages 1 .. last tile stage go out as ONE launch with one
+// workgroup per stage-1 tile: a workgroup that finishes a tile adds the number of survivors it delivered to the arrival
+// counter of each parent tile it fed (at most two: the next stage's tiles are at least as long as this one's); whoever
+// completes a parent's count runs that parent next, in the same workgroup, and so on upwards. Nobody ever waits, so nothing
+// can deadlock; every tile of every chained stage is run exactly once (by the last of its children to arrive). Ordering:
+// every thread fences its survivor stores (agent scope: the parent may run on another XCD, whose L2 is a different one),
+// barrier, one relaxed atomic; the taker fences again before it loads. Counters return to zero (the taker resets them).
+// Only with all D channels in one chunk (D <= 64). The pending parents (depth-first, at most one per stage above) live at
+// the end of the dynamic LDS block, behind what tile_body uses.
+constexpr int CHAIN_MAX = 6;
+template <typename T>
+struct TileChain {
+    TileArgs<T> a[CHAIN_MAX];
+    uint32_t *arrive[CHAIN_MAX];       // arrive[i]: counters of a[i]'s tiles (i >= 1)
+    int n;
+    uint32_t stack_off;                // byte offset of the pending list in the dynamic LDS block
+};
+
+template <typename T, bool QM, int SLOTS>
+__global__ __launch_bounds__(512, (sizeof(T) == 4 ? 6 : 4)) void tile_kernel_chain(const TileChain<T> C,
+                                                   const typename std::conditional<QM, typename StepsFor<T>::type, NoSteps>::type ST)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    uint32_t *pend = (uint32_t *)(smem + C.stack_off);      // [0] = count, [1 + i] = stage << 24 | tile
+    int stage = 0;
+    int64_t tile = blockIdx.x;
+    if (threadIdx.x == 0) pend[0] = 0;
+    for (;;) {
+        tile_body<T, false, false, QM, SLOTS>(C.a[stage], ST, tile, (int64_t)1 << 40, 0);      // (ends with a barrier)
+        if (stage + 1 < C.n) {
+            // this tile's survivor rows, visible device-wide: every thread's stores reach this XCD's L2 (workgroup-scope
+            // release = wait for their acknowledgement), barrier, then ONE agent-scope release (write-back of that L2) by
+            // the thread that signals. (An agent-scope fence in every thread -- 512 write-back + invalidate pairs per tile --
+            // made the chained launch 220 us instead of 31.)
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                const TileArgs<T> &A = C.a[stage];
+                const uint32_t sb = A.surv_off[tile], se = A.surv_off[tile + 1];
+                const uint32_t Rn = (uint32_t)C.a[stage + 1].R, n_next = (uint32_t)C.a[stage + 1].n_entries;
+                uint32_t *arr = C.arrive[stage + 1];
+                for (uint32_t lo = sb; lo < se;) {
+                    const uint32_t pt = lo / Rn, hi = min(se, (pt + 1) * Rn), add = hi - lo;
+                    const uint32_t target = min(Rn, n_next - pt * Rn);
+                    const uint32_t old = atomicAdd(&arr[pt], add);
+                    if (old + add == target) {
+                        arr[pt] = 0;                           // ours now; ready for the next launch
+                        const uint32_t c = pend[0];
+                        pend[1 + c] = ((uint32_t)(stage + 1) << 24) | pt;
+                        pend[0] = c + 1;
+                    }
+                    lo = hi;
+                }
+            }
+            __syncthreads();
+        }
+        const uint32_t c = pend[0];
+        if (c == 0) break;
+        const uint32_t top = pend[c];
+        __syncthreads();                                      // everybody has read the entry before it is popped / overwritten
+        if (threadIdx.x == 0) pend[0] = c - 1;
+        stage = (int)(top >> 24);
+        tile = (int64_t)(top & 0xffffffu);
+        if (threadIdx.x == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");    // the children's rows, not a stale line of this XCD's L2
+        __syncthreads();
+    }
+}
+
 // Several scenes, one launch (raht_*_batch): the same stage of up to TILE_BATCH_MAX scenes. first_tile[s] = number of tiles of the
 // scenes before s; a workgroup finds its scene with a handful of scalar compares and runs ONE tile of it. A frame of ~1 M
 // Gaussians fills the chip's 768 workgroup slots two and a half times and then waits ~20 us for its tail stages (a third of
@@ -1416,6 +1486,77 @@ static int launch_stage_impl(const raht_plan *p, const Schedule &sc, int k, cons
                  : launch_tile_one<T, INV, false, QM, 2>(A, io, grid, G.threads, G.lds, s);
 }
 
+// stages k0 .. k1 (tile stages of one launch shape, forward direction, one channel chunk) as ONE chained launch
+template <typename T, bool QM>
+static int launch_tile_chain(raht_plan *p, Schedule &sc, int k0, int k1, const XformIO<T> &io, int D, int Dc0, hipStream_t s)
+{
+    TileChain<T> C;
+    TileGeom G0;
+    C.n = k1 - k0 + 1;
+    for (int i = 0; i < CHAIN_MAX; ++i) C.arrive[i] = nullptr;
+    for (int k = k0; k <= k1; ++k) {
+        Stage &st = sc.stages[(size_t)k];
+        TileGeom G;
+        RAHT_RET((prepare_tile_stage<T, false, QM>(p, sc, k, io, D, Dc0, 0, C.a[k - k0], G)));
+        if (G.nchunks != 1) { set_error("tile chain: channel-chunked stage"); return RAHT_ERR_INVALID; }
+        if (k == k0) G0 = G;
+        else if (!G.same_shape(G0) || st.tile_rows < sc.stages[(size_t)k - 1].tile_rows) { set_error("tile chain: stages of different launch shapes"); return RAHT_ERR_INVALID; }
+        if (k > k0 && !st.arrive) {
+            RAHT_HIP_CHECK(dev_malloc(&st.arrive, sizeof(uint32_t) * (size_t)st.n_tiles));
+            RAHT_HIP_CHECK(hipMemsetAsync(st.arrive, 0, sizeof(uint32_t) * (size_t)st.n_tiles, s));
+        }
+        C.arrive[k - k0] = st.arrive;
+    }
+    for (int i = C.n; i < CHAIN_MAX; ++i) C.a[i] = C.a[0];
+    C.stack_off = (uint32_t)((G0.lds + 15) & ~(size_t)15);
+    const size_t lds = C.stack_off + 64;
+    const dim3 grid((unsigned)G0.n_tiles, 1);
+    static PerDeviceOnce attr1, attr2;
+    if (G0.one) {
+        if (attr1.first(current_device())) RAHT_HIP_CHECK(hipFuncSetAttribute((const void *)tile_kernel_chain<T, QM, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    } else {
+        if (attr2.first(current_device())) RAHT_HIP_CHECK(hipFuncSetAttribute((const void *)tile_kernel_chain<T, QM, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    }
+    if constexpr (QM) {
+        typename StepsFor<T>::type st;
+        fill_step_table(st, io.steps, io.n_steps);
+        if (G0.one) hipLaunchKernelGGL((tile_kernel_chain<T, true, 1>), grid, dim3(G0.threads), lds, s, C, st);
+        else hipLaunchKernelGGL((tile_kernel_chain<T, true, 2>), grid, dim3(G0.threads), lds, s, C, st);
+    } else {
+        NoSteps ns{0, 0};
+        if (G0.one) hipLaunchKernelGGL((tile_kernel_chain<T, false, 1>), grid, dim3(G0.threads), lds, s, C, ns);
+        else hipLaunchKernelGGL((tile_kernel_chain<T, false, 2>), grid, dim3(G0.threads), lds, s, C, ns);
+    }
+    RAHT_HIP_CHECK(hipGetLastError());
+    return RAHT_OK;
+}
+
+// the forward direction's stage sequence: stage 0, the later tile stages (optionally chained into one launch: see below), the top stage
+template <typename T, bool QM>
+static int launch_forward_stages(raht_plan *p, Schedule &sc, const XformIO<T> &io, int D, int Dc, hipStream_t s)
+{
+    // MEASURED, OFF by default (RAHT_CHAIN=1 switches it on): parity-green, but the fused cfg3 forward takes 0.339 ms chained
+    // against 0.304 ms with one launch per stage -- every tile's agent-scope release is a write-back of its XCD's L2 (the survivor
+    // rows must be visible to a parent that may run on another XCD), 705 of them cost more than the one launch (4.6 us) and the
+    // ~6 us of stage-2 work they hide. (With the fence in every thread: 0.50 ms.)
+    static const bool chain_on = getenv("RAHT_CHAIN") && atoi(getenv("RAHT_CHAIN")) != 0;
+    const int K = (int)sc.stages.size();
+    int k1 = K - 1;
+    while (k1 >= 1 && sc.stages[(size_t)k1].is_top) --k1;          // last tile stage
+    int r1 = 0, dc1 = 0, rf = 0;
+    pick_tail_geometry(p, (int)sizeof(T), D, sc.tile_rows, &r1, &dc1, &rf);
+    const bool chain = chain_on && k1 >= 2 && k1 <= CHAIN_MAX && dc1 >= D && !p->row_map;
+    for (int k = 0; k < K; ++k) {
+        if (chain && k == 1) {
+            RAHT_RET((launch_tile_chain<T, QM>(p, sc, 1, k1, io, D, Dc, s)));
+            k = k1;
+            continue;
+        }
+        RAHT_RET((launch_tile_stage<T, false, QM>(p, sc, k, io, D, Dc, s)));
+    }
+    return RAHT_OK;
+}
+
 // the same tile stage of m <= TILE_BATCH_MAX scenes (equal launch shape) in one launch, one tile per workgroup
 template <typename T, bool INV, bool QM>
 static int launch_tile_batch(int m, const TileArgs<T> *As, const TileGeom *Gs, const XformIO<T> &io, hipStream_t s)
@@ -1530,9 +1671,10 @@ static int run_transform(const raht_plan *cp, const T *src, int64_t ld_src, int 
         XformIO<T> io;
         io.src = src; io.ld_src = ld_src; io.dst = dst; io.ld_dst = ld_dst;
         const int K = (int)sc->stages.size();
-        for (int q = 0; q < K && rc == RAHT_OK; ++q) {
-            const int k = INV ? K - 1 - q : q;
-            rc = launch_tile_stage<T, INV, false>(p, *sc, k, io, D, Dc, s);
+        if constexpr (!INV) {
+            rc = launch_forward_stages<T, false>(p, *sc, io, D, Dc, s);
+        } else {
+            for (int q = 0; q < K && rc == RAHT_OK; ++q) rc = launch_tile_stage<T, INV, false>(p, *sc, K - 1 - q, io, D, Dc, s);
         }
     }
     if (rc == RAHT_OK && w && p->row_map) { set_error("node weights are not available from a row-mapped plan"); return RAHT_ERR_UNSUPPORTED; }
@@ -1589,9 +1731,7 @@ static int fwd_quant_impl(const raht_plan *cp, const T *C, int64_t ldc, int D, c
     }
     XformIO<T> io;
     io.src = C; io.ld_src = ldc; io.Q = Q; io.ldq = ldq; io.steps = steps; io.n_steps = n_steps;
-    const int K = (int)sc->stages.size();
-    for (int k = 0; k < K; ++k) RAHT_RET((launch_tile_stage<T, false, true>(p, *sc, k, io, D, Dc, s)));
-    return RAHT_OK;
+    return launch_forward_stages<T, true>(p, *sc, io, D, Dc, s);
 }
 
 /* Fused un-reorder + dequantize + inverse RAHT (encode_3dgs.py:261,267-268,274 in one pass). */

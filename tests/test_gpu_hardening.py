@@ -10,12 +10,15 @@
 * plans on two devices in one process (skipped on a one-GPU box);
 * the float64 quantizer (reference precision) against the reference's integers.
 """
+import os
+
 import numpy as np
 import pytest
 
 from .conftest import golden_names, load_golden
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.fixture(scope="module")
@@ -258,3 +261,34 @@ def test_float64_quantizer_reproduces_the_reference_integers(rt, name):
         assert (Crec - plan.inverse(Td)).abs().max().item() == 0.0
         ref_rec = g["crec_step" + k[len("q_step"):]]                         # the reference's reconstruction
         np.testing.assert_allclose(Crec.cpu().numpy(), ref_rec, rtol=1e-12, atol=1e-12 * max(1.0, float(np.abs(ref_rec).max())))
+
+
+def test_forward_chaining_of_later_stages_is_bit_identical(tmp_path):
+    """RAHT_CHAIN=1 (measured slower, off by default: DESIGN.md 10): the later tile stages of the forward direction as ONE launch in
+    which the workgroup that completes a parent tile's inputs runs it. Same tiles, same code: bit-identical outputs. Run in a
+    child process (the knob is read once)."""
+    import subprocess
+    import sys
+    code = r'''
+import os, sys, numpy as np, torch
+sys.path.insert(0, %r)
+import raht_3dgs_codec_amd as R
+from raht_3dgs_codec_amd import synth
+V, keys, C = synth.scene(700000, 11, 59, seed=3)
+p = R.RahtPlan.from_keys(torch.from_numpy(keys.view(np.int64)).cuda(), 33)
+st = p.stage_stats(4, 59)
+assert len(st["rows_per_stage"]) >= 4, st
+Cd = torch.from_numpy(C).cuda()
+T = p.forward(Cd, want_w=False); Q = p.forward_quant(Cd, 0.01)
+torch.save((T.cpu(), Q.cpu()), sys.argv[1])
+'''
+    outs = []
+    for chain in ("0", "1"):
+        f = tmp_path / f"out{chain}.pt"
+        env = dict(os.environ, RAHT_CHAIN=chain)
+        r = subprocess.run([sys.executable, "-c", code % ROOT, str(f)], capture_output=True, text=True, env=env, timeout=600)
+        assert r.returncode == 0, r.stderr[-3000:]
+        import torch
+        outs.append(torch.load(f))
+    import torch
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
