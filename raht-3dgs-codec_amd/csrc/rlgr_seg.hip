@@ -15,6 +15,8 @@
 // re-adapts within a few dozen symbols; tests / DESIGN.md quote the measured size difference.
 #include "raht_common.h"
 
+#include <cstdlib>
+
 namespace raht {
 namespace rlgr_seg {
 
@@ -25,7 +27,8 @@ constexpr uint32_t L = 4, U0 = 3, D0 = 1, U1 = 2, D1 = 1;
 template <bool WRITE>
 struct DevBitWriter {
     uint32_t *out32;
-    uint32_t size = 0;       // bytes
+    uint32_t size = 0;       // bytes (keeps counting past cap: the exact length is known either way)
+    uint32_t cap = 0xffffffffu;   // bytes that may be written at out32 (a multiple of 4); past it nothing is stored
     uint64_t acc = 0;
     int nbits = 0;
 
@@ -35,7 +38,7 @@ struct DevBitWriter {
         nbits += bits;
         if (nbits >= 32) {
             nbits -= 32;
-            if (WRITE) out32[size >> 2] = __builtin_bswap32((uint32_t)(acc >> nbits));
+            if (WRITE && size + 4 <= cap) out32[size >> 2] = __builtin_bswap32((uint32_t)(acc >> nbits));
             size += 4;
         }
     }
@@ -62,7 +65,7 @@ struct DevBitWriter {
         if (nbits & 7) put(0, 8 - (nbits & 7));
         if (nbits > 0) {                                            // 1..3 whole bytes left: the last, partial word (zero filled)
             const uint32_t word = (uint32_t)(acc << (32 - nbits));
-            if (WRITE) out32[size >> 2] = __builtin_bswap32(word);
+            if (WRITE && size + 4 <= cap) out32[size >> 2] = __builtin_bswap32(word);
             size += (uint32_t)(nbits >> 3);
             nbits = 0;
         }
@@ -94,10 +97,11 @@ __device__ __forceinline__ int64_t u2s(uint64_t v) { const int64_t d = (int64_t)
 // blocks of 64 (to take the loads and stores off each other's wait counter) changed nothing for the encoder and made the
 // decoder slower (round 3): memory is not what a lane waits for.
 template <bool WRITE, bool VEC>
-__device__ __forceinline__ uint32_t encode_segment(const int32_t *__restrict__ seq, int n, int flag_signed, uint32_t *out32)
+__device__ __forceinline__ uint32_t encode_segment(const int32_t *__restrict__ seq, int n, int flag_signed, uint32_t *out32, uint32_t cap = 0xffffffffu)
 {
     DevBitWriter<WRITE> w;
     w.out32 = out32;
+    w.cap = cap;
     // 32-bit state: u = s2u(int32) < 2^32; inside a segment of n < 2^31 symbols the run counter m and the run exponent
     // k (<= log2 n + 1) stay far below 32 bits; k_RP is capped at 32 L. (The host coder carries them in 64 bits because one
     // stream may hold 2^32 symbols and more; 64-bit integer arithmetic is several instructions per operation here.)
@@ -286,6 +290,42 @@ __global__ __launch_bounds__(64) void seg_encode_kernel(const int32_t *__restric
     }
 }
 
+// ONE encoding pass: every segment into a fixed slot of `slot` bytes (what the raw integers would take, + 16) of a scratch
+// buffer, its exact length recorded; seg_compact_kernel then moves the streams to their places in the container. A segment that
+// does not fit its slot (incompressible data) raises *overflow and the caller falls back to the two exact passes.
+__global__ __launch_bounds__(64) void seg_encode_slots_kernel(const int32_t *__restrict__ Q, int64_t N, int D, int64_t chan_stride, int S, int nseg,
+                                                              int flag_signed, uint32_t *__restrict__ seg_bytes, uint8_t *__restrict__ slots, uint32_t slot,
+                                                              uint32_t *__restrict__ overflow)
+{
+    const int64_t g = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    if (g >= (int64_t)D * nseg) return;
+    const int c = (int)(g / nseg), s = (int)(g - (int64_t)c * nseg);
+    const int64_t i0 = (int64_t)s * S;
+    const int n = (int)min((int64_t)S, N - i0);
+    const int32_t *seq = Q + (int64_t)c * chan_stride + i0;
+    const bool vec = ((((uintptr_t)Q) & 15) == 0) && ((chan_stride & 3) == 0) && ((S & 3) == 0);
+    uint32_t *o = (uint32_t *)(slots + (size_t)g * slot);
+    const uint32_t nb = vec ? encode_segment<true, true>(seq, n, flag_signed, o, slot) : encode_segment<true, false>(seq, n, flag_signed, o, slot);
+    seg_bytes[g] = nb;
+    if (((nb + 3u) & ~3u) > slot) atomicOr(overflow, 1u);
+}
+
+// one wave per segment: its words from the slot to its offset in the container
+__global__ __launch_bounds__(256) void seg_compact_kernel(const uint8_t *__restrict__ slots, uint32_t slot, const uint32_t *__restrict__ seg_bytes,
+                                                          const uint32_t *__restrict__ seg_off, int64_t G, uint8_t *__restrict__ out, uint64_t cap,
+                                                          uint32_t *__restrict__ overflow)
+{
+    const int64_t g = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    if (g >= G) return;
+    const uint32_t nw = (seg_bytes[g] + 3u) >> 2;
+    const uint64_t off = seg_off[g];
+    if (off + 4ull * nw > cap) { if (lane == 0) atomicOr(overflow, 2u); return; }
+    const uint32_t *src = (const uint32_t *)(slots + (size_t)g * slot);
+    uint32_t *dst = (uint32_t *)(out + off);
+    for (uint32_t i = lane; i < nw; i += 64) dst[i] = src[i];
+}
+
 // padded size of every segment (its slot in the container): the input of the offset scan
 __global__ void seg_pad_kernel(const uint32_t *__restrict__ seg_bytes, int64_t n, uint32_t *__restrict__ padded)
 {
@@ -342,6 +382,33 @@ int raht_rlgr_seg_encode(const int32_t *Q, int64_t N, int D, int64_t chan_stride
         uint32_t *padded = tmp.as<uint32_t>(), *flags = padded + G;          // flags[0] = overflow, flags[1] = total
         RAHT_HIP_CHECK(hipMemsetAsync(flags, 0, 8, s));
         const unsigned gb = (unsigned)ceil_div(G, 64);
+        // ONE encoding pass into fixed slots + a compaction, when a scratch buffer of the raw size is to be had; the two exact
+        // passes (sizes, then streams) otherwise, and whenever a segment outgrows its slot
+        static const bool two_pass_only = getenv("RAHT_RLGR_TWO_PASS") != nullptr;      // A/B knob
+        const uint32_t slot = 4u * (uint32_t)seg_len + 16u;
+        if (!two_pass_only && (uint64_t)G * slot < ((uint64_t)1 << 33)) {
+            Scratch slots((size_t)G * slot, s);
+            if (slots.ok()) {
+                hipLaunchKernelGGL(rlgr_seg::seg_encode_slots_kernel, dim3(gb), dim3(64), 0, s, Q, N, D, chan_stride, seg_len, (int)nseg, flag_signed,
+                                   seg_bytes, slots.as<uint8_t>(), slot, flags);
+                hipLaunchKernelGGL(rlgr_seg::seg_pad_kernel, dim3((unsigned)ceil_div(G, 256)), dim3(256), 0, s, seg_bytes, G, padded);
+                RAHT_RET(exclusive_scan_u32(padded, seg_off, G, flags + 1, s));
+                RAHT_HIP_CHECK(hipMemcpyAsync(seg_off + G, flags + 1, 4, hipMemcpyDeviceToDevice, s));
+                hipLaunchKernelGGL(rlgr_seg::seg_compact_kernel, dim3((unsigned)ceil_div(G * 64, 256)), dim3(256), 0, s, slots.as<uint8_t>(), slot, seg_bytes,
+                                   seg_off, G, out, (uint64_t)cap, flags);
+                RAHT_HIP_CHECK(hipGetLastError());
+                uint32_t back[2] = {0, 0};
+                RAHT_RET(read_back_u32(back, flags, 2, nullptr, nullptr, 0, s));    // (synchronises: the scratch may go back to the pool)
+                if (!(back[0] & 1u)) {
+                    *total_bytes = (int64_t)back[1];
+                    if ((back[0] & 2u) || (int64_t)back[1] > cap) { set_error("raht_rlgr_seg_encode: %u bytes needed, cap = %lld", back[1], (long long)cap); return RAHT_ERR_NOMEM; }
+                    return RAHT_OK;
+                }
+                RAHT_HIP_CHECK(hipMemsetAsync(flags, 0, 8, s));                       // a segment outgrew its slot: the exact passes
+            } else {
+                (void)hipGetLastError();
+            }
+        }
         hipLaunchKernelGGL(rlgr_seg::seg_encode_kernel<false>, dim3(gb), dim3(64), 0, s, Q, N, D, chan_stride, seg_len, (int)nseg, flag_signed,
                            seg_bytes, (const uint32_t *)nullptr, (uint8_t *)nullptr, (uint64_t)0, flags);
         hipLaunchKernelGGL(rlgr_seg::seg_pad_kernel, dim3((unsigned)ceil_div(G, 256)), dim3(256), 0, s, seg_bytes, G, padded);

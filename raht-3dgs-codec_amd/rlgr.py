@@ -240,7 +240,15 @@ class SegmentedCoder:
         m = len(cls.MAGIC)
         if blob[:m] != cls.MAGIC:
             raise ValueError("not a segmented RLGR container")
+        if len(blob) < m + 40:
+            raise ValueError("segmented RLGR container: truncated header")
         N, D, S, flag, total = [int(x) for x in np.frombuffer(blob, np.int64, 5, m)]
+        # the header comes off the wire: sizes are checked against the blob BEFORE anything is allocated from them
+        if not (1 <= N < 2 ** 31 and 1 <= D <= 65536 and 64 <= S < 2 ** 31 and flag in (0, 1) and 0 <= total <= len(blob)):
+            raise ValueError("segmented RLGR container: implausible header")
+        G = ((N + S - 1) // S) * D
+        if len(blob) < m + 40 + 4 * G + total:
+            raise ValueError("segmented RLGR container: shorter than its header says")
         sc = cls(N, D, S, flag, device)
         lens = np.frombuffer(blob, np.uint32, sc.G, m + 40).astype(np.int64)
         if total % 4 or total > len(blob) - (m + 40 + 4 * sc.G) or int(((lens + 3) // 4 * 4).sum()) != total:

@@ -47,9 +47,13 @@ def test_every_segment_is_the_host_coders_stream(seg_len):
     back = sc.decode()
     assert torch.equal(back, Qd) and int(sc.bad.item()) == 0
     # ... and of a container that went over the wire
-    sc2 = rlgr.SegmentedCoder.from_container(sc.container())
+    blob = sc.container()
+    sc2 = rlgr.SegmentedCoder.from_container(blob)
     assert torch.equal(sc2.decode(), Qd)
-    assert sc.size_bytes == len(sc.container())
+    assert sc.size_bytes == len(blob)
+    for bad in (blob[:30], blob[:-5], b"XXXXXXXX" + blob[8:], blob[:8] + np.array([-3, D, seg_len, 1, 0], np.int64).tobytes() + blob[48:]):
+        with pytest.raises(ValueError):
+            rlgr.SegmentedCoder.from_container(bad)
     # host decoder on GPU-made segments (any RLGR decoder reads a segment)
     for c, s in ((0, 0), (4, sc.nseg - 1), (6, sc.nseg // 2)):
         n = min(seg_len, N - s * seg_len)
