@@ -104,6 +104,13 @@ int raht_cpu_plan_create_from_keys(const uint64_t *keys_sorted, int64_t N, int n
     return rc;
 }
 
+/* raht_plan_create_from_keys_borrowed: the twin has nothing to borrow (it turns the keys into coordinates at once) */
+int raht_cpu_plan_create_from_keys_borrowed(const uint64_t *keys_sorted, int64_t N, int nbits,
+                                            const int64_t *leaf_weights, raht_stream_t stream, raht_cpu_plan **out)
+{
+    return raht_cpu_plan_create_from_keys(keys_sorted, N, nbits, leaf_weights, stream, out);
+}
+
 int raht_cpu_plan_destroy(raht_cpu_plan *plan)
 {
     if (plan) { orc_param_free(plan->p); free(plan); }
@@ -370,5 +377,38 @@ int raht_cpu_sort_keys(const uint64_t *keys_in, int64_t N, int nbits, uint64_t *
     qsort(t, (size_t)N, sizeof(ki_t), ki_cmp);
     for (int64_t i = 0; i < N; ++i) { keys_out[i] = keys_in[t[i].i]; if (idx_out) idx_out[i] = t[i].i; }
     free(t);
+    return RAHT_OK;
+}
+
+/* raht_*_batch: scene by scene (the product runs stage k of all scenes in one launch; the results are the same) */
+int raht_cpu_fwd_batch(int n, raht_cpu_plan *const *plans, const float *const *C, const int64_t *ldc, int D,
+                       float *const *T, const int64_t *ldt, raht_stream_t stream)
+{
+    if (n < 1 || !plans || !C || !ldc || !T || !ldt) { set_err("raht_cpu_fwd_batch: bad argument"); return RAHT_ERR_INVALID; }
+    for (int i = 0; i < n; ++i) { const int rc = raht_cpu_fwd(plans[i], C[i], ldc[i], D, T[i], ldt[i], NULL, stream); if (rc != RAHT_OK) return rc; }
+    return RAHT_OK;
+}
+
+int raht_cpu_inv_batch(int n, raht_cpu_plan *const *plans, const float *const *T, const int64_t *ldt, int D,
+                       float *const *C, const int64_t *ldc, raht_stream_t stream)
+{
+    if (n < 1 || !plans || !C || !ldc || !T || !ldt) { set_err("raht_cpu_inv_batch: bad argument"); return RAHT_ERR_INVALID; }
+    for (int i = 0; i < n; ++i) { const int rc = raht_cpu_inv(plans[i], T[i], ldt[i], D, C[i], ldc[i], stream); if (rc != RAHT_OK) return rc; }
+    return RAHT_OK;
+}
+
+int raht_cpu_fwd_quant_batch(int n, raht_cpu_plan *const *plans, const float *const *C, const int64_t *ldc, int D,
+                             const float *steps, int n_steps, int32_t *const *Q, const int64_t *ldq, raht_stream_t stream)
+{
+    if (n < 1 || !plans || !C || !ldc || !Q || !ldq) { set_err("raht_cpu_fwd_quant_batch: bad argument"); return RAHT_ERR_INVALID; }
+    for (int i = 0; i < n; ++i) { const int rc = raht_cpu_fwd_quant(plans[i], C[i], ldc[i], D, steps, n_steps, Q[i], ldq[i], stream); if (rc != RAHT_OK) return rc; }
+    return RAHT_OK;
+}
+
+int raht_cpu_dequant_inv_batch(int n, raht_cpu_plan *const *plans, const int32_t *const *Q, const int64_t *ldq, int D,
+                               const float *steps, int n_steps, float *const *C, const int64_t *ldc, raht_stream_t stream)
+{
+    if (n < 1 || !plans || !C || !ldc || !Q || !ldq) { set_err("raht_cpu_dequant_inv_batch: bad argument"); return RAHT_ERR_INVALID; }
+    for (int i = 0; i < n; ++i) { const int rc = raht_cpu_dequant_inv(plans[i], Q[i], ldq[i], D, steps, n_steps, C[i], ldc[i], stream); if (rc != RAHT_OK) return rc; }
     return RAHT_OK;
 }

@@ -28,6 +28,8 @@ int raht_cpu_plan_create(const void *V, int v_dtype, int64_t N, const double min
                      int depth, raht_stream_t stream, raht_cpu_plan **out);
 int raht_cpu_plan_create_from_keys(const uint64_t *keys_sorted, int64_t N, int nbits,
                                const int64_t *leaf_weights, raht_stream_t stream, raht_cpu_plan **out);
+int raht_cpu_plan_create_from_keys_borrowed(const uint64_t *keys_sorted, int64_t N, int nbits,
+                                        const int64_t *leaf_weights, raht_stream_t stream, raht_cpu_plan **out);
 int raht_cpu_plan_destroy(raht_cpu_plan *plan);
 int64_t raht_cpu_plan_size(const raht_cpu_plan *plan);          /* N */
 int raht_cpu_plan_nbits(const raht_cpu_plan *plan);             /* 3 * depth */
@@ -52,6 +54,14 @@ int raht_cpu_fwd_quant_f64(const raht_cpu_plan *plan, const double *C, int64_t l
                        int n_steps, int32_t *Q, int64_t ldq, raht_stream_t stream);
 int raht_cpu_dequant_inv_f64(const raht_cpu_plan *plan, const int32_t *Q, int64_t ldq, int D, const double *steps,
                          int n_steps, double *C, int64_t ldc, raht_stream_t stream);
+int raht_cpu_fwd_batch(int n, raht_cpu_plan *const *plans, const float *const *C, const int64_t *ldc, int D,
+                   float *const *T, const int64_t *ldt, raht_stream_t stream);
+int raht_cpu_inv_batch(int n, raht_cpu_plan *const *plans, const float *const *T, const int64_t *ldt, int D,
+                   float *const *C, const int64_t *ldc, raht_stream_t stream);
+int raht_cpu_fwd_quant_batch(int n, raht_cpu_plan *const *plans, const float *const *C, const int64_t *ldc, int D,
+                         const float *steps, int n_steps, int32_t *const *Q, const int64_t *ldq, raht_stream_t stream);
+int raht_cpu_dequant_inv_batch(int n, raht_cpu_plan *const *plans, const int32_t *const *Q, const int64_t *ldq, int D,
+                           const float *steps, int n_steps, float *const *C, const int64_t *ldc, raht_stream_t stream);
 int raht_cpu_quant_reorder(const raht_cpu_plan *plan, const float *T, int64_t ldt, int D, const float *steps,
                        int n_steps, int32_t *Q, int64_t ldq, raht_stream_t stream);
 int raht_cpu_dequant_unreorder(const raht_cpu_plan *plan, const int32_t *Q, int64_t ldq, int D,

@@ -47,7 +47,8 @@ def test_twin_prototypes_equal_the_product_prototypes(twins):
     # the path's core entry points all have a twin
     for core in ("raht_plan_create", "raht_plan_create_from_keys", "raht_plan_destroy", "raht_plan_levels", "raht_plan_export_level",
                  "raht_plan_order", "raht_fwd", "raht_fwd_f64", "raht_inv", "raht_inv_f64", "raht_fwd_quant", "raht_dequant_inv",
-                 "raht_quant_reorder", "raht_dequant_unreorder", "raht_voxelize", "raht_morton", "raht_sort_keys"):
+                 "raht_quant_reorder", "raht_dequant_unreorder", "raht_voxelize", "raht_morton", "raht_sort_keys",
+                 "raht_plan_create_from_keys_borrowed", "raht_fwd_batch", "raht_inv_batch", "raht_fwd_quant_batch", "raht_dequant_inv_batch"):
         assert core.replace("raht_", "raht_cpu_", 1) in twin, core
 
 
@@ -208,3 +209,41 @@ def test_same_call_sequence_through_both_libraries(twins):
         assert np.all(np.abs(dev["Q64"].astype(np.int64) - host["Q64"])[bad] == 1)
         assert np.all(np.abs(q - np.round(q)) <= 1e-9 * np.maximum(1.0, np.abs(q)))
     assert np.all(np.abs(dev["C_back"] - host["C_back"]).max(axis=0) <= 1e-10 * np.maximum(np.abs(Cm).max(axis=0), 1.0))
+
+
+def test_batch_twins_equal_scene_by_scene_calls(twins):
+    """raht_cpu_*_batch (the twins of the multi-scene entry points): n scenes through one call == one call per scene, and the
+    borrowed-keys constructor builds the same plan."""
+    rng = np.random.default_rng(8)
+    D, n = 5, 3
+    plans, Cs, keys_all = [], [], []
+    for i in range(n):
+        N = 500 + 130 * i
+        keys = np.sort(rng.choice(1 << 15, size=N, replace=False)).astype(np.uint64)
+        h = C.c_void_p()
+        f = twins.raht_cpu_plan_create_from_keys_borrowed if i == 1 else twins.raht_cpu_plan_create_from_keys
+        assert f(_vp(keys), C.c_int64(N), 15, None, None, C.byref(h)) == 0, twins.raht_cpu_last_error()
+        plans.append(h); keys_all.append(keys)
+        Cs.append(rng.standard_normal((N, D)).astype(np.float32))
+    step = (C.c_float * 1)(0.05)
+    vp = C.c_void_p
+    hp = (vp * n)(*[p.value for p in plans])
+    cp = (vp * n)(*[c.ctypes.data for c in Cs])
+    ld = (C.c_int64 * n)(*[D] * n)
+    Qb = [np.zeros((c.shape[0], D), np.int32) for c in Cs]
+    Tb = [np.zeros_like(c) for c in Cs]
+    qp = (vp * n)(*[q.ctypes.data for q in Qb])
+    tp = (vp * n)(*[t.ctypes.data for t in Tb])
+    assert twins.raht_cpu_fwd_quant_batch(n, hp, cp, ld, D, step, 1, qp, ld, None) == 0, twins.raht_cpu_last_error()
+    assert twins.raht_cpu_fwd_batch(n, hp, cp, ld, D, tp, ld, None) == 0
+    Rb = [np.zeros_like(c) for c in Cs]
+    rp = (vp * n)(*[r.ctypes.data for r in Rb])
+    assert twins.raht_cpu_dequant_inv_batch(n, hp, qp, ld, D, step, 1, rp, ld, None) == 0
+    for i in range(n):
+        Q1 = np.zeros_like(Qb[i]); T1 = np.zeros_like(Tb[i]); R1 = np.zeros_like(Rb[i])
+        assert twins.raht_cpu_fwd_quant(plans[i], _vp(Cs[i]), C.c_int64(D), D, step, 1, _vp(Q1), C.c_int64(D), None) == 0
+        assert twins.raht_cpu_fwd(plans[i], _vp(Cs[i]), C.c_int64(D), D, _vp(T1), C.c_int64(D), None, None) == 0
+        assert twins.raht_cpu_dequant_inv(plans[i], _vp(Q1), C.c_int64(D), D, step, 1, _vp(R1), C.c_int64(D), None) == 0
+        assert np.array_equal(Q1, Qb[i]) and np.array_equal(T1, Tb[i]) and np.array_equal(R1, Rb[i])
+        twins.raht_cpu_plan_destroy(plans[i])
+    assert twins.raht_cpu_fwd_batch(0, hp, cp, ld, D, tp, ld, None) != 0
