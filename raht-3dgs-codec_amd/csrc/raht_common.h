@@ -135,6 +135,15 @@ int exclusive_scan_u32(const uint32_t *in, uint32_t *out, int64_t n, uint32_t *t
 // (vals_in == NULL means payload = original index).
 int radix_pass_u64(const uint64_t *keys_in, const uint32_t *vals_in, uint64_t *keys_out,
                    uint32_t *vals_out, int64_t n, int shift, int bits, hipStream_t s);
+// The whole stable sort of (key, original index) by the low nbits key bits in npass + 2 launches: one histogram launch for
+// every digit, one for the digit bases, one launch per digit pass whose tiles chain their offsets by decoupled look-back
+// (scan_sort.hip). tmp_keys / tmp_idx: N-sized ping-pong buffers. err_dev: device word, zeroed by the first launch and set
+// when a tile gave up waiting for its predecessors (bounded waits: the grid always drains) -- the caller reads it back
+// once the stream has drained and falls back to the pass-by-pass sort. Returns 1 (nothing enqueued) when the input does
+// not fit (more than 8 digit passes, N >= 2^30) or RAHT_SORT_ONESWEEP=0. idx64_out (may be NULL): the indices once more as
+// int64, written by the last pass.
+int sort_pairs_onesweep(const uint64_t *keys_in, int64_t n, int nbits, uint64_t *keys_out, uint32_t *idx_out, uint64_t *tmp_keys,
+                        uint32_t *tmp_idx, uint32_t *err_dev, hipStream_t s, int64_t *idx64_out = nullptr);
 // Same for uint8 bucket ids (< 2^bits); produces the stable permutation and, optionally, the
 // start offset of every bucket (bucket_off: device uint32[(1<<bits)+1]).
 int bucket_sort_u8(const uint8_t *bucket, uint32_t *perm_out, int64_t n, int bits,

@@ -490,6 +490,424 @@ int bucket_sort_u8(const uint8_t *bucket, uint32_t *perm_out, int64_t n, int bit
 }
 
 // ------------------------------------------------------------------------------------------------
+// Whole key sort in npass + 2 launches (round 3): ONE histogram launch for the digits of every pass, one launch
+// that reduces its per-block counts, then ONE launch per digit pass whose tiles find their per-digit offsets among
+// themselves instead of through a per-tile histogram, two scan launches and a scatter launch per pass. On 3 M keys a
+// pass of the four-launch form takes ~50 us for 72 MB of traffic -- launch gaps and three extra dependent kernels,
+// not bytes.
+//
+// A tile = OS_TILE consecutive items, one workgroup of four waves; with 16 items per lane a tile takes 42 of the CU's
+// 128 LDS granules, so 768 tiles are resident at once and the 733 tiles of a 3 M-key pass all start together. Tile t
+// is workgroup t (RAHT_SORT_TICKET=1: the t-th workgroup to take a ticket -- see "order" below). Per digit d (thread d)
+// the tile publishes ONE word, state[t][d] = OS_PART | its count, as soon as its histogram is known. Tiles form groups
+// of 32: thread d adds the published counts of the tiles before its own in its group (31 loads in flight at once);
+// the LAST tile of a group then knows the group's total and publishes gstate[g][d] = OS_PART | total, and everybody
+// walks back over the groups before its own, OS_WIN words per round trip, until a word marked OS_INCL (a group's
+// last tile upgrades its word to the inclusive prefix once it knows it; group 0's is inclusive from the start).
+// A plain chain of tiles (the textbook decoupled look-back) costs O(sqrt(tiles)) dependent round trips when all tiles
+// start in the same microsecond; this form costs two or three whatever the tile count, and the loads of the first
+// step are issued BEFORE the ranking phase and the group total leaves in the MIDDLE of it, so that most of the
+// waiting hides behind the ranks (a round trip of these cache-bypassing loads is ~2 us).
+// Flag and value share a word, so relaxed agent-scope atomics are all the ordering needed (they bypass the per-XCD
+// L2s; everything else is ordinary kernel-boundary visibility).
+// Order: a tile only ever waits for tiles with a smaller number. Workgroups are dispatched in index order (round-robin
+// over the XCDs, in order inside each), so the lowest-numbered unfinished tile is always resident and the waits cannot
+// cycle. The library does not stake a GPU on that: every wait is bounded by the 100 MHz wall clock (OS_WAIT_TICKS);
+// a tile that gives up publishes OS_ERR, which later tiles pass on -- they write nothing, the grid drains, the host
+// finds the error word set and repeats the sort pass by pass. RAHT_SORT_TICKET=1 numbers the tiles by an atomic
+// ticket instead (provably free of cycles whatever the dispatch order; 733 atomics on one word: +4 us per pass).
+// Ranks inside a tile are assigned in (wave, round, lane) = memory order, tiles are numbered in memory order: stable.
+// ------------------------------------------------------------------------------------------------
+constexpr int OS_THREADS = 256;
+constexpr int OS_WAVES = 4;
+constexpr int OS_MAX_PASSES = 8;
+constexpr uint32_t OS_PART = 1u << 30, OS_INCL = 2u << 30, OS_ERR = 3u << 30, OS_VALUE = (1u << 30) - 1u;
+constexpr int OS_WIN = 16;                             // group words fetched per round trip of the walk over the groups
+constexpr uint32_t OS_GROUP_LG = 5, OS_GROUP = 1u << OS_GROUP_LG;   // tiles per group
+constexpr uint64_t OS_WAIT_TICKS = 20000000ull;        // 0.2 s of the 100 MHz wall clock
+constexpr int OS_SLICES = 16;                          // the histogram blocks are reduced in this many slices per pass
+constexpr int OS_HIST_BLOCKS = 512;
+
+struct OsPasses {
+    int npass;
+    int shift[OS_MAX_PASSES];
+    int bits[OS_MAX_PASSES];
+};
+
+// The digit of a 64-bit key at a (uniform) shift without a 64-bit shift: a 32-bit window of the key.
+__device__ __forceinline__ uint32_t os_digit(uint64_t k, int shift, uint32_t mask)
+{
+    const uint32_t lo = (uint32_t)k, hi = (uint32_t)(k >> 32);
+    const uint32_t w = shift >= 32 ? (hi >> (shift - 32)) : __builtin_amdgcn_alignbit(hi, lo, (uint32_t)shift);
+    return w & mask;
+}
+
+// partial[b][p * 256 + d] = number of keys of block b whose digit of pass p is d. The same launch zeroes the
+// look-back words of the passes that follow, and the sort's error word.
+__global__ __launch_bounds__(OS_THREADS) void os_hist_kernel(const uint64_t *__restrict__ keys, int64_t n, OsPasses P,
+                                                             uint32_t *__restrict__ partial, uint32_t *__restrict__ zero_words,
+                                                             int64_t n_zero, uint32_t *__restrict__ err)
+{
+    if (blockIdx.x == 0 && threadIdx.x == 0) *err = 0u;
+    __shared__ uint32_t h[OS_MAX_PASSES * 256];
+    for (int k = threadIdx.x; k < P.npass * 256; k += OS_THREADS) h[k] = 0;
+    __syncthreads();
+    const int64_t stride = (int64_t)gridDim.x * OS_THREADS;
+    // eight independent loads in flight per thread (one at a time, the loop is a chain of HBM round trips: 17 us for 24 MB)
+    for (int64_t i0 = (int64_t)blockIdx.x * OS_THREADS + threadIdx.x; i0 < n; i0 += 8 * stride) {
+        uint64_t k[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) k[u] = keys[min(i0 + u * stride, n - 1)];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            if (i0 + u * stride >= n) continue;
+#pragma unroll
+            for (int p = 0; p < OS_MAX_PASSES; ++p)
+                if (p < P.npass) atomicAdd(&h[p * 256 + os_digit(k[u], P.shift[p], (1u << P.bits[p]) - 1u)], 1u);
+        }
+    }
+    for (int64_t i = (int64_t)blockIdx.x * OS_THREADS + threadIdx.x; i < n_zero; i += stride) zero_words[i] = 0u;
+    __syncthreads();
+    for (int k = threadIdx.x; k < P.npass * 256; k += OS_THREADS) partial[(size_t)blockIdx.x * (P.npass * 256) + k] = h[k];
+}
+
+// slices[p][q][d] = keys whose digit of pass p is d, counted over the q-th slice of the histogram blocks (a chain of
+// dependent strided loads is what this launch costs: many short chains; the pass tiles add the OS_SLICES words up).
+__global__ __launch_bounds__(OS_THREADS) void os_base_kernel(const uint32_t *__restrict__ partial, int nblocks, int npass,
+                                                             uint32_t *__restrict__ slices)
+{
+    const int p = blockIdx.x / OS_SLICES, q = blockIdx.x % OS_SLICES, d = threadIdx.x;
+    const uint32_t *src = partial + p * 256 + d;
+    const size_t row = (size_t)npass * 256;
+    const int per = (nblocks + OS_SLICES - 1) / OS_SLICES, b0 = q * per, b1 = min(nblocks, b0 + per);
+    uint32_t acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int b = b0;
+    for (; b + 8 <= b1; b += 8)
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc[u] += src[(size_t)(b + u) * row];
+    for (; b < b1; ++b) acc[0] += src[(size_t)b * row];
+    slices[((size_t)p * OS_SLICES + q) * 256 + d] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+}
+
+__device__ __forceinline__ uint32_t os_load(const uint32_t *p)
+{
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void os_store(uint32_t *p, uint32_t v)
+{
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// x = a look-back word as first loaded; polls until it carries a flag (bounded).
+__device__ __forceinline__ uint32_t os_wait(const uint32_t *p, uint32_t x, bool &bad)
+{
+    if ((x >> 30) == 0) {
+        const uint64_t t0 = wall_clock64();
+        do {
+            __builtin_amdgcn_s_sleep(1);
+            x = os_load(p);
+        } while ((x >> 30) == 0 && wall_clock64() - t0 < OS_WAIT_TICKS);
+        if ((x >> 30) == 0) bad = true;
+    }
+    if ((x >> 30) == 3u) bad = true;
+    return x;
+}
+
+// Block-wide exclusive scans of TWO values per thread at once (256 threads).
+__device__ __forceinline__ void block_excl_scan2_256(uint32_t a, uint32_t b, uint32_t *ea, uint32_t *eb)
+{
+    __shared__ uint32_t wsa[4], wsb[4];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const uint32_t ia = wave_incl_scan(a), ib = wave_incl_scan(b);
+    if (lane == 63) { wsa[wid] = ia; wsb[wid] = ib; }
+    __syncthreads();
+    uint32_t ba = 0, bb = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        if (w < wid) { ba += wsa[w]; bb += wsb[w]; }
+    }
+    __syncthreads();
+    *ea = ba + ia - a;
+    *eb = bb + ib - b;
+}
+
+// Lanes of `valid` that hold the same digit as this lane. Per bit: bal = lanes with the bit set; the lanes that DIFFER from
+// this one in that bit are bal ^ t with t = all ones when this lane's bit is clear... (sign-extended bit: 0 or -1, inverted
+// sense folded into the final complement): the differences of all bits are OR-ed (two bits per v_or3) and complemented once.
+__device__ __forceinline__ uint64_t os_match(uint32_t digit, int bits, uint64_t valid)
+{
+    uint32_t lo = 0, hi = 0;
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+        if (b < bits) {                                 // (uniform)
+            const int32_t t = ((int32_t)(digit << (31 - b))) >> 31;          // -1: bit set
+            const uint64_t bal = __ballot(t != 0);
+            lo |= (uint32_t)bal ^ (uint32_t)t;                               // set bit: differs from the lanes NOT in bal = ~bal = bal ^ -1
+            hi |= (uint32_t)(bal >> 32) ^ (uint32_t)t;
+        }
+    }
+    return ~(((uint64_t)hi << 32) | lo) & valid;
+}
+
+#ifdef RAHT_OS_CLOCKS
+// profiling build only (make EXTRA=-DRAHT_OS_CLOCKS): 100 MHz wall-clock stamps at the phase boundaries of every tile of the
+// pass whose shift is os_dbg_shift (tools/sort_phase_clocks.py)
+__device__ unsigned long long os_dbg[8192 * 8];
+__device__ int os_dbg_shift = 8;
+#define OS_STAMP(k) do { if (threadIdx.x == 0 && shift == os_dbg_shift && tile < 8192) os_dbg[tile * 8 + (k)] = wall_clock64(); } while (0)
+#else
+#define OS_STAMP(k) do { } while (0)
+#endif
+
+template <int ROUNDS, bool HAS_VALS_IN, bool TICKET>
+__global__ __launch_bounds__(OS_THREADS) void os_pass_kernel(const uint64_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in,
+                                                             uint64_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out, int64_t n,
+                                                             int shift, int bits, const uint32_t *__restrict__ slices,
+                                                             uint32_t *__restrict__ state, uint32_t *__restrict__ gstate,
+                                                             uint32_t *__restrict__ ticket, uint32_t *__restrict__ err,
+                                                             int64_t *__restrict__ vals64_out /* last pass: the payload widened, or NULL */)
+{
+    constexpr int WAVE_ITEMS = 64 * ROUNDS, TILE = OS_WAVES * WAVE_ITEMS;
+    // 53 272 bytes with 16 rounds = 42 of the CU's 128 LDS granules: three tiles per CU, 768 on the chip (the 733 tiles of a
+    // 3 M-key pass are all resident at once; one granule more and a third of them would wait for a second round)
+    __shared__ uint32_t wcnt[OS_WAVES][256];
+    uint32_t *gdelta = wcnt[0];                        // global position - tile-local slot, per digit (once the ranks are out)
+    __shared__ uint64_t skey[TILE];
+    __shared__ uint32_t sval[TILE];
+    __shared__ uint32_t s_tile, s_bad;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const uint32_t mask = (1u << bits) - 1u;
+    for (int k = threadIdx.x; k < OS_WAVES * 256; k += OS_THREADS) (&wcnt[0][0])[k] = 0;
+    if (threadIdx.x == 0) { s_tile = TICKET ? atomicAdd(ticket, 1u) : blockIdx.x; s_bad = 0; }
+    __syncthreads();
+    const uint32_t tile = TICKET ? s_tile : blockIdx.x;
+    OS_STAMP(0);
+    const int64_t bbase = (int64_t)tile * TILE;
+    if (bbase >= n) return;                            // (cannot happen: the grid is exactly the tile count)
+    const int64_t wbase = bbase + (int64_t)wid * WAVE_ITEMS;
+    const int nblk = (int)min((int64_t)TILE, n - bbase);
+    uint64_t key[ROUNDS];
+    uint32_t val[ROUNDS], dig[ROUNDS];
+    // phase 1: per-wave digit histogram (keys, payloads and digits stay in registers)
+#pragma unroll
+    for (int r = 0; r < ROUNDS; ++r) {
+        const int64_t i = wbase + r * 64 + lane;
+        key[r] = (i < n) ? keys_in[i] : 0ull;
+        val[r] = HAS_VALS_IN ? ((i < n) ? vals_in[i] : 0u) : (uint32_t)i;
+    }
+#pragma unroll
+    for (int r = 0; r < ROUNDS; ++r) {
+        const int64_t i = wbase + r * 64 + lane;
+        dig[r] = os_digit(key[r], shift, mask);
+        if (i < n) atomicAdd(&wcnt[wid][dig[r]], 1u);
+    }
+    __syncthreads();
+    OS_STAMP(1);
+    // phase 2: publish this tile's count of digit d; counts -> tile-local start slots (digit-major, then wave); digit bases
+    const uint32_t d = threadIdx.x;
+    uint32_t *mine = state + (size_t)tile * 256 + d;
+    const uint32_t g = tile >> OS_GROUP_LG, j = tile & (OS_GROUP - 1u);
+    const uint32_t *row0 = state + (size_t)(g << OS_GROUP_LG) * 256 + d;
+    uint32_t tot = 0, lbase, dbase;
+    uint32_t pv[OS_GROUP - 1];                          // the words of the tiles before this one in its group
+    {
+        uint32_t c[OS_WAVES];
+#pragma unroll
+        for (int w = 0; w < OS_WAVES; ++w) { c[w] = wcnt[w][d]; tot += c[w]; }
+        os_store(mine, OS_PART | tot);
+        uint32_t dtot = 0;
+#pragma unroll
+        for (int q = 0; q < OS_SLICES; ++q) dtot += slices[q * 256 + d];
+        uint32_t run;
+        block_excl_scan2_256(tot, dtot, &run, &dbase);  // (contains the barriers that order the reads above)
+        lbase = run;
+#pragma unroll
+        for (int w = 0; w < OS_WAVES; ++w) { wcnt[w][d] = run; run += c[w]; }
+        // in flight across the first half of the ranks (the neighbours published a moment ago, or will in a moment)
+        if (j > 0) {
+#pragma unroll
+            for (uint32_t u = 0; u < OS_GROUP - 1; ++u) pv[u] = os_load(row0 + (size_t)min(u, j - 1u) * 256);
+        }
+    }
+    __syncthreads();
+    OS_STAMP(2);
+    // phase 3: rank inside the round by ballots, bump the wave's running slot, place into LDS. Within a wave LDS operations
+    // execute in order: the slot counter a round's first lane of a digit writes is what the next round reads.
+    const uint64_t lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    auto rank_round = [&](int r) {
+        const int64_t i = wbase + r * 64 + lane;
+        const bool valid = i < n;
+        const uint64_t vmask = __ballot(valid);
+        if (vmask != 0) {                                // wave-uniform
+            const uint32_t dg = dig[r];
+            const uint64_t same = os_match(dg, bits, vmask);
+            const uint32_t rank = (uint32_t)__popcll(same & lt);
+            uint32_t slot = 0;
+            if (valid) slot = __hip_atomic_load(&wcnt[wid][dg], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT) + rank;
+            __builtin_amdgcn_wave_barrier();
+            if (valid && rank == 0) __hip_atomic_store(&wcnt[wid][dg], slot + (uint32_t)__popcll(same), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            __builtin_amdgcn_wave_barrier();
+            if (valid) { skey[slot] = key[r]; sval[slot] = val[r]; }
+        }
+    };
+#pragma unroll
+    for (int r = 0; r < ROUNDS / 2; ++r) rank_round(r);
+    OS_STAMP(3);
+    // phase 4a: keys of digit d in the tiles before this one in its group; the group's last tile publishes the group's total
+    bool bad = false;
+    uint32_t sum_in = 0;
+    const bool leader = (j == OS_GROUP - 1u);
+    uint32_t *gmine = gstate + (size_t)g * 256 + d;
+    if (j > 0) {
+#pragma unroll
+        for (uint32_t u = 0; u < OS_GROUP - 1; ++u) {
+            if (u >= j) continue;                                           // (j is uniform over the workgroup)
+            sum_in += os_wait(row0 + (size_t)u * 256, pv[u], bad) & OS_VALUE;
+        }
+    }
+    if (leader) os_store(gmine, bad ? OS_ERR : ((g == 0 ? OS_INCL : OS_PART) | ((sum_in + tot) & OS_VALUE)));
+    OS_STAMP(4);
+#pragma unroll
+    for (int r = ROUNDS / 2; r < ROUNDS; ++r) rank_round(r);
+    OS_STAMP(5);
+    // phase 4b: ... and in the groups before it
+    uint32_t gs = 0;
+    if (g > 0) {
+        int64_t b = (int64_t)g - 1;
+        for (bool done = false; !done && !bad && b >= 0;) {
+            uint32_t v[OS_WIN];
+#pragma unroll
+            for (int u = 0; u < OS_WIN; ++u) v[u] = os_load(gstate + (size_t)max(b - u, (int64_t)0) * 256 + d);
+#pragma unroll
+            for (int u = 0; u < OS_WIN; ++u) {
+                if (done || bad || b - u < 0) continue;
+                const uint32_t x = os_wait(gstate + (size_t)(b - u) * 256 + d, v[u], bad);
+                if (bad) break;
+                gs += x & OS_VALUE;
+                if ((x >> 30) == 2u) done = true;
+            }
+            b -= OS_WIN;                                                    // (group 0 publishes OS_INCL: the walk ends there)
+        }
+        if (leader) os_store(gmine, bad ? OS_ERR : (OS_INCL | ((gs + sum_in + tot) & OS_VALUE)));
+    }
+    if (bad) { s_bad = 1; atomicOr(err, 1u); }
+    __syncthreads();                                   // every wave is done with its slot counters: wcnt[0] becomes gdelta
+    gdelta[d] = dbase + gs + sum_in - lbase;
+    __syncthreads();
+    OS_STAMP(6);
+    if (s_bad) return;
+    // phase 5: slots in order -> global memory; consecutive slots of one digit are consecutive there
+    for (int q = threadIdx.x; q < nblk; q += OS_THREADS) {
+        const uint64_t k = skey[q];
+        const uint32_t pos = (uint32_t)q + gdelta[os_digit(k, shift, mask)];
+        if ((int64_t)pos < n) {
+            const uint32_t v = sval[q];
+            keys_out[pos] = k;
+            vals_out[pos] = v;
+            if (vals64_out) vals64_out[pos] = (int64_t)v;
+        }
+    }
+    OS_STAMP(7);
+}
+
+// Items per lane of a tile: the smallest tile whose tile count still fits the chip at once (2048 items: five tiles per CU,
+// 3072 / 4096: three) -- more, smaller tiles overlap their phases better, but a tile that has to wait for a second round of
+// workgroups costs a whole tile lifetime. RAHT_SORT_ROUNDS = 8 / 12 / 16 pins it.
+static int os_rounds(int64_t n)
+{
+    static int forced = -1;
+    if (forced < 0) {
+        const char *e = getenv("RAHT_SORT_ROUNDS");
+        forced = e ? atoi(e) : 0;
+        if (forced != 8 && forced != 12 && forced != 16) forced = 0;
+    }
+    if (forced) return forced;
+    static int cus[RAHT_MAX_DEVICES] = {};
+    const int dev = current_device();
+    if (!cus[dev]) {
+        int v = 0;
+        cus[dev] = (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ? v : 256;
+    }
+    if (ceil_div(n, 2048) <= (int64_t)5 * cus[dev]) return 8;
+    if (ceil_div(n, 3072) <= (int64_t)3 * cus[dev]) return 12;
+    return 16;
+}
+
+static bool sort_onesweep_enabled()
+{
+    static int on = -1;
+    if (on < 0) { const char *e = getenv("RAHT_SORT_ONESWEEP"); on = (e && e[0] == '0') ? 0 : 1; }
+    return on != 0;
+}
+
+template <int ROUNDS>
+static void os_launch_pass(const uint64_t *kin, const uint32_t *vin, uint64_t *kout, uint32_t *vout, int64_t n, int shift, int bits,
+                           const uint32_t *slices, uint32_t *state, uint32_t *gstate, uint32_t *ticket, uint32_t *err, int64_t *v64, hipStream_t s)
+{
+    const unsigned nt = (unsigned)ceil_div(n, (int64_t)OS_WAVES * 64 * ROUNDS);
+    static int tk = -1;
+    if (tk < 0) { const char *e = getenv("RAHT_SORT_TICKET"); tk = (e && e[0] == '1') ? 1 : 0; }
+    if (tk) {
+        if (vin)
+            hipLaunchKernelGGL((os_pass_kernel<ROUNDS, true, true>), dim3(nt), dim3(OS_THREADS), 0, s, kin, vin, kout, vout, n, shift, bits, slices, state, gstate, ticket, err, v64);
+        else
+            hipLaunchKernelGGL((os_pass_kernel<ROUNDS, false, true>), dim3(nt), dim3(OS_THREADS), 0, s, kin, vin, kout, vout, n, shift, bits, slices, state, gstate, ticket, err, v64);
+    } else {
+        if (vin)
+            hipLaunchKernelGGL((os_pass_kernel<ROUNDS, true, false>), dim3(nt), dim3(OS_THREADS), 0, s, kin, vin, kout, vout, n, shift, bits, slices, state, gstate, ticket, err, v64);
+        else
+            hipLaunchKernelGGL((os_pass_kernel<ROUNDS, false, false>), dim3(nt), dim3(OS_THREADS), 0, s, kin, vin, kout, vout, n, shift, bits, slices, state, gstate, ticket, err, v64);
+    }
+}
+
+// Stable sort of (key, original index) by the low `nbits` key bits. tmp_keys / tmp_idx: N-sized ping-pong buffers (unused
+// when one pass is enough). err_dev: device word, zeroed here and set when a tile gave up waiting (the caller reads it back
+// with whatever it reads back anyway, once the stream has drained). Returns 1 when the input does not fit this form (the
+// caller then uses the pass-by-pass sort).
+int sort_pairs_onesweep(const uint64_t *keys_in, int64_t n, int nbits, uint64_t *keys_out, uint32_t *idx_out, uint64_t *tmp_keys,
+                        uint32_t *tmp_idx, uint32_t *err_dev, hipStream_t s, int64_t *idx64_out)
+{
+    if (n <= 0) return RAHT_OK;
+    const int npass = std::max(1, (nbits + 7) / 8);
+    if (npass > OS_MAX_PASSES || n >= ((int64_t)1 << 30) || !err_dev || !sort_onesweep_enabled()) return 1;
+    OsPasses P;
+    P.npass = npass;
+    for (int p = 0, sh = 0; p < OS_MAX_PASSES; ++p) {
+        const int b = p < npass ? std::max(1, (nbits - sh + (npass - p) - 1) / (npass - p)) : 1;    // digits as even as possible: 36 bits = 8,7,7,7,7
+        P.shift[p] = p < npass ? sh : 0;
+        P.bits[p] = b;
+        if (p < npass) sh += b;
+    }
+    const int R = os_rounds(n);
+    const int64_t ntiles = ceil_div(n, (int64_t)OS_WAVES * 64 * R);
+    const int hb = (int)std::min<int64_t>(ceil_div(n, OS_THREADS * 16), OS_HIST_BLOCKS);
+    // [ tickets (npass) | tile and group words (npass x (ntiles + ngroups) x 256) ] zeroed by the histogram launch, then partial, slices
+    const int64_t ngroups = ceil_div(ntiles, (int64_t)OS_GROUP);
+    const int64_t n_zero = OS_MAX_PASSES + (int64_t)npass * (ntiles + ngroups) * 256;
+    Scratch ws(sizeof(uint32_t) * ((size_t)n_zero + (size_t)hb * npass * 256 + (size_t)npass * OS_SLICES * 256), s);
+    if (!ws.ok()) return RAHT_ERR_NOMEM;
+    uint32_t *ticket = ws.as<uint32_t>(), *state = ticket + OS_MAX_PASSES, *err = err_dev;
+    uint32_t *partial = ticket + n_zero, *slices = partial + (size_t)hb * npass * 256;
+    hipLaunchKernelGGL(os_hist_kernel, dim3(hb), dim3(OS_THREADS), 0, s, keys_in, n, P, partial, ticket, n_zero, err);
+    hipLaunchKernelGGL(os_base_kernel, dim3(npass * OS_SLICES), dim3(OS_THREADS), 0, s, partial, hb, npass, slices);
+    const uint64_t *kin = keys_in;
+    const uint32_t *vin = nullptr;
+    for (int ps = 0; ps < npass; ++ps) {
+        const bool to_out = ((npass - 1 - ps) % 2 == 0);
+        uint64_t *ko = to_out ? keys_out : tmp_keys;
+        uint32_t *vo = to_out ? idx_out : tmp_idx;
+        uint32_t *st = state + (size_t)ps * (ntiles + ngroups) * 256, *gst = st + (size_t)ntiles * 256;
+        const uint32_t *sl = slices + (size_t)ps * OS_SLICES * 256;
+        if (R == 8) os_launch_pass<8>(kin, vin, ko, vo, n, P.shift[ps], P.bits[ps], sl, st, gst, ticket + ps, err, ps == npass - 1 ? idx64_out : nullptr, s);
+        else if (R == 12) os_launch_pass<12>(kin, vin, ko, vo, n, P.shift[ps], P.bits[ps], sl, st, gst, ticket + ps, err, ps == npass - 1 ? idx64_out : nullptr, s);
+        else os_launch_pass<16>(kin, vin, ko, vo, n, P.shift[ps], P.bits[ps], sl, st, gst, ticket + ps, err, ps == npass - 1 ? idx64_out : nullptr, s);
+        kin = ko;
+        vin = vo;
+    }
+    RAHT_HIP_CHECK(hipGetLastError());
+    return RAHT_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
 // Stream compaction.
 // ------------------------------------------------------------------------------------------------
 __global__ void compact_scatter_kernel(const uint32_t *in, const uint32_t *flag, const uint32_t *pos,
@@ -590,6 +1008,14 @@ int read_back_u32(uint32_t *dst_a, const uint32_t *dev_a, int na, uint32_t *dst_
 }
 
 }  // namespace raht
+
+#ifdef RAHT_OS_CLOCKS
+extern "C" int raht_debug_sort_clocks(unsigned long long *host_out, int n_tiles, int shift)
+{
+    if (shift >= 0) return hipMemcpyToSymbol(HIP_SYMBOL(raht::os_dbg_shift), &shift, sizeof(int)) == hipSuccess ? 0 : -4;
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(raht::os_dbg), sizeof(unsigned long long) * 8 * (size_t)n_tiles) == hipSuccess ? 0 : -4;
+}
+#endif
 
 extern "C" int raht_release_cached_memory(void)
 {

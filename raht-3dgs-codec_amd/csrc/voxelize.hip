@@ -310,8 +310,11 @@ __global__ __launch_bounds__(256) void voxel_mean_chunk_kernel(const float *__re
     }
 }
 
+// Stable sort of (key, original index). `sort_err` (device word, may be NULL) selects the one-sweep form
+// (scan_sort.hip: npass + 2 launches); the caller checks the word once the stream has drained (sort_failed) and repeats
+// the call with sort_err = NULL -- the pass-by-pass form, four launches per digit -- in the never-seen case that it is set.
 static int sort_keys_u32idx(const uint64_t *keys_in, int64_t N, int nbits, uint64_t *keys_out,
-                                  uint32_t *idx_out, hipStream_t s)
+                                  uint32_t *idx_out, hipStream_t s, uint32_t *sort_err = nullptr, int64_t *idx64_out = nullptr)
 {
     // LSD passes of 8 bits; ping-pong between two (key, index) buffers, last pass lands in *_out
     const int npass = std::max(1, (nbits + 7) / 8);
@@ -319,6 +322,11 @@ static int sort_keys_u32idx(const uint64_t *keys_in, int64_t N, int nbits, uint6
     if (!tmp.ok()) return RAHT_ERR_NOMEM;
     uint64_t *ktmp = tmp.as<uint64_t>();
     uint32_t *itmp = (uint32_t *)(ktmp + N);
+    if (sort_err) {
+        const int rc1 = sort_pairs_onesweep(keys_in, N, nbits, keys_out, idx_out, ktmp, itmp, sort_err, s, idx64_out);
+        if (rc1 <= 0) return rc1;                        // enqueued (or failed); 1 = not applicable
+        RAHT_HIP_CHECK(hipMemsetAsync(sort_err, 0, sizeof(uint32_t), s));
+    }
     const uint64_t *kin = keys_in;
     const uint32_t *iin = nullptr;
     int rc = RAHT_OK;
@@ -331,6 +339,8 @@ static int sort_keys_u32idx(const uint64_t *keys_in, int64_t N, int nbits, uint6
         kin = ko;
         iin = io;
     }
+    if (rc == RAHT_OK && idx64_out)
+        hipLaunchKernelGGL(u32_to_i64_kernel, dim3((unsigned)ceil_div(N, 256)), dim3(256), 0, s, idx_out, N, idx64_out);
     return rc;
 }
 
@@ -350,14 +360,17 @@ int raht_sort_keys(const uint64_t *keys_in, int64_t N, int nbits, uint64_t *keys
     if (!keys_in || !keys_out) { set_error("raht_sort_keys: NULL argument"); return RAHT_ERR_INVALID; }
     if (N >= ((int64_t)1 << 31)) { set_error("raht_sort_keys: N too large"); return RAHT_ERR_INVALID; }
     hipStream_t s = (hipStream_t)stream;
-    Scratch ib(sizeof(uint32_t) * (size_t)N, s);
+    Scratch ib(sizeof(uint32_t) * ((size_t)N + 1), s);
     if (!ib.ok()) return RAHT_ERR_NOMEM;
-    uint32_t *idx32 = ib.as<uint32_t>();
-    RAHT_RET(sort_keys_u32idx(keys_in, N, nbits, keys_out, idx32, s));
-    if (idx_out)
-        hipLaunchKernelGGL(u32_to_i64_kernel, dim3((unsigned)ceil_div(N, 256)), dim3(256), 0, s, idx32, N, idx_out);
-    hipError_t e = hipStreamSynchronize(s);       // idx32 returns to the pool when this frame ends
-    if (e != hipSuccess) { set_error("raht_sort_keys: %s", hipGetErrorString(e)); return RAHT_ERR_HIP; }
+    uint32_t *idx32 = ib.as<uint32_t>(), *sort_err = idx32 + N;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        RAHT_RET(sort_keys_u32idx(keys_in, N, nbits, keys_out, idx32, s, attempt == 0 ? sort_err : nullptr, idx_out));
+        RAHT_HIP_CHECK(hipGetLastError());
+        // idx32 returns to the pool when this frame ends: the read-back of the sort's error word is also the wait for the stream
+        uint32_t bad = 0;
+        RAHT_RET(read_back_u32(&bad, sort_err, 1, nullptr, nullptr, 0, s));
+        if (!bad) break;
+    }
     return RAHT_OK;
 }
 
@@ -446,18 +459,22 @@ int raht_voxelize(const float *PC, int64_t ldpc, int64_t N, int d, const float *
     const float vs = (float)voxel_size;
 
     // ---- keys, sort ----
-    Scratch kb(sizeof(uint64_t) * 2 * (size_t)N, s), ib(sizeof(uint32_t) * 3 * (size_t)N, s);
+    Scratch kb(sizeof(uint64_t) * 2 * (size_t)N, s), ib(sizeof(uint32_t) * (3 * (size_t)N + 1), s);
     if (!kb.ok() || !ib.ok()) return RAHT_ERR_NOMEM;
     uint64_t *keys = kb.as<uint64_t>();
     uint64_t *ks = keys_sorted ? keys_sorted : keys + N;
-    uint32_t *idx = ib.as<uint32_t>(), *flag = idx + N, *vstart = flag + N;
+    uint32_t *idx = ib.as<uint32_t>(), *flag = idx + N, *vstart = flag + N, *sort_err = vstart + N;
     int64_t nv = 0;
     {
         const unsigned gb = (unsigned)ceil_div(N, 256);
         hipLaunchKernelGGL(vox_keys_kernel, dim3((unsigned)ceil_div(N, 256 * 4)), dim3(256), 0, s, PC, ldpc, N, vmin[0], vmin[1], vmin[2], vs, J, keys);
-        RAHT_RET(sort_keys_u32idx(keys, N, 3 * J, ks, idx, s));
-        hipLaunchKernelGGL(boundary_kernel, dim3(gb), dim3(256), 0, s, ks, N, flag);
-        RAHT_RET(compact_u32(nullptr, flag, vstart, N, &nv, s));
+        for (int attempt = 0; attempt < 2; ++attempt) {
+            uint32_t bad = 0;
+            RAHT_RET(sort_keys_u32idx(keys, N, 3 * J, ks, idx, s, attempt == 0 ? sort_err : nullptr, sort_idx));
+            hipLaunchKernelGGL(boundary_kernel, dim3(gb), dim3(256), 0, s, ks, N, flag);
+            RAHT_RET(compact_u32(nullptr, flag, vstart, N, &nv, s, sort_err, &bad));      // (the sort's error word rides along)
+            if (!bad) break;
+        }
         if (PCvox || Vvox) {
             const unsigned gv = (unsigned)std::min<int64_t>(ceil_div(nv, 64), 8192);
             if (PCvox && d >= 8) {
@@ -468,7 +485,6 @@ int raht_voxelize(const float *PC, int64_t ldpc, int64_t N, int d, const float *
                 hipLaunchKernelGGL(voxel_mean_kernel, dim3(gv), dim3(256), 0, s, PC, ldpc, N, d, ks, idx, vstart, nv, PCvox, Vvox);
             }
         }
-        if (sort_idx) hipLaunchKernelGGL(u32_to_i64_kernel, dim3(gb), dim3(256), 0, s, idx, N, sort_idx);
         if (voxel_indices) hipLaunchKernelGGL(u32_to_i64_kernel, dim3((unsigned)ceil_div(nv, 256)), dim3(256), 0, s, vstart, nv, voxel_indices);
         hipError_t e = hipStreamSynchronize(s);
         if (e == hipSuccess) e = hipGetLastError();

@@ -954,3 +954,20 @@ def test_voxelize_plan_feeds_the_plan_from_the_voxelizers_keys(rt, oracle):
     del info, PCvox            # the plan keeps the borrowed key tensor alive
     torch.cuda.empty_cache()
     assert torch.equal(plan.inverse(T0), rt.plan_of(ListC).inverse(T0))
+
+
+# ---- the key sort in its three forms (csrc/scan_sort.hip) --------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("env", [{}, {"RAHT_SORT_TICKET": "1"}, {"RAHT_SORT_ONESWEEP": "0"}, {"RAHT_SORT_ROUNDS": "8"}, {"RAHT_SORT_ROUNDS": "12"}],
+                         ids=["one-sweep", "one-sweep, ticketed tiles", "pass by pass", "2048-item tiles", "3072-item tiles"])
+def test_key_sort_forms_equal_a_stable_sort(env):
+    """raht_sort_keys == torch.sort(stable=True), keys AND permutation, for sizes around the tile edges (1 ... 3 000 017), every
+    digit-pass count (1 ... 63 key bits) and inputs full of duplicates -- in the default one-sweep form (tiles numbered by
+    workgroup index), with ticketed tiles, and in the pass-by-pass form the library falls back to. The knobs are read once per
+    process: each form runs tools/check_sort.py in its own interpreter."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "check_sort.py")], env={**os.environ, **env}, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "correctness: 0 mismatches" in r.stdout
