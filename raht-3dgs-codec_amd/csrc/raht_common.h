@@ -141,9 +141,12 @@ int radix_pass_u64(const uint64_t *keys_in, const uint32_t *vals_in, uint64_t *k
 // when a tile gave up waiting for its predecessors (bounded waits: the grid always drains) -- the caller reads it back
 // once the stream has drained and falls back to the pass-by-pass sort. Returns 1 (nothing enqueued) when the input does
 // not fit (more than 8 digit passes, N >= 2^30) or RAHT_SORT_ONESWEEP=0. idx64_out (may be NULL): the indices once more as
-// int64, written by the last pass.
+// int64, written by the last pass. grid (may be NULL): keys_in is not an input but the voxel keys of the cloud's points
+// (raht_device.h: vox_key), which the histogram launch computes AND stores there on its way.
+struct VoxGrid;
 int sort_pairs_onesweep(const uint64_t *keys_in, int64_t n, int nbits, uint64_t *keys_out, uint32_t *idx_out, uint64_t *tmp_keys,
-                        uint32_t *tmp_idx, uint32_t *err_dev, hipStream_t s, int64_t *idx64_out = nullptr);
+                        uint32_t *tmp_idx, uint32_t *err_dev, hipStream_t s, int64_t *idx64_out = nullptr,
+                        const VoxGrid *grid = nullptr);
 // Same for uint8 bucket ids (< 2^bits); produces the stable permutation and, optionally, the
 // start offset of every bucket (bucket_off: device uint32[(1<<bits)+1]).
 int bucket_sort_u8(const uint8_t *bucket, uint32_t *perm_out, int64_t n, int bits,
@@ -160,6 +163,12 @@ int read_back_u32(uint32_t *dst_a, const uint32_t *dev_a, int na, uint32_t *dst_
 // number of kept items (synchronises the stream).
 int compact_u32(const uint32_t *in, const uint32_t *flag, uint32_t *out, int64_t n,
                 int64_t *count_host, hipStream_t s, const uint32_t *extra_dev = nullptr, uint32_t *extra_host = nullptr);
+
+// starts[k] = index of the first element of the k-th run of equal keys in a SORTED key array; optionally the same as int64
+// (starts64) and the key of every run (run_keys). *count_host = number of runs (synchronises the stream through the mailbox;
+// extra_dev / extra_host: one more device word read back along with it). Two launches.
+int run_starts_u64(const uint64_t *keys_sorted, int64_t n, uint32_t *starts, int64_t *starts64, uint64_t *run_keys,
+                   int64_t *count_host, hipStream_t s, const uint32_t *extra_dev = nullptr, uint32_t *extra_host = nullptr);
 
 // ---- plan (plan.hip) ---------------------------------------------------------------------------
 constexpr int RAHT_TOP_MAX_ROWS = 8192;   // entries the TOP stage can hold (16 bytes each in LDS)

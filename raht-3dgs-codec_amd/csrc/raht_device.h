@@ -111,6 +111,40 @@ __device__ __forceinline__ float refined_rcp(float sp)
 }
 
 
+// ---- voxel keys (voxelize.hip; the key sort's histogram launch can compute them on the way: scan_sort.hip) ----------
+__device__ __forceinline__ uint64_t vx_spread3(uint64_t v)
+{
+    v &= 0x1fffffull;
+    v = (v | (v << 32)) & 0x001f00000000ffffull;
+    v = (v | (v << 16)) & 0x001f0000ff0000ffull;
+    v = (v | (v << 8)) & 0x100f00f00f00f00full;
+    v = (v | (v << 4)) & 0x10c30c30c30c30c3ull;
+    v = (v | (v << 2)) & 0x1249249249249249ull;
+    return v;
+}
+// xyz of one point: 12 bytes at the start of a (3 + d)-float row, as ONE global_load_dwordx3 (element alignment)
+struct __attribute__((packed, aligned(4))) Xyz { float x, y, z; };
+// the cloud and its grid (voxelize_pc.py:87-98)
+struct VoxGrid {
+    const float *PC;
+    int64_t ld;
+    float m0, m1, m2, vs;
+    int J;
+};
+// Morton key of the voxel of one point (voxelize_pc.py:92, 98, 100): shift, IEEE divide, floor, clamp, interleave
+__device__ __forceinline__ uint64_t vox_key(const Xyz &p, const VoxGrid &g)
+{
+    const int64_t hi = ((int64_t)1 << g.J) - 1;
+    const float v[3] = {p.x - g.m0, p.y - g.m1, p.z - g.m2};          // voxelize_pc.py:92
+    int64_t q[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        int64_t t = (int64_t)floorf(__fdiv_rn(v[a], g.vs));           // :98 (IEEE divide, not rcp*mul)
+        q[a] = t < 0 ? 0 : (t > hi ? hi : t);
+    }
+    return vx_spread3((uint64_t)q[2]) | (vx_spread3((uint64_t)q[1]) << 1) | (vx_spread3((uint64_t)q[0]) << 2);
+}
+
 // StepTable from the caller's steps (host)
 inline void fill_step_table(StepTable64 &t, const double *steps, int n_steps)
 {

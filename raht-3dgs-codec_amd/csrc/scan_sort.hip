@@ -5,6 +5,7 @@
 // These are integer/HBM-bound kernels (no MFMA). They run at plan / voxelize time, not inside the
 // transform entry points.
 #include "raht_common.h"
+#include "raht_device.h"
 #include <map>
 #include <mutex>
 #include <unordered_map>
@@ -543,23 +544,37 @@ __device__ __forceinline__ uint32_t os_digit(uint64_t k, int shift, uint32_t mas
 }
 
 // partial[b][p * 256 + d] = number of keys of block b whose digit of pass p is d. The same launch zeroes the
-// look-back words of the passes that follow, and the sort's error word.
-__global__ __launch_bounds__(OS_THREADS) void os_hist_kernel(const uint64_t *__restrict__ keys, int64_t n, OsPasses P,
+// look-back words of the passes that follow, and the sort's error word. FROM_CLOUD: the keys are not read but computed
+// from the cloud's coordinates (and stored): the voxelizer's key kernel and this one are ONE pass over the points.
+template <bool FROM_CLOUD>
+__global__ __launch_bounds__(OS_THREADS) void os_hist_kernel(uint64_t *__restrict__ keys, int64_t n, OsPasses P,
                                                              uint32_t *__restrict__ partial, uint32_t *__restrict__ zero_words,
-                                                             int64_t n_zero, uint32_t *__restrict__ err)
+                                                             int64_t n_zero, uint32_t *__restrict__ err, const VoxGrid G)
 {
     if (blockIdx.x == 0 && threadIdx.x == 0) *err = 0u;
     __shared__ uint32_t h[OS_MAX_PASSES * 256];
     for (int k = threadIdx.x; k < P.npass * 256; k += OS_THREADS) h[k] = 0;
     __syncthreads();
     const int64_t stride = (int64_t)gridDim.x * OS_THREADS;
-    // eight independent loads in flight per thread (one at a time, the loop is a chain of HBM round trips: 17 us for 24 MB)
-    for (int64_t i0 = (int64_t)blockIdx.x * OS_THREADS + threadIdx.x; i0 < n; i0 += 8 * stride) {
-        uint64_t k[8];
+    // eight independent loads in flight per thread (one at a time, the loop is a chain of HBM round trips)
+    constexpr int U = FROM_CLOUD ? 4 : 8;
+    for (int64_t i0 = (int64_t)blockIdx.x * OS_THREADS + threadIdx.x; i0 < n; i0 += U * stride) {
+        uint64_t k[U];
+        if constexpr (FROM_CLOUD) {
+            Xyz pt[U];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) k[u] = keys[min(i0 + u * stride, n - 1)];
+            for (int u = 0; u < U; ++u) pt[u] = *(const Xyz *)(G.PC + min(i0 + u * stride, n - 1) * G.ld);
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+            for (int u = 0; u < U; ++u) {
+                k[u] = vox_key(pt[u], G);
+                if (i0 + u * stride < n) keys[i0 + u * stride] = k[u];
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < U; ++u) k[u] = keys[min(i0 + u * stride, n - 1)];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
             if (i0 + u * stride >= n) continue;
 #pragma unroll
             for (int p = 0; p < OS_MAX_PASSES; ++p)
@@ -864,7 +879,7 @@ static void os_launch_pass(const uint64_t *kin, const uint32_t *vin, uint64_t *k
 // with whatever it reads back anyway, once the stream has drained). Returns 1 when the input does not fit this form (the
 // caller then uses the pass-by-pass sort).
 int sort_pairs_onesweep(const uint64_t *keys_in, int64_t n, int nbits, uint64_t *keys_out, uint32_t *idx_out, uint64_t *tmp_keys,
-                        uint32_t *tmp_idx, uint32_t *err_dev, hipStream_t s, int64_t *idx64_out)
+                        uint32_t *tmp_idx, uint32_t *err_dev, hipStream_t s, int64_t *idx64_out, const VoxGrid *grid)
 {
     if (n <= 0) return RAHT_OK;
     const int npass = std::max(1, (nbits + 7) / 8);
@@ -879,7 +894,10 @@ int sort_pairs_onesweep(const uint64_t *keys_in, int64_t n, int nbits, uint64_t 
     }
     const int R = os_rounds(n);
     const int64_t ntiles = ceil_div(n, (int64_t)OS_WAVES * 64 * R);
-    const int hb = (int)std::min<int64_t>(ceil_div(n, OS_THREADS * 16), OS_HIST_BLOCKS);
+    // (from the cloud: every point costs a 128-byte line, the launch is bound by loads in flight -- more, shorter blocks)
+    static int hb_cloud = 0;
+    if (!hb_cloud) { const char *e = getenv("RAHT_SORT_CLOUD_BLOCKS"); hb_cloud = e ? std::max(1, atoi(e)) : 4 * OS_HIST_BLOCKS; }
+    const int hb = (int)std::min<int64_t>(ceil_div(n, OS_THREADS * 16), grid ? hb_cloud : OS_HIST_BLOCKS);
     // [ tickets (npass) | tile and group words (npass x (ntiles + ngroups) x 256) ] zeroed by the histogram launch, then partial, slices
     const int64_t ngroups = ceil_div(ntiles, (int64_t)OS_GROUP);
     const int64_t n_zero = OS_MAX_PASSES + (int64_t)npass * (ntiles + ngroups) * 256;
@@ -887,7 +905,8 @@ int sort_pairs_onesweep(const uint64_t *keys_in, int64_t n, int nbits, uint64_t 
     if (!ws.ok()) return RAHT_ERR_NOMEM;
     uint32_t *ticket = ws.as<uint32_t>(), *state = ticket + OS_MAX_PASSES, *err = err_dev;
     uint32_t *partial = ticket + n_zero, *slices = partial + (size_t)hb * npass * 256;
-    hipLaunchKernelGGL(os_hist_kernel, dim3(hb), dim3(OS_THREADS), 0, s, keys_in, n, P, partial, ticket, n_zero, err);
+    if (grid) hipLaunchKernelGGL(os_hist_kernel<true>, dim3(hb), dim3(OS_THREADS), 0, s, (uint64_t *)keys_in, n, P, partial, ticket, n_zero, err, *grid);
+    else hipLaunchKernelGGL(os_hist_kernel<false>, dim3(hb), dim3(OS_THREADS), 0, s, (uint64_t *)keys_in, n, P, partial, ticket, n_zero, err, VoxGrid{});
     hipLaunchKernelGGL(os_base_kernel, dim3(npass * OS_SLICES), dim3(OS_THREADS), 0, s, partial, hb, npass, slices);
     const uint64_t *kin = keys_in;
     const uint32_t *vin = nullptr;
@@ -934,6 +953,97 @@ int compact_u32(const uint32_t *in, const uint32_t *flag, uint32_t *out, int64_t
         *count_host = t;
     }
     return rc;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Starts of the runs of equal keys in a sorted key array (the voxelizer's voxel boundaries, voxelize_pc.py:114-118), in TWO
+// launches: per-block counts of run starts straight from the keys, then every block adds up the counts of the blocks
+// before it by itself, ranks its own starts and writes them -- as uint32, and (optionally) widened to int64 and together
+// with the key of every run. (Flag array + generic scan + scatter + widening: five launches and 48 N more bytes.)
+// ------------------------------------------------------------------------------------------------
+// Items of a block are taken in rounds of 256 consecutive keys (lane = key: loads and stores coalesce); a key's predecessor
+// comes from the lane below (lane 0 of every wave loads it).
+__device__ __forceinline__ bool run_start_flag(const uint64_t *__restrict__ keys, int64_t i, int64_t n, uint64_t x)
+{
+    const int lane = threadIdx.x & 63;
+    uint64_t prev = __shfl_up(x, 1, 64);
+    if (lane == 0 && i > 0 && i < n) prev = keys[i - 1];
+    return i < n && (i == 0 || x != prev);
+}
+
+__global__ __launch_bounds__(SCAN_THREADS) void run_count_kernel(const uint64_t *__restrict__ keys, int64_t n, uint32_t *__restrict__ blk)
+{
+    const int64_t base = (int64_t)blockIdx.x * SCAN_BLOCK + threadIdx.x;
+    uint64_t x[SCAN_ITEMS];
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k) x[k] = (base + k * SCAN_THREADS < n) ? keys[base + k * SCAN_THREADS] : 0ull;
+    uint32_t c = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k) c += run_start_flag(keys, base + k * SCAN_THREADS, n, x[k]) ? 1u : 0u;
+    uint32_t tot;
+    (void)block_excl_scan_256(c, &tot);
+    if (threadIdx.x == 0) blk[blockIdx.x] = tot;
+}
+
+__global__ __launch_bounds__(SCAN_THREADS) void run_starts_kernel(const uint64_t *__restrict__ keys, int64_t n, const uint32_t *__restrict__ blk,
+                                                                  uint32_t *__restrict__ starts, int64_t *__restrict__ starts64,
+                                                                  uint64_t *__restrict__ run_keys, uint32_t *__restrict__ total)
+{
+    __shared__ uint32_t wc[SCAN_ITEMS * 4];               // run starts per (round, wave), memory order
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int64_t base = (int64_t)blockIdx.x * SCAN_BLOCK + threadIdx.x;
+    uint64_t x[SCAN_ITEMS];
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k) x[k] = (base + k * SCAN_THREADS < n) ? keys[base + k * SCAN_THREADS] : 0ull;
+    uint32_t part = 0;
+    for (int b = threadIdx.x; b < (int)blockIdx.x; b += SCAN_THREADS) part += blk[b];
+    uint32_t f = 0, rank[SCAN_ITEMS];
+    const uint64_t lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k) {
+        const bool fl = run_start_flag(keys, base + k * SCAN_THREADS, n, x[k]);
+        const uint64_t bal = __ballot(fl);
+        rank[k] = (uint32_t)__popcll(bal & lt);
+        if (fl) f |= 1u << k;
+        if (lane == 0) wc[k * 4 + wid] = (uint32_t)__popcll(bal);
+    }
+    uint32_t before;
+    (void)block_excl_scan_256(part, &before);            // (its barriers also publish wc)
+    uint32_t run = before;
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k) {
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const uint32_t c = wc[k * 4 + w];
+            if (w == wid && (f & (1u << k))) {
+                const uint32_t pos = run + rank[k];
+                const int64_t i = base + k * SCAN_THREADS;
+                starts[pos] = (uint32_t)i;
+                if (starts64) starts64[pos] = i;
+                if (run_keys) run_keys[pos] = x[k];
+            }
+            run += c;
+        }
+    }
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) *total = run;
+}
+
+int run_starts_u64(const uint64_t *keys_sorted, int64_t n, uint32_t *starts, int64_t *starts64, uint64_t *run_keys,
+                   int64_t *count_host, hipStream_t s, const uint32_t *extra_dev, uint32_t *extra_host)
+{
+    *count_host = 0;
+    if (n <= 0) return RAHT_OK;
+    const int64_t nb = ceil_div(n, SCAN_BLOCK);
+    Scratch ws(sizeof(uint32_t) * ((size_t)nb + 1), s);
+    if (!ws.ok()) return RAHT_ERR_NOMEM;
+    uint32_t *blk = ws.as<uint32_t>(), *total = blk + nb;
+    hipLaunchKernelGGL(run_count_kernel, dim3((unsigned)nb), dim3(SCAN_THREADS), 0, s, keys_sorted, n, blk);
+    hipLaunchKernelGGL(run_starts_kernel, dim3((unsigned)nb), dim3(SCAN_THREADS), 0, s, keys_sorted, n, blk, starts, starts64, run_keys, total);
+    RAHT_HIP_CHECK(hipGetLastError());
+    uint32_t t = 0;
+    RAHT_RET(read_back_u32(&t, total, 1, extra_host, extra_dev, extra_dev ? 1 : 0, s));     // (the caller's word rides along)
+    *count_host = t;
+    return RAHT_OK;
 }
 
 // ------------------------------------------------------------------------------------------------

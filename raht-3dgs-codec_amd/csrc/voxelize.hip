@@ -10,17 +10,6 @@
 
 namespace raht {
 
-__device__ __forceinline__ uint64_t vx_spread3(uint64_t v)
-{
-    v &= 0x1fffffull;
-    v = (v | (v << 32)) & 0x001f00000000ffffull;
-    v = (v | (v << 16)) & 0x001f0000ff0000ffull;
-    v = (v | (v << 8)) & 0x100f00f00f00f00full;
-    v = (v | (v << 4)) & 0x10c30c30c30c30c3ull;
-    v = (v | (v << 2)) & 0x1249249249249249ull;
-    return v;
-}
-
 __device__ __forceinline__ uint32_t vx_compact3(uint64_t v)
 {
     v &= 0x1249249249249249ull;
@@ -60,37 +49,25 @@ __global__ __launch_bounds__(256) void minmax_kernel(const float *__restrict__ P
 }
 
 // ---- keys --------------------------------------------------------------------------------------
-// xyz of one point: 12 bytes at the start of a (3 + d)-float row, as ONE global_load_dwordx3 (element alignment), four
-// rows per thread in flight. Every load instruction of a wave touches 64 different 128-byte lines here (row stride 236
-// bytes at d = 56): the kernel moves one line per point (384 MB on 3 M points) whatever the instruction mix -- 126 us
-// with three dword loads per row and with this form alike (3 TB/s of lines for 36 MB of coordinates). Only a layout
-// with the positions apart from the attributes would change that, and the reference's PC matrix is the boundary.
-struct __attribute__((packed, aligned(4))) Xyz { float x, y, z; };
-
-__global__ __launch_bounds__(256) void vox_keys_kernel(const float *__restrict__ PC, int64_t ld, int64_t N, float m0, float m1,
-                                                       float m2, float vs, int J, uint64_t *__restrict__ keys)
+// Every load instruction of a wave touches 64 different 128-byte lines here (row stride 236 bytes at d = 56): the kernel
+// moves one line per point (384 MB on 3 M points) whatever the instruction mix -- 126 us with three dword loads per row and
+// with one dwordx3 alike (3 TB/s of lines for 36 MB of coordinates). Only a layout with the positions apart from the
+// attributes would change that, and the reference's PC matrix is the boundary. (raht_voxelize computes its keys inside the
+// sort's histogram launch -- scan_sort.hip, os_hist_kernel<true> -- this kernel serves raht_voxel_keys.)
+__global__ __launch_bounds__(256) void vox_keys_kernel(const VoxGrid G, int64_t N, uint64_t *__restrict__ keys)
 {
     constexpr int U = 4;                                             // rows per thread: four independent loads in flight
     const int64_t i0 = ((int64_t)blockIdx.x * blockDim.x) * U + threadIdx.x;
-    const int64_t hi = ((int64_t)1 << J) - 1;
     Xyz p[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
         const int64_t i = min(i0 + (int64_t)u * blockDim.x, N - 1);
-        p[u] = *(const Xyz *)(PC + i * ld);
+        p[u] = *(const Xyz *)(G.PC + i * G.ld);
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
         const int64_t i = i0 + (int64_t)u * blockDim.x;
-        if (i >= N) continue;
-        const float v[3] = {p[u].x - m0, p[u].y - m1, p[u].z - m2};  // voxelize_pc.py:92
-        int64_t q[3];
-#pragma unroll
-        for (int a = 0; a < 3; ++a) {
-            int64_t t = (int64_t)floorf(__fdiv_rn(v[a], vs));        // :98 (IEEE divide, not rcp*mul)
-            q[a] = t < 0 ? 0 : (t > hi ? hi : t);
-        }
-        keys[i] = vx_spread3((uint64_t)q[2]) | (vx_spread3((uint64_t)q[1]) << 1) | (vx_spread3((uint64_t)q[0]) << 2);
+        if (i < N) keys[i] = vox_key(p[u], G);
     }
 }
 
@@ -313,8 +290,11 @@ __global__ __launch_bounds__(256) void voxel_mean_chunk_kernel(const float *__re
 // Stable sort of (key, original index). `sort_err` (device word, may be NULL) selects the one-sweep form
 // (scan_sort.hip: npass + 2 launches); the caller checks the word once the stream has drained (sort_failed) and repeats
 // the call with sort_err = NULL -- the pass-by-pass form, four launches per digit -- in the never-seen case that it is set.
+// `grid` (may be NULL): keys_in is an OUTPUT as well -- the keys of the cloud's points, computed on the way (inside the
+// one-sweep form's histogram launch, or by vox_keys_kernel in front of the pass-by-pass form).
 static int sort_keys_u32idx(const uint64_t *keys_in, int64_t N, int nbits, uint64_t *keys_out,
-                                  uint32_t *idx_out, hipStream_t s, uint32_t *sort_err = nullptr, int64_t *idx64_out = nullptr)
+                                  uint32_t *idx_out, hipStream_t s, uint32_t *sort_err = nullptr, int64_t *idx64_out = nullptr,
+                                  const VoxGrid *grid = nullptr)
 {
     // LSD passes of 8 bits; ping-pong between two (key, index) buffers, last pass lands in *_out
     const int npass = std::max(1, (nbits + 7) / 8);
@@ -323,10 +303,11 @@ static int sort_keys_u32idx(const uint64_t *keys_in, int64_t N, int nbits, uint6
     uint64_t *ktmp = tmp.as<uint64_t>();
     uint32_t *itmp = (uint32_t *)(ktmp + N);
     if (sort_err) {
-        const int rc1 = sort_pairs_onesweep(keys_in, N, nbits, keys_out, idx_out, ktmp, itmp, sort_err, s, idx64_out);
+        const int rc1 = sort_pairs_onesweep(keys_in, N, nbits, keys_out, idx_out, ktmp, itmp, sort_err, s, idx64_out, grid);
         if (rc1 <= 0) return rc1;                        // enqueued (or failed); 1 = not applicable
         RAHT_HIP_CHECK(hipMemsetAsync(sort_err, 0, sizeof(uint32_t), s));
     }
+    if (grid) hipLaunchKernelGGL(vox_keys_kernel, dim3((unsigned)ceil_div(N, 256 * 4)), dim3(256), 0, s, *grid, N, (uint64_t *)keys_in);
     const uint64_t *kin = keys_in;
     const uint32_t *iin = nullptr;
     int rc = RAHT_OK;
@@ -382,8 +363,8 @@ int raht_voxel_keys(const float *PC, int64_t ldpc, int64_t N, const float vmin[3
                                                              // neither a data pointer nor meaningful strides
     if (!PC || !keys || ldpc < 3) { set_error("raht_voxel_keys: bad argument"); return RAHT_ERR_INVALID; }
     const float vs = (float)(width / (double)((uint64_t)1 << J));        // voxelize_pc.py:97, as raht_voxelize
-    hipLaunchKernelGGL(vox_keys_kernel, dim3((unsigned)ceil_div(N, 256 * 4)), dim3(256), 0, (hipStream_t)stream, PC, ldpc, N,
-                       vmin[0], vmin[1], vmin[2], vs, J, keys);
+    const VoxGrid G = {PC, ldpc, vmin[0], vmin[1], vmin[2], vs, J};
+    hipLaunchKernelGGL(vox_keys_kernel, dim3((unsigned)ceil_div(N, 256 * 4)), dim3(256), 0, (hipStream_t)stream, G, N, keys);
     RAHT_HIP_CHECK(hipGetLastError());
     return RAHT_OK;
 }
@@ -459,20 +440,18 @@ int raht_voxelize(const float *PC, int64_t ldpc, int64_t N, int d, const float *
     const float vs = (float)voxel_size;
 
     // ---- keys, sort ----
-    Scratch kb(sizeof(uint64_t) * 2 * (size_t)N, s), ib(sizeof(uint32_t) * (3 * (size_t)N + 1), s);
+    Scratch kb(sizeof(uint64_t) * 2 * (size_t)N, s), ib(sizeof(uint32_t) * (2 * (size_t)N + 1), s);
     if (!kb.ok() || !ib.ok()) return RAHT_ERR_NOMEM;
     uint64_t *keys = kb.as<uint64_t>();
     uint64_t *ks = keys_sorted ? keys_sorted : keys + N;
-    uint32_t *idx = ib.as<uint32_t>(), *flag = idx + N, *vstart = flag + N, *sort_err = vstart + N;
+    uint32_t *idx = ib.as<uint32_t>(), *vstart = idx + N, *sort_err = vstart + N;
     int64_t nv = 0;
     {
-        const unsigned gb = (unsigned)ceil_div(N, 256);
-        hipLaunchKernelGGL(vox_keys_kernel, dim3((unsigned)ceil_div(N, 256 * 4)), dim3(256), 0, s, PC, ldpc, N, vmin[0], vmin[1], vmin[2], vs, J, keys);
+        const VoxGrid G = {PC, ldpc, vmin[0], vmin[1], vmin[2], vs, J};
         for (int attempt = 0; attempt < 2; ++attempt) {
             uint32_t bad = 0;
-            RAHT_RET(sort_keys_u32idx(keys, N, 3 * J, ks, idx, s, attempt == 0 ? sort_err : nullptr, sort_idx));
-            hipLaunchKernelGGL(boundary_kernel, dim3(gb), dim3(256), 0, s, ks, N, flag);
-            RAHT_RET(compact_u32(nullptr, flag, vstart, N, &nv, s, sort_err, &bad));      // (the sort's error word rides along)
+            RAHT_RET(sort_keys_u32idx(keys, N, 3 * J, ks, idx, s, attempt == 0 ? sort_err : nullptr, sort_idx, &G));
+            RAHT_RET(run_starts_u64(ks, N, vstart, voxel_indices, nullptr, &nv, s, sort_err, &bad));      // (the sort's error word rides along)
             if (!bad) break;
         }
         if (PCvox || Vvox) {
@@ -485,7 +464,6 @@ int raht_voxelize(const float *PC, int64_t ldpc, int64_t N, int d, const float *
                 hipLaunchKernelGGL(voxel_mean_kernel, dim3(gv), dim3(256), 0, s, PC, ldpc, N, d, ks, idx, vstart, nv, PCvox, Vvox);
             }
         }
-        if (voxel_indices) hipLaunchKernelGGL(u32_to_i64_kernel, dim3((unsigned)ceil_div(nv, 256)), dim3(256), 0, s, vstart, nv, voxel_indices);
         hipError_t e = hipStreamSynchronize(s);
         if (e == hipSuccess) e = hipGetLastError();
         if (e != hipSuccess) { set_error("raht_voxelize: %s", hipGetErrorString(e)); return RAHT_ERR_HIP; }
