@@ -297,6 +297,28 @@ int raht_voxelize(const float *PC, int64_t ldpc, int64_t N, int d, const float *
                   float vmin_out[3], double *width_out, double *voxel_size_out,
                   raht_stream_t stream);
 
+/* voxelize_pc_batched with ALL its outputs in one call (reference python/voxelize_pc.py:62-172 returns PCvox, PCsorted,
+ * voxel_indices, DeltaPC together): raht_voxelize plus PCsorted (N x (3+d), may be NULL) and DeltaPC (N x (3+d), may be NULL;
+ * needs PCvox) as raht_voxelize_residuals defines them, produced by the SAME pass over the gathered rows that forms the
+ * per-voxel means (clouds with >= 5 attribute columns; narrower ones run the two-call sequence inside and then need sort_idx).
+ * Bit-identical to raht_voxelize followed by raht_voxelize_residuals. */
+int raht_voxelize_all(const float *PC, int64_t ldpc, int64_t N, int d, const float *vmin_in, double width_in,
+                      int J, uint64_t *keys_sorted, int64_t *sort_idx, int64_t *voxel_indices, float *PCvox,
+                      int64_t *Vvox, float *PCsorted, float *DeltaPC, int64_t *n_vox, float vmin_out[3],
+                      double *width_out, double *voxel_size_out, raht_stream_t stream);
+
+/* One frame's prelude in one call: raht_voxelize, then the RAHT plan built STRAIGHT from the voxelizer's own sorted,
+ * unique voxel keys (the reference goes through a PLY file and re-derives the same Morton keys from the voxel coordinates:
+ * voxelize_pc_batched, python/voxelize_pc.py:62-172, then RAHT_param_reorder_fast, python/RAHT_param.py:190-279).
+ *   voxel_keys : DEVICE uint64[N], caller-allocated, REQUIRED: the first n_vox entries receive the voxels' keys and are
+ *                BORROWED by the plan (as raht_plan_create_from_keys_borrowed: keep them alive and unchanged while the plan lives)
+ *   other arguments as raht_voxelize; PCvox[:, 3:] is the attribute matrix in the plan's row order.
+ * *plan is NULL on failure. */
+int raht_voxelize_plan(const float *PC, int64_t ldpc, int64_t N, int d, const float *vmin_in, double width_in,
+                       int J, uint64_t *voxel_keys, int64_t *voxel_indices, float *PCvox, int64_t *n_vox,
+                       float vmin_out[3], double *width_out, double *voxel_size_out, raht_stream_t stream,
+                       raht_plan **plan);
+
 /* The voxelizer's secondary outputs (reference python/voxelize_pc.py:103-111, 147-156), from the primary ones of
  * raht_voxelize: PCsorted[k, :] = PC[sort_idx[k], :] (N x (3+d), may be NULL) and the residuals DeltaPC (N x (3+d)):
  * positions V0 - voxel_size * floor(V0 / voxel_size) with V0 = V - vmin, attributes minus their voxel's mean (PCvox).

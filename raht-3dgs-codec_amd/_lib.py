@@ -22,7 +22,7 @@ EXPORTS = [
     "raht_plan_destroy", "raht_plan_set_top_level", "raht_plan_roots", "raht_plan_set_root_buffer", "raht_plan_size", "raht_plan_nbits", "raht_plan_set_engine", "raht_plan_set_tail_tile", "raht_release_cached_memory", "raht_quant_rows", "raht_dequant_rows",
     "raht_plan_levels", "raht_plan_export_level", "raht_plan_order", "raht_plan_arrays",
     "raht_plan_copy_array", "raht_plan_stage_stats", "raht_fwd", "raht_fwd_f64", "raht_inv", "raht_inv_f64", "raht_debug_run_stage", "raht_plan_set_stage0_events", "raht_fwd_quant", "raht_dequant_inv", "raht_plan_prepare",
-    "raht_quant_reorder", "raht_dequant_unreorder", "raht_voxelize", "raht_morton", "raht_sort_keys",
+    "raht_quant_reorder", "raht_dequant_unreorder", "raht_voxelize", "raht_voxelize_all", "raht_voxelize_plan", "raht_morton", "raht_sort_keys",
     "raht_voxel_keys", "raht_voxelize_residuals", "raht_plan_set_row_map", "raht_rows_gather", "raht_rows_scatter",
     "raht_plan_set_max_stages", "raht_quant_reorder_f64", "raht_dequant_unreorder_f64", "raht_fwd_quant_f64", "raht_dequant_inv_f64",
     "raht_fwd_batch", "raht_inv_batch", "raht_fwd_quant_batch", "raht_dequant_inv_batch",
@@ -112,6 +112,10 @@ def lib():
     L.raht_dequant_rows.argtypes = [vp, i64, vp, i64, i32, C.POINTER(C.c_float), i32, vp, i64, vp]
     L.raht_voxelize.argtypes = [vp, i64, i64, i32, C.POINTER(C.c_float), dbl, i32, vp, vp, vp, vp, vp,
                                 C.POINTER(i64), C.POINTER(C.c_float), C.POINTER(dbl), C.POINTER(dbl), vp]
+    L.raht_voxelize_all.argtypes = [vp, i64, i64, i32, C.POINTER(C.c_float), dbl, i32, vp, vp, vp, vp, vp, vp, vp,
+                                    C.POINTER(i64), C.POINTER(C.c_float), C.POINTER(dbl), C.POINTER(dbl), vp]
+    L.raht_voxelize_plan.argtypes = [vp, i64, i64, i32, C.POINTER(C.c_float), dbl, i32, vp, vp, vp, C.POINTER(i64),
+                                     C.POINTER(C.c_float), C.POINTER(dbl), C.POINTER(dbl), vp, C.POINTER(vp)]
     L.raht_morton.argtypes = [vp, i64, i32, vp, vp]
     L.raht_voxel_keys.argtypes = [vp, i64, i64, C.POINTER(C.c_float), dbl, i32, vp, vp]
     L.raht_voxelize_residuals.argtypes = [vp, i64, i64, i32, vp, vp, vp, C.POINTER(C.c_float), dbl, vp, vp, vp]

@@ -305,17 +305,62 @@ __global__ void __launch_bounds__(256) extent_search_kernel(const uint64_t *__re
 // where that block's first row of that bucket goes (exclusive scan of bucket_hist, bucket-major). Inside the
 // block the rank of a row among the rows of its bucket is (rows of that bucket in earlier waves) + (earlier
 // lanes of its wave with the same bucket). Writes the permutation AND its inverse: inv_order[i] = pos.
+// First half of that sort: ONE launch, one workgroup per bin, turns the bin-major per-block counts into positions INSIDE the
+// bin (exclusive, in place) and the bin's total; the scatter adds up the totals of the bins before its own by itself (96 values).
+// (The generic two-launch scan over the whole array cost 17 us of a 200 us build, and a third of a launch gap.)
+constexpr int BSCAN_THREADS = 256;
+__global__ void __launch_bounds__(BSCAN_THREADS) bucket_scan_kernel(uint32_t *__restrict__ hist, uint32_t nblk, uint32_t *__restrict__ bin_total)
+{
+    __shared__ uint32_t ws[BSCAN_THREADS / 64];
+    uint32_t *row = hist + (size_t)blockIdx.x * nblk;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    uint32_t carry = 0;
+    for (uint32_t b0 = 0; b0 < nblk; b0 += BSCAN_THREADS * 8) {
+        const uint32_t i0 = b0 + threadIdx.x * 8;
+        uint32_t v[8], t = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { v[k] = (i0 + k < nblk) ? row[i0 + k] : 0u; t += v[k]; }
+        uint32_t inc = t;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t u = __shfl_up(inc, d, 64); if (lane >= d) inc += u; }
+        if (lane == 63) ws[wid] = inc;
+        __syncthreads();
+        uint32_t before = carry, all = 0;
+#pragma unroll
+        for (int w = 0; w < BSCAN_THREADS / 64; ++w) { const uint32_t x = ws[w]; if (w < wid) before += x; all += x; }
+        __syncthreads();
+        uint32_t ex = before + inc - t;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { if (i0 + k < nblk) row[i0 + k] = ex; ex += v[k]; }
+        carry += all;
+    }
+    if (threadIdx.x == 0) bin_total[blockIdx.x] = carry;
+}
+
 __global__ void __launch_bounds__(EXT_THREADS) order_scatter_kernel(const uint8_t *__restrict__ order_bucket, int64_t N,
                                                                      const uint32_t *__restrict__ bucket_pos,
+                                                                     const uint32_t *__restrict__ bin_total,
                                                                      uint32_t *__restrict__ order, uint32_t *__restrict__ inv_order,
                                                                      uint32_t *__restrict__ level_start)
 {
     __shared__ uint32_t wcnt[EXT_THREADS / 64][ORDER_BUCKETS];
+    __shared__ uint32_t bin_base[ORDER_BUCKETS];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    // level_start[l] = rows with a binary level < l (the scanned level histogram at every level's first block,
-    // minus the N rows counted by the order buckets before it): gathered here for the host's one read-back
-    if (blockIdx.x == 0 && threadIdx.x < 64)
-        level_start[threadIdx.x] = bucket_pos[(size_t)(ORDER_BUCKETS + threadIdx.x) * gridDim.x] - (uint32_t)N;
+    // level_start[l] = rows with a binary level < l: the level bins' totals, scanned -- gathered here for the host's one read-back
+    if (blockIdx.x == 0 && threadIdx.x >= 64 && threadIdx.x < 128) {
+        const uint32_t t = bin_total[ORDER_BUCKETS + lane];
+        uint32_t inc = t;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t u = __shfl_up(inc, d, 64); if (lane >= d) inc += u; }
+        level_start[lane] = inc - t;
+    }
+    if (threadIdx.x < 64) {                             // rows of the order buckets before this one (ORDER_BUCKETS <= 64)
+        const uint32_t t = lane < ORDER_BUCKETS ? bin_total[lane] : 0u;
+        uint32_t inc = t;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t u = __shfl_up(inc, d, 64); if (lane >= d) inc += u; }
+        if (lane < ORDER_BUCKETS) bin_base[lane] = inc - t;
+    }
     const int64_t i = (int64_t)blockIdx.x * EXT_THREADS + threadIdx.x;
     const bool valid = i < N;
     const uint32_t b = valid ? order_bucket[i] : 0u;
@@ -338,7 +383,7 @@ __global__ void __launch_bounds__(EXT_THREADS) order_scatter_kernel(const uint8_
     if (valid) {
         uint32_t before = 0;
         for (int w = 0; w < wid; ++w) before += wcnt[w][b];
-        const uint32_t pos = bucket_pos[(size_t)b * gridDim.x + blockIdx.x] + before + rank;
+        const uint32_t pos = bin_base[b] + bucket_pos[(size_t)b * gridDim.x + blockIdx.x] + before + rank;
         order[pos] = (uint32_t)i;
         inv_order[i] = pos;
     }
@@ -613,6 +658,16 @@ __global__ __launch_bounds__(64) void tile_heights_kernel(const HeightArgs H)
     for (int s = 0; s < SPL; ++s) { const int j = lane + s * 64; if (j < nt) S.ht[e0 + j] = (uint8_t)ht[s]; }
 }
 
+static void launch_heights_kernel(const HeightArgs &H, int maxR, bool any_rows, hipStream_t s)
+{
+    const size_t lds = (size_t)((maxR + 15) & ~15) + (any_rows ? (size_t)maxR * 4 : 0);
+    const int spl = (maxR + 63) / 64;
+    if (spl <= 3) hipLaunchKernelGGL(tile_heights_kernel<3>, dim3(H.n_tiles), dim3(64), lds, s, H);
+    else if (spl <= 4) hipLaunchKernelGGL(tile_heights_kernel<4>, dim3(H.n_tiles), dim3(64), lds, s, H);
+    else if (spl <= 8) hipLaunchKernelGGL(tile_heights_kernel<8>, dim3(H.n_tiles), dim3(64), lds, s, H);
+    else hipLaunchKernelGGL(tile_heights_kernel<16>, dim3(H.n_tiles), dim3(64), lds, s, H);
+}
+
 // heights of every tile stage of a finished schedule: one launch (sizes are known on the host by now; enqueued, not
 // waited for: the transforms that read them run behind this on the same stream)
 static int launch_stage_heights(raht_plan *plan, Schedule &sc, hipStream_t s)
@@ -635,12 +690,7 @@ static int launch_stage_heights(raht_plan *plan, Schedule &sc, hipStream_t s)
     }
     if (H.n_stages == 0) return RAHT_OK;
     for (int q = H.n_stages; q < HT_MAX_STAGES; ++q) H.st[q] = H.st[0];
-    const size_t lds = (size_t)((maxR + 15) & ~15) + (any_rows ? (size_t)maxR * 4 : 0);
-    const int spl = (maxR + 63) / 64;
-    if (spl <= 3) hipLaunchKernelGGL(tile_heights_kernel<3>, dim3(H.n_tiles), dim3(64), lds, s, H);
-    else if (spl <= 4) hipLaunchKernelGGL(tile_heights_kernel<4>, dim3(H.n_tiles), dim3(64), lds, s, H);
-    else if (spl <= 8) hipLaunchKernelGGL(tile_heights_kernel<8>, dim3(H.n_tiles), dim3(64), lds, s, H);
-    else hipLaunchKernelGGL(tile_heights_kernel<16>, dim3(H.n_tiles), dim3(64), lds, s, H);
+    launch_heights_kernel(H, maxR, any_rows, s);
     RAHT_HIP_CHECK(hipGetLastError());
     return RAHT_OK;
 }
@@ -1385,11 +1435,12 @@ static int finish_plan(raht_plan *p, const int64_t *leaf_weights, hipStream_t s,
     const unsigned nblk = (unsigned)ceil_div(N, EXT_THREADS);
     // scratch: error word | level starts [64] | (order bucket + level) histograms / positions [(ORDER_BUCKETS + 64) x nblk]
     //          | search queue [EXT_QCAP x nblk] + counts [nblk] | bucket ids [N]
-    Scratch tmp(sizeof(PlanErr) + sizeof(uint32_t) * (64 + (size_t)(ORDER_BUCKETS + 64 + EXT_QCAP + 1) * nblk) + (size_t)N, s);
+    Scratch tmp(sizeof(PlanErr) + sizeof(uint32_t) * (64 + (ORDER_BUCKETS + 64) + (size_t)(ORDER_BUCKETS + 64 + EXT_QCAP + 1) * nblk) + (size_t)N, s);
     if (!tmp.ok()) return RAHT_ERR_NOMEM;
     PlanErr *derr = tmp.as<PlanErr>();
     uint32_t *lhist = (uint32_t *)((char *)tmp.ptr() + sizeof(PlanErr));
-    uint32_t *bhist = lhist + 64;
+    uint32_t *bin_total = lhist + 64;
+    uint32_t *bhist = bin_total + (ORDER_BUCKETS + 64);
     uint32_t *gq = bhist + (size_t)(ORDER_BUCKETS + 64) * nblk, *gq_count = gq + (size_t)EXT_QCAP * nblk;
     uint8_t *bucket = (uint8_t *)(gq_count + nblk);
     static_assert(sizeof(PlanErr) == 2 * sizeof(uint32_t), "PlanErr is read back as two words");
@@ -1408,9 +1459,12 @@ static int finish_plan(raht_plan *p, const int64_t *leaf_weights, hipStream_t s,
                        p->nbits, p->lvl, bucket, p->wl, p->wr, derr, bhist, gq, gq_count);
     hipLaunchKernelGGL(extent_search_kernel, dim3((unsigned)ceil_div((int64_t)nblk * EXT_QCAP, 256)), dim3(256), 0, s, p->keys, N, p->lvl,
                        gq, gq_count, nblk, p->wl, p->wr);
-    // order_RAGFT and its inverse: stable counting sort by bucket (histogram from the pass above)
-    RAHT_RET(exclusive_scan_u32(bhist, bhist, (int64_t)(ORDER_BUCKETS + 64) * nblk, nullptr, s));
-    hipLaunchKernelGGL(order_scatter_kernel, dim3(nblk), dim3(EXT_THREADS), 0, s, bucket, N, bhist, p->order, p->inv_order, lhist);
+    // order_RAGFT and its inverse: stable counting sort by bucket (histogram from the pass above). (Measured and dropped,
+    // round 3: this pair on a second stream next to the extent searches and the first schedule pass, and the stage-0 butterfly
+    // heights on a third next to the whole schedule build -- 0.245 / 0.235 ms against 0.226 ms on one stream: a cross-queue
+    // dependency costs ~13 us, and kernels this small slow each other down when they share the chip.)
+    hipLaunchKernelGGL(bucket_scan_kernel, dim3(ORDER_BUCKETS + 64), dim3(BSCAN_THREADS), 0, s, bhist, nblk, bin_total);
+    hipLaunchKernelGGL(order_scatter_kernel, dim3(nblk), dim3(EXT_THREADS), 0, s, bucket, N, bhist, bin_total, p->order, p->inv_order, lhist);
     if (getenv("RAHT_DEBUG_IDENTITY_ORDER")) {    // timing experiments only: order_RAGFT := identity
         hipLaunchKernelGGL(order_to_identity_kernel, dim3(gb), dim3(256), 0, s, p->order, N);
         hipLaunchKernelGGL(invert_perm_kernel, dim3(gb), dim3(256), 0, s, p->order, N, p->inv_order);

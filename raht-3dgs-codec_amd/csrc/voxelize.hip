@@ -217,26 +217,30 @@ __global__ __launch_bounds__(256) void voxel_mean_kernel(const float *__restrict
     }
 }
 
-// The same on 16-byte row chunks (raht_device.h) for d >= 8 attribute columns: a lane owns 4 columns of
-// a voxel, G lanes cover the row, a wave instruction moves 64 / G voxels and four such groups are in
-// flight; the last chunk of a row whose length is not a multiple of 4 is the 16 bytes that END it.
-// Duplicate points are still added in sorted order, and the division is the same correctly rounded
-// one, so results are bit-identical to the kernel above.
-__global__ __launch_bounds__(256) void voxel_mean_chunk_kernel(const float *__restrict__ PC, int64_t ld, int64_t N, int d, int lg,
+// Mean AND the voxelizer's secondary outputs in one pass over the gathered rows (ld = 3 + d >= 8 columns, 16-byte chunks of
+// the WHOLE row: chunk 0 = x, y, z and the first attribute). Two kernels (voxel_mean_chunk_kernel, then residual_chunk_kernel)
+// gather every point's row twice and read PCvox back once per point: 5 GB on 3 M x 59 where this form moves 3.2 GB. Per voxel
+// and chunk: first member's chunk (four voxel groups in flight), further members added in sorted order (:140-144), the mean
+// (:137,:144; columns < 3: the voxel's integer coordinates from its key, :152,:155), then -- members of a multi-point voxel are
+// gathered once more, the usual single point is still in its register -- PCsorted[k] = the row (:103-108) and DeltaPC[k] =
+// row - mean, positions: V0 - voxel_size * floor(V0 / voxel_size) (:110-111, :147-156). Same operations on the same operands
+// in the same order as the two kernels: bit-identical outputs.
+__global__ __launch_bounds__(256) void voxel_full_chunk_kernel(const float *__restrict__ PC, int64_t ldin, int64_t N, int ld, int lg,
                                                                const uint64_t *__restrict__ keys_sorted,
                                                                const uint32_t *__restrict__ sort_idx,
                                                                const uint32_t *__restrict__ vstart, int64_t nvox,
-                                                               float *__restrict__ PCvox, int64_t *__restrict__ Vvox)
+                                                               float *__restrict__ PCvox, int64_t *__restrict__ Vvox,
+                                                               float *__restrict__ PCsorted, float *__restrict__ Delta,
+                                                               float m0, float m1, float m2, float vsz)
 {
     const int lane = threadIdx.x & 63;
     const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
-    const int ldo = 3 + d;
     const int G = 1 << lg, rpi = 64 >> lg;                    // lg >= 1: rpi <= 32
     const int U = min(4, 32 / rpi);                           // voxel groups in flight; U * rpi <= 32 voxels per iteration
     const int vpi = U * rpi;
     const int g = lane >> lg, c4 = lane & (G - 1);
-    const int NC = (d + 3) >> 2;
+    const int NC = (ld + 3) >> 2;
     for (int64_t v0 = wave * vpi; v0 < nvox; v0 += nwaves * vpi) {
         const int64_t vi = v0 + lane;
         const uint32_t vs = (lane <= vpi && vi < nvox) ? vstart[vi] : (uint32_t)N;
@@ -245,43 +249,70 @@ __global__ __launch_bounds__(256) void voxel_mean_chunk_kernel(const float *__re
             first = sort_idx[vs];
             const uint64_t k = keys_sorted[vs];
             klo = (uint32_t)k; khi = (uint32_t)(k >> 32);
-            // integer voxel coordinates from the key (:152,:155)
-            const uint64_t key = ((uint64_t)khi << 32) | klo;
-            const uint32_t x = vx_compact3(key >> 2), y = vx_compact3(key >> 1), z = vx_compact3(key);
-            if (PCvox) { PCvox[vi * ldo + 0] = (float)x; PCvox[vi * ldo + 1] = (float)y; PCvox[vi * ldo + 2] = (float)z; }
-            if (Vvox) { Vvox[vi * 3 + 0] = x; Vvox[vi * 3 + 1] = y; Vvox[vi * 3 + 2] = z; }
+            if (Vvox) {
+                Vvox[vi * 3 + 0] = vx_compact3(k >> 2); Vvox[vi * 3 + 1] = vx_compact3(k >> 1); Vvox[vi * 3 + 2] = vx_compact3(k);
+            }
         }
-        if (!PCvox) continue;
-        // this lane's voxels: extents and first member. Shuffled here, with every lane active -- inside
-        // the chunk loop the idle lanes of a row group are masked off and a shuffle would read garbage
-        // from them (an extent of garbage is a multi-million-iteration member loop)
-        uint32_t s0[4], e0[4], i0[4];
+        // this lane's voxels: extents, first member, key. Shuffled here, with every lane active -- inside the chunk loop the
+        // idle lanes of a row group are masked off and a shuffle would read garbage from them (an extent of garbage is a
+        // multi-million-iteration member loop)
+        uint32_t s0[4], e0[4], i0[4], kl[4], kh[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int sel = min(u, U - 1) * rpi + g;
             s0[u] = (uint32_t)__shfl((int)vs, sel, 64);
             e0[u] = (uint32_t)__shfl((int)vs, sel + 1, 64);
             i0[u] = (uint32_t)__shfl((int)first, sel, 64);
+            kl[u] = (uint32_t)__shfl((int)klo, sel, 64);
+            kh[u] = (uint32_t)__shfl((int)khi, sel, 64);
         }
         for (int cc = c4; cc < NC; cc += G) {
-            const int goff = 3 + min(cc * 4, d - 4);
+            const int goff = min(cc * 4, ld - 4);
             RegChunk<float> acc[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) acc[u] = ld_chunk<float, true>(PC + (int64_t)i0[u] * ld + goff);
+            for (int u = 0; u < 4; ++u) acc[u] = ld_chunk<float, true>(PC + (int64_t)i0[u] * ldin + goff);
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int64_t v = v0 + u * rpi + g;
                 if (u >= U || v >= nvox) continue;
                 RegChunk<float> a = acc[u];
                 for (uint32_t i = s0[u] + 1; i < e0[u]; ++i) {       // further members (rare), sorted order (:140-144)
-                    const RegChunk<float> b = ld_chunk<float, true>(PC + (int64_t)sort_idx[i] * ld + goff);
+                    const RegChunk<float> b = ld_chunk<float, true>(PC + (int64_t)sort_idx[i] * ldin + goff);
 #pragma unroll
                     for (int q = 0; q < 4; ++q) a.v[q] += b.v[q];
                 }
                 const float cnt = (float)(e0[u] - s0[u]);
 #pragma unroll
                 for (int q = 0; q < 4; ++q) a.v[q] = __fdiv_rn(a.v[q], cnt);                  // :137,:144
-                st_chunk<float, true>(PCvox + v * ldo + goff, a);
+                if (goff < 3) {                                                                 // integer voxel coordinates from the key (:152,:155)
+                    const uint64_t key = ((uint64_t)kh[u] << 32) | kl[u];
+                    const float cx = (float)vx_compact3(key >> 2), cy = (float)vx_compact3(key >> 1), cz = (float)vx_compact3(key);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int c = goff + q;
+                        if (c < 3) a.v[q] = (c == 0) ? cx : (c == 1 ? cy : cz);
+                    }
+                }
+                if (PCvox) st_chunk<float, true>(PCvox + v * ld + goff, a);
+                if (!PCsorted && !Delta) continue;
+                for (uint32_t i = s0[u]; i < e0[u]; ++i) {
+                    const RegChunk<float> x = (i == s0[u]) ? acc[u] : ld_chunk<float, true>(PC + (int64_t)sort_idx[i] * ldin + goff);
+                    if (PCsorted) st_chunk<float, true>(PCsorted + (int64_t)i * ld + goff, x);  // :103-108
+                    if (Delta) {
+                        RegChunk<float> dl;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const int c = goff + q;
+                            if (c < 3) {
+                                const float w0 = x.v[q] - (c == 0 ? m0 : (c == 1 ? m1 : m2));    // :92, :103
+                                dl.v[q] = __fsub_rn(w0, __fmul_rn(vsz, floorf(__fdiv_rn(w0, vsz))));  // :110-111 (no fma: two torch ops)
+                            } else {
+                                dl.v[q] = x.v[q] - a.v[q];                                      // :147-148
+                            }
+                        }
+                        st_chunk<float, true>(Delta + (int64_t)i * ld + goff, dl);
+                    }
+                }
             }
         }
     }
@@ -399,10 +430,11 @@ int raht_voxelize_residuals(const float *PC, int64_t ldpc, int64_t N, int d, con
     return RAHT_OK;
 }
 
-int raht_voxelize(const float *PC, int64_t ldpc, int64_t N, int d, const float *vmin_in, double width_in,
-                  int J, uint64_t *keys_sorted, int64_t *sort_idx, int64_t *voxel_indices, float *PCvox,
-                  int64_t *Vvox, int64_t *n_vox, float vmin_out[3], double *width_out,
-                  double *voxel_size_out, raht_stream_t stream)
+static int voxelize_impl(const float *PC, int64_t ldpc, int64_t N, int d, const float *vmin_in, double width_in,
+                         int J, uint64_t *keys_sorted, int64_t *sort_idx, int64_t *voxel_indices, float *PCvox,
+                         int64_t *Vvox, int64_t *n_vox, float vmin_out[3], double *width_out,
+                         double *voxel_size_out, raht_stream_t stream, uint64_t *voxel_keys,
+                         float *PCsorted = nullptr, float *DeltaPC = nullptr)
 {
     if (!PC || N < 1 || d < 0 || ldpc < 3 + d || J < 1 || J > 21 || !n_vox) { set_error("raht_voxelize: bad argument"); return RAHT_ERR_INVALID; }
     if (N >= ((int64_t)1 << 31)) { set_error("raht_voxelize: N too large"); return RAHT_ERR_INVALID; }
@@ -451,18 +483,27 @@ int raht_voxelize(const float *PC, int64_t ldpc, int64_t N, int d, const float *
         for (int attempt = 0; attempt < 2; ++attempt) {
             uint32_t bad = 0;
             RAHT_RET(sort_keys_u32idx(keys, N, 3 * J, ks, idx, s, attempt == 0 ? sort_err : nullptr, sort_idx, &G));
-            RAHT_RET(run_starts_u64(ks, N, vstart, voxel_indices, nullptr, &nv, s, sort_err, &bad));      // (the sort's error word rides along)
+            RAHT_RET(run_starts_u64(ks, N, vstart, voxel_indices, voxel_keys, &nv, s, sort_err, &bad));      // (the sort's error word rides along)
             if (!bad) break;
         }
-        if (PCvox || Vvox) {
+        const bool want_res = PCsorted || DeltaPC;
+        const bool fused = PCvox && d >= 5;                                 // whole rows in 16-byte chunks: 3 + d >= 8 columns
+        if (PCvox || Vvox || want_res) {
             const unsigned gv = (unsigned)std::min<int64_t>(ceil_div(nv, 64), 8192);
-            if (PCvox && d >= 8) {
+            if (fused) {
                 int lg = 1;
-                while ((1 << lg) < (d + 3) / 4 && lg < 6) ++lg;
-                hipLaunchKernelGGL(voxel_mean_chunk_kernel, dim3(gv), dim3(256), 0, s, PC, ldpc, N, d, lg, ks, idx, vstart, nv, PCvox, Vvox);
+                while ((1 << lg) < (3 + d + 3) / 4 && lg < 6) ++lg;
+                hipLaunchKernelGGL(voxel_full_chunk_kernel, dim3(gv), dim3(256), 0, s, PC, ldpc, N, 3 + d, lg, ks, idx, vstart, nv, PCvox, Vvox,
+                                   PCsorted, DeltaPC, vmin[0], vmin[1], vmin[2], vs);
             } else {
                 hipLaunchKernelGGL(voxel_mean_kernel, dim3(gv), dim3(256), 0, s, PC, ldpc, N, d, ks, idx, vstart, nv, PCvox, Vvox);
             }
+        }
+        if (want_res && !fused) {
+            // narrow clouds: the two-call sequence (sort_idx as int64 is what raht_voxelize_residuals takes)
+            if (!sort_idx) { set_error("raht_voxelize: residuals of a cloud with fewer than 5 attribute columns need sort_idx"); return RAHT_ERR_INVALID; }
+            if (DeltaPC) RAHT_RET(raht_voxelize_residuals(PC, ldpc, N, d, ks, sort_idx, PCvox, vmin, voxel_size, PCsorted, DeltaPC, stream));
+            else RAHT_RET(raht_rows_gather(PC, ldpc, sort_idx, N, 3 + d, 4, PCsorted, 3 + d, stream));
         }
         hipError_t e = hipStreamSynchronize(s);
         if (e == hipSuccess) e = hipGetLastError();
@@ -473,6 +514,40 @@ int raht_voxelize(const float *PC, int64_t ldpc, int64_t N, int d, const float *
     if (width_out) *width_out = width;
     if (voxel_size_out) *voxel_size_out = voxel_size;
     return RAHT_OK;
+}
+
+int raht_voxelize(const float *PC, int64_t ldpc, int64_t N, int d, const float *vmin_in, double width_in,
+                  int J, uint64_t *keys_sorted, int64_t *sort_idx, int64_t *voxel_indices, float *PCvox,
+                  int64_t *Vvox, int64_t *n_vox, float vmin_out[3], double *width_out,
+                  double *voxel_size_out, raht_stream_t stream)
+{
+    return voxelize_impl(PC, ldpc, N, d, vmin_in, width_in, J, keys_sorted, sort_idx, voxel_indices, PCvox, Vvox, n_vox, vmin_out,
+                         width_out, voxel_size_out, stream, nullptr);
+}
+
+int raht_voxelize_all(const float *PC, int64_t ldpc, int64_t N, int d, const float *vmin_in, double width_in,
+                      int J, uint64_t *keys_sorted, int64_t *sort_idx, int64_t *voxel_indices, float *PCvox,
+                      int64_t *Vvox, float *PCsorted, float *DeltaPC, int64_t *n_vox, float vmin_out[3], double *width_out,
+                      double *voxel_size_out, raht_stream_t stream)
+{
+    if (DeltaPC && d > 0 && !PCvox) { set_error("raht_voxelize_all: DeltaPC needs PCvox"); return RAHT_ERR_INVALID; }
+    return voxelize_impl(PC, ldpc, N, d, vmin_in, width_in, J, keys_sorted, sort_idx, voxel_indices, PCvox, Vvox, n_vox, vmin_out,
+                         width_out, voxel_size_out, stream, nullptr, PCsorted, DeltaPC);
+}
+
+int raht_voxelize_plan(const float *PC, int64_t ldpc, int64_t N, int d, const float *vmin_in, double width_in,
+                       int J, uint64_t *voxel_keys, int64_t *voxel_indices, float *PCvox, int64_t *n_vox,
+                       float vmin_out[3], double *width_out, double *voxel_size_out, raht_stream_t stream, raht_plan **plan)
+{
+    if (!voxel_keys || !plan) { set_error("raht_voxelize_plan: NULL argument"); return RAHT_ERR_INVALID; }
+    *plan = nullptr;
+    int64_t nv = 0;
+    RAHT_RET(voxelize_impl(PC, ldpc, N, d, vmin_in, width_in, J, nullptr, nullptr, voxel_indices, PCvox, nullptr, &nv, vmin_out,
+                           width_out, voxel_size_out, stream, voxel_keys));
+    if (n_vox) *n_vox = nv;
+    // the voxels' keys are sorted and unique by construction; the plan build checks them anyway (it reads them to find the
+    // levels) and BORROWS the caller's array
+    return raht_plan_create_from_keys_borrowed(voxel_keys, nv, 3 * J, nullptr, stream, plan);
 }
 
 }  // extern "C"

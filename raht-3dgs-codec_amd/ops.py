@@ -640,9 +640,9 @@ def voxelize_pc_batched(PC, vmin=None, width=None, J=10, device="cuda", residual
 
     Returns (PCvox, PCsorted, voxel_indices, DeltaPC, info) like the reference. PCvox,
     voxel_indices, info['sort_idx'] and the sorted Morton keys (info['keys_sorted'], extra) come
-    from the HIP voxelizer; PCsorted / DeltaPC are its secondary outputs (``raht_voxelize_residuals``;
-    ``residuals=False`` skips DeltaPC; ``sorted_points=False`` also skips PCsorted -- a full gather of the
-    cloud -- and returns None in its place; the codec path only consumes PCvox).
+    from the HIP voxelizer; PCsorted / DeltaPC are its secondary outputs, produced by the same call (``raht_voxelize_all``:
+    the pass that forms the voxel means writes them too; ``residuals=False`` skips DeltaPC; ``sorted_points=False`` skips
+    PCsorted and returns None in its place; the codec path only consumes PCvox).
     """
     PC = PC.to(device)
     _need_cuda(PC, "PC")
@@ -660,28 +660,21 @@ def voxelize_pc_batched(PC, vmin=None, width=None, J=10, device="cuda", residual
     vm = None
     if vmin is not None:
         vm = (C.c_float * 3)(*[float(x) for x in (vmin.detach().cpu().tolist() if isinstance(vmin, torch.Tensor) else vmin)])
+    # the secondary outputs (voxelize_pc.py:103-111, 147-156) come out of the same call: the pass that forms the voxel means
+    # has every point's row in registers anyway (raht_voxelize_all; raht_voxelize + raht_voxelize_residuals give the same bits)
+    PCsorted = torch.empty((N, ld), dtype=torch.float32, device=dev) if sorted_points else None
+    DeltaPC = torch.empty((N, ld), dtype=torch.float32, device=dev) if residuals else None
     with torch.cuda.device(dev):
-        check(_lib.lib().raht_voxelize(C.c_void_p(PC.data_ptr()), ld, N, d, vm, -1.0 if width is None else float(width),
-                                       int(J), C.c_void_p(keys.data_ptr()), C.c_void_p(idx.data_ptr()),
-                                       C.c_void_p(vidx.data_ptr()), C.c_void_p(pcv.data_ptr()), None, C.byref(nvox),
-                                       vmin_out, C.byref(w_out), C.byref(vs_out), _stream()))
+        check(_lib.lib().raht_voxelize_all(C.c_void_p(PC.data_ptr()), ld, N, d, vm, -1.0 if width is None else float(width),
+                                           int(J), C.c_void_p(keys.data_ptr()), C.c_void_p(idx.data_ptr()),
+                                           C.c_void_p(vidx.data_ptr()), C.c_void_p(pcv.data_ptr()), None,
+                                           C.c_void_p(PCsorted.data_ptr()) if PCsorted is not None else None,
+                                           C.c_void_p(DeltaPC.data_ptr()) if DeltaPC is not None else None, C.byref(nvox),
+                                           vmin_out, C.byref(w_out), C.byref(vs_out), _stream()))
     nv = nvox.value
     voxel_indices = vidx[:nv]
     PCvox = pcv[:nv]
     vmin_t = torch.tensor(list(vmin_out), dtype=torch.float32, device=dev)
-    PCsorted, DeltaPC = None, None
-    if residuals or sorted_points:
-        # the secondary outputs, behind the C ABI as well (voxelize_pc.py:103-111, 147-156)
-        PCsorted = torch.empty((N, ld), dtype=torch.float32, device=dev) if (sorted_points or not residuals) else None
-        if residuals:
-            DeltaPC = torch.empty((N, ld), dtype=torch.float32, device=dev)
-            with torch.cuda.device(dev):
-                check(_lib.lib().raht_voxelize_residuals(C.c_void_p(PC.data_ptr()), ld, N, d, C.c_void_p(keys.data_ptr()),
-                                                         C.c_void_p(idx.data_ptr()), C.c_void_p(PCvox.data_ptr()), vmin_out,
-                                                         vs_out.value, C.c_void_p(PCsorted.data_ptr()) if PCsorted is not None else None,
-                                                         C.c_void_p(DeltaPC.data_ptr()), _stream()))
-        else:
-            rows_gather(PC, idx, PCsorted)
     info = {"Nvox": nv, "voxel_size": vs_out.value, "vmin": vmin_t, "width": w_out.value, "N": N,
             "sort_idx": idx, "keys_sorted": keys}
     return PCvox, PCsorted, voxel_indices, DeltaPC, info
@@ -692,10 +685,32 @@ def voxelize_plan(PC, vmin=None, width=None, J=10, device="cuda"):
     """Unsorted cloud -> (PCvox, plan, info): the voxelizer's own sorted voxel keys go STRAIGHT into the RAHT plan
     (reference: voxelize_pc_batched, python/voxelize_pc.py:62-172, then -- one script later, through a PLY file --
     RAHT_param_reorder_fast on the voxel coordinates, python/RAHT_param.py:190-279, which re-derives the same Morton keys).
-    No key recomputation, no key copy (the plan borrows the key tensor and keeps it alive), one plan build per frame.
-    PCvox[:, 3:] is the attribute matrix in the plan's row order."""
-    PCvox, _, vidx, _, info = voxelize_pc_batched(PC, vmin, width, J, device=device, residuals=False, sorted_points=False)
-    vkeys = info["keys_sorted"][vidx]                     # first point of every voxel: sorted, unique
-    plan = RahtPlan.from_keys(vkeys, 3 * int(J), borrow=True)
-    info = dict(info, voxel_keys=vkeys, voxel_indices=vidx)
-    return PCvox, plan, info
+    No key recomputation, no key copy (the plan borrows the key tensor and keeps it alive), one plan build per frame, ONE call
+    through the C ABI (raht_voxelize_plan). PCvox[:, 3:] is the attribute matrix in the plan's row order. info: Nvox,
+    voxel_size, vmin (HOST tensor), width, N, voxel_keys, voxel_indices."""
+    PC = PC.to(device)
+    _need_cuda(PC, "PC")
+    PC = PC.to(torch.float32).contiguous()
+    N, ld = PC.shape
+    dev = PC.device
+    vkeys = torch.empty(N, dtype=torch.int64, device=dev)
+    vidx = torch.empty(N, dtype=torch.int64, device=dev)
+    pcv = torch.empty((N, ld), dtype=torch.float32, device=dev)
+    nvox = C.c_int64()
+    vmin_out = (C.c_float * 3)()
+    w_out, vs_out = C.c_double(), C.c_double()
+    vm = None
+    if vmin is not None:
+        vm = (C.c_float * 3)(*[float(x) for x in (vmin.detach().cpu().tolist() if isinstance(vmin, torch.Tensor) else vmin)])
+    h = C.c_void_p()
+    with torch.cuda.device(dev):
+        check(_lib.lib().raht_voxelize_plan(C.c_void_p(PC.data_ptr()), ld, N, ld - 3, vm, -1.0 if width is None else float(width),
+                                            int(J), C.c_void_p(vkeys.data_ptr()), C.c_void_p(vidx.data_ptr()), C.c_void_p(pcv.data_ptr()),
+                                            C.byref(nvox), vmin_out, C.byref(w_out), C.byref(vs_out), _stream(), C.byref(h)))
+    nv = nvox.value
+    plan = RahtPlan(h, dev)
+    vkeys = vkeys[:nv]
+    plan._keys_ref = vkeys                                # borrowed by the plan: alive as long as it is
+    info = {"Nvox": nv, "voxel_size": vs_out.value, "vmin": torch.tensor(list(vmin_out), dtype=torch.float32), "width": w_out.value,
+            "N": N, "voxel_keys": vkeys, "voxel_indices": vidx[:nv]}
+    return pcv[:nv], plan, info

@@ -329,6 +329,44 @@ def test_voxelizer_residuals(rt, oracle, name):
     assert out[3] is None and np.array_equal(out[1].cpu().numpy(), pcs)
 
 
+@pytest.mark.parametrize("d,J,n", [(5, 5, 30000), (11, 6, 40000), (56, 9, 60000), (56, 4, 20000), (61, 7, 30000), (70, 6, 20000), (130, 6, 9000)])
+def test_voxelizer_all_outputs_in_one_pass(rt, oracle, d, J, n):
+    """raht_voxelize_all (clouds with >= 5 attribute columns: means, PCsorted and DeltaPC from ONE pass over the gathered rows)
+    against the oracle's voxelizer bit for bit, and against the two-call sequence raht_voxelize + raht_voxelize_residuals;
+    voxels with many points (J = 4: ~5 per voxel), row lengths that are / are not multiples of four, rows longer than a wave's
+    64 chunks' worth of lanes."""
+    import ctypes as C
+    import torch
+    from raht_3dgs_codec_amd import _lib
+    rng = np.random.default_rng(1000 + d + J)
+    P = (rng.random((n, 3)) * 3.0 - 0.5).astype(np.float32)
+    P[::5] = P[1::5][: P[::5].shape[0]]                       # exact duplicates as well
+    PC = np.concatenate([P, rng.standard_normal((n, d)).astype(np.float32)], axis=1)
+    PCvox, PCsorted, vidx, DeltaPC, info = rt.voxelize_pc_batched(_dev(PC), None, None, J, device="cuda")
+    r = oracle.voxelize(PC, J)
+    pcs, dl = oracle.voxel_residuals(PC, r)
+    assert info["Nvox"] == r["Nvox"]
+    assert np.array_equal(info["sort_idx"].cpu().numpy(), r["sort_idx"]) and np.array_equal(vidx.cpu().numpy(), r["voxel_indices"])
+    np.testing.assert_array_equal(PCvox.cpu().numpy(), r["PCvox"])
+    np.testing.assert_array_equal(PCsorted.cpu().numpy(), pcs)
+    np.testing.assert_array_equal(DeltaPC.cpu().numpy(), dl)
+    # the two-call sequence through the C ABI
+    L = _lib.lib()
+    vp = C.c_void_p
+    PCd = _dev(PC)
+    ld = 3 + d
+    keys = torch.empty(n, dtype=torch.int64, device="cuda"); idx = torch.empty_like(keys); vi2 = torch.empty_like(keys)
+    pcv2 = torch.empty((n, ld), dtype=torch.float32, device="cuda")
+    nv = C.c_int64(); vmin = (C.c_float * 3)(); w = C.c_double(); vs = C.c_double()
+    _lib.check(L.raht_voxelize(vp(PCd.data_ptr()), ld, n, d, None, -1.0, J, vp(keys.data_ptr()), vp(idx.data_ptr()), vp(vi2.data_ptr()),
+                               vp(pcv2.data_ptr()), None, C.byref(nv), vmin, C.byref(w), C.byref(vs), None))
+    pcs2 = torch.empty((n, ld), dtype=torch.float32, device="cuda"); dl2 = torch.empty_like(pcs2)
+    _lib.check(L.raht_voxelize_residuals(vp(PCd.data_ptr()), ld, n, d, vp(keys.data_ptr()), vp(idx.data_ptr()), vp(pcv2.data_ptr()), vmin,
+                                         vs.value, vp(pcs2.data_ptr()), vp(dl2.data_ptr()), None))
+    torch.cuda.synchronize()
+    assert nv.value == r["Nvox"] and torch.equal(pcv2[: nv.value], PCvox) and torch.equal(pcs2, PCsorted) and torch.equal(dl2, DeltaPC)
+
+
 def test_voxelize_matches_oracle_bitwise(rt, oracle):
     """Same stable order and sequential float32 sums as the C oracle -> means are bit-identical."""
     rng = np.random.default_rng(5)
@@ -945,6 +983,10 @@ def test_voxelize_plan_feeds_the_plan_from_the_voxelizers_keys(rt, oracle):
     PCvox, plan, info = rt.voxelize_plan(torch.from_numpy(PC).cuda(), None, None, J)
     ref = oracle.voxelize(PC, J)
     assert plan.N == ref["Nvox"] and np.array_equal(PCvox.cpu().numpy(), ref["PCvox"])
+    # the one-call entry point (raht_voxelize_plan) hands out what the two-call sequence would: voxel starts and voxel keys
+    assert np.array_equal(info["voxel_indices"].cpu().numpy(), ref["voxel_indices"])
+    assert np.array_equal(info["voxel_keys"].cpu().numpy().view(np.uint64), np.asarray(ref["keys_sorted"]).view(np.uint64)[ref["voxel_indices"]])
+    assert info["Nvox"] == ref["Nvox"] and abs(info["voxel_size"] - float(ref["voxel_size"])) <= 1e-12 * float(ref["voxel_size"])
     V = PCvox[:, :3].double()
     ListC, _, _, order = rt.raht_fn["RAHT_param"](V, torch.zeros(3, dtype=torch.float64, device="cuda"), 2 ** J, J)
     assert torch.equal(order, plan.order_RAGFT)
