@@ -165,10 +165,10 @@ int compact_u32(const uint32_t *in, const uint32_t *flag, uint32_t *out, int64_t
                 int64_t *count_host, hipStream_t s, const uint32_t *extra_dev = nullptr, uint32_t *extra_host = nullptr);
 
 // starts[k] = index of the first element of the k-th run of equal keys in a SORTED key array; optionally the same as int64
-// (starts64) and the key of every run (run_keys). *count_host = number of runs (synchronises the stream through the mailbox;
-// extra_dev / extra_host: one more device word read back along with it). Two launches.
+// (starts64) and the key of every run (run_keys). *count_dev (DEVICE word) = number of runs. Two launches, no host round trip:
+// the voxelizer's next kernel reads the count on the device.
 int run_starts_u64(const uint64_t *keys_sorted, int64_t n, uint32_t *starts, int64_t *starts64, uint64_t *run_keys,
-                   int64_t *count_host, hipStream_t s, const uint32_t *extra_dev = nullptr, uint32_t *extra_host = nullptr);
+                   uint32_t *count_dev, hipStream_t s);
 
 // ---- plan (plan.hip) ---------------------------------------------------------------------------
 constexpr int RAHT_TOP_MAX_ROWS = 8192;   // entries the TOP stage can hold (16 bytes each in LDS)

@@ -679,7 +679,8 @@ __global__ __launch_bounds__(OS_THREADS) void os_pass_kernel(const uint64_t *__r
                                                              int shift, int bits, const uint32_t *__restrict__ slices,
                                                              uint32_t *__restrict__ state, uint32_t *__restrict__ gstate,
                                                              uint32_t *__restrict__ ticket, uint32_t *__restrict__ err,
-                                                             int64_t *__restrict__ vals64_out /* last pass: the payload widened, or NULL */)
+                                                             int64_t *__restrict__ vals64_out /* last pass: the payload widened, or NULL */,
+                                                             uint32_t fail_tile /* tests: this tile gives up (RAHT_SORT_DEBUG_FAIL_TILE) */)
 {
     constexpr int WAVE_ITEMS = 64 * ROUNDS, TILE = OS_WAVES * WAVE_ITEMS;
     // 53 272 bytes with 16 rounds = 42 of the CU's 128 LDS granules: three tiles per CU, 768 on the chip (the 733 tiles of a
@@ -768,7 +769,7 @@ __global__ __launch_bounds__(OS_THREADS) void os_pass_kernel(const uint64_t *__r
     for (int r = 0; r < ROUNDS / 2; ++r) rank_round(r);
     OS_STAMP(3);
     // phase 4a: keys of digit d in the tiles before this one in its group; the group's last tile publishes the group's total
-    bool bad = false;
+    bool bad = (tile == fail_tile);
     uint32_t sum_in = 0;
     const bool leader = (j == OS_GROUP - 1u);
     uint32_t *gmine = gstate + (size_t)g * 256 + d;
@@ -860,17 +861,21 @@ static void os_launch_pass(const uint64_t *kin, const uint32_t *vin, uint64_t *k
 {
     const unsigned nt = (unsigned)ceil_div(n, (int64_t)OS_WAVES * 64 * ROUNDS);
     static int tk = -1;
-    if (tk < 0) { const char *e = getenv("RAHT_SORT_TICKET"); tk = (e && e[0] == '1') ? 1 : 0; }
+    static uint32_t fail_tile = 0xffffffffu;
+    if (tk < 0) {
+        const char *e = getenv("RAHT_SORT_TICKET"); tk = (e && e[0] == '1') ? 1 : 0;
+        const char *f = getenv("RAHT_SORT_DEBUG_FAIL_TILE"); if (f) fail_tile = (uint32_t)strtoul(f, nullptr, 10);
+    }
     if (tk) {
         if (vin)
-            hipLaunchKernelGGL((os_pass_kernel<ROUNDS, true, true>), dim3(nt), dim3(OS_THREADS), 0, s, kin, vin, kout, vout, n, shift, bits, slices, state, gstate, ticket, err, v64);
+            hipLaunchKernelGGL((os_pass_kernel<ROUNDS, true, true>), dim3(nt), dim3(OS_THREADS), 0, s, kin, vin, kout, vout, n, shift, bits, slices, state, gstate, ticket, err, v64, fail_tile);
         else
-            hipLaunchKernelGGL((os_pass_kernel<ROUNDS, false, true>), dim3(nt), dim3(OS_THREADS), 0, s, kin, vin, kout, vout, n, shift, bits, slices, state, gstate, ticket, err, v64);
+            hipLaunchKernelGGL((os_pass_kernel<ROUNDS, false, true>), dim3(nt), dim3(OS_THREADS), 0, s, kin, vin, kout, vout, n, shift, bits, slices, state, gstate, ticket, err, v64, fail_tile);
     } else {
         if (vin)
-            hipLaunchKernelGGL((os_pass_kernel<ROUNDS, true, false>), dim3(nt), dim3(OS_THREADS), 0, s, kin, vin, kout, vout, n, shift, bits, slices, state, gstate, ticket, err, v64);
+            hipLaunchKernelGGL((os_pass_kernel<ROUNDS, true, false>), dim3(nt), dim3(OS_THREADS), 0, s, kin, vin, kout, vout, n, shift, bits, slices, state, gstate, ticket, err, v64, fail_tile);
         else
-            hipLaunchKernelGGL((os_pass_kernel<ROUNDS, false, false>), dim3(nt), dim3(OS_THREADS), 0, s, kin, vin, kout, vout, n, shift, bits, slices, state, gstate, ticket, err, v64);
+            hipLaunchKernelGGL((os_pass_kernel<ROUNDS, false, false>), dim3(nt), dim3(OS_THREADS), 0, s, kin, vin, kout, vout, n, shift, bits, slices, state, gstate, ticket, err, v64, fail_tile);
     }
 }
 
@@ -1029,20 +1034,16 @@ __global__ __launch_bounds__(SCAN_THREADS) void run_starts_kernel(const uint64_t
 }
 
 int run_starts_u64(const uint64_t *keys_sorted, int64_t n, uint32_t *starts, int64_t *starts64, uint64_t *run_keys,
-                   int64_t *count_host, hipStream_t s, const uint32_t *extra_dev, uint32_t *extra_host)
+                   uint32_t *count_dev, hipStream_t s)
 {
-    *count_host = 0;
     if (n <= 0) return RAHT_OK;
     const int64_t nb = ceil_div(n, SCAN_BLOCK);
-    Scratch ws(sizeof(uint32_t) * ((size_t)nb + 1), s);
+    Scratch ws(sizeof(uint32_t) * (size_t)nb, s);
     if (!ws.ok()) return RAHT_ERR_NOMEM;
-    uint32_t *blk = ws.as<uint32_t>(), *total = blk + nb;
+    uint32_t *blk = ws.as<uint32_t>();
     hipLaunchKernelGGL(run_count_kernel, dim3((unsigned)nb), dim3(SCAN_THREADS), 0, s, keys_sorted, n, blk);
-    hipLaunchKernelGGL(run_starts_kernel, dim3((unsigned)nb), dim3(SCAN_THREADS), 0, s, keys_sorted, n, blk, starts, starts64, run_keys, total);
+    hipLaunchKernelGGL(run_starts_kernel, dim3((unsigned)nb), dim3(SCAN_THREADS), 0, s, keys_sorted, n, blk, starts, starts64, run_keys, count_dev);
     RAHT_HIP_CHECK(hipGetLastError());
-    uint32_t t = 0;
-    RAHT_RET(read_back_u32(&t, total, 1, extra_host, extra_dev, extra_dev ? 1 : 0, s));     // (the caller's word rides along)
-    *count_host = t;
     return RAHT_OK;
 }
 

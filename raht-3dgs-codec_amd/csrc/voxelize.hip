@@ -168,9 +168,14 @@ __global__ void u32_to_i64_kernel(const uint32_t *__restrict__ in, int64_t n, in
 __global__ __launch_bounds__(256) void voxel_mean_kernel(const float *__restrict__ PC, int64_t ld, int64_t N, int d,
                                                          const uint64_t *__restrict__ keys_sorted,
                                                          const uint32_t *__restrict__ sort_idx,
-                                                         const uint32_t *__restrict__ vstart, int64_t nvox,
+                                                         const uint32_t *__restrict__ vstart, const uint32_t *__restrict__ nvox_dev,
                                                          float *__restrict__ PCvox, int64_t *__restrict__ Vvox)
 {
+    // the voxel count comes from the launch before this one and the sort's error word from the launches before that: no
+    // host round trip in between. A sort that gave up (never seen; the host then repeats it pass by pass) left stale
+    // indices behind: nothing may be gathered through them.
+    if (nvox_dev[-1] != 0u) return;
+    const int64_t nvox = *nvox_dev;
     const int lane = threadIdx.x & 63;
     const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
@@ -228,11 +233,16 @@ __global__ __launch_bounds__(256) void voxel_mean_kernel(const float *__restrict
 __global__ __launch_bounds__(256) void voxel_full_chunk_kernel(const float *__restrict__ PC, int64_t ldin, int64_t N, int ld, int lg,
                                                                const uint64_t *__restrict__ keys_sorted,
                                                                const uint32_t *__restrict__ sort_idx,
-                                                               const uint32_t *__restrict__ vstart, int64_t nvox,
+                                                               const uint32_t *__restrict__ vstart, const uint32_t *__restrict__ nvox_dev,
                                                                float *__restrict__ PCvox, int64_t *__restrict__ Vvox,
                                                                float *__restrict__ PCsorted, float *__restrict__ Delta,
                                                                float m0, float m1, float m2, float vsz)
 {
+    // the voxel count comes from the launch before this one and the sort's error word from the launches before that: no
+    // host round trip in between. A sort that gave up (never seen; the host then repeats it pass by pass) left stale
+    // indices behind: nothing may be gathered through them.
+    if (nvox_dev[-1] != 0u) return;
+    const int64_t nvox = *nvox_dev;
     const int lane = threadIdx.x & 63;
     const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
@@ -319,13 +329,13 @@ __global__ __launch_bounds__(256) void voxel_full_chunk_kernel(const float *__re
 }
 
 // Stable sort of (key, original index). `sort_err` (device word, may be NULL) selects the one-sweep form
-// (scan_sort.hip: npass + 2 launches); the caller checks the word once the stream has drained (sort_failed) and repeats
-// the call with sort_err = NULL -- the pass-by-pass form, four launches per digit -- in the never-seen case that it is set.
+// (scan_sort.hip: npass + 2 launches); the caller checks the word once the stream has drained and repeats the call with
+// onesweep = false -- the pass-by-pass form, four launches per digit; the word is cleared -- in the never-seen case that it is set.
 // `grid` (may be NULL): keys_in is an OUTPUT as well -- the keys of the cloud's points, computed on the way (inside the
 // one-sweep form's histogram launch, or by vox_keys_kernel in front of the pass-by-pass form).
 static int sort_keys_u32idx(const uint64_t *keys_in, int64_t N, int nbits, uint64_t *keys_out,
                                   uint32_t *idx_out, hipStream_t s, uint32_t *sort_err = nullptr, int64_t *idx64_out = nullptr,
-                                  const VoxGrid *grid = nullptr)
+                                  const VoxGrid *grid = nullptr, bool onesweep = true)
 {
     // LSD passes of 8 bits; ping-pong between two (key, index) buffers, last pass lands in *_out
     const int npass = std::max(1, (nbits + 7) / 8);
@@ -334,7 +344,7 @@ static int sort_keys_u32idx(const uint64_t *keys_in, int64_t N, int nbits, uint6
     uint64_t *ktmp = tmp.as<uint64_t>();
     uint32_t *itmp = (uint32_t *)(ktmp + N);
     if (sort_err) {
-        const int rc1 = sort_pairs_onesweep(keys_in, N, nbits, keys_out, idx_out, ktmp, itmp, sort_err, s, idx64_out, grid);
+        const int rc1 = onesweep ? sort_pairs_onesweep(keys_in, N, nbits, keys_out, idx_out, ktmp, itmp, sort_err, s, idx64_out, grid) : 1;
         if (rc1 <= 0) return rc1;                        // enqueued (or failed); 1 = not applicable
         RAHT_HIP_CHECK(hipMemsetAsync(sort_err, 0, sizeof(uint32_t), s));
     }
@@ -376,7 +386,7 @@ int raht_sort_keys(const uint64_t *keys_in, int64_t N, int nbits, uint64_t *keys
     if (!ib.ok()) return RAHT_ERR_NOMEM;
     uint32_t *idx32 = ib.as<uint32_t>(), *sort_err = idx32 + N;
     for (int attempt = 0; attempt < 2; ++attempt) {
-        RAHT_RET(sort_keys_u32idx(keys_in, N, nbits, keys_out, idx32, s, attempt == 0 ? sort_err : nullptr, idx_out));
+        RAHT_RET(sort_keys_u32idx(keys_in, N, nbits, keys_out, idx32, s, sort_err, idx_out, nullptr, attempt == 0));
         RAHT_HIP_CHECK(hipGetLastError());
         // idx32 returns to the pool when this frame ends: the read-back of the sort's error word is also the wait for the stream
         uint32_t bad = 0;
@@ -472,42 +482,46 @@ static int voxelize_impl(const float *PC, int64_t ldpc, int64_t N, int d, const 
     const float vs = (float)voxel_size;
 
     // ---- keys, sort ----
-    Scratch kb(sizeof(uint64_t) * 2 * (size_t)N, s), ib(sizeof(uint32_t) * (2 * (size_t)N + 1), s);
+    Scratch kb(sizeof(uint64_t) * 2 * (size_t)N, s), ib(sizeof(uint32_t) * (2 * (size_t)N + 2), s);
     if (!kb.ok() || !ib.ok()) return RAHT_ERR_NOMEM;
     uint64_t *keys = kb.as<uint64_t>();
     uint64_t *ks = keys_sorted ? keys_sorted : keys + N;
-    uint32_t *idx = ib.as<uint32_t>(), *vstart = idx + N, *sort_err = vstart + N;
+    uint32_t *idx = ib.as<uint32_t>(), *vstart = idx + N, *sort_err = vstart + N, *nv_dev = sort_err + 1;      // (the voxel kernels read nv_dev[-1])
     int64_t nv = 0;
+    const bool want_res = PCsorted || DeltaPC;
+    const bool fused = PCvox && d >= 5;                                 // whole rows in 16-byte chunks: 3 + d >= 8 columns
+    if (want_res && !fused && !sort_idx) { set_error("raht_voxelize: residuals of a cloud with fewer than 5 attribute columns need sort_idx"); return RAHT_ERR_INVALID; }
     {
+        // ONE host round trip per call, at the end: keys + histogram, digit bases, the sort's passes, voxel starts (count on the
+        // device), means / residuals are enqueued back to back; the read-back of the count and of the sort's error word is the wait
         const VoxGrid G = {PC, ldpc, vmin[0], vmin[1], vmin[2], vs, J};
         for (int attempt = 0; attempt < 2; ++attempt) {
-            uint32_t bad = 0;
-            RAHT_RET(sort_keys_u32idx(keys, N, 3 * J, ks, idx, s, attempt == 0 ? sort_err : nullptr, sort_idx, &G));
-            RAHT_RET(run_starts_u64(ks, N, vstart, voxel_indices, voxel_keys, &nv, s, sort_err, &bad));      // (the sort's error word rides along)
-            if (!bad) break;
-        }
-        const bool want_res = PCsorted || DeltaPC;
-        const bool fused = PCvox && d >= 5;                                 // whole rows in 16-byte chunks: 3 + d >= 8 columns
-        if (PCvox || Vvox || want_res) {
-            const unsigned gv = (unsigned)std::min<int64_t>(ceil_div(nv, 64), 8192);
-            if (fused) {
-                int lg = 1;
-                while ((1 << lg) < (3 + d + 3) / 4 && lg < 6) ++lg;
-                hipLaunchKernelGGL(voxel_full_chunk_kernel, dim3(gv), dim3(256), 0, s, PC, ldpc, N, 3 + d, lg, ks, idx, vstart, nv, PCvox, Vvox,
-                                   PCsorted, DeltaPC, vmin[0], vmin[1], vmin[2], vs);
-            } else {
-                hipLaunchKernelGGL(voxel_mean_kernel, dim3(gv), dim3(256), 0, s, PC, ldpc, N, d, ks, idx, vstart, nv, PCvox, Vvox);
+            RAHT_RET(sort_keys_u32idx(keys, N, 3 * J, ks, idx, s, sort_err, sort_idx, &G, attempt == 0));
+            RAHT_RET(run_starts_u64(ks, N, vstart, voxel_indices, voxel_keys, nv_dev, s));
+            if (PCvox || Vvox || want_res) {
+                const unsigned gv = (unsigned)std::min<int64_t>(ceil_div(N, 64), 8192);        // (N >= the voxel count)
+                if (fused) {
+                    int lg = 1;
+                    while ((1 << lg) < (3 + d + 3) / 4 && lg < 6) ++lg;
+                    hipLaunchKernelGGL(voxel_full_chunk_kernel, dim3(gv), dim3(256), 0, s, PC, ldpc, N, 3 + d, lg, ks, idx, vstart, nv_dev, PCvox, Vvox,
+                                       PCsorted, DeltaPC, vmin[0], vmin[1], vmin[2], vs);
+                } else {
+                    hipLaunchKernelGGL(voxel_mean_kernel, dim3(gv), dim3(256), 0, s, PC, ldpc, N, d, ks, idx, vstart, nv_dev, PCvox, Vvox);
+                }
             }
+            RAHT_HIP_CHECK(hipGetLastError());
+            uint32_t back[2] = {0, 0};                       // { sort error, voxel count }: adjacent device words
+            RAHT_RET(read_back_u32(back, sort_err, 2, nullptr, nullptr, 0, s));
+            nv = back[1];
+            if (!back[0]) break;                             // (else: once more with the pass-by-pass sort)
         }
         if (want_res && !fused) {
             // narrow clouds: the two-call sequence (sort_idx as int64 is what raht_voxelize_residuals takes)
-            if (!sort_idx) { set_error("raht_voxelize: residuals of a cloud with fewer than 5 attribute columns need sort_idx"); return RAHT_ERR_INVALID; }
             if (DeltaPC) RAHT_RET(raht_voxelize_residuals(PC, ldpc, N, d, ks, sort_idx, PCvox, vmin, voxel_size, PCsorted, DeltaPC, stream));
             else RAHT_RET(raht_rows_gather(PC, ldpc, sort_idx, N, 3 + d, 4, PCsorted, 3 + d, stream));
+            hipError_t e = hipStreamSynchronize(s);
+            if (e != hipSuccess) { set_error("raht_voxelize: %s", hipGetErrorString(e)); return RAHT_ERR_HIP; }
         }
-        hipError_t e = hipStreamSynchronize(s);
-        if (e == hipSuccess) e = hipGetLastError();
-        if (e != hipSuccess) { set_error("raht_voxelize: %s", hipGetErrorString(e)); return RAHT_ERR_HIP; }
     }
     *n_vox = nv;
     if (vmin_out) { vmin_out[0] = vmin[0]; vmin_out[1] = vmin[1]; vmin_out[2] = vmin[2]; }

@@ -1000,13 +1000,18 @@ def test_voxelize_plan_feeds_the_plan_from_the_voxelizers_keys(rt, oracle):
 
 # ---- the key sort in its three forms (csrc/scan_sort.hip) --------------------------------------------------------------
 @pytest.mark.gpu
-@pytest.mark.parametrize("env", [{}, {"RAHT_SORT_TICKET": "1"}, {"RAHT_SORT_ONESWEEP": "0"}, {"RAHT_SORT_ROUNDS": "8"}, {"RAHT_SORT_ROUNDS": "12"}],
-                         ids=["one-sweep", "one-sweep, ticketed tiles", "pass by pass", "2048-item tiles", "3072-item tiles"])
+@pytest.mark.parametrize("env", [{}, {"RAHT_SORT_TICKET": "1"}, {"RAHT_SORT_ONESWEEP": "0"}, {"RAHT_SORT_ROUNDS": "8"}, {"RAHT_SORT_ROUNDS": "12"},
+                                 {"RAHT_SORT_DEBUG_FAIL_TILE": "0"}, {"RAHT_SORT_DEBUG_FAIL_TILE": "37"}],
+                         ids=["one-sweep", "one-sweep, ticketed tiles", "pass by pass", "2048-item tiles", "3072-item tiles",
+                              "tile 0 gives up -> fallback", "tile 37 gives up -> fallback"])
 def test_key_sort_forms_equal_a_stable_sort(env):
     """raht_sort_keys == torch.sort(stable=True), keys AND permutation, for sizes around the tile edges (1 ... 3 000 017), every
     digit-pass count (1 ... 63 key bits) and inputs full of duplicates -- in the default one-sweep form (tiles numbered by
-    workgroup index), with ticketed tiles, and in the pass-by-pass form the library falls back to. The knobs are read once per
-    process: each form runs tools/check_sort.py in its own interpreter."""
+    workgroup index), with ticketed tiles, and in the pass-by-pass form the library falls back to; and with one tile of every
+    one-sweep pass made to give up (RAHT_SORT_DEBUG_FAIL_TILE): the tiles after it pass the error on and write nothing, the grid
+    drains, the host finds the error word and repeats the sort pass by pass -- same results, and the voxelizer (whose mean
+    kernel is enqueued BEHIND the sort without a host round trip) must not gather through the stale indices. The knobs are read
+    once per process: each form runs tools/check_sort.py in its own interpreter."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

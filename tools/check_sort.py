@@ -23,6 +23,21 @@ for n in (1, 2, 63, 64, 65, 255, 256, 257, 2047, 2048, 2049, 4095, 4096, 4097, 1
         if not ok:
             bad += 1
             print("MISMATCH n=%d nbits=%d keys_equal=%s idx_equal=%s" % (n, nbits, bool((ks == rs).all()), bool((idx == ri).all())))
+# the voxelizer on top of the same sort (its mean kernel runs behind the sort without a host round trip in between)
+rng = np.random.default_rng(3)
+for n, d, J in ((5000, 11, 6), (200000, 56, 8), (9000, 2, 5)):
+    P = (rng.random((n, 3)) * 2.0).astype(np.float32)
+    PC = torch.from_numpy(np.concatenate([P, rng.standard_normal((n, d)).astype(np.float32)], axis=1)).to(dev)
+    PCvox, PCsorted, vidx, DeltaPC, info = R.voxelize_pc_batched(PC, None, None, J, device=dev)
+    k = info["keys_sorted"]
+    si = info["sort_idx"]
+    ok = bool((k[1:] >= k[:-1]).all()) and bool(torch.equal(PCsorted, PC[si])) and int(vidx.shape[0]) == int((k[1:] != k[:-1]).sum()) + 1
+    cnt = torch.diff(torch.cat([vidx, torch.tensor([n], device=dev)]))
+    mean0 = torch.zeros(vidx.shape[0], device=dev, dtype=torch.float64).index_add_(0, torch.repeat_interleave(torch.arange(vidx.shape[0], device=dev), cnt), PCsorted[:, 3].double()) / cnt
+    ok = ok and bool((PCvox[:, 3].double() - mean0).abs().max() < 1e-5)
+    if not ok:
+        bad += 1
+        print("VOXELIZER MISMATCH n=%d d=%d J=%d" % (n, d, J))
 print("correctness: %d mismatches" % bad)
 if "--time" in sys.argv:
     n, J, D, seed = synth.CONFIGS["cfg3"]
