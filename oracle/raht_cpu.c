@@ -352,6 +352,57 @@ int raht_cpu_voxelize_residuals(const float *PC, int64_t ldpc, int64_t N, int d,
     return rc == 0 ? RAHT_OK : RAHT_ERR_INVALID;
 }
 
+/* raht_voxelize_all: the two calls in sequence (the product produces all outputs from one pass; the results are the same) */
+int raht_cpu_voxelize_all(const float *PC, int64_t ldpc, int64_t N, int d, const float *vmin_in, double width_in,
+                          int J, uint64_t *keys_sorted, int64_t *sort_idx, int64_t *voxel_indices, float *PCvox,
+                          int64_t *Vvox, float *PCsorted, float *DeltaPC, int64_t *n_vox, float vmin_out[3],
+                          double *width_out, double *voxel_size_out, raht_stream_t stream)
+{
+    if (!PC || N < 1 || d < 0 || !n_vox) { set_err("raht_cpu_voxelize_all: bad argument"); return RAHT_ERR_INVALID; }
+    if (DeltaPC && d > 0 && !PCvox) { set_err("raht_cpu_voxelize_all: DeltaPC needs PCvox"); return RAHT_ERR_INVALID; }
+    const int ld = 3 + d;
+    uint64_t *ks = keys_sorted ? keys_sorted : (uint64_t *)malloc(sizeof(uint64_t) * (size_t)N);
+    int64_t *si = sort_idx ? sort_idx : (int64_t *)malloc(sizeof(int64_t) * (size_t)N);
+    float vm[3]; double w = 0, vs = 0;
+    int rc = (ks && si) ? raht_cpu_voxelize(PC, ldpc, N, d, vmin_in, width_in, J, ks, si, voxel_indices, PCvox, Vvox, n_vox, vm, &w, &vs, stream)
+                        : RAHT_ERR_NOMEM;
+    if (rc == RAHT_OK && DeltaPC) rc = raht_cpu_voxelize_residuals(PC, ldpc, N, d, ks, si, PCvox, vm, vs, PCsorted, DeltaPC, stream);
+    else if (rc == RAHT_OK && PCsorted)
+        for (int64_t k = 0; k < N; ++k) memcpy(PCsorted + k * ld, PC + si[k] * ldpc, sizeof(float) * (size_t)ld);      /* voxelize_pc.py:103-108 */
+    if (rc == RAHT_OK) {
+        if (vmin_out) memcpy(vmin_out, vm, sizeof(vm));
+        if (width_out) *width_out = w;
+        if (voxel_size_out) *voxel_size_out = vs;
+    }
+    if (!keys_sorted) free(ks);
+    if (!sort_idx) free(si);
+    return rc;
+}
+
+/* raht_voxelize_plan: voxelize, the keys of the voxels' first points, the plan from those keys (borrowed) */
+int raht_cpu_voxelize_plan(const float *PC, int64_t ldpc, int64_t N, int d, const float *vmin_in, double width_in,
+                           int J, uint64_t *voxel_keys, int64_t *voxel_indices, float *PCvox, int64_t *n_vox,
+                           float vmin_out[3], double *width_out, double *voxel_size_out, raht_stream_t stream,
+                           raht_cpu_plan **plan)
+{
+    if (!voxel_keys || !plan) { set_err("raht_cpu_voxelize_plan: NULL argument"); return RAHT_ERR_INVALID; }
+    *plan = NULL;
+    if (N < 1) { set_err("raht_cpu_voxelize_plan: bad argument"); return RAHT_ERR_INVALID; }
+    uint64_t *ks = (uint64_t *)malloc(sizeof(uint64_t) * (size_t)N);
+    int64_t *vi = voxel_indices ? voxel_indices : (int64_t *)malloc(sizeof(int64_t) * (size_t)N);
+    int64_t nv = 0;
+    int rc = (ks && vi) ? raht_cpu_voxelize(PC, ldpc, N, d, vmin_in, width_in, J, ks, NULL, vi, PCvox, NULL, &nv, vmin_out, width_out, voxel_size_out, stream)
+                        : RAHT_ERR_NOMEM;
+    if (rc == RAHT_OK) {
+        for (int64_t v = 0; v < nv; ++v) voxel_keys[v] = ks[vi[v]];
+        if (n_vox) *n_vox = nv;
+        rc = raht_cpu_plan_create_from_keys_borrowed(voxel_keys, nv, 3 * J, NULL, stream, plan);
+    }
+    free(ks);
+    if (!voxel_indices) free(vi);
+    return rc;
+}
+
 int raht_cpu_morton(const int64_t *V, int64_t N, int J, uint64_t *keys, raht_stream_t stream)
 {
     (void)stream;

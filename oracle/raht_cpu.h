@@ -81,6 +81,14 @@ int raht_cpu_voxelize(const float *PC, int64_t ldpc, int64_t N, int d, const flo
 int raht_cpu_voxelize_residuals(const float *PC, int64_t ldpc, int64_t N, int d, const uint64_t *keys_sorted,
                             const int64_t *sort_idx, const float *PCvox, const float vmin[3], double voxel_size,
                             float *PCsorted, float *DeltaPC, raht_stream_t stream);
+int raht_cpu_voxelize_all(const float *PC, int64_t ldpc, int64_t N, int d, const float *vmin_in, double width_in,
+                      int J, uint64_t *keys_sorted, int64_t *sort_idx, int64_t *voxel_indices, float *PCvox,
+                      int64_t *Vvox, float *PCsorted, float *DeltaPC, int64_t *n_vox, float vmin_out[3],
+                      double *width_out, double *voxel_size_out, raht_stream_t stream);
+int raht_cpu_voxelize_plan(const float *PC, int64_t ldpc, int64_t N, int d, const float *vmin_in, double width_in,
+                       int J, uint64_t *voxel_keys, int64_t *voxel_indices, float *PCvox, int64_t *n_vox,
+                       float vmin_out[3], double *width_out, double *voxel_size_out, raht_stream_t stream,
+                       raht_cpu_plan **plan);
 int raht_cpu_morton(const int64_t *V, int64_t N, int J, uint64_t *keys, raht_stream_t stream);
 int raht_cpu_sort_keys(const uint64_t *keys_in, int64_t N, int nbits, uint64_t *keys_out,
                    int64_t *idx_out, raht_stream_t stream);

@@ -247,3 +247,82 @@ def test_batch_twins_equal_scene_by_scene_calls(twins):
         assert np.array_equal(Q1, Qb[i]) and np.array_equal(T1, Tb[i]) and np.array_equal(R1, Rb[i])
         twins.raht_cpu_plan_destroy(plans[i])
     assert twins.raht_cpu_fwd_batch(0, hp, cp, ld, D, tp, ld, None) != 0
+
+
+def _voxelize_calls(lib, prefix, ptr, alloc, fetch, PC, J):
+    """raht[_cpu]_voxelize_all and raht[_cpu]_voxelize_plan on one cloud -> dict of their outputs (numpy)."""
+    n, ld = PC.shape
+    d = ld - 3
+    vp = C.c_void_p
+    P = alloc((n, ld), np.float32, PC)
+    keys, idx, vi = alloc((n,), np.int64), alloc((n,), np.int64), alloc((n,), np.int64)
+    pcv, pcs, dl = alloc((n, ld), np.float32), alloc((n, ld), np.float32), alloc((n, ld), np.float32)
+    nv = C.c_int64(); vmin = (C.c_float * 3)(); w = C.c_double(); vs = C.c_double()
+    f = getattr(lib, prefix + "voxelize_all")
+    f.argtypes = [vp, C.c_int64, C.c_int64, C.c_int, C.POINTER(C.c_float), C.c_double, C.c_int, vp, vp, vp, vp, vp, vp, vp,
+                  C.POINTER(C.c_int64), C.POINTER(C.c_float), C.POINTER(C.c_double), C.POINTER(C.c_double), vp]
+    assert f(ptr(P), ld, n, d, None, -1.0, J, ptr(keys), ptr(idx), ptr(vi), ptr(pcv), None, ptr(pcs), ptr(dl), C.byref(nv), vmin,
+             C.byref(w), C.byref(vs), None) == 0
+    out = dict(nv=nv.value, keys=fetch(keys).copy(), idx=fetch(idx).copy(), vi=fetch(vi)[: nv.value].copy(), pcv=fetch(pcv)[: nv.value].copy(),
+               pcs=fetch(pcs).copy(), dl=fetch(dl).copy(), vmin=list(vmin), width=w.value, vs=vs.value)
+    g = getattr(lib, prefix + "voxelize_plan")
+    g.argtypes = [vp, C.c_int64, C.c_int64, C.c_int, C.POINTER(C.c_float), C.c_double, C.c_int, vp, vp, vp, C.POINTER(C.c_int64),
+                  C.POINTER(C.c_float), C.POINTER(C.c_double), C.POINTER(C.c_double), vp, C.POINTER(vp)]
+    vk, vi2, pcv2 = alloc((n,), np.int64), alloc((n,), np.int64), alloc((n, ld), np.float32)
+    h = vp()
+    assert g(ptr(P), ld, n, d, None, -1.0, J, ptr(vk), ptr(vi2), ptr(pcv2), C.byref(nv), vmin, C.byref(w), C.byref(vs), None, C.byref(h)) == 0
+    size = getattr(lib, prefix + "plan_size"); size.argtypes = [vp]; size.restype = C.c_int64
+    order = alloc((nv.value,), np.int64)
+    po = getattr(lib, prefix + "plan_order"); po.argtypes = [vp, vp, vp]
+    assert size(h) == nv.value and po(h, ptr(order), None) == 0
+    out.update(vkeys=fetch(vk)[: nv.value].copy(), vi2=fetch(vi2)[: nv.value].copy(), pcv2=fetch(pcv2)[: nv.value].copy(), order=fetch(order).copy())
+    pd = getattr(lib, prefix + "plan_destroy"); pd.argtypes = [vp]
+    assert pd(h) == 0
+    return out
+
+
+def _cloud(seed, n, d):
+    rng = np.random.default_rng(seed)
+    P = (rng.random((n, 3)) * 4.0 - 1.0).astype(np.float32)
+    P[::7] = P[1::7][: P[::7].shape[0]]
+    return np.concatenate([P, rng.standard_normal((n, d)).astype(np.float32)], axis=1)
+
+
+def test_voxelizer_twins_one_call_forms(twins):
+    """raht_cpu_voxelize_all == raht_cpu_voxelize + raht_cpu_voxelize_residuals (which the golden fixtures pin), and
+    raht_cpu_voxelize_plan builds its plan from the keys of the voxels' first points."""
+    from oracle import oracle as orc
+    PC = _cloud(21, 4000, 6)
+    o = _voxelize_calls(twins, "raht_cpu_", _vp, lambda s, t, i=None: (np.ascontiguousarray(i, dtype=t).copy() if i is not None else np.zeros(s, t)), lambda a: a, PC, 6)
+    r = orc.voxelize(PC, 6)
+    pcs, dl = orc.voxel_residuals(PC, r)
+    assert o["nv"] == r["Nvox"] and np.array_equal(o["idx"], r["sort_idx"]) and np.array_equal(o["vi"], r["voxel_indices"])
+    assert np.array_equal(o["pcv"], r["PCvox"]) and np.array_equal(o["pcs"], pcs) and np.array_equal(o["dl"], dl)
+    assert np.array_equal(o["vkeys"].view(np.uint64), np.asarray(r["keys_sorted"]).view(np.uint64)[r["voxel_indices"]])
+    assert np.array_equal(o["vi2"], o["vi"]) and np.array_equal(o["pcv2"], o["pcv"])
+    assert np.array_equal(np.sort(o["order"]), np.arange(o["nv"]))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("d", [2, 11, 56])
+def test_voxelizer_one_call_forms_through_both_libraries(twins, d):
+    """raht_voxelize_all / raht_voxelize_plan on the MI355X against their host twins: every output bit for bit (narrow clouds take
+    the two-call sequence inside, wide ones the one-pass kernel)."""
+    import torch
+    from raht_3dgs_codec_amd import _lib
+    PC = _cloud(30 + d, 30000, d)
+    host = _voxelize_calls(twins, "raht_cpu_", _vp, lambda s, t, i=None: (np.ascontiguousarray(i, dtype=t).copy() if i is not None else np.zeros(s, t)), lambda a: a, PC, 7)
+    keep = []
+
+    def alloc(shape, dtype, init=None):
+        t = torch.zeros(tuple(shape), dtype=getattr(torch, np.dtype(dtype).name), device="cuda")
+        if init is not None:
+            t.copy_(torch.from_numpy(np.ascontiguousarray(init, dtype=dtype)))
+        keep.append(t)
+        return t
+    dev = _voxelize_calls(_lib.lib(), "raht_", lambda t: C.c_void_p(t.data_ptr()), alloc, lambda t: (torch.cuda.synchronize(), t.cpu().numpy())[1], PC, 7)
+    for k in host:
+        if isinstance(host[k], np.ndarray):
+            assert np.array_equal(dev[k], host[k]), k
+        else:
+            assert dev[k] == host[k], k
