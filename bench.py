@@ -748,6 +748,11 @@ def main():
             # sorted voxel keys (borrowed, not copied)
             pre["voxelize_plan"] = roof(wall(lambda: R.voxelize_plan(PC, [0.0, 0.0, 0.0], float(2 ** J), J, device=dev)), vox_alg + 17.0 * N)
             pre["plan_from_sorted_keys_borrowed"] = roof(wall(lambda: R.RahtPlan.from_keys(kd, 3 * J, borrow=True)), 9.0 * N + 8.0 * N)
+            # what a frame of a dynamic sequence pays in front of its transform, stage by stage (the round-2 review's target: <= 0.9 ms)
+            pre["plan_plus_sort_plus_voxelize_ms"] = round(pre["plan_from_sorted_keys"]["ms"] + pre["radix_sort_%dbit" % (3 * J)]["ms"] + pre["voxelize"]["ms"], 4)
+            pre["note"] = ("sort: one histogram launch for every digit + one launch per digit pass whose tiles chain their offsets (scan_sort.hip); voxelize: keys "
+                           "inside the sort's histogram launch, voxel starts in two launches, one host round trip; voxelize_with_residuals: raht_voxelize_all, "
+                           "means + PCsorted + DeltaPC from one pass over the gathered rows; voxelize_plan: raht_voxelize_plan (one call)")
             out["prelude"] = pre
             del PC, xyz, ku, perm
 
