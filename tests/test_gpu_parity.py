@@ -367,6 +367,30 @@ def test_voxelizer_all_outputs_in_one_pass(rt, oracle, d, J, n):
     assert nv.value == r["Nvox"] and torch.equal(pcv2[: nv.value], PCvox) and torch.equal(pcs2, PCsorted) and torch.equal(dl2, DeltaPC)
 
 
+@pytest.mark.parametrize("n,d,J,mode", [(1, 6, 5, "rand"), (2, 6, 5, "same"), (63, 9, 3, "rand"), (5000, 7, 1, "rand"), (4097, 5, 6, "same"),
+                                        (2049, 56, 10, "rand"), (300, 0, 4, "rand"), (300, 3, 4, "same")])
+def test_voxelizer_edge_shapes(rt, oracle, n, d, J, mode):
+    """One point, two identical points, every point in one voxel (one run of equal keys spanning several blocks of the run-start
+    kernels), a cloud of one voxel per point, position-only clouds, fewer points than a wave -- all outputs against the oracle."""
+    rng = np.random.default_rng(n * 31 + d)
+    P = (rng.random((n, 3)) * 2.0).astype(np.float32)
+    if mode == "same":
+        P[1:] = P[0]
+    PC = np.concatenate([P, rng.standard_normal((n, d)).astype(np.float32)], axis=1)
+    vmin, width = ([0.0, 0.0, 0.0], 2.0) if (n < 3 or mode == "same") else (None, None)          # (identical points have no extent of their own)
+    PCvox, PCsorted, vidx, DeltaPC, info = rt.voxelize_pc_batched(_dev(PC), vmin, width, J, device="cuda")
+    r = oracle.voxelize(PC, J, vmin=None if vmin is None else np.asarray(vmin, np.float32), width=width)
+    pcs, dl = oracle.voxel_residuals(PC, r)
+    assert info["Nvox"] == r["Nvox"] and (mode != "same" or info["Nvox"] == 1)
+    assert np.array_equal(info["sort_idx"].cpu().numpy(), r["sort_idx"]) and np.array_equal(vidx.cpu().numpy(), r["voxel_indices"])
+    np.testing.assert_array_equal(PCvox.cpu().numpy(), r["PCvox"])
+    np.testing.assert_array_equal(PCsorted.cpu().numpy(), pcs)
+    np.testing.assert_array_equal(DeltaPC.cpu().numpy(), dl)
+    if d >= 1 and n >= 2:
+        PCvox2, plan, info2 = rt.voxelize_plan(_dev(PC), vmin, width, J)
+        assert plan.N == r["Nvox"] and np.array_equal(PCvox2.cpu().numpy(), r["PCvox"])
+
+
 def test_voxelize_matches_oracle_bitwise(rt, oracle):
     """Same stable order and sequential float32 sums as the C oracle -> means are bit-identical."""
     rng = np.random.default_rng(5)
