@@ -444,6 +444,13 @@ int raht_rlgr_seg_decode(const uint8_t *in, int64_t in_bytes, const uint32_t *se
                          int D, int seg_len, int flag_signed, int32_t *Q, int64_t chan_stride, uint32_t *bad_dev,
                          raht_stream_t stream);
 
+/* out[c] = sum over rows of (A[i, c] - B[i, c])^2, DEVICE double[D]: what the drivers' five PSNR columns are made of
+ * (python/encode_3dgs.py:298-310: torch.mean((C - C_rec) ** 2) over all / quats / scales / opacity / colour columns -- each a
+ * sum of these D numbers divided by the element count). A, B: N x D DEVICE matrices of dtype RAHT_F32 or RAHT_F64 (differences
+ * in that type, squares and sums in float64, deterministic). Two launches, no host round trip. */
+int raht_sqdiff_columns(const void *A, int64_t lda, const void *B, int64_t ldb, int64_t N, int D, int dtype, double *out,
+                        raht_stream_t stream);
+
 /* Host: are two contiguous int32 arrays equal? *first_diff = index of the first difference or -1. Threaded (the drivers'
  * round-trip assertion, python/encode_3dgs.py:242-245, on 10^8 symbols). */
 int raht_i32_equal(const int32_t *a, const int32_t *b, int64_t n, int nthreads, int64_t *first_diff);

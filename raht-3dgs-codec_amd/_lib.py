@@ -26,7 +26,7 @@ EXPORTS = [
     "raht_voxel_keys", "raht_voxelize_residuals", "raht_plan_set_row_map", "raht_rows_gather", "raht_rows_scatter",
     "raht_plan_set_max_stages", "raht_quant_reorder_f64", "raht_dequant_unreorder_f64", "raht_fwd_quant_f64", "raht_dequant_inv_f64",
     "raht_fwd_batch", "raht_inv_batch", "raht_fwd_quant_batch", "raht_dequant_inv_batch",
-    "raht_rlgr_bound", "raht_rlgr_encode", "raht_rlgr_decode", "raht_rlgr_encode_channels", "raht_rlgr_decode_channels", "raht_transpose_i32", "raht_i32_equal", "raht_merge_clusters", "raht_rlgr_seg_encode", "raht_rlgr_seg_decode",
+    "raht_rlgr_bound", "raht_rlgr_encode", "raht_rlgr_decode", "raht_rlgr_encode_channels", "raht_rlgr_decode_channels", "raht_transpose_i32", "raht_i32_equal", "raht_sqdiff_columns", "raht_merge_clusters", "raht_rlgr_seg_encode", "raht_rlgr_seg_decode",
     "raht_xchg_bytes", "raht_xchg_alloc", "raht_xchg_open", "raht_xchg_close", "raht_xchg_free", "raht_xchg_gather", "raht_xchg_buffer", "raht_xchg_status",
 ]
 
@@ -112,6 +112,7 @@ def lib():
     L.raht_dequant_rows.argtypes = [vp, i64, vp, i64, i32, C.POINTER(C.c_float), i32, vp, i64, vp]
     L.raht_voxelize.argtypes = [vp, i64, i64, i32, C.POINTER(C.c_float), dbl, i32, vp, vp, vp, vp, vp,
                                 C.POINTER(i64), C.POINTER(C.c_float), C.POINTER(dbl), C.POINTER(dbl), vp]
+    L.raht_sqdiff_columns.argtypes = [vp, i64, vp, i64, i64, i32, i32, vp, vp]
     L.raht_voxelize_all.argtypes = [vp, i64, i64, i32, C.POINTER(C.c_float), dbl, i32, vp, vp, vp, vp, vp, vp, vp,
                                     C.POINTER(i64), C.POINTER(C.c_float), C.POINTER(dbl), C.POINTER(dbl), vp]
     L.raht_voxelize_plan.argtypes = [vp, i64, i64, i32, C.POINTER(C.c_float), dbl, i32, vp, vp, vp, C.POINTER(i64),

@@ -398,7 +398,8 @@ __global__ __launch_bounds__(RP_THREADS) void radix_scatter_kernel(
     }
     __syncthreads();
     // phase 3: rank inside the round by ballots, bump the wave's running slot, place into LDS
-    volatile uint32_t *myc = wcnt[wid];
+    // (wavefront-scope atomics, not a volatile pointer: hipcc turns volatile LDS accesses through a pointer into FLAT loads /
+    // stores with system-scope cache bits and a s_waitcnt vmcnt(0) each. Within a wave LDS operations execute in order.)
     const uint64_t lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
 #pragma unroll
     for (int r = 0; r < RP_ROUNDS; ++r) {
@@ -410,9 +411,9 @@ __global__ __launch_bounds__(RP_THREADS) void radix_scatter_kernel(
         const uint64_t same = match_digit(d, bits, vmask);
         const uint32_t rank = (uint32_t)__popcll(same & lt);
         uint32_t slot = 0;
-        if (valid) slot = myc[d] + rank;
+        if (valid) slot = __hip_atomic_load(&wcnt[wid][d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT) + rank;
         __builtin_amdgcn_wave_barrier();
-        if (valid && rank == 0) myc[d] = slot + (uint32_t)__popcll(same);
+        if (valid && rank == 0) __hip_atomic_store(&wcnt[wid][d], slot + (uint32_t)__popcll(same), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
         __builtin_amdgcn_wave_barrier();
         if (valid) { skey[slot] = key[r]; sval[slot] = val[r]; }
     }

@@ -257,12 +257,24 @@ __device__ __forceinline__ P *row_far(P *base, uint32_t row, uint32_t ld, uint32
 // that LDS is being written, so it neither drains the load at the next LDS access it cannot tell apart from the
 // destination (every one, with one dynamic LDS block) nor counts it -- its own s_waitcnt vmcnt(n) are then merely
 // stricter than needed (the counter retires in order). The kernel waits for the data itself: tile_kernel, sync #3.
-template <bool STREAM = false>                          // STREAM: nontemporal (matrices touched once: C, T, Q)
+template <int MODE = 0>      // 0: default policy; 1: nontemporal (matrices touched once: C, T, Q); 2: agent-coherent (sc1: rows another
+                             // workgroup of the SAME launch has just written through -- forward chaining, tile_kernel_chain)
 __device__ __forceinline__ void glds16(const void *g, uint32_t lds_base)
 {
     const uint32_t b = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_base);
-    if constexpr (STREAM) asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off nt" :: "v"(g), "s"(b) : "memory");
+    if constexpr (MODE == 1) asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off nt" :: "v"(g), "s"(b) : "memory");
+    else if constexpr (MODE == 2) asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off sc1" :: "v"(g), "s"(b) : "memory");
     else asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(g), "s"(b) : "memory");
+}
+// 16 bytes written THROUGH the XCD's L2 (sc1: agent scope): visible to the other XCDs once the store has been acknowledged
+// (s_waitcnt vmcnt(0)), without the L2 write-back an agent-scope release fence costs
+template <typename T>
+__device__ __forceinline__ void st_chunk_wt(T *p, const RegChunk<T> &x)
+{
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 v;
+    __builtin_memcpy(&v, &x, 16);
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(p), "v"(v) : "memory");
 }
 
 // IDENT = true is stage 0 (entries are the rows themselves: the HBM-heavy launch); IDENT = false
@@ -280,7 +292,7 @@ __device__ __forceinline__ void glds16(const void *g, uint32_t lds_base)
 //
 // tile_body is the kernel; tile_kernel runs it for ONE scene (workgroup b takes tiles b, b + gridDim.x, ...), tile_kernel_batch
 // for several scenes in one launch (workgroup b takes ONE tile of the scene whose tile range holds b).
-template <typename T, bool INV, bool IDENT, bool QM, int SLOTS>
+template <typename T, bool INV, bool IDENT, bool QM, int SLOTS, bool WT = false>
 __device__ __forceinline__ void tile_body(const TileArgs<T> &A, const typename std::conditional<QM, typename StepsFor<T>::type, NoSteps>::type &ST,
                                           const int64_t first_tile, const int64_t tile_stride, const int chunk_y)
 {
@@ -418,7 +430,7 @@ __device__ __forceinline__ void tile_body(const TileArgs<T> &A, const typename s
         // forward: this stage's entries, entry order (C or ws_k); plain inverse of stage 0: T rows [e0, e0+nt)
         const uint32_t lds = (uint32_t)(INV ? A.ld_fin : A.ld_in);
         const T *src = (INV ? (const T *)A.fin : A.in) + e0 * (int64_t)lds;      // wave-uniform
-        load_rows(std::integral_constant<bool, IDENT>(), tile, nt,                // stage 0: C (or T) itself, touched once
+        load_rows(std::integral_constant<int, (WT && !IDENT) ? 2 : (IDENT ? 1 : 0)>(), tile, nt,      // stage 0: C (or T) itself, touched once
                   [&](int jr, uint32_t go) { return row_at(src, (uint32_t)jr, lds, go); });
     }
     if (INV) {
@@ -789,7 +801,9 @@ __device__ __forceinline__ void tile_body(const TileArgs<T> &A, const typename s
             if (active) for (uint32_t it = wid; (it << lr) < surv_cnt; it += nw) {
                 const uint32_t q = min((it << lr) + g, surv_cnt - 1);
                 const V16 x = *(const V16 *)&tile[__mul24((int)ssurv[q], Dp) + coff];
-                st_chunk<T>(row_at(dstb + (int64_t)surv_base * ldb, q, (uint32_t)ldb, (uint32_t)goff), x);
+                if constexpr (WT) { if (!A.last_stage) st_chunk_wt<T>(row_at(dstb + (int64_t)surv_base * ldb, q, (uint32_t)ldb, (uint32_t)goff), x);
+                                    else st_chunk<T>(row_at(dstb + (int64_t)surv_base * ldb, q, (uint32_t)ldb, (uint32_t)goff), x); }
+                else st_chunk<T>(row_at(dstb + (int64_t)surv_base * ldb, q, (uint32_t)ldb, (uint32_t)goff), x);
             }
         }
         // rows finalised here: T[row], or, fused, quantized to Q[inv_order[row]] (encode_3dgs.py:204,210,215)
@@ -849,9 +863,13 @@ __global__ __launch_bounds__(512, (sizeof(T) == 4 ? 6 : 4)) void tile_kernel(con
 // workgroup per stage-1 tile: a workgroup that finishes a tile adds the number of survivors it delivered to the arrival
 // counter of each parent tile it fed (at most two: the next stage's tiles are at least as long as this one's); whoever
 // completes a parent's count runs that parent next, in the same workgroup, and so on upwards. Nobody ever waits, so nothing
-// can deadlock; every tile of every chained stage is run exactly once (by the last of its children to arrive). Ordering:
-// every thread fences its survivor stores (agent scope: the parent may run on another XCD, whose L2 is a different one),
-// barrier, one relaxed atomic; the taker fences again before it loads. Counters return to zero (the taker resets them).
+// can deadlock; every tile of every chained stage is run exactly once (by the last of its children to arrive). Ordering
+// (the parent may run on another XCD, whose L2 is a different one): survivor rows are written THROUGH the L2 (st_chunk_wt,
+// sc1), every thread waits for its stores' acknowledgement, barrier, one relaxed agent-scope atomic; the taker loads the rows
+// past its own L2 (glds16<2>). Counters return to zero (the taker resets them). MEASURED, OFF by default (RAHT_CHAIN=1):
+// fused cfg3 forward 0.3038 -> 0.3112 ms -- the acknowledgement wait, the atomic and the parent's coherent loads are three
+// ~2 us round trips on every tile's way up, more than the 4.6 us launch gap and the ~6 us of stage-2 work the chaining hides
+// (the first version, with agent-scope fences = L2 write-backs instead of write-through stores: 0.339 ms).
 // Only with all D channels in one chunk (D <= 64). The pending parents (depth-first, at most one per stage above) live at
 // the end of the dynamic LDS block, behind what tile_body uses.
 constexpr int CHAIN_MAX = 6;
@@ -873,16 +891,15 @@ __global__ __launch_bounds__(512, (sizeof(T) == 4 ? 6 : 4)) void tile_kernel_cha
     int64_t tile = blockIdx.x;
     if (threadIdx.x == 0) pend[0] = 0;
     for (;;) {
-        tile_body<T, false, false, QM, SLOTS>(C.a[stage], ST, tile, (int64_t)1 << 40, 0);      // (ends with a barrier)
+        tile_body<T, false, false, QM, SLOTS, true>(C.a[stage], ST, tile, (int64_t)1 << 40, 0);      // (ends with a barrier)
         if (stage + 1 < C.n) {
-            // this tile's survivor rows, visible device-wide: every thread's stores reach this XCD's L2 (workgroup-scope
-            // release = wait for their acknowledgement), barrier, then ONE agent-scope release (write-back of that L2) by
-            // the thread that signals. (An agent-scope fence in every thread -- 512 write-back + invalidate pairs per tile --
-            // made the chained launch 220 us instead of 31.)
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            // this tile's survivor rows were written THROUGH the L2 (st_chunk_wt): once every thread's stores are acknowledged
+            // they are visible device-wide, and the parent tile loads them past its own XCD's L2 (glds16<2>). No fence: an
+            // agent-scope release is a write-back of the whole L2 (round 3, first version: the chained launch 35 us SLOWER than
+            // the separate launches; with a fence in every thread 220 us instead of 31).
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             if (threadIdx.x == 0) {
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
                 const TileArgs<T> &A = C.a[stage];
                 const uint32_t sb = A.surv_off[tile], se = A.surv_off[tile + 1];
                 const uint32_t Rn = (uint32_t)C.a[stage + 1].R, n_next = (uint32_t)C.a[stage + 1].n_entries;
@@ -909,7 +926,6 @@ __global__ __launch_bounds__(512, (sizeof(T) == 4 ? 6 : 4)) void tile_kernel_cha
         if (threadIdx.x == 0) pend[0] = c - 1;
         stage = (int)(top >> 24);
         tile = (int64_t)(top & 0xffffffu);
-        if (threadIdx.x == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");    // the children's rows, not a stale line of this XCD's L2
         __syncthreads();
     }
 }

@@ -251,6 +251,26 @@ def _encode_frame_gpu_entropy(V_int, attributes, J, steps, frame, device, dtype,
 
 
 def _psnr_columns(r, C, C_rec):
+    """The five PSNR columns of encode_3dgs.py:298-310 from ONE pass over C and C_rec: per-column sums of squared differences on
+    the device (raht_sqdiff_columns, float64 sums), grouped on the host -- instead of five torch.mean reductions with a host round
+    trip each (2.0 -> 0.2 ms per step on a 3 M x 56 frame)."""
+    if C.is_cuda and C.dtype in (torch.float32, torch.float64) and C.dim() == 2 and C.shape == C_rec.shape and C.dtype == C_rec.dtype \
+            and C.stride(1) == 1 and C_rec.stride(1) == 1:
+        import ctypes as _C
+        from . import _lib
+        N, D = C.shape
+        out = torch.empty(D, dtype=torch.float64, device=C.device)
+        with torch.cuda.device(C.device):
+            _lib.check(_lib.lib().raht_sqdiff_columns(_C.c_void_p(C.data_ptr()), C.stride(0), _C.c_void_p(C_rec.data_ptr()), C_rec.stride(0), N, D,
+                                                      _lib.RAHT_F32 if C.dtype == torch.float32 else _lib.RAHT_F64, _C.c_void_p(out.data_ptr()),
+                                                      _C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        ssd = out.cpu().numpy()                               # (the one synchronisation)
+
+        def col(lo, hi):
+            return -10 * math.log10(float(ssd[lo:hi].sum()) / (N * (hi - lo)) + 1e-10)
+        r["PSNR_all"] = col(0, D)
+        r["PSNR_quats"], r["PSNR_scales"], r["PSNR_opacity"], r["PSNR_colors"] = col(0, 4), col(4, 7), col(7, 8), col(8, D)
+        return
     r["PSNR_all"] = _psnr(C, C_rec)                                                 # encode_3dgs.py:298-310
     r["PSNR_quats"] = _psnr(C[:, 0:4], C_rec[:, 0:4])
     r["PSNR_scales"] = _psnr(C[:, 4:7], C_rec[:, 4:7])
