@@ -216,7 +216,10 @@ __device__ __forceinline__ void decode_segment(const uint32_t *in32, uint32_t nb
 {
     DevBitReader r;
     r.in32 = in32; r.size = nbytes;
-    uint64_t k_P = 0, k_RP = 2 * L;
+    // 32-bit state, as in the encoder: inside a segment of n < 2^31 symbols of int32 data the symbol values (< 2^32), the run
+    // length m and the exponents stay within 32 bits; a corrupt stream may overflow them -- it then decodes to different garbage
+    // than a 64-bit decoder would, inside the same bounds (every store is at i < n, every read below `size`).
+    uint32_t k_P = 0, k_RP = 2 * L;
     int i = 0;
     int4 buf = make_int4(0, 0, 0, 0);
     auto emit = [&](int32_t v) {
@@ -230,29 +233,31 @@ __device__ __forceinline__ void decode_segment(const uint32_t *in32, uint32_t nb
         }
     };
     while (i < n) {                                                  // membuf.cpp:270-331
-        uint64_t k = k_P / L;
-        const uint64_t k_R = k_RP / L;
+        uint32_t k = k_P / L;
+        const uint32_t k_R = k_RP / L;
         if (k) {
-            uint64_t m = 0;
+            uint32_t m = 0;
             while (r.bit()) {
-                m += 1ull << k;
+                if (k >= 31) { m = (uint32_t)n; break; }             // corrupt stream guard (a run of 2^31 zeros in one segment)
+                m += 1u << k;
                 k_P += U1;
                 k = k_P / L;
-                if (m > (uint64_t)n) break;                          // corrupt stream guard
+                if (m > (uint32_t)n) break;                          // corrupt stream guard
             }
-            m += r.get_wide((int)k);
+            m += (uint32_t)r.get_wide((int)min(k, 32u));
             while (m-- && i < n) emit(0);
             if (i >= n) break;
-            const uint64_t u = r.golomb_rice((int)k_R);
-            emit((int32_t)(flag_signed ? u2s(u + 1) : (int64_t)(u + 1)));
-            const uint64_t p = u >> k_R;
-            RLGS_ADAPT_KRP(p);
+            const uint32_t u = (uint32_t)r.golomb_rice((int)k_R);
+            const uint32_t u1 = u + 1u;
+            emit(flag_signed ? ((u1 & 1u) ? -(int32_t)(u1 >> 1) - 1 : (int32_t)(u1 >> 1)) : (int32_t)u1);
+            const uint32_t p = (k_R < 32) ? (u >> k_R) : 0u;
+            RLGS_ADAPT_KRP32(p);
             k_P = (k_P < D1) ? 0 : k_P - D1;
         } else {
-            const uint64_t u = r.golomb_rice((int)k_R);
-            emit((int32_t)(flag_signed ? u2s(u) : (int64_t)u));
-            const uint64_t p = u >> k_R;
-            RLGS_ADAPT_KRP(p);
+            const uint32_t u = (uint32_t)r.golomb_rice((int)k_R);
+            emit(flag_signed ? ((u & 1u) ? -(int32_t)(u >> 1) - 1 : (int32_t)(u >> 1)) : (int32_t)u);
+            const uint32_t p = (k_R < 32) ? (u >> k_R) : 0u;
+            RLGS_ADAPT_KRP32(p);
             if (u) k_P = (k_P < D0) ? 0 : k_P - D0;
             else k_P += U0;
         }
