@@ -874,9 +874,35 @@ __global__ __launch_bounds__(SB_THREADS) void sched_count_kernel(SchedState *__r
     uint32_t j0 = (uint32_t)base / (uint32_t)R * (uint32_t)R;
     int64_t start = 0, end = 0;
     bool fresh = true;
+    // the thread's 8 consecutive entries in a few wide loads (32 / 32 / 8 / 32 bytes) instead of 8 x 4 narrow ones: the launch is
+    // bound by its load instructions, not by the 27 MB it reads on cfg3 (20 -> ~12 us)
+    int32_t v_wl[SB_ITEMS], v_wr[SB_ITEMS];
+    uint32_t v_row[SB_ITEMS];
+    uint8_t v_lv[SB_ITEMS];
+    if (base + SB_ITEMS <= n) {
+        const int4 a0 = *(const int4 *)(wl + base), a1 = *(const int4 *)(wl + base + 4);
+        const int4 b0 = *(const int4 *)(wr + base), b1 = *(const int4 *)(wr + base + 4);
+        const uint2 l8 = *(const uint2 *)(lvl + base);
+        v_wl[0] = a0.x; v_wl[1] = a0.y; v_wl[2] = a0.z; v_wl[3] = a0.w; v_wl[4] = a1.x; v_wl[5] = a1.y; v_wl[6] = a1.z; v_wl[7] = a1.w;
+        v_wr[0] = b0.x; v_wr[1] = b0.y; v_wr[2] = b0.z; v_wr[3] = b0.w; v_wr[4] = b1.x; v_wr[5] = b1.y; v_wr[6] = b1.z; v_wr[7] = b1.w;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { v_lv[q] = (uint8_t)(l8.x >> (8 * q)); v_lv[4 + q] = (uint8_t)(l8.y >> (8 * q)); }
+        if (rows) {
+            const uint4 r0 = *(const uint4 *)(rows + base), r1 = *(const uint4 *)(rows + base + 4);
+            v_row[0] = r0.x; v_row[1] = r0.y; v_row[2] = r0.z; v_row[3] = r0.w; v_row[4] = r1.x; v_row[5] = r1.y; v_row[6] = r1.z; v_row[7] = r1.w;
+        }
+    } else {
+#pragma unroll
+        for (int q = 0; q < SB_ITEMS; ++q) {
+            const int64_t j = min(base + q, n - 1);
+            v_wl[q] = wl[j]; v_wr[q] = wr[j]; v_lv[q] = lvl[j]; v_row[q] = rows ? rows[j] : 0u;
+        }
+    }
+    uint8_t fl[SB_ITEMS];
 #pragma unroll
     for (int q = 0; q < SB_ITEMS; ++q) {
         const int64_t j = base + q;
+        fl[q] = 0;
         if (j < n) {
             if ((uint32_t)j >= j0 + (uint32_t)R) { j0 += (uint32_t)R; fresh = true; }
             if (fresh) {
@@ -885,11 +911,20 @@ __global__ __launch_bounds__(SB_THREADS) void sched_count_kernel(SchedState *__r
                 end = (j1 < n) ? (rows ? (int64_t)rows[j1] : j1) : N;
                 fresh = false;
             }
-            const int64_t r = rows ? (int64_t)rows[j] : j;
-            const bool merged = (r > 0) && ((int)lvl[j] < top_level) && (r - wl[j] >= start) && (r + wr[j] <= end);
-            flags[j] = merged ? 0 : 1;
+            const int64_t r = rows ? (int64_t)v_row[q] : j;
+            const bool merged = (r > 0) && ((int)v_lv[q] < top_level) && (r - v_wl[q] >= start) && (r + v_wr[q] <= end);
+            fl[q] = merged ? 0 : 1;
             cnt += merged ? 0u : 1u;
         }
+    }
+    if (base + SB_ITEMS <= n) {
+        uint2 f8;
+        f8.x = (uint32_t)fl[0] | ((uint32_t)fl[1] << 8) | ((uint32_t)fl[2] << 16) | ((uint32_t)fl[3] << 24);
+        f8.y = (uint32_t)fl[4] | ((uint32_t)fl[5] << 8) | ((uint32_t)fl[6] << 16) | ((uint32_t)fl[7] << 24);
+        *(uint2 *)(flags + base) = f8;
+    } else {
+#pragma unroll
+        for (int q = 0; q < SB_ITEMS; ++q) if (base + q < n) flags[base + q] = fl[q];
     }
     const uint32_t tot = block_sum_256(cnt, red);
     if (threadIdx.x == 0) blk_cnt[blockIdx.x] = tot;
@@ -919,8 +954,16 @@ __global__ __launch_bounds__(SB_THREADS) void sched_emit_kernel(SchedState *__re
     const int64_t base = (int64_t)blockIdx.x * SB_BLOCK + (int64_t)threadIdx.x * SB_ITEMS;
     uint8_t f[SB_ITEMS];
     uint32_t mine = 0;
+    if (base + SB_ITEMS <= n) {                             // (8 flags in one load: the buffer is 16-byte aligned)
+        const uint2 f8 = *(const uint2 *)(flags + base);
 #pragma unroll
-    for (int q = 0; q < SB_ITEMS; ++q) { f[q] = (base + q < n) ? flags[base + q] : 0; mine += f[q]; }
+        for (int q = 0; q < 4; ++q) { f[q] = (uint8_t)(f8.x >> (8 * q)); f[4 + q] = (uint8_t)(f8.y >> (8 * q)); }
+#pragma unroll
+        for (int q = 0; q < SB_ITEMS; ++q) mine += f[q];
+    } else {
+#pragma unroll
+        for (int q = 0; q < SB_ITEMS; ++q) { f[q] = (base + q < n) ? flags[base + q] : 0; mine += f[q]; }
+    }
     uint32_t inc = mine;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
 #pragma unroll
@@ -1204,7 +1247,7 @@ static int build_schedule_fast(raht_plan *plan, int R0, int R1, int Rf, hipStrea
     take(&t_pj, 4 * tm); take(&t_ab32, 8 * tm); take(&t_ab64, 16 * tm); take(&t_root, 4 * tm); take(&t_lev, 4 * 128);
     // scratch: state | per-block counts | flags
     const size_t nblk0 = (size_t)ceil_div(N, SB_BLOCK);
-    Scratch scr(sizeof(SchedState) + sizeof(uint32_t) * nblk0 + (size_t)N, s);
+    Scratch scr(sizeof(SchedState) + sizeof(uint32_t) * nblk0 + (size_t)N + 16, s);
     auto release = [&]() {
         for (auto &b : B) { dev_free(b.rows); dev_free(b.wl); dev_free(b.wr); dev_free(b.lvl); dev_free(b.pos); dev_free(b.surv); }
         dev_free(t_pj); dev_free(t_ab32); dev_free(t_ab64); dev_free(t_root); dev_free(t_lev);
@@ -1212,7 +1255,7 @@ static int build_schedule_fast(raht_plan *plan, int R0, int R1, int Rf, hipStrea
     if (!ok || !scr.ok()) { (void)hipDeviceSynchronize(); release(); return RAHT_ERR_NOMEM; }
     SchedState *dS = scr.as<SchedState>();
     uint32_t *blk_cnt = (uint32_t *)(dS + 1);
-    uint8_t *flags = (uint8_t *)(blk_cnt + nblk0);
+    uint8_t *flags = (uint8_t *)(((uintptr_t)(blk_cnt + nblk0) + 15) & ~(uintptr_t)15);      // (sched_count_kernel stores 8 flags at a time)
     SchedStageBufs SB;
     for (int k = 0; k <= KB + 1 && k < SCHED_SPEC_MAX + 2; ++k) {
         const Bufs &b = B[(size_t)k];
