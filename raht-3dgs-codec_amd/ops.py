@@ -634,6 +634,21 @@ def sort_keys(keys, nbits=64):
     return ko, idx
 
 
+_VMIN_CACHE = {}
+
+
+def _vmin_tensor(vmin, dev):
+    """info['vmin'] as a device tensor (the reference's is one). The frames of a sequence share their bounding box: the 12-byte
+    upload (a synchronising copy, ~30 us of a 0.7 ms call) is made once per (device, box), the tensor handed out is a clone."""
+    key = (str(dev), vmin)
+    t = _VMIN_CACHE.get(key)
+    if t is None:
+        if len(_VMIN_CACHE) > 64:
+            _VMIN_CACHE.clear()
+        t = _VMIN_CACHE[key] = torch.tensor(list(vmin), dtype=torch.float32, device=dev)
+    return t.clone()
+
+
 @torch.no_grad()
 def voxelize_pc_batched(PC, vmin=None, width=None, J=10, device="cuda", residuals=True, sorted_points=True):
     """Drop-in for reference python/voxelize_pc.py:62-172.
@@ -674,7 +689,7 @@ def voxelize_pc_batched(PC, vmin=None, width=None, J=10, device="cuda", residual
     nv = nvox.value
     voxel_indices = vidx[:nv]
     PCvox = pcv[:nv]
-    vmin_t = torch.tensor(list(vmin_out), dtype=torch.float32, device=dev)
+    vmin_t = _vmin_tensor(tuple(vmin_out), dev)
     info = {"Nvox": nv, "voxel_size": vs_out.value, "vmin": vmin_t, "width": w_out.value, "N": N,
             "sort_idx": idx, "keys_sorted": keys}
     return PCvox, PCsorted, voxel_indices, DeltaPC, info
