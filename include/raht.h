@@ -215,6 +215,26 @@ int raht_fwd_quant_f64(const raht_plan *plan, const double *C, int64_t ldc, int 
 int raht_dequant_inv_f64(const raht_plan *plan, const int32_t *Q, int64_t ldq, int D, const double *steps,
                          int n_steps, double *C, int64_t ldc, raht_stream_t stream);
 
+/* MIXED PRECISION: float32 rows whose first n_wide channels (1..4) are carried in float64 through the whole transform, in the
+ * SAME launches as the float32 channels (csrc/transform_mx.hip). What it is for: the reference quantizes float64 coefficients
+ * (python/encode_3dgs.py:82-83,204), and on a 59-column frame whose columns 0-2 are the voxel coordinates
+ * (python/voxelize_pc.py:155) those three columns' coefficients reach 1e6, i.e. |T| / step > 2^24 at the steps the attribute
+ * channels need -- float32 integers are tens of units off there (see above) while the 56 attribute columns are fine.
+ *   channels [0, n_wide)  : input converted exactly to float64, float64 butterflies with float64 a / b, IEEE double division by
+ *                           the float64 step: Q bit-identical to raht_fwd_quant_f64 on those columns, i.e. the reference's
+ *                           integers (up to 1-ulp transform noise on exact rounding ties); the inverse rounds once, on output;
+ *   channels [n_wide, D)  : float32 arithmetic with (float) steps[c]: bit-identical to raht_fwd_quant / raht_dequant_inv.
+ * steps: HOST float64[n_steps], n_steps == 1 or D. D - n_wide >= 4 and D <= 68 run the mixed tile kernels (one pass, ~5 % slower
+ * than the float32 kernels); other shapes, and plans switched to the level engine, run the float32 path followed by a float64
+ * pass over the n_wide columns (same results up to rounding ties). Not available for row-mapped or truncated plans. */
+int raht_fwd_quant_mixed(const raht_plan *plan, const float *C, int64_t ldc, int D, const double *steps, int n_steps,
+                         int n_wide, int32_t *Q, int64_t ldq, raht_stream_t stream);
+int raht_dequant_inv_mixed(const raht_plan *plan, const int32_t *Q, int64_t ldq, int D, const double *steps, int n_steps,
+                           int n_wide, float *C, int64_t ldc, raht_stream_t stream);
+/* Tile rows / stage sizes the mixed kernels use for (D, n_wide); *tile_rows = 0 when the shape takes the two-pass path. */
+int raht_plan_mixed_stats(raht_plan *plan, int D, int n_wide, int *tile_rows, int *n_stages, int64_t *rows_per_stage,
+                          int max_stages);
+
 /* SEVERAL SCENES IN ONE SET OF LAUNCHES (BASELINE configs[3] is a batch of scenes; the frames of a dynamic sequence are
  * one too). Scene i = (plans[i], C[i] / Q[i] with row strides ldc[i] / ldq[i]); all scenes share D and the step table.
  * Stage k of every scene runs in ONE tile-kernel launch (a workgroup finds its scene from its index) and the top stages in

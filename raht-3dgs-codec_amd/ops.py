@@ -354,6 +354,45 @@ class RahtPlan:
                 self._set_roots_buffer(None, D, torch.float32)
         return out
 
+    def forward_quant_mixed(self, Cmat, steps, n_wide=3):
+        """Forward RAHT + quantize + reorder of a float32 matrix whose first ``n_wide`` channels (the xyz columns of a
+        59-column frame, python/voxelize_pc.py:155) are carried in float64 -- the reference's precision
+        (python/encode_3dgs.py:82-83,204) where float32 cannot hold the quotient -- in the same launches as the float32
+        channels. Wide columns: bit-identical to the float64 kernels; the others: bit-identical to ``forward_quant``."""
+        _need_cuda(Cmat, "C")
+        X = Cmat.to(torch.float32)
+        if X.stride(1) != 1 or X.stride(0) < X.shape[1]:
+            X = X.contiguous()
+        D = X.shape[1]
+        st = _steps64(steps, D)
+        Q = torch.empty((self.N, D), dtype=torch.int32, device=X.device)
+        with torch.cuda.device(X.device):
+            check(_lib.lib().raht_fwd_quant_mixed(self._h, C.c_void_p(X.data_ptr()), X.stride(0), D, st, len(st), int(n_wide),
+                                                  C.c_void_p(Q.data_ptr()), D, _stream()))
+        return Q
+
+    def dequant_inverse_mixed(self, Q, steps, n_wide=3, out=None):
+        """Un-reorder + dequantize + inverse RAHT -> float32 C, the first ``n_wide`` channels computed in float64 and
+        rounded once on output (counterpart of ``forward_quant_mixed``)."""
+        _need_cuda(Q, "Q")
+        Q = Q.to(torch.int32).contiguous()
+        D = Q.shape[1]
+        st = _steps64(steps, D)
+        if out is None:
+            out = torch.empty((self.N, D), dtype=torch.float32, device=Q.device)
+        with torch.cuda.device(Q.device):
+            check(_lib.lib().raht_dequant_inv_mixed(self._h, C.c_void_p(Q.data_ptr()), D, D, st, len(st), int(n_wide),
+                                                    C.c_void_p(out.data_ptr()), out.stride(0), _stream()))
+        return out
+
+    def mixed_stats(self, D=59, n_wide=3):
+        """Tile rows and rows per stage of the mixed-precision schedule (tile_rows 0: the shape takes the two-pass path)."""
+        tr, ns = C.c_int(0), C.c_int(0)
+        rows = (C.c_int64 * 64)()
+        with torch.cuda.device(self.device):
+            check(_lib.lib().raht_plan_mixed_stats(self._h, int(D), int(n_wide), C.byref(tr), C.byref(ns), rows, 64))
+        return {"tile_rows": tr.value, "rows_per_stage": [int(rows[i]) for i in range(ns.value)]}
+
     def quant_reorder(self, T, steps):
         """int32 Q[k] = floor(T[order[k]] / step + 0.5)  (encode_3dgs.py:204,210,215)."""
         _need_cuda(T, "T")

@@ -483,3 +483,18 @@ def voxel_residual_cases():
 
 if __name__ == "__main__" and os.environ.get("GOLDEN_ONLY", "") in ("", "voxres"):
     voxel_residual_cases()
+
+
+def mixed_cases():
+    """Frames as the voxelizer hands them over: columns 0-2 are the integer voxel coordinates (python/voxelize_pc.py:155),
+    the rest 3DGS attributes; quantized at the fine steps unit-range attributes need, where the xyz columns' quotients
+    exceed 2^24 (what raht_fwd_quant_mixed / raht_dequant_inv_mixed exist for)."""
+    rng = np.random.default_rng(20261005)
+    for name, n, J, D in (("mx_n2000_j10_d59", 2000, 10, 59), ("mx_n1500_j12_d59", 1500, 12, 59), ("mx_n1000_j10_d14", 1000, 10, 14)):
+        V = sorted_unique_voxels(blob_cloud(rng, n, J), J)
+        C = np.concatenate([V.astype(np.float32), gaussian_attrs(rng, V.shape[0], D - 3)], axis=1)
+        transform_case(name, V, J, C, steps=(0.01, 1))
+
+
+if __name__ == "__main__" and os.environ.get("GOLDEN_ONLY", "") in ("", "mixed"):
+    mixed_cases()

@@ -186,6 +186,10 @@ def test_quantize_reorder_and_back(rt, name):
         bad = np.argwhere(Q != ref)
         pre = g["T"][order] / step + 0.5
         scale = np.abs(g["T"]).max(axis=0) / step
+        if name.startswith("mx_"):
+            # frames with xyz columns at fine steps: |T| / step exceeds 2^24 there, float32 integers are not the reference's
+            # (include/raht.h at raht_fwd_quant; tests/test_gpu_mixed.py covers these columns through raht_fwd_quant_mixed)
+            bad = bad[(bad[:, 1] >= 3) | (scale[bad[:, 1]] < 2.0 ** 22)]
         for r, c in bad:
             assert abs(int(Q[r, c]) - int(ref[r, c])) == 1
             # fp32 coefficient error (<= 2e-6 of the column max) can only flip values that close to a tie

@@ -19,10 +19,11 @@ HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="needs hipcc")
-def test_m0_is_only_touched_by_the_lds_direct_loads(tmp_path):
+@pytest.mark.parametrize("tu", ["transform.hip", "transform_mx.hip"])
+def test_m0_is_only_touched_by_the_lds_direct_loads(tmp_path, tu):
     out = tmp_path / "transform.s"
     r = subprocess.run([HIPCC, "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-I" + os.path.join(ROOT, "include"), "-fno-fast-math",
-                        "-ffp-contract=on", "-S", "--offload-device-only", os.path.join(CSRC, "transform.hip"), "-o", str(out)],
+                        "-ffp-contract=on", "-S", "--offload-device-only", os.path.join(CSRC, tu), "-o", str(out)],
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = out.read_text().splitlines()
@@ -41,12 +42,13 @@ def test_m0_is_only_touched_by_the_lds_direct_loads(tmp_path):
 
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="needs hipcc")
-def test_tile_kernels_do_not_spill():
+@pytest.mark.parametrize("tu,at_least", [("transform.hip", 16), ("transform_mx.hip", 10)])
+def test_tile_kernels_do_not_spill(tu, at_least):
     """Any scratch use in a tile / top kernel is a regression (a kernel that touches scratch lost 30 %)."""
-    r = subprocess.run(["bash", os.path.join(ROOT, "tools", "reg_report.sh")], capture_output=True, text=True, timeout=900)
+    r = subprocess.run(["bash", os.path.join(ROOT, "tools", "reg_report.sh"), tu], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     rows = [ln for ln in r.stdout.splitlines() if "vgpr" in ln]
-    assert len(rows) >= 16, r.stdout[-2000:]
+    assert len(rows) >= at_least, r.stdout[-2000:]
     for ln in rows:
         m = re.search(r"spill (\d+) scratch (\d+)", ln)
         assert m and int(m.group(1)) == 0 and int(m.group(2)) == 0, ln
