@@ -606,6 +606,8 @@ def main():
         step()
     torch.cuda.synchronize(); barrier()
     dt = time.perf_counter() - t0
+    if not solo and a.direct:
+        sh.check_exchange()                                # a direct gather that timed out: no number for stale buffers
     if world > 1:
         tt = torch.tensor([dt, float(N)], dtype=torch.float64, device=dev if a.backend == "nccl" else "cpu")
         tmax = tt.clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)

@@ -672,14 +672,28 @@ static void launch_heights_kernel(const HeightArgs &H, int maxR, bool any_rows, 
 // waited for: the transforms that read them run behind this on the same stream)
 static int launch_stage_heights(raht_plan *plan, Schedule &sc, hipStream_t s)
 {
+    // up to HT_MAX_STAGES tile stages per launch; deeper schedules (deep or unbalanced key sets, small tail_rows / final_rows
+    // overrides: get_schedule_exact builds up to plan->max_stages = 24 of them) take several launches
     HeightArgs H;
-    H.n_stages = 0; H.n_tiles = 0; H.N = plan->N; H.top_level = plan->top_level;
     int maxR = 0;
     bool any_rows = false;
+    auto reset = [&]() { H.n_stages = 0; H.n_tiles = 0; H.N = plan->N; H.top_level = plan->top_level; maxR = 0; any_rows = false; };
+    auto flush = [&]() -> int {
+        if (H.n_stages == 0) return RAHT_OK;
+        for (int q = H.n_stages; q < HT_MAX_STAGES; ++q) H.st[q] = H.st[0];
+        launch_heights_kernel(H, maxR, any_rows, s);
+        RAHT_HIP_CHECK(hipGetLastError());
+        reset();
+        return RAHT_OK;
+    };
+    reset();
+    // (testing aid, read per schedule: RAHT_HEIGHT_STAGES_PER_LAUNCH=2 walks the several-launches path on ordinary scenes)
+    const char *ge = getenv("RAHT_HEIGHT_STAGES_PER_LAUNCH");
+    const int group = ge ? std::min(std::max(atoi(ge), 1), HT_MAX_STAGES) : HT_MAX_STAGES;
     for (size_t k = 0; k < sc.stages.size(); ++k) {
         Stage &st = sc.stages[k];
         if (st.is_top || st.n_entries < 1) continue;
-        if (st.tile_rows > HT_MAX_ROWS || H.n_stages >= HT_MAX_STAGES) { set_error("tile heights: %d rows per tile / %d tile stages not supported", st.tile_rows, (int)sc.stages.size()); return RAHT_ERR_UNSUPPORTED; }
+        if (st.tile_rows > HT_MAX_ROWS) { set_error("tile heights: %d rows per tile not supported", st.tile_rows); return RAHT_ERR_UNSUPPORTED; }
         if (!st.e_ht) RAHT_HIP_CHECK(dev_malloc(&st.e_ht, (size_t)st.n_entries));
         HeightStage &h = H.st[H.n_stages++];
         h.rows = st.rows; h.wl = st.rows ? st.e_wl : plan->wl; h.wr = st.rows ? st.e_wr : plan->wr; h.lvl = st.rows ? st.e_lvl : plan->lvl;
@@ -687,12 +701,9 @@ static int launch_stage_heights(raht_plan *plan, Schedule &sc, hipStream_t s)
         H.n_tiles += (uint32_t)st.n_tiles;
         maxR = std::max(maxR, st.tile_rows);
         any_rows = any_rows || st.rows != nullptr;
+        if (H.n_stages == group) RAHT_RET(flush());
     }
-    if (H.n_stages == 0) return RAHT_OK;
-    for (int q = H.n_stages; q < HT_MAX_STAGES; ++q) H.st[q] = H.st[0];
-    launch_heights_kernel(H, maxR, any_rows, s);
-    RAHT_HIP_CHECK(hipGetLastError());
-    return RAHT_OK;
+    return flush();
 }
 
 // ---- TOP stage: every butterfly still to do, resolved against the stage's entry list ----------------

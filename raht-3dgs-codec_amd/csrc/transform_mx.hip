@@ -31,8 +31,18 @@
 
 namespace raht {
 
+// Profiling build only (-DRAHT_PHASE_CLOCKS, tools/phase_clocks_mx.py): thread 0 of the first stage-0 workgroups stamps the
+// shader clock at the phase boundaries of its tile.
+#ifdef RAHT_PHASE_CLOCKS
+constexpr int MX_CLK_TILES = 4096, MX_CLK_SLOTS = 12;
+__device__ unsigned long long g_phase_clk_mx[MX_CLK_TILES][MX_CLK_SLOTS];
+#define MX_STAMP(k) do { if (IDENT && threadIdx.x == 0 && tile_id < MX_CLK_TILES) g_phase_clk_mx[tile_id][k] = __builtin_readcyclecounter(); } while (0)
+#else
+#define MX_STAMP(k) do { } while (0)
+#endif
+
 constexpr int MX_MAX_WIDE = 4;          // the wide channels are the row's first 16 bytes
-constexpr int MX_PRE_ROWS = 12;         // survivor rows prefetched by the inverse before flags are known
+constexpr int MX_PRE_ROWS = 8;          // survivor rows prefetched by the inverse before flags are known
 constexpr int MX_THREADS = 512;
 constexpr int MX_TOP_THREADS = 1024;
 constexpr int MX_TOP_SLOTS = RAHT_TOP_MAX_ROWS / MX_TOP_THREADS;
@@ -46,13 +56,32 @@ struct StepTableMX {
 static size_t tile_lds_bytes_mx(int R, int NCp, bool ident)
 {
     const size_t data = (size_t)R * NCp * 16;
-    const size_t meta = (size_t)R * (sizeof(MRec<double>) + (ident ? 0 : 4) + 4 + 1);
+    const size_t meta = (size_t)R * (16 + 4 + (ident ? 0 : 4) + 4 + 1);        // a, b (float64) + operand slots; row id; Q position; flag
     const size_t surv = ((size_t)R * 2 + 15) & ~(size_t)15;
     return data + ((meta + 15) & ~(size_t)15) + 1024 + surv + (size_t)MX_PRE_ROWS * NCp * 16;
 }
 
+// out = the row's first four channels: the n_wide wide values w[0 .. n_wide), then the first 4 - n_wide values of the row's first
+// float chunk f (selects on the wave-uniform n_wide: an index computed from it would put the arrays into scratch)
+template <typename E>
+__device__ __forceinline__ void first_four(const E (&w)[4], const E (&f)[4], int nwide, E (&out)[4])
+{
+    out[0] = w[0];
+    out[1] = nwide > 1 ? w[1] : f[0];
+    out[2] = nwide > 2 ? w[2] : (nwide == 2 ? f[0] : f[1]);
+    out[3] = nwide > 3 ? w[3] : (nwide == 3 ? f[0] : (nwide == 2 ? f[1] : f[2]));
+}
+
+// the wide parts of the workspaces a stage touches (a workspace row is stored as two dense arrays: the float places of every
+// entry, then the wide places of every entry; TileArgs::in / out / wsn point at the float parts)
+struct MxPtrs {
+    const float *in_w;       // fwd, stages >= 1: wide part of ws_k
+    float *out_w;            // inv, stages >= 1: wide part of ws_k
+    float *wsn_w;            // wide part of ws_{k+1}
+};
+
 template <bool INV, bool IDENT, int SLOTS>
-__device__ __forceinline__ void tile_body_mx(const TileArgs<float> &A, const StepTableMX &ST, const int64_t tile_id)
+__device__ __forceinline__ void tile_body_mx(const TileArgs<float> &A, const MxPtrs &P, const StepTableMX &ST, const int64_t tile_id)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     typedef RegChunk<float> V16;
@@ -61,18 +90,22 @@ __device__ __forceinline__ void tile_body_mx(const TileArgs<float> &A, const Ste
     const int R = A.R;
     const int tid0 = threadIdx.x;
     const int nthreads = blockDim.x, nwv = nthreads >> 6;
-    const int nwide = A.nwide, NW2 = (nwide + 1) >> 1;     // wide channels, wide chunk places
+    const int nwide = A.nwide, NW2 = (nwide + 1) >> 1;     // wide channels, wide chunk places per row (1 or 2)
+    const int lgw = NW2 > 1 ? 1 : 0;
     const int Df = A.D - nwide;                            // float32 channels (>= 4)
-    const int Dp = A.Dp, NCp = Dp >> 2;                    // LDS row stride in floats, chunk places per row
-    const int lg = A.lg, lr = 6 - A.lg;
-    const uint32_t NCm = ((1u << 20) + (uint32_t)NCp - 1) / (uint32_t)NCp;   // c / NCp == (c * NCm) >> 20 for c < 2^15
+    const int Fp = A.Dp, NF = Fp >> 2;                     // float tile: row stride in floats, chunk places per row
+    const int Wp = NW2 * 4;                                // wide tile: row stride in floats (16 or 32 bytes)
+    const int lg = A.lg, lr = 6 - A.lg;                    // 2^lg >= NF + 1 lanes per row: NF float lanes and the head lane
+    const uint32_t NFm = ((1u << 20) + (uint32_t)NF - 1) / (uint32_t)NF;     // c / NF == (c * NFm) >> 20 for c < 2^15
     auto sync_lds = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
     auto wait_landed = [&]() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
 
     // ---- LDS carve-up (must match tile_lds_bytes_mx) ----
-    size_t off = (size_t)R * Dp * 4;
-    float *tile = (float *)smem;
-    MRec<double> *mrec = (MRec<double> *)(smem + off); off += (size_t)R * sizeof(MRec<double>);
+    size_t off = 0;
+    float *ftile = (float *)smem; off += (size_t)R * Fp * 4;              // float32 channels, NF places per row
+    float *wt = (float *)(smem + off); off += (size_t)R * Wp * 4;         // wide channels, NW2 places of two doubles per row
+    W16 *rec_ab = (W16 *)(smem + off); off += (size_t)R * 16;             // butterfly records: a, b in float64 ...
+    uint32_t *rec_pj = (uint32_t *)(smem + off); off += (size_t)R * 4;    // ... and the two operand slots (partner | own << 16)
     int32_t *srow = (int32_t *)(smem + off); if (!IDENT) off += (size_t)R * 4;
     int32_t *sdst = (int32_t *)(smem + off); off += (size_t)R * 4;
     uint8_t *sflag = (uint8_t *)(smem + off); off += (size_t)R;
@@ -84,28 +117,29 @@ __device__ __forceinline__ void tile_body_mx(const TileArgs<float> &A, const Ste
     off += 1024;
     uint16_t *ssurv = (uint16_t *)(smem + off);
     off += ((size_t)R * 2 + 15) & ~(size_t)15;
-    float *spre = (float *)(smem + off);
+    float *spre_f = (float *)(smem + off); off += (size_t)MX_PRE_ROWS * Fp * 4;
+    float *spre_w = (float *)(smem + off);
 
     TileMeta<SLOTS> M;
     load_tile_meta<float, IDENT, true, SLOTS>(A, tile_id, tid0, nthreads, M);
 
-    // lane geometry: lane c4 of a group of 2^lg owns chunk place c4 of the group's row. Places [0, NW2) are wide (two doubles:
-    // channels 2 c4, 2 c4 + 1), places [NW2, NCp) float (channels goff .. goff + 3 of the global row)
-    auto lane_geom = [&](int tid, int &lane, int &wid, int &g, int &c4c, int &coff, int &goff, bool &active, bool &wide) {
+    // lane geometry of the row loops: lane c4 of a group of 2^lg works on one row; c4 < NF: float place c4 (channels goff .. goff + 3
+    // of the caller's rows); c4 == NF: the HEAD lane, which assembles a caller row's first 16 bytes (the wide channels + the first
+    // 4 - n_wide float channels) in the write-backs; lanes past it idle. fl: the float place a lane reads in the butterflies (head
+    // and idle lanes shadow the last one: same reads, same writes); sp: the place whose channels / steps it quantizes (head: place 0)
+    auto lane_geom = [&](int tid, int &lane, int &wid, int &g, int &c4, int &fl, int &sp, int &goff, bool &head) {
         lane = tid & 63;
         wid = __builtin_amdgcn_readfirstlane(tid >> 6);
         g = lane >> lg;
-        const int c4 = lane & ((1 << lg) - 1);
-        active = c4 < NCp;
-        c4c = min(c4, NCp - 1);
-        coff = c4c * 4;
-        wide = c4c < NW2;
-        goff = nwide + min(max(c4c - NW2, 0) * 4, Df - 4);
+        c4 = lane & ((1 << lg) - 1);
+        fl = min(c4, NF - 1);
+        head = c4 == NF;
+        sp = head ? 0 : fl;
+        goff = nwide + min(fl * 4, Df - 4);
     };
     float my_step[4], my_rcp[4];
-    auto load_steps = [&](int ln) {
-        const int c4c = min(ln & ((1 << lg) - 1), NCp - 1);
-        const int g0 = nwide + min(max(c4c - NW2, 0) * 4, Df - 4);
+    auto load_steps = [&](int place) {
+        const int g0 = nwide + min(place * 4, Df - 4);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             my_step[i] = ST.f.v[ST.f.n == 1 ? 0 : g0 + i];
@@ -115,8 +149,8 @@ __device__ __forceinline__ void tile_body_mx(const TileArgs<float> &A, const Ste
 
     int tid = tid0;
     asm volatile("" : "+v"(tid));
-    int lane, wid, g, c4c, coff, goff; bool active, wide;
-    lane_geom(tid, lane, wid, g, c4c, coff, goff, active, wide);
+    int lane, wid, g, c4, fl, sp, goff; bool head;
+    lane_geom(tid, lane, wid, g, c4, fl, sp, goff, head);
     const int64_t e0 = tile_id * R;
     const int nt = (int)min((int64_t)R, A.n_entries - e0);
     const int64_t start_row = M.start_row, end_row = M.end_row;
@@ -129,54 +163,52 @@ __device__ __forceinline__ void tile_body_mx(const TileArgs<float> &A, const Ste
         m_row[s] = M.row[s]; m_wl[s] = M.wl[s]; m_wr[s] = M.wr[s]; m_pos[s] = M.pos[s]; m_lv[s] = M.lv[s]; m_ht[s] = M.ht[s] & 63;
     }
     if (tid < 64) hist[tid] = 0;
+    MX_STAMP(0);
 
-    // Row transfers, lane-linear over the nt * NCp chunk places of the tile (place c = 64 * instruction + lane -> LDS byte 16 c).
-    //   image rows (workspaces): every place from the row's own chunk;
-    //   caller rows (C / Q, element type = 4 bytes either way): float places from channels goff.., place 0 the row's first 16
-    //   bytes (raw wide channels, widened in place by widen_rows once landed), other wide places nothing
-    auto load_image_rows = [&](const float *dst, int rows, const float *src) {
+    // LDS-direct transfers, lane-linear: instruction `it` of a transfer fills LDS bytes [1024 it, 1024 it + 1024) of its region.
+    //   contiguous: row images (both parts of a workspace row are stored as separate, dense arrays)
+    //   caller rows (C / Q: 4-byte elements either way): the float places from channels n_wide + 4 ch .., and the row's first 16
+    //   bytes -- the raw wide channels, widened in place by widen_row once landed -- into the row's first wide place
+    auto load_linear = [&](const float *dst, int chunks, const float *src) {
         const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void *)dst;
-        const int total = rows * NCp;
-        for (int it = wid; (it << 6) < total; it += nwv) {
+        for (int it = wid; (it << 6) < chunks; it += nwv) {
             const int c = (it << 6) + lane;
-            if (c < total) glds16<0>(src + (uint32_t)c * 4u, lds0 + ((uint32_t)it << 10));
+            if (c < chunks) glds16<0>(src + (uint32_t)c * 4u, lds0 + ((uint32_t)it << 10));
         }
     };
-    auto load_caller_rows = [&](const float *dst, int rows, auto src) {
-        const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void *)dst;
-        const int total = rows * NCp;
-        for (int it = wid; (it << 6) < total; it += nwv) {
-            const int c = (it << 6) + lane;
-            const int jr = (int)(((uint32_t)c * NCm) >> 20), ch = c - jr * NCp;
-            if (c < total && (ch >= NW2 || ch == 0))
-                glds16<1>(src(jr, (uint32_t)(ch >= NW2 ? nwide + min((ch - NW2) * 4, Df - 4) : 0)), lds0 + ((uint32_t)it << 10));
-        }
-    };
-    // the lane that loaded a row's raw first 16 bytes widens them: float32 -> float64 (forward), int32 * float64 step (inverse,
-    // encode_3dgs.py:261); its own load has landed (s_waitcnt vmcnt(0) in front), nobody else touches the wide places before
-    // the barrier that follows
-    auto widen_rows = [&](float *dst, int rows, auto is_int) {
-        const int total = rows * NCp;
-        for (int it = wid; (it << 6) < total; it += nwv) {
-            const int c = (it << 6) + lane;
-            const int jr = (int)(((uint32_t)c * NCm) >> 20), ch = c - jr * NCp;
-            if (c < total && ch == 0) {
-                float *row = dst + __mul24(jr, Dp);
-                double d[4];
-                if constexpr (decltype(is_int)::value) {
-                    const I16 raw = *(const I16 *)row;
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) d[i] = i < nwide ? (double)raw.v[i] * ST.w[i] : 0.0;
-                } else {
-                    const V16 raw = *(const V16 *)row;
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) d[i] = i < nwide ? (double)raw.v[i] : 0.0;
-                }
-                W16 w0; w0.v[0] = d[0]; w0.v[1] = d[1];
-                *(W16 *)row = w0;
-                if (NW2 > 1) { W16 w1; w1.v[0] = d[2]; w1.v[1] = d[3]; *(W16 *)(row + 4) = w1; }
+    auto load_caller_rows = [&](int rows, auto src) {
+        {
+            const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void *)ftile;
+            const int total = rows * NF;
+            for (int it = wid; (it << 6) < total; it += nwv) {
+                const int c = (it << 6) + lane;
+                const int jr = (int)(((uint32_t)c * NFm) >> 20), ch = c - jr * NF;
+                if (c < total) glds16<1>(src(jr, (uint32_t)(nwide + min(ch * 4, Df - 4))), lds0 + ((uint32_t)it << 10));
             }
         }
+        {
+            const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void *)wt;
+            const int total = rows << lgw;
+            for (int it = nwv - 1 - wid; (it << 6) < total; it += nwv) {          // (from the last wave down: the float part's tail is uneven)
+                const int c = (it << 6) + lane;
+                if (c < total && (c & (NW2 - 1)) == 0) glds16<1>(src(c >> lgw, 0u), lds0 + ((uint32_t)it << 10));
+            }
+        }
+    };
+    // Widening of the raw wide channels a caller row arrived with: float32 -> float64 (forward), int32 * float64 step (inverse,
+    // encode_3dgs.py:261), in place. One ROW per thread, after the barrier behind which every wave's rows have landed.
+    auto widen_row = [&](int j, auto is_int) {
+        float *row = wt + __mul24(j, Wp);
+        const V16 raw = *(const V16 *)row;
+        double d[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if constexpr (decltype(is_int)::value) d[i] = i < nwide ? (double)__float_as_int(raw.v[i]) * ST.w[i] : 0.0;
+            else d[i] = i < nwide ? (double)raw.v[i] : 0.0;
+        }
+        W16 w0; w0.v[0] = d[0]; w0.v[1] = d[1];
+        *(W16 *)row = w0;
+        if (NW2 > 1) { W16 w1; w1.v[0] = d[2]; w1.v[1] = d[3]; *(W16 *)(row + 4) = w1; }
     };
 
     // ---- P0b. transfers whose addresses do not depend on the plan metadata ----
@@ -184,24 +216,28 @@ __device__ __forceinline__ void tile_body_mx(const TileArgs<float> &A, const Ste
         if constexpr (IDENT) {
             const uint32_t ldc = (uint32_t)A.ld_in;
             const float *src = A.in + e0 * (int64_t)ldc;
-            load_caller_rows(tile, nt, [&](int jr, uint32_t go) { return row_at(src, (uint32_t)jr, ldc, go); });
+            load_caller_rows(nt, [&](int jr, uint32_t go) { return row_at(src, (uint32_t)jr, ldc, go); });
         } else {
-            load_image_rows(tile, nt, A.in + e0 * (int64_t)Dp);
+            load_linear(ftile, nt * NF, A.in + e0 * (int64_t)Fp);
+            load_linear(wt, nt << lgw, P.in_w + e0 * (int64_t)Wp);
         }
     } else {
         const int npre = A.last_stage ? 0 : (int)min(surv_cnt, (uint32_t)MX_PRE_ROWS);
-        load_image_rows(spre, npre, (const float *)A.wsn + (int64_t)surv_base * Dp);
+        load_linear(spre_f, npre * NF, (const float *)A.wsn + (int64_t)surv_base * Fp);
+        load_linear(spre_w, npre << lgw, (const float *)P.wsn_w + (int64_t)surv_base * Wp);
     }
 #pragma unroll
     for (int s = 0; s < SLOTS; ++s) {
         const int j = tid + s * nthreads;
         if (j < nt) { if (!IDENT) srow[j] = m_row[s]; if (INV) sdst[j] = m_pos[s]; }
     }
+    MX_STAMP(1);
     sync_lds();                                                            // sync #1
+    MX_STAMP(2);
 
     if constexpr (INV) {
         // every slot's quantized row (survivor slots are overwritten in P3b)
-        load_caller_rows(tile, nt, [&](int jr, uint32_t go) {
+        load_caller_rows(nt, [&](int jr, uint32_t go) {
             return (const void *)row_far((const int32_t *)A.Q, (uint32_t)sdst[jr], (uint32_t)A.ldq, go); });
     }
 
@@ -227,6 +263,7 @@ __device__ __forceinline__ void tile_body_mx(const TileArgs<float> &A, const Ste
         if (lane == 0 && s * nwv + wid < 32) scnt[s * nwv + wid] = (uint32_t)__popcll(bal);
     }
     sync_lds();                                                            // sync #2
+    MX_STAMP(3);
 
     // ---- P2. round offsets (wave 0); survivor destinations ----
     if (wid == 0) {
@@ -249,24 +286,28 @@ __device__ __forceinline__ void tile_body_mx(const TileArgs<float> &A, const Ste
             ssurv[before + (uint32_t)m_rank[s]] = (uint16_t)j;
         }
     }
+    if constexpr (INV) wait_landed();                                      // this wave's Q rows (and survivor prefetch) are in LDS
+    sync_lds();                                                            // sync #3 (inverse: every row has landed)
+    MX_STAMP(4);
     if constexpr (INV) {
-        wait_landed();                                                     // this wave's Q rows (and survivor prefetch) are in LDS
-        widen_rows(tile, nt, std::true_type());
-    }
-    sync_lds();                                                            // sync #3
-    if constexpr (INV) {
-        load_steps(lane);
+        load_steps(fl);
         // roots finalised by a last TILE stage come straight from Q as well: dequantize them in place (no butterfly will)
-        if (A.last_stage && active && !wide) for (int it = wid; (it << lr) < nt; it += nwv) {
+        if (A.last_stage && c4 < NF) for (int it = wid; (it << lr) < nt; it += nwv) {
             const int j = (it << lr) + g;
             if (j < nt && sflag[j] == 2) {
-                V16 *pr = (V16 *)&tile[__mul24(j, Dp) + coff];
+                V16 *pr = (V16 *)&ftile[__mul24(j, Fp) + fl * 4];
                 const I16 raw = *(const I16 *)pr;
                 V16 x;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) x.v[i] = (float)raw.v[i] * my_step[i];            // encode_3dgs.py:261
                 *pr = x;
             }
+        }
+        // the wide channels of the rows finalised here (survivor slots are filled by P3b, with images)
+#pragma unroll
+        for (int s = 0; s < SLOTS; ++s) {
+            const int j = tid + s * nthreads;
+            if (j < nt && (m_merged[s] || A.last_stage)) widen_row(j, std::true_type());
         }
     }
 
@@ -292,40 +333,69 @@ __device__ __forceinline__ void tile_body_mx(const TileArgs<float> &A, const Ste
             double w0, w1;
             pair_weights(r, l, m_wr[s], A.wsum, w0, w1);
             const double den = w0 + w1;
-            MRec<double> rec;
-            rec.po = (uint32_t)__mul24((int)p, Dp);
-            rec.jo = (uint32_t)__mul24((int)j, Dp);
-            rec.a = sqrt(w0 / den);                       // RAHT.py:321-322 (float64; the float32 lanes round it once)
-            rec.b = sqrt(w1 / den);
+            W16 ab;
+            ab.v[0] = sqrt(w0 / den);                     // RAHT.py:321-322 (float64; the float32 lanes round it once)
+            ab.v[1] = sqrt(w1 / den);
             const uint32_t pos = atomicAdd(&cursor[m_ht[s]], 1u);
-            mrec[pos] = rec;
+            rec_ab[pos] = ab;
+            rec_pj[pos] = (uint32_t)p | ((uint32_t)j << 16);
         }
     }
     // ---- P3b. inverse: the survivors' low-pass rows (images, from the stage above) into their slots ----
     if (INV && !A.last_stage) {
         const uint32_t n_pre = min(surv_cnt, (uint32_t)MX_PRE_ROWS);
-        if (active) for (uint32_t it = wid; (it << lr) < n_pre; it += nwv) {
+        // float part: a lane group per row; wide part: NW2 lanes per row
+        if (c4 < NF) for (uint32_t it = wid; (it << lr) < n_pre; it += nwv) {
             const uint32_t qc = min((it << lr) + g, n_pre - 1);
-            const V16 x = *(const V16 *)&spre[__mul24((int)qc, Dp) + coff];
-            *(V16 *)&tile[__mul24((int)ssurv[qc], Dp) + coff] = x;
+            const V16 x = *(const V16 *)&spre_f[__mul24((int)qc, Fp) + fl * 4];
+            *(V16 *)&ftile[__mul24((int)ssurv[qc], Fp) + fl * 4] = x;
         }
-        if (active) for (uint32_t it = wid; MX_PRE_ROWS + (it << lr) < surv_cnt; it += nwv) {
+        for (uint32_t c = (uint32_t)tid; c < (n_pre << lgw); c += (uint32_t)nthreads) {
+            const uint32_t qc = c >> lgw, part = c & (uint32_t)(NW2 - 1);
+            *(V16 *)&wt[__mul24((int)ssurv[qc], Wp) + part * 4] = *(const V16 *)&spre_w[c * 4];
+        }
+        if (c4 < NF) for (uint32_t it = wid; MX_PRE_ROWS + (it << lr) < surv_cnt; it += nwv) {
             const uint32_t qc = min(MX_PRE_ROWS + (it << lr) + g, surv_cnt - 1);
-            const V16 x = ld_chunk<float>(row_at((const float *)A.wsn + (int64_t)surv_base * Dp, qc, (uint32_t)Dp, (uint32_t)coff));
-            *(V16 *)&tile[__mul24((int)ssurv[qc], Dp) + coff] = x;
+            const V16 x = ld_chunk<float>(row_at((const float *)A.wsn + (int64_t)surv_base * Fp, qc, (uint32_t)Fp, (uint32_t)(fl * 4)));
+            *(V16 *)&ftile[__mul24((int)ssurv[qc], Fp) + fl * 4] = x;
+        }
+        for (uint32_t c = ((uint32_t)MX_PRE_ROWS << lgw) + (uint32_t)tid; c < (surv_cnt << lgw); c += (uint32_t)nthreads) {
+            const uint32_t qc = c >> lgw, part = c & (uint32_t)(NW2 - 1);
+            const V16 x = ld_chunk<float>((const float *)P.wsn_w + (int64_t)surv_base * Wp + c * 4);
+            *(V16 *)&wt[__mul24((int)ssurv[qc], Wp) + part * 4] = x;
         }
     }
     if constexpr (!INV) {
         wait_landed();                                                     // this wave's rows are in LDS
-        if constexpr (IDENT) widen_rows(tile, nt, std::false_type());
+        if constexpr (IDENT) {
+            sync_lds();                                                    // every wave's
+#pragma unroll
+            for (int s = 0; s < SLOTS; ++s) {
+                const int j = tid + s * nthreads;
+                if (j < nt) widen_row(j, std::false_type());
+            }
+        }
         sync_lds();                                                        // sync #4
     } else {
         __syncthreads();
     }
+    MX_STAMP(5);
 
-    // ---- P4. butterflies, one round per height present; a lane group handles one butterfly ----
+    // ---- P4. butterflies, one round per height present ----
+    // The float32 channels run exactly as in the float32 kernels: a lane group per butterfly (head and idle lanes shadow the
+    // group's last float lane: same reads, same writes, no exec-mask juggling). The wide channels of a level are a SEPARATE, dense
+    // pass over their own LDS array -- NW2 lanes per butterfly, 32 or 64 butterflies per wave instruction -- on other waves.
+    // Levels that fit one wave instruction (most: the chain of small levels needs no workgroup barrier, a wave's LDS operations
+    // execute in order) are walked by wave 0 (float) and wave 1 (wide) side by side. (First version: one row array with the wide
+    // places in front, the wide lanes taking a float64 branch inside every float butterfly instruction: both branches issued for
+    // every instruction of every wave, and every same-place access of many 256-byte rows a bank conflict: LDS busy twice as long
+    // as in the float32 kernel, rocprofv3 SQ_LDS_BANK_CONFLICT 39 M against 11 M cycles per launch.)
     {
         const uint32_t stride = (uint32_t)(nwv << lr);
+        const uint32_t gw = (uint32_t)lane >> lgw, cw4 = (uint32_t)(lane & (NW2 - 1)) * 4u;
+        const uint32_t bw = 64u >> lgw;                        // wide butterflies per wave instruction
+        const uint32_t cf = (uint32_t)fl * 4u;
+        const int wsh = 2 + lgw;                               // slot -> wide-tile offset (floats)
         bool chained = false;
         const int loff_v = (int)loff[lane], hist_v = (int)hist[lane];
         uint64_t mask = __ballot(hist_v > 0);
@@ -333,164 +403,201 @@ __device__ __forceinline__ void tile_body_mx(const TileArgs<float> &A, const Ste
             const int l = INV ? (63 - __clzll((long long)mask)) : (__ffsll((long long)mask) - 1);
             mask &= ~(1ull << l);
             const uint32_t base = (uint32_t)__builtin_amdgcn_readlane(loff_v, l), cnt = (uint32_t)__builtin_amdgcn_readlane(hist_v, l);
-            auto apply = [&](auto UC, uint32_t mb) {
+            auto apply_f = [&](auto UC, uint32_t mb) {
                 constexpr int U = decltype(UC)::value;
-                MRec<double> r[U];
+                W16 ab[U];
+                uint32_t pj[U];
 #pragma unroll
-                for (int u = 0; u < U; ++u) r[u] = mrec[base + min(mb + u * stride + g, cnt - 1)];
+                for (int u = 0; u < U; ++u) { const uint32_t m = base + min(mb + u * stride + g, cnt - 1); pj[u] = rec_pj[m]; ab[u] = rec_ab[m]; }
                 uint32_t ip[U], ij[U];
                 V16 x0[U], x1[U];
 #pragma unroll
-                for (int u = 0; u < U; ++u) { ip[u] = r[u].po + coff; ij[u] = r[u].jo + coff; }
+                for (int u = 0; u < U; ++u) { ip[u] = __umul24(pj[u] & 0xffffu, (uint32_t)Fp) + cf; ij[u] = __umul24(pj[u] >> 16, (uint32_t)Fp) + cf; }
 #pragma unroll
-                for (int u = 0; u < U; ++u) { x0[u] = *(const V16 *)&tile[ip[u]]; x1[u] = *(const V16 *)&tile[ij[u]]; }
-                if (wide) {
-#pragma unroll
-                    for (int u = 0; u < U; ++u) {
-                        W16 d0, d1, lo, hi;
-                        __builtin_memcpy(&d0, &x0[u], 16);
-                        __builtin_memcpy(&d1, &x1[u], 16);
-                        const double ca = r[u].a, cb = r[u].b;
-#pragma unroll
-                        for (int i = 0; i < 2; ++i) {
-                            if (!INV) {                       // RAHT.py:331-332
-                                lo.v[i] = ca * d0.v[i] + cb * d1.v[i];
-                                hi.v[i] = ca * d1.v[i] - cb * d0.v[i];
-                            } else {                          // iRAHT.py:108-109
-                                lo.v[i] = ca * d0.v[i] - cb * d1.v[i];
-                                hi.v[i] = cb * d0.v[i] + ca * d1.v[i];
-                            }
-                        }
-                        if (u == 0 || mb + u * stride < cnt) { *(W16 *)&tile[ip[u]] = lo; *(W16 *)&tile[ij[u]] = hi; }
-                    }
-                } else {
-                    if constexpr (INV) {                      // the high-pass operand is still the quantized integer (encode_3dgs.py:261)
-#pragma unroll
-                        for (int u = 0; u < U; ++u) {
-#pragma unroll
-                            for (int i = 0; i < 4; ++i) x1[u].v[i] = (float)__float_as_int(x1[u].v[i]) * my_step[i];
-                        }
-                    }
+                for (int u = 0; u < U; ++u) { x0[u] = *(const V16 *)&ftile[ip[u]]; x1[u] = *(const V16 *)&ftile[ij[u]]; }
+                if constexpr (INV) {                          // the high-pass operand is still the quantized integer (encode_3dgs.py:261)
 #pragma unroll
                     for (int u = 0; u < U; ++u) {
-                        const float ca = (float)r[u].a, cb = (float)r[u].b;
-                        V16 lo, hi;
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) {
-                            if (!INV) {
-                                lo.v[i] = ca * x0[u].v[i] + cb * x1[u].v[i];
-                                hi.v[i] = ca * x1[u].v[i] - cb * x0[u].v[i];
-                            } else {
-                                lo.v[i] = ca * x0[u].v[i] - cb * x1[u].v[i];
-                                hi.v[i] = cb * x0[u].v[i] + ca * x1[u].v[i];
-                            }
-                        }
-                        if (u == 0 || mb + u * stride < cnt) { *(V16 *)&tile[ip[u]] = lo; *(V16 *)&tile[ij[u]] = hi; }
+                        for (int i = 0; i < 4; ++i) x1[u].v[i] = (float)__float_as_int(x1[u].v[i]) * my_step[i];
                     }
                 }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const float ca = (float)ab[u].v[0], cb = (float)ab[u].v[1];
+                    V16 lo, hi;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        if (!INV) {                           // RAHT.py:331-332
+                            lo.v[i] = ca * x0[u].v[i] + cb * x1[u].v[i];
+                            hi.v[i] = ca * x1[u].v[i] - cb * x0[u].v[i];
+                        } else {                              // iRAHT.py:108-109
+                            lo.v[i] = ca * x0[u].v[i] - cb * x1[u].v[i];
+                            hi.v[i] = cb * x0[u].v[i] + ca * x1[u].v[i];
+                        }
+                    }
+                    if (u == 0 || mb + u * stride < cnt) { *(V16 *)&ftile[ip[u]] = lo; *(V16 *)&ftile[ij[u]] = hi; }
+                }
             };
-            auto pass = [&](auto UC) {
+            auto pass_f = [&](auto UC) {
                 constexpr int U = decltype(UC)::value;
-                for (uint32_t mb = (uint32_t)(wid << lr); mb < cnt; mb += stride * U) apply(UC, mb);
+                for (uint32_t mb = (uint32_t)(wid << lr); mb < cnt; mb += stride * U) apply_f(UC, mb);
+            };
+            // butterflies m0 + gw of this level, wide channels (lanes past the last one redo it in lockstep with its owner)
+            auto apply_w = [&](uint32_t m0) {
+                const uint32_t m = base + min(m0 + gw, cnt - 1);
+                const uint32_t pj = rec_pj[m];
+                const W16 ab = rec_ab[m];
+                const uint32_t ip = ((pj & 0xffffu) << wsh) + cw4, ij = ((pj >> 16) << wsh) + cw4;
+                const W16 d0 = *(const W16 *)&wt[ip], d1 = *(const W16 *)&wt[ij];
+                const double ca = ab.v[0], cb = ab.v[1];
+                W16 lo, hi;
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    if (!INV) {                               // RAHT.py:331-332
+                        lo.v[i] = ca * d0.v[i] + cb * d1.v[i];
+                        hi.v[i] = ca * d1.v[i] - cb * d0.v[i];
+                    } else {                                  // iRAHT.py:108-109
+                        lo.v[i] = ca * d0.v[i] - cb * d1.v[i];
+                        hi.v[i] = cb * d0.v[i] + ca * d1.v[i];
+                    }
+                }
+                *(W16 *)&wt[ip] = lo; *(W16 *)&wt[ij] = hi;
             };
             if (cnt <= (1u << lr)) {
-                if (wid == 0) pass(std::integral_constant<int, 1>());     // fits one wave instruction: wave 0 alone, no barrier
+                if (wid == 0) pass_f(std::integral_constant<int, 1>());
+                else if (wid == 1) apply_w(0u);
                 chained = true;
             } else {
                 if (chained) { __syncthreads(); chained = false; }
-                if (cnt <= stride) pass(std::integral_constant<int, 1>());
-                else pass(std::integral_constant<int, TILE_ROUND_U>());
+                if (cnt <= stride) pass_f(std::integral_constant<int, 1>());
+                else pass_f(std::integral_constant<int, TILE_ROUND_U>());
+                for (uint32_t m0 = (uint32_t)(nwv - 1 - wid) * bw; m0 < cnt; m0 += (uint32_t)nwv * bw) apply_w(m0);   // from the last wave down
                 __syncthreads();
             }
         }
         if (chained) __syncthreads();
     }
 
+    MX_STAMP(6);
     // ---- P5. write back ----
     {
         int tid5 = tid0;
         asm volatile("" : "+v"(tid5));
-        lane_geom(tid5, lane, wid, g, c4c, coff, goff, active, wide);
+        lane_geom(tid5, lane, wid, g, c4, fl, sp, goff, head);
     }
+    const bool rowlane = c4 <= NF;                        // float lanes and the head lane
     if constexpr (INV) {
         if constexpr (IDENT) {
-            // stage 0 -> the caller's C rows [e0, e0 + nt): float chunks as they are, the wide lanes round their two channels
+            // stage 0 -> the caller's C rows [e0, e0 + nt). ONE store instruction writes a whole row: the float lanes their chunks,
+            // the head lane the row's first 16 bytes -- the wide channels rounded to float32 and, behind them, the first
+            // 4 - n_wide float channels once more (the same values their own lane stores). A row start written by a second,
+            // narrower store instruction becomes a partial-line write of its own: the fused forward took 0.92 ms instead of
+            // 0.31 ms that way (rows are 236 bytes: every line is shared by two rows)
             float *base = A.out + e0 * A.ld_out;
-            if (active) for (int it = wid; (it << lr) < nt; it += nwv) {
-                const int j = min((it << lr) + g, nt - 1);
-                const V16 x = *(const V16 *)&tile[__mul24(j, Dp) + coff];
-                if (!wide) {
-                    st_chunk<float, true>(row_at(base, (uint32_t)j, (uint32_t)A.ld_out, (uint32_t)goff), x);
-                } else {
-                    W16 d;
-                    __builtin_memcpy(&d, &x, 16);
-                    float *pr = row_at(base, (uint32_t)j, (uint32_t)A.ld_out, (uint32_t)(2 * c4c));
+            // (two row instructions per trip, every LDS read of both in front of the first branch: a trip is one LDS round trip,
+            // and a read inside the head lane's branch would be another one)
+            if (rowlane) for (int it = wid; (it << lr) < nt; it += 2 * nwv) {
+                int j[2]; V16 x[2]; W16 w0[2], w1[2];
 #pragma unroll
-                    for (int i = 0; i < 2; ++i) if (2 * c4c + i < nwide) __builtin_nontemporal_store((float)d.v[i], pr + i);
+                for (int u = 0; u < 2; ++u) {
+                    j[u] = min(((it + u * nwv) << lr) + g, nt - 1);
+                    x[u] = *(const V16 *)&ftile[__mul24(j[u], Fp) + sp * 4];
+                    w0[u] = *(const W16 *)&wt[__mul24(j[u], Wp)];
+                    w1[u] = *(const W16 *)&wt[__mul24(j[u], Wp) + (NW2 - 1) * 4];
+                }
+                asm volatile("" : "+v"(w0[0].v[0]), "+v"(w1[0].v[0]), "+v"(w0[1].v[0]), "+v"(w1[1].v[0]));
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    if (head) {
+                        const float d[4] = {(float)w0[u].v[0], (float)w0[u].v[1], NW2 > 1 ? (float)w1[u].v[0] : 0.0f, NW2 > 1 ? (float)w1[u].v[1] : 0.0f};
+                        const V16 fx = x[u];
+                        first_four(d, fx.v, nwide, x[u].v);
+                    }
+                    if (u == 0 || ((it + nwv) << lr) < nt)
+                        st_chunk<float, true>(row_at(base, (uint32_t)j[u], (uint32_t)A.ld_out, (uint32_t)(head ? 0 : goff)), x[u]);
                 }
             }
         } else {
-            // stage k -> ws_k, row images
-            float *base = A.out + e0 * (int64_t)Dp;
-            if (active) for (int it = wid; (it << lr) < nt; it += nwv) {
-                const int j = min((it << lr) + g, nt - 1);
-                const V16 x = *(const V16 *)&tile[__mul24(j, Dp) + coff];
-                st_chunk<float>(row_at(base, (uint32_t)j, (uint32_t)Dp, (uint32_t)coff), x);
-            }
+            // stage k -> ws_k: both parts are contiguous runs of chunks
+            float *bf = A.out + e0 * (int64_t)Fp, *bw_ = P.out_w + e0 * (int64_t)Wp;
+            for (int c = tid; c < nt * NF; c += nthreads) st_chunk<float>(bf + c * 4, *(const V16 *)&ftile[c * 4]);
+            for (int c = tid; c < (nt << lgw); c += nthreads) st_chunk<float>(bw_ + c * 4, *(const V16 *)&wt[c * 4]);
         }
     } else {
-        // survivors, compacted, to the next stage's workspace (row images)
+        // survivors, compacted, to the next stage's workspace (row images, two dense arrays)
         if (!A.last_stage) {
-            float *base = A.wsn + (int64_t)surv_base * Dp;
-            if (active) for (uint32_t it = wid; (it << lr) < surv_cnt; it += nwv) {
+            float *bf = A.wsn + (int64_t)surv_base * Fp, *bw_ = P.wsn_w + (int64_t)surv_base * Wp;
+            if (c4 < NF) for (uint32_t it = wid; (it << lr) < surv_cnt; it += nwv) {
                 const uint32_t q = min((it << lr) + g, surv_cnt - 1);
-                const V16 x = *(const V16 *)&tile[__mul24((int)ssurv[q], Dp) + coff];
-                st_chunk<float>(row_at(base, q, (uint32_t)Dp, (uint32_t)coff), x);
+                const V16 x = *(const V16 *)&ftile[__mul24((int)ssurv[q], Fp) + fl * 4];
+                st_chunk<float>(row_at(bf, q, (uint32_t)Fp, (uint32_t)(fl * 4)), x);
+            }
+            for (uint32_t c = (uint32_t)tid; c < (surv_cnt << lgw); c += (uint32_t)nthreads) {
+                const uint32_t q = c >> lgw, part = c & (uint32_t)(NW2 - 1);
+                st_chunk<float>(bw_ + c * 4, *(const V16 *)&wt[__mul24((int)ssurv[q], Wp) + part * 4]);
             }
         }
-        // rows finalised here, quantized to Q[inv_order[row]] (encode_3dgs.py:204,210,215): the float32 channels ...
-        load_steps(lane);
-        auto store_final = [&](auto fast_div) {
-            if (active && !wide) for (int it = wid; (it << lr) < nt; it += nwv) {
-                const int jc = min((it << lr) + g, nt - 1);
-                V16 x = *(const V16 *)&tile[__mul24(jc, Dp) + coff];
-                const uint32_t dv = (uint32_t)sdst[jc];
-                asm volatile("" : "+v"(x.v[0]));
-                if (dv >> 31) {
-                    I16 qv;
+        // rows finalised here, quantized to Q[inv_order[row]] (encode_3dgs.py:204,210,215).
+        // (a) the wide channels: one ROW per thread -- the IEEE double division is ~40 instructions a channel, so it runs on
+        //     whole waves of rows -- and the integers go back into the row's first wide place (a row finalised here is nobody's
+        //     survivor)
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) qv.v[i] = quantize_one(x.v[i], my_step[i], my_rcp[i], decltype(fast_div)::value);
-                    st_chunk<int32_t, true>(row_far(A.Q, dv & 0x7fffffffu, (uint32_t)A.ldq, (uint32_t)goff), qv);
+        for (int s = 0; s < SLOTS; ++s) {
+            const int j = tid0 + s * nthreads;
+            if (j < nt && ((uint32_t)sdst[j] >> 31)) {
+                float *row = &wt[__mul24(j, Wp)];
+                double d[4];
+                { const W16 w0 = *(const W16 *)row; d[0] = w0.v[0]; d[1] = w0.v[1]; }
+                d[2] = 0.0; d[3] = 0.0;
+                if (NW2 > 1) { const W16 w1 = *(const W16 *)(row + 4); d[2] = w1.v[0]; d[3] = w1.v[1]; }
+                I16 qi;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) qi.v[i] = i < nwide ? quantize_one_f64(d[i], ST.w[i]) : 0;
+                *(I16 *)row = qi;
+            }
+        }
+        sync_lds();
+        MX_STAMP(7);
+        // (b) ONE store instruction per row group writes whole rows of Q: the float lanes their quantized chunks, the head lane the
+        //     row's first 16 bytes = the wide integers and, behind them, the first 4 - n_wide float channels quantized once more
+        //     (same values as their own lane's). See the inverse's write-back for why.
+        load_steps(sp);
+        auto store_final = [&](auto fast_div) {
+            if (rowlane) for (int it = wid; (it << lr) < nt; it += 2 * nwv) {
+                int jc[2]; V16 x[2]; I16 qi[2]; uint32_t dv[2];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    jc[u] = min(((it + u * nwv) << lr) + g, nt - 1);
+                    x[u] = *(const V16 *)&ftile[__mul24(jc[u], Fp) + sp * 4];
+                    qi[u] = *(const I16 *)&wt[__mul24(jc[u], Wp)];
+                    dv[u] = (uint32_t)sdst[jc[u]];
+                }
+                asm volatile("" : "+v"(x[0].v[0]), "+v"(qi[0].v[0]), "+v"(x[1].v[0]), "+v"(qi[1].v[0]));
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    if ((dv[u] >> 31) && (u == 0 || ((it + nwv) << lr) < nt)) {
+                        I16 qv;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) qv.v[i] = quantize_one(x[u].v[i], my_step[i], my_rcp[i], decltype(fast_div)::value);
+                        if (head) {
+                            const I16 t = qv;
+                            first_four(qi[u].v, t.v, nwide, qv.v);
+                        }
+                        st_chunk<int32_t, true>(row_far(A.Q, dv[u] & 0x7fffffffu, (uint32_t)A.ldq, (uint32_t)(head ? 0 : goff)), qv);
+                    }
                 }
             }
         };
         if (ST.f.fast_div) store_final(std::true_type()); else store_final(std::false_type());
-        // ... and the wide channels: one ROW per thread (the IEEE double division is ~40 instructions a channel: run on whole
-        // waves of rows instead of on the few wide lanes of every row instruction)
-#pragma unroll
-        for (int s = 0; s < SLOTS; ++s) {
-            const int j = tid0 + s * nthreads;
-            if (j < nt) {
-                const uint32_t dv = (uint32_t)sdst[j];
-                if (dv >> 31) {
-                    const float *row = &tile[__mul24(j, Dp)];
-                    double d[4];
-                    { const W16 w0 = *(const W16 *)row; d[0] = w0.v[0]; d[1] = w0.v[1]; }
-                    d[2] = 0.0; d[3] = 0.0;
-                    if (NW2 > 1) { const W16 w1 = *(const W16 *)(row + 4); d[2] = w1.v[0]; d[3] = w1.v[1]; }
-                    int32_t *qrow = row_far(A.Q, dv & 0x7fffffffu, (uint32_t)A.ldq, 0u);
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) if (i < nwide) __builtin_nontemporal_store(quantize_one_f64(d[i], ST.w[i]), qrow + i);
-                }
-            }
-        }
     }
+    MX_STAMP(8);
 }
 
 template <bool INV, bool IDENT, int SLOTS>
-__global__ __launch_bounds__(MX_THREADS, 6) void tile_kernel_mx(const TileArgs<float> A, const StepTableMX ST)
+__global__ __launch_bounds__(MX_THREADS, 6) void tile_kernel_mx(const TileArgs<float> A, const MxPtrs P, const StepTableMX ST)
 {
-    tile_body_mx<INV, IDENT, SLOTS>(A, ST, (int64_t)blockIdx.x);
+    tile_body_mx<INV, IDENT, SLOTS>(A, P, ST, (int64_t)blockIdx.x);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -499,14 +606,14 @@ __global__ __launch_bounds__(MX_THREADS, 6) void tile_kernel_mx(const TileArgs<f
 // ------------------------------------------------------------------------------------------------
 struct TopArgsMX {
     const float *in_rows;  int64_t ld_in;    // fwd, single-stage schedule: the caller's C rows (entry = row)
-    const float *in_img;                     // fwd, later stage: workspace row images, entry order
+    const float *in_img, *in_img_w;          // fwd, later stage: workspace row images, entry order (float places; wide places)
     float *out_rows;       int64_t ld_out;   // inv, single-stage schedule: the caller's C rows
-    float *out_img;                          // inv, later stage: workspace row images
+    float *out_img, *out_img_w;              // inv, later stage: workspace row images
     int32_t *Q;            int64_t ldq;
     const uint32_t *e_pos;                   // entry -> position in Q
     const uint32_t *pj;                      // butterflies sorted by level: partner entry | own entry << 16
     const float *ab32;  const double *ab64;  // a, b per butterfly
-    int n, n_merges, D, nwide, Dp;
+    int n, n_merges, D, nwide, Fp;           // Fp: floats per row of the float part of an image (the wide part: 4 NW2)
     const uint32_t *lev;
     int nlev, nbig;
     uint32_t small_start;
@@ -524,7 +631,7 @@ __device__ __forceinline__ void top_body_mx(const TopArgsMX &A, const StepTableM
     const int tid = threadIdx.x;
     const int nwide = A.nwide, NW2 = (nwide + 1) >> 1, Df = A.D - nwide;
     const int goff = WIDE ? 2 * chunk : nwide + min(chunk * 4, Df - 4);     // first channel of this chunk in the caller's rows
-    const int ioff = WIDE ? chunk * 4 : (NW2 + chunk) * 4;                    // its place in a row image (floats)
+    const int istride = WIDE ? NW2 * 4 : A.Fp, ioff = chunk * 4;              // its place in a row image (floats)
     const int n = A.n, nm = A.n_merges;
     if (tid < 2 * A.nlev) s_lev[tid] = A.lev[tid];
     const T *ab = WIDE ? (const T *)A.ab64 : (const T *)A.ab32;
@@ -562,7 +669,7 @@ __device__ __forceinline__ void top_body_mx(const TopArgsMX &A, const StepTableM
         V16 v;
         if constexpr (!INV) {
             if (A.in_img) {
-                v = *(const V16 *)(A.in_img + (int64_t)e * A.Dp + ioff);
+                v = *(const V16 *)((WIDE ? A.in_img_w : A.in_img) + (int64_t)e * istride + ioff);
             } else if constexpr (WIDE) {
 #pragma unroll
                 for (int i = 0; i < VN; ++i) v.v[i] = live[i] ? (double)A.in_rows[(int64_t)e * A.ld_in + goff + i] : 0.0;
@@ -636,7 +743,7 @@ __device__ __forceinline__ void top_body_mx(const TopArgsMX &A, const StepTableM
         const V16 v = tile[e];
         if constexpr (INV) {
             if (A.out_img) {
-                *(V16 *)(A.out_img + (int64_t)e * A.Dp + ioff) = v;
+                *(V16 *)((WIDE ? A.out_img_w : A.out_img) + (int64_t)e * istride + ioff) = v;
             } else if constexpr (WIDE) {
 #pragma unroll
                 for (int i = 0; i < VN; ++i) if (live[i]) A.out_rows[(int64_t)e * A.ld_out + goff + i] = (float)v.v[i];
@@ -684,7 +791,7 @@ __global__ void mx_cols_from_f64_kernel(const double *__restrict__ W, int64_t N,
 
 // ---- host side -------------------------------------------------------------------------------------------------------
 struct MxGeom {
-    int nwide = 0, NCp = 0, Dp = 0, lg = 0;
+    int nwide = 0, NCp = 0, Dp = 0, lg = 0;     // NCp: chunk places per row (wide + float); Dp: floats per row of the float tile
     int R0 = 0, R1 = 0, Rf = 0;
 };
 
@@ -694,23 +801,24 @@ static bool mx_geometry(const raht_plan *p, int D, int nwide, MxGeom &g)
     const int Df = D - nwide;
     if (Df < 4 || D > 64 + MX_MAX_WIDE) return false;
     g.nwide = nwide;
-    g.NCp = (nwide + 1) / 2 + (Df + 3) / 4;
-    if (g.NCp > 32) return false;
-    g.Dp = g.NCp * 4;
+    const int NF = (Df + 3) / 4;
+    g.NCp = (nwide + 1) / 2 + NF;
+    if (NF > 31) return false;
+    g.Dp = NF * 4;
     g.lg = 0;
-    while ((1 << g.lg) < g.NCp) ++g.lg;
+    while ((1 << g.lg) < NF + 1) ++g.lg;                  // the NF float lanes of a row and its head lane
     int r1 = 0, dc1 = 0;
     pick_tail_geometry(p, 4, D, 512, &r1, &dc1, &g.Rf);
     const size_t budget = (size_t)42 * 1280;              // three workgroups per CU
     auto fit = [&](int hi, bool ident, size_t cap) {
-        for (int R = hi; R >= 64; R -= 4) if (tile_lds_bytes_mx(R, g.NCp, ident) <= cap) return R;
+        for (int R = hi; R >= 64; --R) if (tile_lds_bytes_mx(R, g.NCp, ident) <= cap) return R;
         return 0;
     };
-    g.R0 = p->tile_rows_override > 0 ? fit(std::min(p->tile_rows_override, TILE_MAX_SLOTS * MX_THREADS) / 4 * 4 + 0, true, (size_t)128 * 1280)
+    g.R0 = p->tile_rows_override > 0 ? fit(std::min(p->tile_rows_override, TILE_MAX_SLOTS * MX_THREADS), true, (size_t)128 * 1280)
                                      : fit(512, true, budget);
     if (p->tile_rows_override > 0 && p->tile_rows_override < 64) g.R0 = 0;
     if (g.R0 == 0) return false;
-    g.R1 = p->tail_rows_override > 0 ? fit(std::min(p->tail_rows_override, TILE_MAX_SLOTS * MX_THREADS) / 4 * 4, false, (size_t)128 * 1280)
+    g.R1 = p->tail_rows_override > 0 ? fit(std::min(p->tail_rows_override, TILE_MAX_SLOTS * MX_THREADS), false, (size_t)128 * 1280)
                                      : fit(g.R0, false, budget);
     if (p->tail_rows_override > 0 && p->tail_rows_override < 64) g.R1 = 0;
     return g.R1 != 0;
@@ -725,12 +833,12 @@ static void fill_steps_mx(StepTableMX &t, const double *steps, int n_steps, int 
 }
 
 template <bool INV, bool IDENT, int SLOTS>
-static int launch_tile_mx_one(const TileArgs<float> &A, const StepTableMX &st, unsigned n_tiles, size_t lds, hipStream_t s)
+static int launch_tile_mx_one(const TileArgs<float> &A, const MxPtrs &P, const StepTableMX &st, unsigned n_tiles, size_t lds, hipStream_t s)
 {
     static PerDeviceOnce attr;
     if (attr.first(current_device()))
         RAHT_HIP_CHECK(hipFuncSetAttribute((const void *)tile_kernel_mx<INV, IDENT, SLOTS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    hipLaunchKernelGGL((tile_kernel_mx<INV, IDENT, SLOTS>), dim3(n_tiles), dim3(MX_THREADS), lds, s, A, st);
+    hipLaunchKernelGGL((tile_kernel_mx<INV, IDENT, SLOTS>), dim3(n_tiles), dim3(MX_THREADS), lds, s, A, P, st);
     RAHT_HIP_CHECK(hipGetLastError());
     return RAHT_OK;
 }
@@ -746,18 +854,24 @@ static int launch_stage_mx(const raht_plan *p, const Schedule &sc, int k, const 
 {
     const Stage &st = sc.stages[(size_t)k];
     const int K = (int)sc.stages.size();
+    // a stage's workspace: the float places of every entry, then the wide places of every entry
+    const int Wp = ((g.nwide + 1) / 2) * 4;
     float *ws_k = (k >= 1) ? (float *)st.ws : nullptr;
     float *ws_n = (k + 1 < K) ? (float *)sc.stages[(size_t)k + 1].ws : nullptr;
+    float *ws_k_w = ws_k ? ws_k + (size_t)st.n_entries * g.Dp : nullptr;
+    float *ws_n_w = ws_n ? ws_n + (size_t)sc.stages[(size_t)k + 1].n_entries * g.Dp : nullptr;
+    (void)Wp;
     if (k >= 1 && !ws_k) { set_error("mixed stage %d: missing stage workspace", k); return RAHT_ERR_INVALID; }
     if (st.is_top) {
         TopArgsMX A;
-        A.in_rows = nullptr; A.ld_in = 0; A.in_img = nullptr; A.out_rows = nullptr; A.ld_out = 0; A.out_img = nullptr;
-        if (!INV) { if (k == 0) { A.in_rows = io.C_in; A.ld_in = io.ldc; } else A.in_img = ws_k; }
-        else { if (k == 0) { A.out_rows = io.C_out; A.ld_out = io.ldc; } else A.out_img = ws_k; }
+        A.in_rows = nullptr; A.ld_in = 0; A.in_img = nullptr; A.in_img_w = nullptr;
+        A.out_rows = nullptr; A.ld_out = 0; A.out_img = nullptr; A.out_img_w = nullptr;
+        if (!INV) { if (k == 0) { A.in_rows = io.C_in; A.ld_in = io.ldc; } else { A.in_img = ws_k; A.in_img_w = ws_k_w; } }
+        else { if (k == 0) { A.out_rows = io.C_out; A.ld_out = io.ldc; } else { A.out_img = ws_k; A.out_img_w = ws_k_w; } }
         A.Q = io.Q; A.ldq = io.ldq;
         A.e_pos = st.rows ? st.e_pos : p->inv_order;
         A.pj = st.t_pj; A.ab32 = st.t_ab32; A.ab64 = st.t_ab64;
-        A.n = (int)st.n_entries; A.n_merges = (int)st.n_merges; A.D = D; A.nwide = g.nwide; A.Dp = g.Dp;
+        A.n = (int)st.n_entries; A.n_merges = (int)st.n_merges; A.D = D; A.nwide = g.nwide; A.Fp = g.Dp;
         A.lev = st.t_lev; A.nlev = st.t_nlev; A.nbig = st.t_nbig; A.small_start = st.t_small_start;
         if (!A.e_pos || !A.pj || !A.ab32 || !A.ab64 || !A.lev || !A.Q) { set_error("mixed top stage: missing plan arrays"); return RAHT_ERR_INVALID; }
         const size_t n_small = st.n_merges - st.t_small_start;
@@ -796,13 +910,17 @@ static int launch_stage_mx(const raht_plan *p, const Schedule &sc, int k, const 
                  (int64_t)st.tile_rows * std::max<int64_t>(io.ldc, g.Dp) * 4 >= ((int64_t)1 << 31)) bad = "tile geometry (32-bit row offsets)";
         if (bad) { set_error("mixed tile stage %d (%s): missing %s", k, INV ? "inverse" : "forward", bad); return RAHT_ERR_INVALID; }
     }
+    MxPtrs P;
+    P.in_w = (!INV && k >= 1) ? ws_k_w : nullptr;
+    P.out_w = (INV && k >= 1) ? ws_k_w : nullptr;
+    P.wsn_w = ws_n_w;
     const size_t lds = tile_lds_bytes_mx(st.tile_rows, g.NCp, st.rows == nullptr);
     const bool one = st.tile_rows <= MX_THREADS;
     const unsigned nt = (unsigned)st.n_tiles;
     if (k == 0 && p->ev_before) RAHT_HIP_CHECK(hipEventRecord(p->ev_before, s));
     int rc;
-    if (k == 0) rc = one ? launch_tile_mx_one<INV, true, 1>(A, stp, nt, lds, s) : launch_tile_mx_one<INV, true, 2>(A, stp, nt, lds, s);
-    else rc = one ? launch_tile_mx_one<INV, false, 1>(A, stp, nt, lds, s) : launch_tile_mx_one<INV, false, 2>(A, stp, nt, lds, s);
+    if (k == 0) rc = one ? launch_tile_mx_one<INV, true, 1>(A, P, stp, nt, lds, s) : launch_tile_mx_one<INV, true, 2>(A, P, stp, nt, lds, s);
+    else rc = one ? launch_tile_mx_one<INV, false, 1>(A, P, stp, nt, lds, s) : launch_tile_mx_one<INV, false, 2>(A, P, stp, nt, lds, s);
     if (k == 0 && p->ev_before) RAHT_HIP_CHECK(hipEventRecord(p->ev_after, s));
     return rc;
 }
@@ -919,6 +1037,15 @@ int raht_dequant_inv_mixed(const raht_plan *plan, const int32_t *Q, int64_t ldq,
 {
     return guarded("raht_dequant_inv_mixed", [&]() { return dequant_inv_mixed_impl(plan, Q, ldq, D, steps, n_steps, n_wide, C, ldc, stream); });
 }
+
+#ifdef RAHT_PHASE_CLOCKS
+int raht_debug_read_phase_clocks_mx(unsigned long long *dst, int n_tiles)
+{
+    RAHT_HIP_CHECK(hipDeviceSynchronize());
+    RAHT_HIP_CHECK(hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_phase_clk_mx), sizeof(unsigned long long) * MX_CLK_SLOTS * (size_t)std::min(n_tiles, MX_CLK_TILES)));
+    return MX_CLK_SLOTS;
+}
+#endif
 
 /* Tile rows and stage sizes the mixed kernels use for (D, n_wide): tile_rows = 0 when this shape takes the two-pass fallback. */
 int raht_plan_mixed_stats(raht_plan *plan, int D, int n_wide, int *tile_rows, int *n_stages, int64_t *rows_per_stage, int max_stages)

@@ -138,11 +138,16 @@ class ShardedRaht:
         force_collectives: issue the all-gathers even in a one-rank group (exercises the RCCL path on one GPU).
         direct: the two all-gathers of a step as DIRECT writes into the peers' gather buffers (include/raht.h, raht_xchg_*:
         one launch per direction, every rank writes its <= 15 KB slot to each peer over its own xGMI link and raises a flag;
-        SURVEY.md 5 / 8e) instead of RCCL's all_gather_into_tensor. Opt-in; the process group is still used once per
-        (D, dtype) to exchange the hipIpc handles. Call close() (collective) before dropping the object."""
+        SURVEY.md 5 / 8e) instead of RCCL's all_gather_into_tensor. Opt-in and EXPERIMENTAL: hipIpc + fine-grained memory +
+        peer mapping have only been exercised by ranks sharing ONE GPU (tests/test_gpu_sharded.py); no run over xGMI exists.
+        The process group is still used once per (D, dtype) to exchange the hipIpc handles. A peer that never arrives ends a
+        bounded wait, not a hung GPU -- and leaves a status word: check_exchange() (called by close(), roundtrip_error(),
+        check_against_unsharded()) raises on it, and every later direct gather of the object refuses to run. Call close()
+        (collective) before dropping the object."""
         self.ops = local_ops or HipLocalOps
         self.force = bool(force_collectives)
         self.direct = bool(direct)
+        self._direct_failed = False
         self._xchg_bases = []
         self.qdt = getattr(self.ops, "quant_dtype", torch.float32)
         self.dist = _dist()
@@ -286,6 +291,9 @@ class ShardedRaht:
     def _direct_gather(self, b):
         import ctypes as C
         from . import _lib
+        if self._direct_failed:
+            raise RuntimeError("ShardedRaht(direct=True): an earlier direct gather timed out waiting for a peer; the ranks are out of "
+                               "phase and the double buffers no longer mean anything -- rebuild the object (or use the RCCL path)")
         x = b["xchg"]
         x["seq"] += 1
         with torch.cuda.device(self.device):
@@ -306,7 +314,19 @@ class ShardedRaht:
             with torch.cuda.device(self.device):
                 _lib.check(_lib.lib().raht_xchg_status(x["base"], self.world, x["slot_bytes"], C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream), C.byref(st)))
             worst = max(worst, st.value)
+        if worst:
+            self._direct_failed = True
         return worst
+
+    def check_exchange(self):
+        """(synchronises) Raise if a direct gather timed out: the transforms that followed it ran the top tree on a stale or
+        partially written gather buffer and returned without an error (the wait is bounded so that a missing peer cannot
+        hang the GPU; what it leaves behind is the status word this reads). Called by close(), roundtrip_error() and
+        check_against_unsharded(); a caller of the direct path should call it wherever it synchronises anyway. After a
+        timeout every further direct gather of this object raises."""
+        if self.exchange_status():
+            raise RuntimeError("ShardedRaht(direct=True): a direct gather timed out waiting for a peer (raht_xchg_status = 1): "
+                               "results since then are not valid")
 
     def close(self):
         """COLLECTIVE: unmap the peers' exchange blocks and free this rank's (direct=True). A block must outlive every peer's
@@ -314,6 +334,7 @@ class ShardedRaht:
         from . import _lib
         if not any("xchg" in b for b in self._bufs.values()):
             return
+        failed = bool(self.exchange_status())                  # (synchronises) reported after the blocks are gone
         torch.cuda.synchronize(self.device)
         self.dist.barrier(group=self.group)
         for b in self._bufs.values():
@@ -330,6 +351,8 @@ class ShardedRaht:
         for base in self._xchg_bases:
             _lib.check(_lib.lib().raht_xchg_free(base))
         self._xchg_bases = []
+        if failed:
+            raise RuntimeError("ShardedRaht(direct=True): a direct gather timed out waiting for a peer; results since then are not valid")
 
     def _gather_roots(self, b, which):
         gather = (lambda: self._direct_gather(b)) if "xchg" in b else (lambda: self._all_gather(b["send"], out=b["recv"]))
@@ -417,6 +440,8 @@ class ShardedRaht:
 
     def roundtrip_error(self, C):
         R = self.inverse(self.forward(C))
+        if self.direct:
+            self.check_exchange()
         if self.N == 0:
             return 0.0
         return float(((R - C).abs().max() / C.abs().max()).item())
@@ -461,6 +486,10 @@ class ShardedRaht:
                 out["max_dequantized_distance_over_step"] = worst / quant_step
                 out["ok"] = out["ok"] and worst <= 0.5 * quant_step * 1.0001
                 out["quantized_roundtrip_max_err_over_step"] = float((R - C).abs().max().item()) / quant_step
+        if self.direct:
+            st = self.exchange_status()
+            out["direct_exchange_status"] = st
+            out["ok"] = out["ok"] and st == 0
         if self.world > 1:
             flag = torch.tensor([[1 if out["ok"] else 0]], dtype=torch.int64, device=C.device)
             out["ok"] = bool(self._all_gather(flag).min().item() == 1)

@@ -168,6 +168,30 @@ def test_schedule_chain_exits(rt, case):
     assert (R - Cd).abs().max().item() <= 1e-11 * Cd.abs().max().item()
 
 
+def test_deep_schedules_take_several_height_launches(rt, monkeypatch):
+    """The butterfly heights of a schedule's tile stages come from one launch per 8 stages (plan.hip: launch_stage_heights);
+    schedules with more tile stages (deep / unbalanced key sets, small tail tiles) used to be refused, failing every transform
+    of the plan. Here the per-launch group is cut to 2 so that an ordinary four-stage schedule walks the several-launches
+    path: same heights, hence bit-identical transforms."""
+    import torch
+    rng = np.random.default_rng(11)
+    N, nbits, D = 30000, 30, 9
+    keys = torch.from_numpy(np.unique(rng.integers(0, (1 << nbits) - 1, size=N + 64, dtype=np.int64))[:N]).cuda()
+    C = torch.from_numpy(rng.normal(size=(N, D)).astype(np.float32)).cuda()
+    p0 = rt.RahtPlan.from_keys(keys, nbits)
+    p0.set_engine("tile", 64, 64, 0, 64)
+    T0 = p0.forward(C, want_w=False)
+    Q0 = p0.forward_quant(C, 0.02)
+    monkeypatch.setenv("RAHT_HEIGHT_STAGES_PER_LAUNCH", "2")
+    p1 = rt.RahtPlan.from_keys(keys, nbits)
+    p1.set_engine("tile", 64, 64, 0, 64)
+    st = p1.stage_stats(4, D)
+    assert st["valid"] and len(st["rows_per_stage"]) >= 4
+    assert torch.equal(p1.forward(C, want_w=False), T0)
+    assert torch.equal(p1.forward_quant(C, 0.02), Q0)
+    assert torch.equal(p1.dequant_inverse(Q0, 0.02), p0.dequant_inverse(Q0, 0.02))
+
+
 # ----------------------------------------------------------- several schedules alive on one plan
 def test_schedule_cache_growth_keeps_earlier_schedules_usable(rt):
     """float32 D = 59 (default schedule), float64, D = 200 (channel chunks), forced geometries: each adds a

@@ -11,7 +11,7 @@ for f in sorted(glob.glob(sys.argv[1] + "/p*/*/*counter_collection.csv")):
     for k, v in tmp.items():
         for c, x in v.items():
             agg[k][c] = sum(x) / len(x)
-for k in sorted(agg, key=lambda k: -agg[k].get("SQ_INSTS_VALU", 0))[:4]:
+for k in sorted(agg, key=lambda k: -agg[k].get("SQ_INSTS_VALU", 0))[:int(sys.argv[2]) if len(sys.argv) > 2 else 4]:
     print(k)
     for c, v in agg[k].items():
         print("    %-34s %16.0f" % (c, v))
