@@ -85,6 +85,9 @@ def parse():
                     help="--gpus > 1 / --sharded: the two all-gathers of a step as direct writes into the peers' buffers over hipIpc "
                          "(raht_xchg_*, one launch per direction) instead of the collective backend's all_gather_into_tensor")
     ap.add_argument("--unfused", action="store_true", help="quantize / dequantize as separate passes")
+    ap.add_argument("--f32-only", action="store_true",
+                    help="frames with xyz columns (14 / 59 channels): time the all-float32 fused kernels instead of the mixed-precision ones "
+                         "(raht_fwd_quant_mixed: xyz columns in float64, the reference's integers there)")
     ap.add_argument("--ablate", type=int, default=0, help="kernel-timing experiment for the roofline probe only (0 = real kernel; needs a make ABLATE=1 library)")
     return ap.parse_args()
 
@@ -133,7 +136,7 @@ def oracle_pass(V, C32, J, repeats, single_core):
     return dict(orc=orc, param=p, T=T, s_all=best_all, s_one=best_one, threads=nthr, err=err)
 
 
-def oracle_gate(ob, T32, Q32, step):
+def oracle_gate(ob, T32, Q32, step, mixed=False):
     """float32 coefficients / fused integers of the HIP path against the oracle on the whole scene. Raises on failure."""
     To = ob["T"]
     N, D = To.shape
@@ -169,7 +172,19 @@ def oracle_gate(ob, T32, Q32, step):
         g["q_beyond_coefficient_error_bound"] = nbad
         if a0:
             g["q_xyz_columns_max_abs_diff"] = int(dq[:, :a0].max())
-            g["q_xyz_note"] = "xyz coefficients reach |T| / step > 2^24 at small steps: float32 integers cannot be exact there (use raht_fwd_quant_f64)"
+            if mixed:
+                # raht_fwd_quant_mixed: the xyz columns are carried in float64 -- the oracle's integers, except where 1-ulp transform
+                # noise tips an exact rounding tie of the oracle's own quotient (the float64 kernels' bar)
+                bad = np.nonzero(dq[:, :a0])
+                q = To[order[bad[0]], bad[1]] / step + 0.5
+                off_tie = int((np.abs(q - np.round(q)) > 1e-9 * np.maximum(1.0, np.abs(q))).sum())
+                g["q_xyz_path"] = "float64 inside the float32 launches (raht_fwd_quant_mixed, n_wide = 3)"
+                g["q_xyz_mismatches"] = int(bad[0].size)
+                g["q_xyz_mismatches_off_a_rounding_tie"] = off_tie
+                if int(dq[:, :a0].max()) > 1 or off_tie:
+                    raise AssertionError(f"oracle gate: mixed-precision xyz integers differ from the oracle: max {int(dq[:, :a0].max())}, {off_tie} off a rounding tie")
+            else:
+                g["q_xyz_note"] = "xyz coefficients reach |T| / step > 2^24 at small steps: float32 integers cannot be exact there (raht_fwd_quant_mixed carries them in float64)"
         if nbad:
             raise AssertionError(f"oracle gate: {nbad} fused quantized integers differ from the oracle by more than the coefficient error allows")
         if int(dq[:, a0:].max()) > 1 or int(nz.sum()) > 4.0 * expected + 8.0 * np.sqrt(expected) + 10:
@@ -323,6 +338,11 @@ class SoloScene:
         self.es = es
         self.steps32 = (C.c_float * 1)(a.quant_step)
         self.steps64 = (C.c_double * 1)(a.quant_step)
+        # frames that carry their xyz columns (python/voxelize_pc.py:155): those three channels in float64 inside the float32
+        # launches (raht_fwd_quant_mixed / raht_dequant_inv_mixed) -- the reference's integers there, where float32 cannot hold them
+        self.n_wide = 3
+        self.mixed = (not self.f64 and D in (14, 59) and a.engine == "tile" and not getattr(a, "f32_only", False)
+                      and self.plan.mixed_stats(D, self.n_wide)["tile_rows"] > 0)
 
     def s_(self):
         return C.c_void_p(torch.cuda.current_stream().cuda_stream)
@@ -358,12 +378,26 @@ class SoloScene:
         if self.f64:
             self._lib.check(self.L.raht_fwd_quant_f64(self.plan._h, vp(self.Cd.data_ptr()), self.D, self.D, self.steps64, 1, vp(self.Q.data_ptr()), self.D, self.s_()))
             return
+        if self.mixed:
+            self._lib.check(self.L.raht_fwd_quant_mixed(self.plan._h, vp(self.Cd.data_ptr()), self.D, self.D, self.steps64, 1, self.n_wide, vp(self.Q.data_ptr()), self.D, self.s_()))
+            return
         self._lib.check(self.L.raht_fwd_quant(self.plan._h, vp(self.Cd.data_ptr()), self.D, self.D, self.steps32, 1, vp(self.Q.data_ptr()), self.D, self.s_()))
+
+    def fwd_quant_f32(self):
+        vp = C.c_void_p
+        self._lib.check(self.L.raht_fwd_quant(self.plan._h, vp(self.Cd.data_ptr()), self.D, self.D, self.steps32, 1, vp(self.Q.data_ptr()), self.D, self.s_()))
+
+    def dequant_inv_f32(self):
+        vp = C.c_void_p
+        self._lib.check(self.L.raht_dequant_inv(self.plan._h, vp(self.Q.data_ptr()), self.D, self.D, self.steps32, 1, vp(self.Crec.data_ptr()), self.D, self.s_()))
 
     def dequant_inv(self):
         vp = C.c_void_p
         if self.f64:
             self._lib.check(self.L.raht_dequant_inv_f64(self.plan._h, vp(self.Q.data_ptr()), self.D, self.D, self.steps64, 1, vp(self.Crec.data_ptr()), self.D, self.s_()))
+            return
+        if self.mixed:
+            self._lib.check(self.L.raht_dequant_inv_mixed(self.plan._h, vp(self.Q.data_ptr()), self.D, self.D, self.steps64, 1, self.n_wide, vp(self.Crec.data_ptr()), self.D, self.s_()))
             return
         self._lib.check(self.L.raht_dequant_inv(self.plan._h, vp(self.Q.data_ptr()), self.D, self.D, self.steps32, 1, vp(self.Crec.data_ptr()), self.D, self.s_()))
 
@@ -556,7 +590,7 @@ def main():
             if not a.no_quant:
                 sc.fwd_quant(); torch.cuda.synchronize()
                 Q32 = sc.Q.cpu().numpy()
-            gate = oracle_gate(ob, T32, Q32, a.quant_step)          # raises -> no JSON line
+            gate = oracle_gate(ob, T32, Q32, a.quant_step, mixed=sc.mixed)          # raises -> no JSON line
             gate["order_RAGFT_equal"] = bool(np.array_equal(sc.plan.order_RAGFT.cpu().numpy(), ob["param"].order))
             assert gate["order_RAGFT_equal"], "oracle gate: order_RAGFT differs"
             del T32, Q32
@@ -619,6 +653,9 @@ def main():
 
     quant_txt = ("fwd + inv RAHT" if a.no_quant else "fwd RAHT + quantize/reorder + dequantize/un-reorder + inv RAHT"
                  + (" (separate passes)" if a.unfused else " (quantization fused into the transform kernels)"))
+    use_mixed = bool(sc is not None and sc.mixed and not a.no_quant and not a.unfused)
+    if use_mixed:
+        quant_txt += "; the 3 xyz columns carried in float64 inside the same launches (raht_fwd_quant_mixed / raht_dequant_inv_mixed): the reference's integers on every column"
     if solo:
         par = "1 GPU" if world == 1 else f"{world} independent scenes, one per GPU, no collective"
     else:
@@ -630,7 +667,7 @@ def main():
         "metric": "M-Gaussians/s fwd+inv RAHT, 59-ch SH3 3DGS" if D == 59 else "M-Gaussians/s fwd+inv RAHT, 14-ch SH0 3DGS",
         "value": round(value, 2), "unit": "M-Gaussians/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "settle_steps": settle,
         "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
+        "dtype": "f32 (xyz columns: f64)" if use_mixed else "f32", "data": "synthetic",
         "config": {
             "workload": f"{a.workload}: {total_rows} Gaussians ({'1-6 M' if a.workload == 'cfg4' and world > 1 else n_draws} draws{'' if scaling == 'strong' else '/GPU'}, J={J}, {D} channels), " + quant_txt,
             "rows_per_gpu": N, "channels": D, "depth_J": J, "engine": a.engine, "quantize": not a.no_quant,
@@ -655,10 +692,26 @@ def main():
             br["dequant_unreorder_ms"] = timed(sc.dequant, reps)
             br["fwd_quant_fused_ms"] = timed(sc.fwd_quant, reps)
             br["dequant_inv_fused_ms"] = timed(sc.dequant_inv, reps)
+            if sc.mixed:
+                # the all-float32 fused kernels on the same scene (xyz integers off the reference's by tens of units at this step)
+                br["fwd_quant_fused_f32_only_ms"] = timed(sc.fwd_quant_f32, reps)
+                br["dequant_inv_fused_f32_only_ms"] = timed(sc.dequant_inv_f32, reps)
+                sc.fwd_quant()                                 # leave the mixed integers in Q
         out["breakdown_ms"] = {k: round(v, 4) for k, v in br.items()}
-        st = plan.stage_stats(4, D)
+        st = plan.mixed_stats(D, sc.n_wide) if use_mixed else plan.stage_stats(4, D)
         out["config"]["tile_rows"] = st["tile_rows"]
         out["config"]["active_rows_per_stage"] = st["rows_per_stage"]
+        if use_mixed:
+            out["config"]["precision"] = {"channels_0_2": "float64 (float32 input widened exactly, float64 butterflies, IEEE double division)", "channels_3_up": "float32", "n_wide": sc.n_wide}
+            f32_step = lambda: (sc.fwd_quant_f32(), sc.dequant_inv_f32())
+            for _ in range(20):
+                f32_step()
+            t32 = timed(f32_step, reps)
+            sc.fwd_quant()
+            out["f32_only"] = {"what": "the same step through the all-float32 fused kernels (raht_fwd_quant + raht_dequant_inv; --f32-only times it as the headline): "
+                                       "xyz integers off the reference's by tens of units at this step (round 3's headline)",
+                               "ms_per_step": round(t32, 4), "value": round(N / (t32 * 1e-3) / 1e6, 1), "unit": "M-Gaussians/s",
+                               "frac_of_peak": round(2 * (8.0 * N * D + 8.0 * N) / (t32 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
 
         # ---- roofline of the dominant kernel: stage-0 LDS-tile kernel, forward and inverse ----
         # ALGORITHMIC bytes per launch (per direction): read N*D*4 + write N*D*4 + 8 B/row of plan
@@ -666,6 +719,8 @@ def main():
         if a.engine == "tile":
             fused = not (a.no_quant or a.unfused)
             qp, qs_ = (vp(sc.Q.data_ptr()), a.quant_step) if fused else (None, 0.0)
+            # (raht_debug_run_stage launches the float32 kernels: with the mixed kernels as the step, only the in-step timing below
+            # describes the dominant kernel; the isolated figure is then the float32 kernel's, for comparison)
 
             def k_fwd():
                 _lib.check(L.raht_debug_run_stage(h, 0, 0, vp(sc.Cd.data_ptr()), D, D, vp(sc.T.data_ptr()), D, qp, D, qs_, a.ablate, sc.s_()))
@@ -697,14 +752,26 @@ def main():
                 except Exception:
                     pass
             tq = "true" if fused else "false"
-            out["roofline"] = {"kernel": f"raht::tile_kernel<float, false, true, {tq}, 1> (forward, stage 0"
+            kf = "raht::tile_kernel_mx<false, true, 1>" if use_mixed else f"raht::tile_kernel<float, false, true, {tq}, 1>"
+            ki = "raht::tile_kernel_mx<true, true, 1>" if use_mixed else f"raht::tile_kernel<float, true, true, {tq}, 1>"
+            if use_mixed:
+                traffic, traffic_note = None, traffic_note if "another build" in traffic_note else "profiles/traffic.json describes the float32 kernels"
+                tp2 = os.path.join(ROOT, "profiles", "traffic.json")
+                try:
+                    tj = json.load(open(tp2)).get(a.workload, {})
+                    if tj.get("source_hash") == kernel_source_hash() and "mixed" in tj:
+                        traffic = tj["mixed"].get("fwd_stage0_bytes")
+                        traffic_note = f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this build ({tj.get('source')}, source_hash {tj.get('source_hash')})"
+                except Exception:
+                    pass
+            out["roofline"] = {"kernel": f"{kf} (forward, stage 0"
                                          + (", fused quantize+reorder)" if fused else ")"), "bound": "hbm",
                                "achieved": round(alg / (tf * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": round(alg / (tf * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_note,
                                "alg_bytes_per_launch": alg, "avg_launch_ms": round(tf, 4),
                                "timed": "HIP events around the stage-0 launch inside real steps" if a.ablate == 0 else "isolated launches",
-                               "isolated_launch_ms": round(tf_iso, 4)}
-            out["roofline_inv"] = {"kernel": f"raht::tile_kernel<float, true, true, {tq}, 1> (inverse, stage 0"
+                               "isolated_launch_ms": round(tf_iso, 4), "isolated_launch_is": "the float32 kernel's (raht_debug_run_stage)" if use_mixed else "this kernel's"}
+            out["roofline_inv"] = {"kernel": f"{ki} (inverse, stage 0"
                                              + (", fused un-reorder+dequantize)" if fused else ")"), "bound": "hbm",
                                    "achieved": round(alg / (ti * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                    "frac": round(alg / (ti * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),

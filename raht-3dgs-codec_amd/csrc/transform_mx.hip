@@ -61,17 +61,6 @@ static size_t tile_lds_bytes_mx(int R, int NCp, bool ident)
     return data + ((meta + 15) & ~(size_t)15) + 1024 + surv + (size_t)MX_PRE_ROWS * NCp * 16;
 }
 
-// out = the row's first four channels: the n_wide wide values w[0 .. n_wide), then the first 4 - n_wide values of the row's first
-// float chunk f (selects on the wave-uniform n_wide: an index computed from it would put the arrays into scratch)
-template <typename E>
-__device__ __forceinline__ void first_four(const E (&w)[4], const E (&f)[4], int nwide, E (&out)[4])
-{
-    out[0] = w[0];
-    out[1] = nwide > 1 ? w[1] : f[0];
-    out[2] = nwide > 2 ? w[2] : (nwide == 2 ? f[0] : f[1]);
-    out[3] = nwide > 3 ? w[3] : (nwide == 3 ? f[0] : (nwide == 2 ? f[1] : f[2]));
-}
-
 // the wide parts of the workspaces a stage touches (a workspace row is stored as two dense arrays: the float places of every
 // entry, then the wide places of every entry; TileArgs::in / out / wsn point at the float parts)
 struct MxPtrs {
@@ -92,10 +81,10 @@ __device__ __forceinline__ void tile_body_mx(const TileArgs<float> &A, const MxP
     const int nthreads = blockDim.x, nwv = nthreads >> 6;
     const int nwide = A.nwide, NW2 = (nwide + 1) >> 1;     // wide channels, wide chunk places per row (1 or 2)
     const int lgw = NW2 > 1 ? 1 : 0;
-    const int Df = A.D - nwide;                            // float32 channels (>= 4)
+    const int Df = A.D;                                    // the float tile holds ALL D channels, laid out as in the float32 kernels
     const int Fp = A.Dp, NF = Fp >> 2;                     // float tile: row stride in floats, chunk places per row
     const int Wp = NW2 * 4;                                // wide tile: row stride in floats (16 or 32 bytes)
-    const int lg = A.lg, lr = 6 - A.lg;                    // 2^lg >= NF + 1 lanes per row: NF float lanes and the head lane
+    const int lg = A.lg, lr = 6 - A.lg;                    // 2^lg >= NF lanes per row
     const uint32_t NFm = ((1u << 20) + (uint32_t)NF - 1) / (uint32_t)NF;     // c / NF == (c * NFm) >> 20 for c < 2^15
     auto sync_lds = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
     auto wait_landed = [&]() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
@@ -123,23 +112,23 @@ __device__ __forceinline__ void tile_body_mx(const TileArgs<float> &A, const MxP
     TileMeta<SLOTS> M;
     load_tile_meta<float, IDENT, true, SLOTS>(A, tile_id, tid0, nthreads, M);
 
-    // lane geometry of the row loops: lane c4 of a group of 2^lg works on one row; c4 < NF: float place c4 (channels goff .. goff + 3
-    // of the caller's rows); c4 == NF: the HEAD lane, which assembles a caller row's first 16 bytes (the wide channels + the first
-    // 4 - n_wide float channels) in the write-backs; lanes past it idle. fl: the float place a lane reads in the butterflies (head
-    // and idle lanes shadow the last one: same reads, same writes); sp: the place whose channels / steps it quantizes (head: place 0)
+    // lane geometry of the row loops, as in the float32 kernels: lane c4 of a group of 2^lg works on float place fl = min(c4, NF - 1)
+    // of one row (channels goff .. goff + 3; lanes past the last place shadow it: same reads, same writes). The lane of place 0
+    // is the row's HEAD lane: the wide channels are the first n_wide <= 4 channels of its chunk, and in the write-backs it
+    // substitutes their float64 results for what the float32 arithmetic made of them.
     auto lane_geom = [&](int tid, int &lane, int &wid, int &g, int &c4, int &fl, int &sp, int &goff, bool &head) {
         lane = tid & 63;
         wid = __builtin_amdgcn_readfirstlane(tid >> 6);
         g = lane >> lg;
         c4 = lane & ((1 << lg) - 1);
         fl = min(c4, NF - 1);
-        head = c4 == NF;
-        sp = head ? 0 : fl;
-        goff = nwide + min(fl * 4, Df - 4);
+        head = c4 == 0;
+        sp = fl;
+        goff = min(fl * 4, Df - 4);
     };
     float my_step[4], my_rcp[4];
     auto load_steps = [&](int place) {
-        const int g0 = nwide + min(place * 4, Df - 4);
+        const int g0 = min(place * 4, Df - 4);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             my_step[i] = ST.f.v[ST.f.n == 1 ? 0 : g0 + i];
@@ -177,29 +166,21 @@ __device__ __forceinline__ void tile_body_mx(const TileArgs<float> &A, const MxP
         }
     };
     auto load_caller_rows = [&](int rows, auto src) {
-        {
-            const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void *)ftile;
-            const int total = rows * NF;
-            for (int it = wid; (it << 6) < total; it += nwv) {
-                const int c = (it << 6) + lane;
-                const int jr = (int)(((uint32_t)c * NFm) >> 20), ch = c - jr * NF;
-                if (c < total) glds16<1>(src(jr, (uint32_t)(nwide + min(ch * 4, Df - 4))), lds0 + ((uint32_t)it << 10));
-            }
-        }
-        {
-            const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void *)wt;
-            const int total = rows << lgw;
-            for (int it = nwv - 1 - wid; (it << 6) < total; it += nwv) {          // (from the last wave down: the float part's tail is uneven)
-                const int c = (it << 6) + lane;
-                if (c < total && (c & (NW2 - 1)) == 0) glds16<1>(src(c >> lgw, 0u), lds0 + ((uint32_t)it << 10));
-            }
+        const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void *)ftile;
+        const int total = rows * NF;
+        for (int it = wid; (it << 6) < total; it += nwv) {
+            const int c = (it << 6) + lane;
+            const int jr = (int)(((uint32_t)c * NFm) >> 20), ch = c - jr * NF;
+            if (c < total) glds16<1>(src(jr, (uint32_t)min(ch * 4, Df - 4)), lds0 + ((uint32_t)it << 10));
         }
     };
-    // Widening of the raw wide channels a caller row arrived with: float32 -> float64 (forward), int32 * float64 step (inverse,
-    // encode_3dgs.py:261), in place. One ROW per thread, after the barrier behind which every wave's rows have landed.
+    // Widening of the wide channels a caller row arrived with (the first n_wide elements of its first float chunk): float32 ->
+    // float64 (forward), int32 * float64 step (inverse, encode_3dgs.py:261), into the wide tile. One ROW per thread, after the
+    // barrier behind which every wave's rows have landed. (The float tile keeps those elements and carries them through its
+    // float32 butterflies like any other channel: the write-backs drop what comes out of that.)
     auto widen_row = [&](int j, auto is_int) {
         float *row = wt + __mul24(j, Wp);
-        const V16 raw = *(const V16 *)row;
+        const V16 raw = *(const V16 *)(ftile + __mul24(j, Fp));          // the row's first chunk, as it arrived
         double d[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -299,15 +280,18 @@ __device__ __forceinline__ void tile_body_mx(const TileArgs<float> &A, const MxP
                 const I16 raw = *(const I16 *)pr;
                 V16 x;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) x.v[i] = (float)raw.v[i] * my_step[i];            // encode_3dgs.py:261
+                for (int i = 0; i < 4; ++i)       // encode_3dgs.py:261 (the wide elements stay raw: widen_row reads them in this phase)
+                    x.v[i] = (head && i < nwide) ? __int_as_float(raw.v[i]) : (float)raw.v[i] * my_step[i];
                 *pr = x;
             }
         }
         // the wide channels of the rows finalised here (survivor slots are filled by P3b, with images)
+        // (by the thread half a workgroup away from the row's own: tiles of <= 256 rows keep waves 0 .. 3 busy with P3a
+        // below, the widening then runs next to it on the idle ones; sflag: 0 = survivor)
 #pragma unroll
         for (int s = 0; s < SLOTS; ++s) {
-            const int j = tid + s * nthreads;
-            if (j < nt && (m_merged[s] || A.last_stage)) widen_row(j, std::true_type());
+            const int j = ((tid + (nthreads >> 1)) & (nthreads - 1)) + s * nthreads;
+            if (j < nt && (sflag[j] != 0)) widen_row(j, std::true_type());
         }
     }
 
@@ -486,7 +470,7 @@ __device__ __forceinline__ void tile_body_mx(const TileArgs<float> &A, const MxP
         asm volatile("" : "+v"(tid5));
         lane_geom(tid5, lane, wid, g, c4, fl, sp, goff, head);
     }
-    const bool rowlane = c4 <= NF;                        // float lanes and the head lane
+    const bool rowlane = c4 < NF;
     if constexpr (INV) {
         if constexpr (IDENT) {
             // stage 0 -> the caller's C rows [e0, e0 + nt). ONE store instruction writes a whole row: the float lanes their chunks,
@@ -498,24 +482,29 @@ __device__ __forceinline__ void tile_body_mx(const TileArgs<float> &A, const MxP
             // (two row instructions per trip, every LDS read of both in front of the first branch: a trip is one LDS round trip,
             // and a read inside the head lane's branch would be another one)
             if (rowlane) for (int it = wid; (it << lr) < nt; it += 2 * nwv) {
-                int j[2]; V16 x[2]; W16 w0[2], w1[2];
+                int j[2]; V16 x[2]; W16 w0[2] = {}, w1[2] = {};
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
                     j[u] = min(((it + u * nwv) << lr) + g, nt - 1);
                     x[u] = *(const V16 *)&ftile[__mul24(j[u], Fp) + sp * 4];
-                    w0[u] = *(const W16 *)&wt[__mul24(j[u], Wp)];
-                    w1[u] = *(const W16 *)&wt[__mul24(j[u], Wp) + (NW2 - 1) * 4];
+                }
+                if (head) {                                   // (only the head lanes: a read by all 64 lanes moves 1 KiB through the LDS)
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        w0[u] = *(const W16 *)&wt[__mul24(j[u], Wp)];
+                        w1[u] = *(const W16 *)&wt[__mul24(j[u], Wp) + (NW2 - 1) * 4];
+                    }
                 }
                 asm volatile("" : "+v"(w0[0].v[0]), "+v"(w1[0].v[0]), "+v"(w0[1].v[0]), "+v"(w1[1].v[0]));
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
                     if (head) {
                         const float d[4] = {(float)w0[u].v[0], (float)w0[u].v[1], NW2 > 1 ? (float)w1[u].v[0] : 0.0f, NW2 > 1 ? (float)w1[u].v[1] : 0.0f};
-                        const V16 fx = x[u];
-                        first_four(d, fx.v, nwide, x[u].v);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) x[u].v[i] = i < nwide ? d[i] : x[u].v[i];
                     }
                     if (u == 0 || ((it + nwv) << lr) < nt)
-                        st_chunk<float, true>(row_at(base, (uint32_t)j[u], (uint32_t)A.ld_out, (uint32_t)(head ? 0 : goff)), x[u]);
+                        st_chunk<float, true>(row_at(base, (uint32_t)j[u], (uint32_t)A.ld_out, (uint32_t)goff), x[u]);
                 }
             }
         } else {
@@ -565,13 +554,16 @@ __device__ __forceinline__ void tile_body_mx(const TileArgs<float> &A, const MxP
         load_steps(sp);
         auto store_final = [&](auto fast_div) {
             if (rowlane) for (int it = wid; (it << lr) < nt; it += 2 * nwv) {
-                int jc[2]; V16 x[2]; I16 qi[2]; uint32_t dv[2];
+                int jc[2]; V16 x[2]; I16 qi[2] = {}; uint32_t dv[2];
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
                     jc[u] = min(((it + u * nwv) << lr) + g, nt - 1);
                     x[u] = *(const V16 *)&ftile[__mul24(jc[u], Fp) + sp * 4];
-                    qi[u] = *(const I16 *)&wt[__mul24(jc[u], Wp)];
                     dv[u] = (uint32_t)sdst[jc[u]];
+                }
+                if (head) {                                   // (only the head lanes: a read by all 64 lanes moves 1 KiB through the LDS)
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) qi[u] = *(const I16 *)&wt[__mul24(jc[u], Wp)];
                 }
                 asm volatile("" : "+v"(x[0].v[0]), "+v"(qi[0].v[0]), "+v"(x[1].v[0]), "+v"(qi[1].v[0]));
 #pragma unroll
@@ -581,10 +573,10 @@ __device__ __forceinline__ void tile_body_mx(const TileArgs<float> &A, const MxP
 #pragma unroll
                         for (int i = 0; i < 4; ++i) qv.v[i] = quantize_one(x[u].v[i], my_step[i], my_rcp[i], decltype(fast_div)::value);
                         if (head) {
-                            const I16 t = qv;
-                            first_four(qi[u].v, t.v, nwide, qv.v);
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) qv.v[i] = i < nwide ? qi[u].v[i] : qv.v[i];
                         }
-                        st_chunk<int32_t, true>(row_far(A.Q, dv[u] & 0x7fffffffu, (uint32_t)A.ldq, (uint32_t)(head ? 0 : goff)), qv);
+                        st_chunk<int32_t, true>(row_far(A.Q, dv[u] & 0x7fffffffu, (uint32_t)A.ldq, (uint32_t)goff), qv);
                     }
                 }
             }
@@ -629,8 +621,9 @@ __device__ __forceinline__ void top_body_mx(const TopArgsMX &A, const StepTableM
     V16 *tile = (V16 *)smem;
     __shared__ uint32_t s_lev[2 * 64];
     const int tid = threadIdx.x;
-    const int nwide = A.nwide, NW2 = (nwide + 1) >> 1, Df = A.D - nwide;
-    const int goff = WIDE ? 2 * chunk : nwide + min(chunk * 4, Df - 4);     // first channel of this chunk in the caller's rows
+    const int nwide = A.nwide, NW2 = (nwide + 1) >> 1;
+    const int goff = WIDE ? 2 * chunk : min(chunk * 4, A.D - 4);            // first channel of this chunk in the caller's rows
+    // (float chunk 0 holds the wide channels too, as float32 ballast: it never writes them to Q / C -- the wide workgroups do)
     const int istride = WIDE ? NW2 * 4 : A.Fp, ioff = chunk * 4;              // its place in a row image (floats)
     const int n = A.n, nm = A.n_merges;
     if (tid < 2 * A.nlev) s_lev[tid] = A.lev[tid];
@@ -649,7 +642,7 @@ __device__ __forceinline__ void top_body_mx(const TopArgsMX &A, const StepTableM
 #pragma unroll
     for (int i = 0; i < VN; ++i) {
         if constexpr (WIDE) { live[i] = goff + i < nwide; my_step[i] = live[i] ? ST.w[goff + i] : 1.0; my_rcp[i] = 1.0f; }
-        else { live[i] = true; my_step[i] = ST.f.v[ST.f.n == 1 ? 0 : goff + i]; my_rcp[i] = refined_rcp(my_step[i]); }
+        else { live[i] = !(chunk == 0 && i < nwide); my_step[i] = ST.f.v[ST.f.n == 1 ? 0 : goff + i]; my_rcp[i] = refined_rcp(my_step[i]); }
     }
     uint32_t pj[MX_TOP_SLOTS];
     T ra[MX_TOP_SLOTS], rb[MX_TOP_SLOTS];
@@ -747,6 +740,9 @@ __device__ __forceinline__ void top_body_mx(const TopArgsMX &A, const StepTableM
             } else if constexpr (WIDE) {
 #pragma unroll
                 for (int i = 0; i < VN; ++i) if (live[i]) A.out_rows[(int64_t)e * A.ld_out + goff + i] = (float)v.v[i];
+            } else if (chunk == 0) {
+#pragma unroll
+                for (int i = 0; i < VN; ++i) if (live[i]) A.out_rows[(int64_t)e * A.ld_out + goff + i] = v.v[i];
             } else {
                 st_chunk<float>(A.out_rows + (int64_t)e * A.ld_out + goff, v);
             }
@@ -759,7 +755,12 @@ __device__ __forceinline__ void top_body_mx(const TopArgsMX &A, const StepTableM
                 RegChunk<int32_t> qv;
 #pragma unroll
                 for (int i = 0; i < VN; ++i) qv.v[i] = quantize_one(v.v[i], my_step[i], my_rcp[i], ST.f.fast_div);
-                st_chunk<int32_t>(q, qv);
+                if (chunk == 0) {
+#pragma unroll
+                    for (int i = 0; i < VN; ++i) if (live[i]) q[i] = qv.v[i];
+                } else {
+                    st_chunk<int32_t>(q, qv);
+                }
             }
         }
     }
@@ -798,15 +799,15 @@ struct MxGeom {
 // Chunk places and tile rows for (D, n_wide). false: the mixed tile kernels do not cover this shape (fallback).
 static bool mx_geometry(const raht_plan *p, int D, int nwide, MxGeom &g)
 {
-    const int Df = D - nwide;
-    if (Df < 4 || D > 64 + MX_MAX_WIDE) return false;
+    // D - 4 >= n_wide: the row's LAST 16-byte chunk (channels [D - 4, D), which overlaps its neighbour when D % 4 != 0) must not
+    // reach into the wide channels, whose float32 copies are ballast that only the first chunk's lane knows to replace
+    if (D - 4 < nwide || D > 64 + MX_MAX_WIDE) return false;
     g.nwide = nwide;
-    const int NF = (Df + 3) / 4;
+    const int NF = (D + 3) / 4;                           // float places: ALL D channels, the float32 kernels' row layout
     g.NCp = (nwide + 1) / 2 + NF;
-    if (NF > 31) return false;
     g.Dp = NF * 4;
     g.lg = 0;
-    while ((1 << g.lg) < NF + 1) ++g.lg;                  // the NF float lanes of a row and its head lane
+    while ((1 << g.lg) < NF) ++g.lg;
     int r1 = 0, dc1 = 0;
     pick_tail_geometry(p, 4, D, 512, &r1, &dc1, &g.Rf);
     const size_t budget = (size_t)42 * 1280;              // three workgroups per CU

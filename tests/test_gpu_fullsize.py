@@ -39,11 +39,6 @@ def _cases():
     return {"cfg2": synth.CONFIGS["cfg2"], "cfg3": synth.CONFIGS["cfg3"], "cfg4_6M": (6_000_000, 12, 59, 11)}
 
 
-# measured attribute-channel mismatch rates at step 0.01 (round 3): cfg3 7.9e-7, cfg4 (6 M rows) 6.7e-7, cfg2 2.2e-6 -- every
-# channel of the SH0 scene carries
-# O(1) coefficients in every channel, so their float32 error per step is larger
-_RATE_SLACK = {"cfg2": 2.0}
-
 
 def _col_stats(T32, T64):
     """per-column max / rms error of a float32 result against the float64 oracle, blockwise (bounded temporaries)"""
@@ -150,17 +145,39 @@ def test_full_scene_matches_oracle(rt, oracle, name):
         # (the prediction treats error and distance-to-boundary as independent; they are mildly correlated -- large
         # coefficients carry the large errors -- hence the factor)
         assert n_bad <= 4.0 * expected + 8.0 * np.sqrt(expected) + 10, (name, step, n_bad, expected)
-        assert rate <= 2e-6 * max(1.0, 0.01 / step) * _RATE_SLACK.get(name, 1.0), (name, step, rate)
-        # xyz columns: reported above on their own; every element is inside (a). Their integer-valued inputs put ~1 % of
+        # (no separate rate cap: the count bound above IS the float32 contract -- DESIGN.md 3 -- and a cap set from a
+        # measurement can only catch regressions. Measured rates at step 0.01: cfg3 7.9e-7, cfg4-6M 6.7e-7, cfg2 2.2e-6.)
+        # xyz columns in float32: reported above on their own; every element is inside (a). Their integer-valued inputs put ~1 % of
         # the coefficients on EXACT rounding ties at step 1 (see the float64 comparison above), which float32 noise tips
         # either way, so no rate is asserted for them.
         del dT, nz
+        # ---- mixed precision: the xyz columns carried in float64 inside the float32 launches (raht_fwd_quant_mixed) ----
+        # those columns: the oracle's integers except on exact rounding ties (the float64 bar); the others: the float32 kernels'
+        # integers bit for bit
+        if a0:
+            Qmx = plan.forward_quant_mixed(Cd, step, a0).cpu().numpy()
+            assert np.array_equal(Qmx[:, a0:], Q32[:, a0:]), (name, step)
+            badx = np.nonzero(Qmx[:, :a0] != Qo[:, :a0])
+            if badx[0].size:
+                q = To[order[badx[0]], badx[1]] / step
+                assert np.all(np.abs(Qmx[:, :a0][badx].astype(np.int64) - Qo[:, :a0][badx]) == 1)
+                assert np.all(np.abs(q + 0.5 - np.round(q + 0.5)) <= 1e-9 * np.maximum(1.0, np.abs(q))), (name, step, badx[0].size)
+            print(f"[fullsize] {name} step {step}: mixed precision: xyz integers off the oracle's {badx[0].size} (all on exact rounding ties), "
+                  f"float32 alone: max |dQ| {int(dq[:, :a0].max())}")
+            del Qmx
         del lim, dq, Q32
         # ... and back, from the ORACLE's integers: dequantize + un-reorder + inverse (encode_3dgs.py:261,267-268,274)
         Cq = plan.dequant_inverse(_dev(Qo), step)
         ref = torch.from_numpy(threaded.inverse(oracle, oracle.dequant_unreorder(Qo, step, order), po)).cuda()
         cs = ref.abs().amax(dim=0).clamp_min(1.0)
         assert bool(((Cq.double() - ref).abs() <= 1e-5 * cs).all()), (name, step)
+        if a0:
+            # mixed decode: the xyz columns = the float64 inverse rounded once to float32; the others bit-identical to the float32 decode
+            Cmx = plan.dequant_inverse_mixed(_dev(Qo), step, a0)
+            assert torch.equal(Cmx[:, a0:], Cq[:, a0:]), (name, step)
+            ex = (Cmx[:, :a0].double() - ref[:, :a0]).abs()
+            assert bool((ex <= 6e-8 * ref[:, :a0].abs() + 1e-10 * cs[:a0]).all()), (name, step, float(ex.max()))
+            del Cmx
         del Qo, Cq, ref
 
 

@@ -78,6 +78,8 @@ def main():
                   "inv_stage0_bytes": pick("tile_kernel<float, true, true, true")},
         "plain": {"fwd_stage0_bytes": pick("tile_kernel<float, false, true, false"),
                   "inv_stage0_bytes": pick("tile_kernel<float, true, true, false")},
+        "mixed": {"fwd_stage0_bytes": pick("tile_kernel_mx<false, true"),
+                  "inv_stage0_bytes": pick("tile_kernel_mx<true, true")},
         "source": f"profiles/{tag}_pmc_summary.csv",
         "source_hash": kernel_source_hash(),
     }
