@@ -360,6 +360,15 @@ int raht_morton(const int64_t *V, int64_t N, int J, uint64_t *keys, raht_stream_
  * (idx_out[k] = original position). DEVICE buffers. */
 int raht_sort_keys(const uint64_t *keys_in, int64_t N, int nbits, uint64_t *keys_out,
                    int64_t *idx_out, raht_stream_t stream);
+/* The sort runs one launch per digit pass whose tiles hand their offsets to each other inside the launch (csrc/scan_sort.hip).
+ * A tile waits for the tiles numbered before it; tiles are numbered by workgroup index, which cannot deadlock as long as the
+ * lowest-numbered unfinished workgroup is resident -- how this GPU dispatches, but not a documented guarantee -- so every wait is
+ * bounded by the wall clock (0.2 s): a tile that gives up raises an error word, nothing is written through stale offsets, and
+ * the call (raht_sort_keys, raht_voxelize*) REPEATS the sort with one launch chain per digit, which needs no such property.
+ * The caller sees a correct result and a slower call; this counter (process-wide, monotonic) says how often it happened.
+ * Expected 0: tools/check_big.py and the GPU suite assert it. RAHT_SORT_TICKET=1 numbers the tiles by an atomic ticket
+ * instead (acyclic whatever the dispatch order; +4 us per pass). */
+int64_t raht_sort_fallbacks(void);
 
 /* ------------------------------------------------------------------------------------------------
  * Per-voxel Gaussian merge. Replaces merge_clusters_cuda / merge_weighted_mean_kernel

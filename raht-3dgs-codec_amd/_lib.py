@@ -23,7 +23,7 @@ EXPORTS = [
     "raht_plan_levels", "raht_plan_export_level", "raht_plan_order", "raht_plan_arrays",
     "raht_plan_copy_array", "raht_plan_stage_stats", "raht_fwd", "raht_fwd_f64", "raht_inv", "raht_inv_f64", "raht_debug_run_stage", "raht_plan_set_stage0_events", "raht_fwd_quant", "raht_dequant_inv", "raht_plan_prepare",
     "raht_quant_reorder", "raht_dequant_unreorder", "raht_voxelize", "raht_voxelize_all", "raht_voxelize_plan", "raht_morton", "raht_sort_keys",
-    "raht_voxel_keys", "raht_voxelize_residuals", "raht_plan_set_row_map", "raht_rows_gather", "raht_rows_scatter",
+    "raht_voxel_keys", "raht_sort_fallbacks", "raht_voxelize_residuals", "raht_plan_set_row_map", "raht_rows_gather", "raht_rows_scatter",
     "raht_plan_set_max_stages", "raht_quant_reorder_f64", "raht_dequant_unreorder_f64", "raht_fwd_quant_f64", "raht_dequant_inv_f64",
     "raht_fwd_quant_mixed", "raht_dequant_inv_mixed", "raht_plan_mixed_stats",
     "raht_fwd_batch", "raht_inv_batch", "raht_fwd_quant_batch", "raht_dequant_inv_batch",
@@ -125,6 +125,8 @@ def lib():
     L.raht_voxel_keys.argtypes = [vp, i64, i64, C.POINTER(C.c_float), dbl, i32, vp, vp]
     L.raht_voxelize_residuals.argtypes = [vp, i64, i64, i32, vp, vp, vp, C.POINTER(C.c_float), dbl, vp, vp, vp]
     L.raht_sort_keys.argtypes = [vp, i64, i32, vp, vp, vp]
+    L.raht_sort_fallbacks.argtypes = []
+    L.raht_sort_fallbacks.restype = i64
     L.raht_rlgr_bound.argtypes = [i64]
     L.raht_rlgr_bound.restype = i64
     L.raht_rlgr_encode.argtypes = [vp, i64, i64, i32, vp, i64, C.POINTER(i64)]

@@ -3,6 +3,7 @@
 // Replaces voxelize_pc_batched (reference python/voxelize_pc.py:62-172). Float32 arithmetic, as
 // torch performs it on a float32 point cloud; integer outputs are bit-exact.
 #include "raht_common.h"
+#include <atomic>
 #include "raht_device.h"
 
 #include <algorithm>
@@ -328,6 +329,10 @@ __global__ __launch_bounds__(256) void voxel_full_chunk_kernel(const float *__re
     }
 }
 
+// How often a one-sweep sort gave up (a tile's bounded wait for its predecessors ran out) and the call repeated the sort pass
+// by pass: raht_sort_fallbacks(). Expected to stay 0; the result of the call is correct either way.
+static std::atomic<int64_t> g_sort_fallbacks{0};
+
 // Stable sort of (key, original index). `sort_err` (device word, may be NULL) selects the one-sweep form
 // (scan_sort.hip: npass + 2 launches); the caller checks the word once the stream has drained and repeats the call with
 // onesweep = false -- the pass-by-pass form, four launches per digit; the word is cleared -- in the never-seen case that it is set.
@@ -392,9 +397,12 @@ int raht_sort_keys(const uint64_t *keys_in, int64_t N, int nbits, uint64_t *keys
         uint32_t bad = 0;
         RAHT_RET(read_back_u32(&bad, sort_err, 1, nullptr, nullptr, 0, s));
         if (!bad) break;
+        g_sort_fallbacks.fetch_add(1, std::memory_order_relaxed);
     }
     return RAHT_OK;
 }
+
+int64_t raht_sort_fallbacks(void) { return g_sort_fallbacks.load(std::memory_order_relaxed); }
 
 int raht_voxel_keys(const float *PC, int64_t ldpc, int64_t N, const float vmin[3], double width, int J,
                     uint64_t *keys, raht_stream_t stream)
@@ -514,6 +522,7 @@ static int voxelize_impl(const float *PC, int64_t ldpc, int64_t N, int d, const 
             RAHT_RET(read_back_u32(back, sort_err, 2, nullptr, nullptr, 0, s));
             nv = back[1];
             if (!back[0]) break;                             // (else: once more with the pass-by-pass sort)
+            g_sort_fallbacks.fetch_add(1, std::memory_order_relaxed);
         }
         if (want_res && !fused) {
             // narrow clouds: the two-call sequence (sort_idx as int64 is what raht_voxelize_residuals takes)

@@ -1046,3 +1046,8 @@ def test_key_sort_forms_equal_a_stable_sort(env):
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "check_sort.py")], env={**os.environ, **env}, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "correctness: 0 mismatches" in r.stdout
+    # raht_sort_fallbacks(): 0 unless a tile was made to give up (then > 0: the fallback is observable, not silent)
+    if "RAHT_SORT_DEBUG_FAIL_TILE" in env:
+        assert "sort fallbacks: 0" not in r.stdout
+    else:
+        assert "sort fallbacks: 0" in r.stdout

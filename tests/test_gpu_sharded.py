@@ -180,13 +180,13 @@ def _rank_main(rank, world, port, J, n, d, q):
         q.put((rank, traceback.format_exc()))
 
 
-@pytest.mark.parametrize("world", [4])
+@pytest.mark.parametrize("world", [4, 5])
 def test_four_ranks_share_the_gpu_exchange_and_transform(rt, world):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_rank_main, args=(r, world, port, 10, 300000, 14, q)) for r in range(world)]
+    procs = [ctx.Process(target=_rank_main, args=(r, world, port, 10, 300000 if world == 4 else 120000, 14, q)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=600) for _ in range(world)]
@@ -387,9 +387,11 @@ def _direct_main(rank, world, port, q):
         q.put((rank, traceback.format_exc()))
 
 
-@pytest.mark.parametrize("world", [1, 2, 3])
+@pytest.mark.parametrize("world", [1, 2, 3, 5])
 def test_direct_exchange_equals_the_collective(rt, world):
-    """ShardedRaht(direct=True): every rank writes its root slot into each peer's gather buffer (hipIpc-mapped fine-grained
+    """(world 5: the most ranks this box lets share its GPU -- at most 6 processes may use the card at once and this test process is
+    one of them; an 8-rank group has only ever run on the CPU, tests/test_sharded_gloo.py.)
+    ShardedRaht(direct=True): every rank writes its root slot into each peer's gather buffer (hipIpc-mapped fine-grained
     device memory) and raises a flag -- one launch per direction -- instead of all_gather_into_tensor. Bit-identical results;
     here the 'peers' are processes sharing this box's one GPU (IPC to the same device), on xGMI they are the other GPUs."""
     import torch.multiprocessing as mp

@@ -1,4 +1,5 @@
-"""World-size-2 (and 3) gloo tests of the Morton-prefix sharded RAHT on CPU.
+"""World-size-2, 3 and 8 gloo tests of the Morton-prefix sharded RAHT on CPU (8 = the node the north star names:
+no xGMI / RCCL run with more than one rank exists anywhere, so the 8-rank control flow is at least walked here).
 
 The host-side logic under test is raht_3dgs_codec_amd.sharded.ShardedRaht: prefix-range shards,
 root directory exchange, ONE all-gather per direction, replicated weighted top tree, write-back of
@@ -92,7 +93,7 @@ def _worker(rank, world, port, J, n, D, q, balanced=False, prefix_range=None):
 
 
 @pytest.mark.parametrize("world,J,n,D,balanced", [(2, 6, 6000, 5, False), (2, 10, 4000, 14, False), (3, 5, 3000, 3, False),
-                                                  (3, 8, 5000, 7, True)])
+                                                  (3, 8, 5000, 7, True), (8, 7, 6000, 5, True), (8, 6, 4000, 3, False)])
 def test_sharded_matches_unsharded_oracle(world, J, n, D, balanced):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -100,14 +101,15 @@ def test_sharded_matches_unsharded_oracle(world, J, n, D, balanced):
     procs = [ctx.Process(target=_worker, args=(r, world, port, J, n, D, q, balanced)) for r in range(world)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=240) for _ in range(world)]
+    res = [q.get(timeout=420) for _ in range(world)]
     for p in procs:
         p.join(timeout=60)
     for rank, msg in res:
         assert msg == "ok", f"rank {rank}:\n{msg}"
 
 
-@pytest.mark.parametrize("world,J,n,D,prefix_range", [(3, 6, 3000, 5, (0, 300, 9)), (2, 5, 1500, 3, (256, 512, 9)), (3, 6, 2000, 4, (200, 320, 9))])
+@pytest.mark.parametrize("world,J,n,D,prefix_range", [(3, 6, 3000, 5, (0, 300, 9)), (2, 5, 1500, 3, (256, 512, 9)), (3, 6, 2000, 4, (200, 320, 9)),
+                                                      (8, 6, 3000, 4, (0, 200, 9)), (8, 6, 2500, 3, (70, 330, 9))])
 def test_rank_without_rows_still_joins_the_collectives(world, J, n, D, prefix_range):
     """A prefix range that holds no point (uneven scenes; fewer occupied prefixes than ranks): that rank has no plan and
     no roots but must enter every collective -- round 2 raised on it and left the other ranks blocked."""
@@ -117,7 +119,7 @@ def test_rank_without_rows_still_joins_the_collectives(world, J, n, D, prefix_ra
     procs = [ctx.Process(target=_worker, args=(r, world, port, J, n, D, q, False, prefix_range)) for r in range(world)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=240) for _ in range(world)]
+    res = [q.get(timeout=420) for _ in range(world)]
     for p in procs:
         p.join(timeout=60)
     for rank, msg in res:
@@ -183,7 +185,8 @@ def _worker_frontend(rank, world, port, J, n, d, q, empty_rank=-1):
         q.put((rank, traceback.format_exc()))
 
 
-@pytest.mark.parametrize("world,J,n,d,empty_rank", [(2, 6, 5000, 3, -1), (3, 8, 7000, 5, -1), (3, 6, 4000, 3, 1), (2, 6, 3000, 2, 0)])
+@pytest.mark.parametrize("world,J,n,d,empty_rank", [(2, 6, 5000, 3, -1), (3, 8, 7000, 5, -1), (3, 6, 4000, 3, 1), (2, 6, 3000, 2, 0),
+                                                    (8, 7, 9000, 3, 2)])
 def test_unpartitioned_cloud_exchange_then_sharded_transform(world, J, n, d, empty_rank):
     """all-to-all bucket exchange by 9-bit Morton prefix + local radix sort / voxelizer, against the
     oracle's sort of the whole cloud (reference python/voxelize_pc.py:97-118)."""
@@ -193,7 +196,7 @@ def test_unpartitioned_cloud_exchange_then_sharded_transform(world, J, n, d, emp
     procs = [ctx.Process(target=_worker_frontend, args=(r, world, port, J, n, d, q, empty_rank)) for r in range(world)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=240) for _ in range(world)]
+    res = [q.get(timeout=420) for _ in range(world)]
     for p in procs:
         p.join(timeout=60)
     for rank, msg in res:

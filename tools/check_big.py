@@ -30,3 +30,7 @@ cnt = torch.diff(torch.cat([starts, torch.tensor([n], device="cuda")]))
 seg = torch.repeat_interleave(torch.arange(starts.shape[0], device="cuda"), cnt)
 ok = ok and bool(torch.equal(Dl[:, 3:], PCs[:, 3:] - PCvox[seg][:, 3:]))
 print("voxelize n=%d d=%d J=%d nvox=%d ok=%s %.2f ms" % (n, d, J, info["Nvox"], ok, dt * 1e3))
+from raht_3dgs_codec_amd import _lib as _l  # noqa: E402
+nfb = int(_l.lib().raht_sort_fallbacks())
+print("sort fallbacks: %d" % nfb, flush=True)
+assert nfb == 0, "a one-sweep sort gave up and fell back to the pass-by-pass form"

@@ -39,6 +39,18 @@ for n, d, J in ((5000, 11, 6), (200000, 56, 8), (9000, 2, 5)):
         bad += 1
         print("VOXELIZER MISMATCH n=%d d=%d J=%d" % (n, d, J))
 print("correctness: %d mismatches" % bad)
+# how often a one-sweep sort gave up and the call repeated the sort pass by pass (include/raht.h: raht_sort_fallbacks): 0 in
+# every form but the ones that make a tile give up on purpose
+from raht_3dgs_codec_amd import _lib as _l
+nfb = int(_l.lib().raht_sort_fallbacks())
+print("sort fallbacks: %d" % nfb)
+if os.environ.get("RAHT_SORT_DEBUG_FAIL_TILE") is None:
+    if nfb != 0:
+        bad += 1
+        print("UNEXPECTED SORT FALLBACKS: %d" % nfb)
+elif os.environ.get("RAHT_SORT_ONESWEEP") != "0" and nfb == 0:
+    bad += 1
+    print("the forced give-up did not register as a fallback")
 if "--time" in sys.argv:
     n, J, D, seed = synth.CONFIGS["cfg3"]
     keys = synth.sorted_unique_keys(n, J, seed)
