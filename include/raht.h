@@ -206,6 +206,18 @@ int raht_fwd_quant(const raht_plan *plan, const float *C, int64_t ldc, int D, co
 int raht_dequant_inv(const raht_plan *plan, const int32_t *Q, int64_t ldq, int D, const float *steps,
                      int n_steps, float *C, int64_t ldc, raht_stream_t stream);
 
+/* raht_dequant_inv fused with the drivers' distortion measurement (python/encode_3dgs.py:274 C_rec = iRAHT(...), then :298-310
+ * torch.mean((C - C_rec) ** 2) over all / quats / scales / opacity / colour columns): the stage-0 kernel of the fused inverse
+ * compares every row it reconstructs with the ORIGINAL attributes C_ref on its way out.
+ *   sqdiff : DEVICE double[D]: sum over rows of (C_rec[i, c] - C_ref[i, c])^2 -- differences in float32, squares and sums in
+ *            float64, summed in a fixed order (deterministic); what raht_sqdiff_columns(C_ref, C_rec) returns, up to the order
+ *            of the float64 additions;
+ *   C_rec  : the reconstruction, bit-identical to raht_dequant_inv's -- or NULL: then it is never written (the PSNR columns
+ *            need the sums only), and a decode step is one pass over Q and C_ref instead of Q -> C_rec, then C_ref and C_rec.
+ * Shapes outside the fused path (D > 64, trees of one launch, level engine, truncated plans) run the two calls inside. */
+int raht_dequant_inv_sqdiff(const raht_plan *plan, const int32_t *Q, int64_t ldq, int D, const float *steps, int n_steps,
+                            const float *C_ref, int64_t ld_ref, float *C_rec, int64_t ldc, double *sqdiff, raht_stream_t stream);
+
 /* The same two at the reference's own precision (python/encode_3dgs.py:82-83: float64 coefficients are what
  * :204 quantizes): the float64 tile kernels with the float64 quantizer (IEEE double division, float64 steps) in their
  * write-back / row gather -- one pass, no N x D temporary. Q is bit-identical to raht_fwd_f64 + raht_quant_reorder_f64,

@@ -43,6 +43,9 @@ struct TileArgs {
     T *root_buf;         // optional compact (n_roots x D) buffer: forward writes the rows still carrying
                          // a low-pass value there, inverse reads them from there (nullptr: T / Q rows)
     int nwide;           // mixed precision (transform_mx.hip): the first nwide channels are carried as float64; 0 elsewhere
+    // raht_dequant_inv_sqdiff (stage 0 of the fused inverse only): the matrix the reconstruction is compared with, and where this
+    // tile's per-chunk-element sums of squared differences go ([n_tiles x 4 ceil(D / 4)] float64); out may then be nullptr
+    const T *ref; int64_t ld_ref; double *sq_part;
 };
 
 // One butterfly, resolved: LDS element offsets of the partner (low-pass) row and of the own

@@ -170,7 +170,7 @@ __device__ __forceinline__ void st_chunk_wt(T *p, const RegChunk<T> &x)
 //
 // tile_body is the kernel; tile_kernel runs it for ONE scene (workgroup b takes tiles b, b + gridDim.x, ...), tile_kernel_batch
 // for several scenes in one launch (workgroup b takes ONE tile of the scene whose tile range holds b).
-template <typename T, bool INV, bool IDENT, bool QM, int SLOTS, bool WT = false>
+template <typename T, bool INV, bool IDENT, bool QM, int SLOTS, bool WT = false, bool SQ = false>
 __device__ __forceinline__ void tile_body(const TileArgs<T> &A, const typename std::conditional<QM, typename StepsFor<T>::type, NoSteps>::type &ST,
                                           const int64_t first_tile, const int64_t tile_stride, const int chunk_y)
 {
@@ -664,7 +664,57 @@ __device__ __forceinline__ void tile_body(const TileArgs<T> &A, const typename s
         asm volatile("" : "+v"(tid5));
         lane_geom(tid5, lane, wid, g, coff, goff, active);
     }
-    if (INV) {
+    if constexpr (INV && SQ) {
+        // raht_dequant_inv_sqdiff: the reconstruction is compared with A.ref on its way out -- per column sum (x - ref)^2, differences
+        // in T, squares and sums in float64 (what raht_sqdiff_columns computes from two matrices) -- and written only when the caller
+        // wants it (the drivers' PSNR columns, python/encode_3dgs.py:298-310, need the sums, not C_rec). SB row instructions' worth
+        // of reference chunks are in flight at a time; per tile: lanes -> the wave's row groups (shuffles) -> the workgroup's
+        // waves (LDS, fixed order) -> one float64 per chunk element in sq_part: a deterministic sum.
+        constexpr int SB = 4;
+        double acc[VN];
+#pragma unroll
+        for (int i = 0; i < VN; ++i) acc[i] = 0.0;
+        const T *rbase = A.ref + e0 * A.ld_ref;
+        if (active) for (int it0 = wid; (it0 << lr) < nt; it0 += nw * SB) {
+            V16 c[SB];
+#pragma unroll
+            for (int u = 0; u < SB; ++u) {
+                const int j = min(((it0 + u * nw) << lr) + g, nt - 1);
+                c[u] = ld_chunk<T, true>(row_at(rbase, (uint32_t)j, (uint32_t)A.ld_ref, (uint32_t)goff));
+            }
+#pragma unroll
+            for (int u = 0; u < SB; ++u) {
+                const int jr = ((it0 + u * nw) << lr) + g;
+                if (((it0 + u * nw) << lr) < nt) {                           // (wave-uniform)
+                    const int j = min(jr, nt - 1);
+                    const V16 x = *(const V16 *)&tile[__mul24(j, Dp) + coff];
+                    if (A.out) st_chunk<T, true>(row_at(A.out + e0 * A.ld_out, (uint32_t)j, (uint32_t)A.ld_out, (uint32_t)goff), x);
+                    if (jr < nt) {
+#pragma unroll
+                        for (int i = 0; i < VN; ++i) { const T d = x.v[i] - c[u].v[i]; acc[i] += (double)d * (double)d; }
+                    }
+                }
+            }
+        }
+        // lanes of one chunk place across the wave's row groups
+#pragma unroll
+        for (int i = 0; i < VN; ++i) {
+            for (int sh = 1 << lg; sh < 64; sh <<= 1) acc[i] += __shfl_xor(acc[i], sh, 64);
+        }
+        __syncthreads();                                                      // every wave has read its rows: the tile's LDS is free
+        double *sacc = (double *)smem;                                        // [nw][NC * VN]
+        const int c4s = lane & ((1 << lg) - 1);
+        if (g == 0 && c4s < NC) {
+#pragma unroll
+            for (int i = 0; i < VN; ++i) sacc[(wid * NC + c4s) * VN + i] = acc[i];
+        }
+        __syncthreads();
+        if (tid0 < NC * VN) {
+            double t = 0.0;
+            for (int w = 0; w < nw; ++w) t += sacc[w * NC * VN + tid0];
+            A.sq_part[(int64_t)tile_id * (NC * VN) + tid0] = t;
+        }
+    } else if (INV) {
         // the whole tile, entry order: stage 0 -> C rows [e0, e0+nt); stage k -> ws_k
         if (active) for (int it = wid; (it << lr) < nt; it += nw) {
             const int j = min((it << lr) + g, nt - 1);
@@ -734,6 +784,32 @@ __global__ __launch_bounds__(512, (sizeof(T) == 4 ? 6 : 4)) void tile_kernel(con
                                                    const typename std::conditional<QM, typename StepsFor<T>::type, NoSteps>::type ST)
 {
     tile_body<T, INV, IDENT, QM, SLOTS>(A, ST, (int64_t)blockIdx.x, (int64_t)gridDim.x, (int)blockIdx.y);
+}
+
+// stage 0 of raht_dequant_inv_sqdiff (tile_body, SQ): the fused inverse that compares its output with a reference matrix on the way out
+template <int SLOTS>
+__global__ __launch_bounds__(512, 6) void tile_kernel_sq(const TileArgs<float> A, const StepTable ST)
+{
+    tile_body<float, true, true, true, SLOTS, false, true>(A, ST, (int64_t)blockIdx.x, (int64_t)gridDim.x, (int)blockIdx.y);
+}
+
+// out[ch] = sum over tiles of the partial that holds channel ch (a row's last chunk is the 16 bytes that END the row: when D is not
+// a multiple of 4 it repeats channels of its neighbour, which are counted from their own chunk only)
+__global__ __launch_bounds__(256) void sq_final_kernel(const double *__restrict__ part, int64_t n_tiles, int D, int ncv, double *__restrict__ out)
+{
+    __shared__ double red[256];
+    const int ch = blockIdx.x;
+    const int full = (D / 4) * 4;                          // channels [0, full): chunk ch / 4, element ch % 4
+    const int e = ch < full ? ch : (ncv - 4) + (ch - (D - 4));
+    double t = 0.0;
+    for (int64_t k = threadIdx.x; k < n_tiles; k += 256) t += part[k * ncv + e];
+    red[threadIdx.x] = t;
+    __syncthreads();
+    for (int sft = 128; sft > 0; sft >>= 1) {
+        if ((int)threadIdx.x < sft) red[threadIdx.x] += red[threadIdx.x + sft];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[ch] = red[0];
 }
 
 // FORWARD CHAINING of the later tile stages (round 3). Stage k + 1's tile P can run as soon as the tiles of stage k that
@@ -1297,7 +1373,7 @@ static int prepare_tile_stage(const raht_plan *p, const Schedule &sc, int k, con
     A.ht = rounds_by_level ? A.lvl : st.e_ht;
     A.Q = io.Q; A.ldq = io.ldq;
     A.top_level = p->top_level; A.root_buf = (T *)p->root_buf;
-    A.dbg = dbg; A.nwide = 0;
+    A.dbg = dbg; A.nwide = 0; A.ref = nullptr; A.ld_ref = 0; A.sq_part = nullptr;
     A.ld_ws = D;
     A.wsn = (k + 1 < K) ? (T *)sc.stages[(size_t)k + 1].ws : nullptr;
     T *ws_k = (k >= 1) ? (T *)st.ws : nullptr;
@@ -1655,6 +1731,68 @@ static int dequant_inv_impl(const raht_plan *cp, const int32_t *Q, int64_t ldq, 
     return RAHT_OK;
 }
 
+/* raht_dequant_inv fused with the drivers' distortion measurement (python/encode_3dgs.py:274,298-310: C_rec = iRAHT(...), then
+ * torch.mean((C - C_rec) ** 2) over all / quats / scales / opacity / colour columns): the stage-0 kernel of the fused inverse
+ * compares every row it reconstructs with the original on its way out and leaves per-column sums of squared differences; C_rec
+ * itself is written only if the caller passes a buffer. One pass over Q and C instead of Q -> C_rec, then C and C_rec again. */
+static int dequant_inv_sqdiff_impl(const raht_plan *cp, const int32_t *Q, int64_t ldq, int D, const float *steps, int n_steps,
+                                   const float *Cref, int64_t ldref, float *Crec, int64_t ldc, double *sq, raht_stream_t stream)
+{
+    raht_plan *p = const_cast<raht_plan *>(cp);
+    hipStream_t s = (hipStream_t)stream;
+    if (!p || !Q || !Cref || !sq || D < 1 || ldq < D || ldref < D || (Crec && ldc < D)) { set_error("raht_dequant_inv_sqdiff: bad argument"); return RAHT_ERR_INVALID; }
+    RAHT_RET(check_plan_device(p, "raht_dequant_inv_sqdiff"));
+    if (p->row_map) { set_error("raht_dequant_inv_sqdiff: not available for a row-mapped plan"); return RAHT_ERR_UNSUPPORTED; }
+    RAHT_RET(check_steps(steps, n_steps, D));
+    Schedule *sc = nullptr;
+    int Dc = 0;
+    RAHT_RET(tile_setup<float>(p, D, std::max(std::max(ldref, ldq), Crec ? ldc : (int64_t)D), s, &sc, &Dc));
+    const bool fusable = sc && Dc >= D && sc->stages.size() >= 2 && !sc->stages[0].is_top && !p->root_buf && p->top_level >= 64;
+    if (!fusable) {
+        // level engine, channel-chunked rows (D > 64), one-launch trees, truncated plans: the two passes
+        Scratch tmp(Crec ? 16 : sizeof(float) * (size_t)p->N * (size_t)D, s);
+        if (!tmp.ok()) return RAHT_ERR_NOMEM;
+        float *out = Crec ? Crec : tmp.as<float>();
+        const int64_t ldo = Crec ? ldc : D;
+        RAHT_RET(dequant_inv_impl<float>(p, Q, ldq, D, steps, n_steps, out, ldo, stream));
+        return raht_sqdiff_columns(Cref, ldref, out, ldo, p->N, D, RAHT_F32, sq, stream);
+    }
+    XformIO<float> io;
+    io.dst = Crec; io.ld_dst = Crec ? ldc : D; io.Q = const_cast<int32_t *>(Q); io.ldq = ldq; io.steps = steps; io.n_steps = n_steps;
+    const int K = (int)sc->stages.size();
+    for (int k = K - 1; k >= 1; --k) RAHT_RET((launch_tile_stage<float, true, true>(p, *sc, k, io, D, Dc, s)));
+    // stage 0: the comparing kernel
+    TileArgs<float> A;
+    TileGeom G;
+    XformIO<float> io0 = io;
+    if (!Crec) io0.dst = const_cast<float *>(Cref);            // (only so that the argument check sees an output; overridden below)
+    RAHT_RET((prepare_tile_stage<float, true, true>(p, *sc, 0, io0, D, Dc, 0, A, G)));
+    const int ncv = ((D + 3) / 4) * 4;
+    Scratch part(sizeof(double) * (size_t)G.n_tiles * (size_t)ncv, s);
+    if (!part.ok()) return RAHT_ERR_NOMEM;
+    A.out = Crec; A.ld_out = Crec ? ldc : 0;
+    A.ref = Cref; A.ld_ref = ldref; A.sq_part = part.as<double>();
+    if (G.nchunks != 1 || !G.ident || G.grid_x != (unsigned)G.n_tiles || (size_t)G.threads / 64 * (size_t)ncv * 8 > G.lds) {
+        set_error("raht_dequant_inv_sqdiff: unexpected stage-0 geometry");
+        return RAHT_ERR_INVALID;
+    }
+    StepTable st;
+    fill_step_table(st, steps, n_steps);
+    static PerDeviceOnce attr1, attr2;
+    if (p->ev_before) RAHT_HIP_CHECK(hipEventRecord(p->ev_before, s));
+    if (G.one) {
+        if (attr1.first(current_device())) RAHT_HIP_CHECK(hipFuncSetAttribute((const void *)tile_kernel_sq<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        hipLaunchKernelGGL((tile_kernel_sq<1>), dim3(G.grid_x), dim3(G.threads), G.lds, s, A, st);
+    } else {
+        if (attr2.first(current_device())) RAHT_HIP_CHECK(hipFuncSetAttribute((const void *)tile_kernel_sq<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        hipLaunchKernelGGL((tile_kernel_sq<2>), dim3(G.grid_x), dim3(G.threads), G.lds, s, A, st);
+    }
+    if (p->ev_before) RAHT_HIP_CHECK(hipEventRecord(p->ev_after, s));
+    hipLaunchKernelGGL(sq_final_kernel, dim3((unsigned)D), dim3(256), 0, s, part.as<double>(), G.n_tiles, D, ncv, sq);
+    RAHT_HIP_CHECK(hipGetLastError());
+    return RAHT_OK;
+}
+
 // ---- several scenes, one set of launches (raht_*_batch) ----------------------------------------------
 // Round r of the forward direction runs stage r of every scene that has one (inverse: the stages from the top of the
 // deepest schedule downwards, a scene joining when its own top stage comes up); within a round the tile stages of equal
@@ -1788,6 +1926,12 @@ int raht_dequant_inv(const raht_plan *plan, const int32_t *Q, int64_t ldq, int D
                      float *C, int64_t ldc, raht_stream_t stream)
 {
     return guarded("raht_dequant_inv", [&]() { return dequant_inv_impl<float>(plan, Q, ldq, D, steps, n_steps, C, ldc, stream); });
+}
+
+int raht_dequant_inv_sqdiff(const raht_plan *plan, const int32_t *Q, int64_t ldq, int D, const float *steps, int n_steps,
+                            const float *C_ref, int64_t ld_ref, float *C_rec, int64_t ldc, double *sqdiff, raht_stream_t stream)
+{
+    return guarded("raht_dequant_inv_sqdiff", [&]() { return dequant_inv_sqdiff_impl(plan, Q, ldq, D, steps, n_steps, C_ref, ld_ref, C_rec, ldc, sqdiff, stream); });
 }
 
 int raht_dequant_inv_f64(const raht_plan *plan, const int32_t *Q, int64_t ldq, int D, const double *steps, int n_steps,

@@ -893,7 +893,7 @@ static int launch_stage_mx(const raht_plan *p, const Schedule &sc, int k, const 
     else { A.lvl = p->lvl; A.wl = p->wl; A.wr = p->wr; A.inv_order = p->inv_order; }
     A.ht = st.e_ht;
     A.Q = io.Q; A.ldq = io.ldq;
-    A.top_level = p->top_level; A.root_buf = nullptr; A.dbg = 0;
+    A.top_level = p->top_level; A.root_buf = nullptr; A.dbg = 0; A.ref = nullptr; A.ld_ref = 0; A.sq_part = nullptr;
     A.ld_ws = g.Dp; A.wsn = ws_n;
     A.fin = nullptr; A.ld_fin = 0;
     if (!INV) { A.in = (k == 0) ? io.C_in : ws_k; A.ld_in = (k == 0) ? io.ldc : g.Dp; A.out = nullptr; A.ld_out = 0; }

@@ -354,6 +354,25 @@ class RahtPlan:
                 self._set_roots_buffer(None, D, torch.float32)
         return out
 
+    def dequant_inverse_sqdiff(self, Q, steps, C_ref, want_rec=True):
+        """Un-reorder + dequantize + inverse RAHT (float32, fused) that also compares its output with the original attributes on the
+        way out: -> (C_rec or None, float64[D] per-column sums of (C_rec - C_ref)^2). What the drivers' five PSNR columns are made of
+        (python/encode_3dgs.py:274,298-310) without a pass of its own; with ``want_rec=False`` C_rec is never written."""
+        _need_cuda(Q, "Q")
+        _need_cuda(C_ref, "C_ref")
+        Q = Q.to(torch.int32).contiguous()
+        D = Q.shape[1]
+        X = C_ref.to(torch.float32)
+        if X.stride(1) != 1 or X.stride(0) < D:
+            X = X.contiguous()
+        st = _steps(steps, D)
+        out = torch.empty((self.N, D), dtype=torch.float32, device=Q.device) if want_rec else None
+        ssd = torch.empty(D, dtype=torch.float64, device=Q.device)
+        with torch.cuda.device(Q.device):
+            check(_lib.lib().raht_dequant_inv_sqdiff(self._h, C.c_void_p(Q.data_ptr()), D, D, st, len(st), C.c_void_p(X.data_ptr()), X.stride(0),
+                                                     C.c_void_p(out.data_ptr()) if want_rec else None, D, C.c_void_p(ssd.data_ptr()), _stream()))
+        return out, ssd
+
     def forward_quant_mixed(self, Cmat, steps, n_wide=3):
         """Forward RAHT + quantize + reorder of a float32 matrix whose first ``n_wide`` channels (the xyz columns of a
         59-column frame, python/voxelize_pc.py:155) are carried in float64 -- the reference's precision

@@ -39,24 +39,26 @@ def _psnr(a, b):
 
 
 def encode_frame(V_int, attributes, J, steps, frame=1, device="cuda:0", dtype=torch.float32, fused=True,
-                 nthreads=0, channel_major=True, overlap=False, entropy="host", seg_len=2048):
+                 nthreads=0, channel_major=True, overlap=False, entropy="host", seg_len=2048, keep_rec=True):
     """One frame through the whole pipeline. Returns a list of dict rows (one per step) with the CSV
     columns plus ``size_bytes`` and ``C_rec`` (last step) for inspection, and the stages the reference's CSV has no
     column for (``Transpose_time``, ``D2H_time``, ``H2D_time``, ``PSNR_time``, ``Step_wall_time``).
 
     overlap=True (fused path): the steps are software-pipelined -- while the host threads entropy-code step s, the GPU
     already transforms / quantizes / copies step s + 1 and decodes step s - 1 (the reference serialises all of it,
-    python/encode_3dgs.py:199-275). Same rows, same bytes; ``Step_wall_time`` is then the pipeline's period."""
-    """
+    python/encode_3dgs.py:199-275). Same rows, same bytes; ``Step_wall_time`` is then the pipeline's period.
+
+    keep_rec=False (fused float32 path): the reconstruction is never written -- the decode side is ONE pass that dequantizes,
+    inverts and accumulates the PSNR columns' sums of squares (raht_dequant_inv_sqdiff); rows then carry ``C_rec = None``.
     entropy="gpu": the RLGR stage on the device, segmented (rlgr.SegmentedCoder: every ``seg_len`` symbols of a channel an
     independent stream, byte-identical to the reference coder's output for that slice): the integers never leave the GPU, only
     the container's bytes do (``D2H_time``). Rates then count the container (streams + 4 bytes per segment)."""
     if entropy == "gpu":
         if not fused:
             raise ValueError("entropy='gpu' goes with the fused path")
-        return _encode_frame_gpu_entropy(V_int, attributes, J, steps, frame, device, dtype, seg_len)
+        return _encode_frame_gpu_entropy(V_int, attributes, J, steps, frame, device, dtype, seg_len, keep_rec)
     if overlap and fused:
-        return _encode_frame_overlapped(V_int, attributes, J, steps, frame, device, dtype, nthreads)
+        return _encode_frame_overlapped(V_int, attributes, J, steps, frame, device, dtype, nthreads, keep_rec)
     N = V_int.shape[0]
     C = attributes.to(dtype=dtype).contiguous().to(device)
     _sync()
@@ -147,11 +149,13 @@ def encode_frame(V_int, attributes, J, steps, frame=1, device="cuda:0", dtype=to
             qd = rlgr_mod.transpose_on_device(qd)
             _sync()
             r["Transpose_time"] += time.time() - t0
+        measured = False
         if use_fused:
             t0 = time.time()
-            C_rec = plan.dequant_inverse(qd, step_arg, dtype=dtype)                 # :261 + :267-268 + :274
+            C_rec = _decode_and_measure(plan, qd, step_arg, C, dtype, r, keep_rec)  # :261 + :267-268 + :274 (+ :298-310 in the same pass)
             _sync()
             r["iRAHT_time"], r["Dequant_time"], r["Coeff_reorder_dec_time"] = time.time() - t0, 0.0, 0.0
+            measured = True
         else:
             t0 = time.time()
             Coeff_dec = qd.to(dtype) * step                                         # :261
@@ -173,7 +177,8 @@ def encode_frame(V_int, attributes, J, steps, frame=1, device="cuda:0", dtype=to
         r["Rate_bpp"] = size_bytes * 8 / N                                          # :403
         r["size_bytes"] = size_bytes
         t0 = time.time()
-        _psnr_columns(r, C, C_rec)
+        if not measured:
+            _psnr_columns(r, C, C_rec)
         r["PSNR_time"] = time.time() - t0
         r["Step_wall_time"] = time.time() - t_step0
         r["C_rec"] = C_rec
@@ -181,7 +186,7 @@ def encode_frame(V_int, attributes, J, steps, frame=1, device="cuda:0", dtype=to
     return rows
 
 
-def _encode_frame_gpu_entropy(V_int, attributes, J, steps, frame, device, dtype, seg_len):
+def _encode_frame_gpu_entropy(V_int, attributes, J, steps, frame, device, dtype, seg_len, keep_rec=True):
     """encode_frame with the entropy stage on the device (entropy="gpu"): forward RAHT + quantize + reorder -> channel-major
     transpose -> segmented RLGR encode (device) -> [container bytes to the host: the codec's output] -> segmented RLGR decode
     (device) -> round-trip check (device) -> transpose -> dequantize + un-reorder + inverse RAHT -> PSNR."""
@@ -232,7 +237,7 @@ def _encode_frame_gpu_entropy(V_int, attributes, J, steps, frame, device, dtype,
         _sync()
         r["Transpose_time"] += time.time() - t0
         t0 = time.time()
-        C_rec = plan.dequant_inverse(qd, step_arg, dtype=dtype)
+        C_rec = _decode_and_measure(plan, qd, step_arg, C, dtype, r, keep_rec)      # inverse + the PSNR columns' sums, one pass
         _sync()
         r["iRAHT_time"], r["Dequant_time"], r["Coeff_reorder_dec_time"] = time.time() - t0, 0.0, 0.0
         r["RAHT_prelude_time"] = t_prelude
@@ -241,9 +246,7 @@ def _encode_frame_gpu_entropy(V_int, attributes, J, steps, frame, device, dtype,
         r["Pipeline_time"] = t_prelude + r["Total_enc_time"] + r["Total_dec_time"]
         r["Rate_bpp"] = size_bytes * 8 / N
         r["size_bytes"] = size_bytes
-        t0 = time.time()
-        _psnr_columns(r, C, C_rec)
-        r["PSNR_time"] = time.time() - t0
+        r["PSNR_time"] = 0.0                                   # (inside iRAHT_time: the fused inverse measures on its way out)
         r["Step_wall_time"] = time.time() - t_step0
         r["C_rec"] = C_rec
         rows.append(r)
@@ -264,12 +267,7 @@ def _psnr_columns(r, C, C_rec):
             _lib.check(_lib.lib().raht_sqdiff_columns(_C.c_void_p(C.data_ptr()), C.stride(0), _C.c_void_p(C_rec.data_ptr()), C_rec.stride(0), N, D,
                                                       _lib.RAHT_F32 if C.dtype == torch.float32 else _lib.RAHT_F64, _C.c_void_p(out.data_ptr()),
                                                       _C.c_void_p(torch.cuda.current_stream().cuda_stream)))
-        ssd = out.cpu().numpy()                               # (the one synchronisation)
-
-        def col(lo, hi):
-            return -10 * math.log10(float(ssd[lo:hi].sum()) / (N * (hi - lo)) + 1e-10)
-        r["PSNR_all"] = col(0, D)
-        r["PSNR_quats"], r["PSNR_scales"], r["PSNR_opacity"], r["PSNR_colors"] = col(0, 4), col(4, 7), col(7, 8), col(8, D)
+        _psnr_from_ssd(r, out, N)
         return
     r["PSNR_all"] = _psnr(C, C_rec)                                                 # encode_3dgs.py:298-310
     r["PSNR_quats"] = _psnr(C[:, 0:4], C_rec[:, 0:4])
@@ -278,7 +276,35 @@ def _psnr_columns(r, C, C_rec):
     r["PSNR_colors"] = _psnr(C[:, 8:], C_rec[:, 8:])
 
 
-def _encode_frame_overlapped(V_int, attributes, J, steps, frame, device, dtype, nthreads):
+def _psnr_from_ssd(r, ssd_dev, N):
+    """the five PSNR columns from per-column sums of squared differences (float64, on the device); an empty column group (frames
+    with fewer than 9 attribute columns) gives nan, as torch.mean of an empty slice does in the reference (encode_3dgs.py:298-310)"""
+    ssd = ssd_dev.cpu().numpy()                               # (the one synchronisation)
+    D = ssd.shape[0]
+
+    def col(lo, hi):
+        hi = min(hi, D)
+        if hi <= lo:
+            return float("nan")
+        return -10 * math.log10(float(ssd[lo:hi].sum()) / (N * (hi - lo)) + 1e-10)
+    r["PSNR_all"] = col(0, D)
+    r["PSNR_quats"], r["PSNR_scales"], r["PSNR_opacity"], r["PSNR_colors"] = col(0, 4), col(4, 7), col(7, 8), col(8, D)
+
+
+def _decode_and_measure(plan, qd, step_arg, C, dtype, r, keep_rec=True):
+    """dequantize + un-reorder + inverse RAHT + the five PSNR columns (encode_3dgs.py:261-275, 298-310). float32 frames: ONE fused
+    pass (raht_dequant_inv_sqdiff: the inverse's stage-0 kernel compares its rows with C on the way out; C_rec is written only when
+    asked for); float64: the float64 fused inverse, then one pass over C and C_rec."""
+    if dtype == torch.float32 and C.is_cuda and C.dtype == torch.float32:
+        C_rec, ssd = plan.dequant_inverse_sqdiff(qd, step_arg, C, want_rec=keep_rec)
+        _psnr_from_ssd(r, ssd, C.shape[0])
+        return C_rec
+    C_rec = plan.dequant_inverse(qd, step_arg, dtype=dtype)
+    _psnr_columns(r, C, C_rec)
+    return C_rec
+
+
+def _encode_frame_overlapped(V_int, attributes, J, steps, frame, device, dtype, nthreads, keep_rec=True):
     """The same frame, software-pipelined over the quantization steps (encode_frame, overlap=True).
 
     GPU (this thread):   step s: forward RAHT + quantize + reorder (fused) -> channel-major transpose -> device-to-host copy into
@@ -355,9 +381,9 @@ def _encode_frame_overlapped(V_int, attributes, J, steps, frame, device, dtype, 
                 t0 = time.time()
                 qd = pin_up[k % 2].to(dev, non_blocking=True)
                 f0.record(main)
-                C_rec = plan.dequant_inverse(rlgr_mod.transpose_on_device(qd), sa, dtype=dtype)
+                qt = rlgr_mod.transpose_on_device(qd)
+                C_rec = _decode_and_measure(plan, qt, sa, C, dtype, r, keep_rec)     # (synchronises: reads the sums back)
                 f1.record(main)
-                _psnr_columns(r, C, C_rec)                    # (synchronises: .item())
                 t_gpu_dec = time.time() - t0
                 e0, e1 = t_enc_gpu[k]
                 r["RAHT_transform_time"] = e0.elapsed_time(e1) * 1e-3          # forward + quantize + reorder + transpose (GPU time)

@@ -1051,3 +1051,51 @@ def test_key_sort_forms_equal_a_stable_sort(env):
         assert "sort fallbacks: 0" not in r.stdout
     else:
         assert "sort fallbacks: 0" in r.stdout
+
+
+# ---- raht_dequant_inv_sqdiff: the fused inverse that measures its own distortion (encode_3dgs.py:274,298-310) -----------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("tile_rows,tail_rows,final_rows", [(0, 0, 0), (64, 64, 64), (128, 64, 0), (256, 128, 256)])
+@pytest.mark.parametrize("name", ["n1000_j10_d14", "n1500_j12_d56", "n2000_j10_d59", "n257_j3_d11", "n3000_j18_d3", "n8_cube_j1"])
+def test_dequant_inverse_sqdiff_equals_the_two_passes(rt, name, tile_rows, tail_rows, final_rows):
+    """C_rec bit-identical to raht_dequant_inv; the per-column sums equal raht_sqdiff_columns(C, C_rec) up to the order of the
+    float64 additions -- with and without writing C_rec; one-launch trees and narrow rows take the two-pass path inside."""
+    import ctypes as C
+    import torch
+    from raht_3dgs_codec_amd import _lib
+    g = load_golden(name)
+    p = _plan(rt, g, "tile", tile_rows, tail_rows, 0, final_rows)
+    Cd = _dev(g["C"])
+    N, D = Cd.shape
+    for steps in (0.37, [0.05 + 0.01 * c for c in range(D)]):
+        Q = p.forward_quant(Cd, steps)
+        ref = p.dequant_inverse(Q, steps)
+        want = torch.empty(D, dtype=torch.float64, device="cuda")
+        _lib.check(_lib.lib().raht_sqdiff_columns(C.c_void_p(Cd.data_ptr()), D, C.c_void_p(ref.data_ptr()), D, N, D, _lib.RAHT_F32,
+                                                  C.c_void_p(want.data_ptr()), None))
+        rec, ssd = p.dequant_inverse_sqdiff(Q, steps, Cd)
+        assert torch.equal(rec, ref)
+        assert torch.allclose(ssd, want, rtol=1e-12, atol=1e-300), (name, float((ssd - want).abs().max()))
+        exact = ((ref.double() - Cd.double()) ** 2).sum(dim=0)          # (differences in float32 first, as the drivers' float32 frames do)
+        f32d = ((ref - Cd).double() ** 2).sum(dim=0)
+        assert torch.allclose(ssd, f32d, rtol=1e-9, atol=1e-300) and torch.allclose(ssd, exact, rtol=1e-3, atol=1e-12)
+        none, ssd2 = p.dequant_inverse_sqdiff(Q, steps, Cd, want_rec=False)
+        assert none is None and torch.equal(ssd2, ssd)                    # a deterministic sum
+
+
+@pytest.mark.gpu
+def test_dequant_inverse_sqdiff_strided_reference_and_big_scene(rt):
+    import torch
+    from raht_3dgs_codec_amd import synth
+    V, keys, Ch = synth.scene(300000, 10, 56, seed=4)
+    p = rt.RahtPlan.from_keys(_dev(keys.view(np.int64)), 30)
+    N, D = Ch.shape
+    big = torch.zeros((N, 64), dtype=torch.float32, device="cuda")
+    big[:, :D] = _dev(Ch)
+    Q = p.forward_quant(big[:, :D], 0.02)
+    rec, ssd = p.dequant_inverse_sqdiff(Q, 0.02, big[:, :D])
+    assert torch.equal(rec, p.dequant_inverse(Q, 0.02))
+    f32d = ((rec - big[:, :D]).double() ** 2).sum(dim=0)
+    assert torch.allclose(ssd, f32d, rtol=1e-9)
+    # orthonormal transform: the distortion equals the quantization error of the coefficients (Parseval), ~ N step^2 / 12 per column
+    assert 0.5 < float(ssd.mean()) / (N * 0.02 ** 2 / 12) < 1.5
