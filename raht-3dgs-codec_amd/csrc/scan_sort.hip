@@ -23,12 +23,21 @@ Scratch::Scratch(size_t bytes, hipStream_t stream)
     if (bytes == 0) bytes = 16;
     const int dev = current_device();
     int best = -1, n_dev = 0;
+    // best fit among the free blocks whose last user ran on THIS stream (or that were never used): a block last used on another
+    // stream costs a device synchronisation before it may be handed out, which would serialise a caller that works on two
+    // streams at once (raht_voxelize_plan: the plan build next to the voxelizer's mean kernel) -- such a block is only taken
+    // when the pool is already large
+    int n_free_other = 0, best_other = -1;
     for (int i = 0; i < (int)g_pool.size(); ++i) {
         const PoolBlock &b = g_pool[(size_t)i];
         if (b.device != dev || !b.p) continue;
         ++n_dev;
-        if (!b.used && b.bytes >= bytes && (best < 0 || b.bytes < g_pool[(size_t)best].bytes)) best = i;
+        if (b.used || b.bytes < bytes) continue;
+        if (!b.touched || b.last_stream == stream) { if (best < 0 || b.bytes < g_pool[(size_t)best].bytes) best = i; }
+        else { ++n_free_other; if (best_other < 0 || b.bytes < g_pool[(size_t)best_other].bytes) best_other = i; }
     }
+    if (best < 0 && best_other >= 0 && n_dev >= 40) best = best_other;
+    (void)n_free_other;
     if (best < 0) {
         // recycle the largest free block (of this device) that is too small, else grow the pool
         int victim = -1, empty = -1;
@@ -39,7 +48,7 @@ Scratch::Scratch(size_t bytes, hipStream_t stream)
         }
         void *q = nullptr;
         const size_t want = bytes + bytes / 4;                 // head-room against slow growth
-        if (victim >= 0 && n_dev >= 24) {
+        if (victim >= 0 && n_dev >= 48) {
             (void)hipFree(g_pool[(size_t)victim].p);
             // a failed allocation leaves an EMPTY slot behind: erasing it would shift the slot indices that
             // live Scratch objects hold, and a later destructor would release somebody else's block

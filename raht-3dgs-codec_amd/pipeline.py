@@ -384,6 +384,7 @@ def _encode_frame_overlapped(V_int, attributes, J, steps, frame, device, dtype, 
                 qt = rlgr_mod.transpose_on_device(qd)
                 C_rec = _decode_and_measure(plan, qt, sa, C, dtype, r, keep_rec)     # (synchronises: reads the sums back)
                 f1.record(main)
+                f1.synchronize()
                 t_gpu_dec = time.time() - t0
                 e0, e1 = t_enc_gpu[k]
                 r["RAHT_transform_time"] = e0.elapsed_time(e1) * 1e-3          # forward + quantize + reorder + transpose (GPU time)

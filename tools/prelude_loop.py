@@ -43,3 +43,4 @@ if "vox" in what:
     PC = torch.cat([xyz, torch.from_numpy(Ch).to(dev)[perm][:, :56]], dim=1).contiguous()
     print("voxelize ms", round(wall(lambda: R.voxelize_pc_batched(PC, [0.0, 0.0, 0.0], float(2 ** J), J, device=dev, residuals=False, sorted_points=False), 10), 4))
     print("voxelize_with_residuals ms", round(wall(lambda: R.voxelize_pc_batched(PC, [0.0, 0.0, 0.0], float(2 ** J), J, device=dev), 10), 4))
+    print("voxelize_plan ms", round(wall(lambda: R.voxelize_plan(PC, [0.0, 0.0, 0.0], float(2 ** J), J, device=dev), 20), 4))
