@@ -42,7 +42,7 @@ __device__ unsigned long long g_phase_clk_mx[MX_CLK_TILES][MX_CLK_SLOTS];
 #endif
 
 constexpr int MX_MAX_WIDE = 4;          // the wide channels are the row's first 16 bytes
-constexpr int MX_PRE_ROWS = 8;          // survivor rows prefetched by the inverse before flags are known
+constexpr int MX_PRE_ROWS = 12;         // survivor rows prefetched by the inverse before flags are known
 constexpr int MX_THREADS = 512;
 constexpr int MX_TOP_THREADS = 1024;
 constexpr int MX_TOP_SLOTS = RAHT_TOP_MAX_ROWS / MX_TOP_THREADS;
@@ -53,20 +53,20 @@ struct StepTableMX {
 };
 
 // (must match the carve-up in tile_body_mx)
-static size_t tile_lds_bytes_mx(int R, int NCp, bool ident)
+static size_t tile_lds_bytes_mx(int R, int NF, int nwide, bool ident)
 {
-    const size_t data = (size_t)R * NCp * 16;
+    const size_t data = (size_t)R * NF * 16 + (((size_t)R * nwide * 8 + 15) & ~(size_t)15);   // float tile + wide tile (8 bytes per wide channel)
     const size_t meta = (size_t)R * (16 + 4 + (ident ? 0 : 4) + 4 + 1);        // a, b (float64) + operand slots; row id; Q position; flag
     const size_t surv = ((size_t)R * 2 + 15) & ~(size_t)15;
-    return data + ((meta + 15) & ~(size_t)15) + 1024 + surv + (size_t)MX_PRE_ROWS * NCp * 16;
+    return data + ((meta + 15) & ~(size_t)15) + 1024 + surv;                  // (the inverse's survivor prefetch shares the records' bytes)
 }
 
 // the wide parts of the workspaces a stage touches (a workspace row is stored as two dense arrays: the float places of every
 // entry, then the wide places of every entry; TileArgs::in / out / wsn point at the float parts)
 struct MxPtrs {
-    const float *in_w;       // fwd, stages >= 1: wide part of ws_k
-    float *out_w;            // inv, stages >= 1: wide part of ws_k
-    float *wsn_w;            // wide part of ws_{k+1}
+    const double *in_w;      // fwd, stages >= 1: wide part of ws_k (n_wide doubles per entry)
+    double *out_w;           // inv, stages >= 1: wide part of ws_k
+    double *wsn_w;           // wide part of ws_{k+1}
 };
 
 template <bool INV, bool IDENT, int SLOTS>
@@ -79,11 +79,10 @@ __device__ __forceinline__ void tile_body_mx(const TileArgs<float> &A, const MxP
     const int R = A.R;
     const int tid0 = threadIdx.x;
     const int nthreads = blockDim.x, nwv = nthreads >> 6;
-    const int nwide = A.nwide, NW2 = (nwide + 1) >> 1;     // wide channels, wide chunk places per row (1 or 2)
-    const int lgw = NW2 > 1 ? 1 : 0;
+    const int nwide = A.nwide;                             // wide channels (1 .. 4): one double each per row of the wide tile
+    const int lgw = nwide > 2 ? 2 : nwide - 1;             // log2(lanes per butterfly in the wide pass)
     const int Df = A.D;                                    // the float tile holds ALL D channels, laid out as in the float32 kernels
     const int Fp = A.Dp, NF = Fp >> 2;                     // float tile: row stride in floats, chunk places per row
-    const int Wp = NW2 * 4;                                // wide tile: row stride in floats (16 or 32 bytes)
     const int lg = A.lg, lr = 6 - A.lg;                    // 2^lg >= NF lanes per row
     const uint32_t NFm = ((1u << 20) + (uint32_t)NF - 1) / (uint32_t)NF;     // c / NF == (c * NFm) >> 20 for c < 2^15
     auto sync_lds = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
@@ -92,9 +91,15 @@ __device__ __forceinline__ void tile_body_mx(const TileArgs<float> &A, const MxP
     // ---- LDS carve-up (must match tile_lds_bytes_mx) ----
     size_t off = 0;
     float *ftile = (float *)smem; off += (size_t)R * Fp * 4;              // float32 channels, NF places per row
-    float *wt = (float *)(smem + off); off += (size_t)R * Wp * 4;         // wide channels, NW2 places of two doubles per row
+    double *wd = (double *)(smem + off); off += ((size_t)R * nwide * 8 + 15) & ~(size_t)15;   // wide channels: nwide doubles per row
+    unsigned char *rec_base = smem + off;
     W16 *rec_ab = (W16 *)(smem + off); off += (size_t)R * 16;             // butterfly records: a, b in float64 ...
     uint32_t *rec_pj = (uint32_t *)(smem + off); off += (size_t)R * 4;    // ... and the two operand slots (partner | own << 16)
+    // inverse: the survivor rows prefetched at kernel start wait in the records' bytes (records are written once they have moved
+    // into their slots: P3b, a barrier, P3a) -- as many as fit, at most MX_PRE_ROWS
+    const int pre_rows = min(MX_PRE_ROWS, (R * 20 - 8) / (Fp * 4 + nwide * 8));      // (- 8: the wide part arrives in 16-byte chunks)
+    float *spre_f = (float *)rec_base;
+    double *spre_w = (double *)(rec_base + (size_t)pre_rows * Fp * 4);
     int32_t *srow = (int32_t *)(smem + off); if (!IDENT) off += (size_t)R * 4;
     int32_t *sdst = (int32_t *)(smem + off); off += (size_t)R * 4;
     uint8_t *sflag = (uint8_t *)(smem + off); off += (size_t)R;
@@ -106,8 +111,6 @@ __device__ __forceinline__ void tile_body_mx(const TileArgs<float> &A, const MxP
     off += 1024;
     uint16_t *ssurv = (uint16_t *)(smem + off);
     off += ((size_t)R * 2 + 15) & ~(size_t)15;
-    float *spre_f = (float *)(smem + off); off += (size_t)MX_PRE_ROWS * Fp * 4;
-    float *spre_w = (float *)(smem + off);
 
     TileMeta<SLOTS> M;
     load_tile_meta<float, IDENT, true, SLOTS>(A, tile_id, tid0, nthreads, M);
@@ -179,7 +182,7 @@ __device__ __forceinline__ void tile_body_mx(const TileArgs<float> &A, const MxP
     // barrier behind which every wave's rows have landed. (The float tile keeps those elements and carries them through its
     // float32 butterflies like any other channel: the write-backs drop what comes out of that.)
     auto widen_row = [&](int j, auto is_int) {
-        float *row = wt + __mul24(j, Wp);
+        double *row = wd + __mul24(j, nwide);
         const V16 raw = *(const V16 *)(ftile + __mul24(j, Fp));          // the row's first chunk, as it arrived
         double d[4];
 #pragma unroll
@@ -187,9 +190,8 @@ __device__ __forceinline__ void tile_body_mx(const TileArgs<float> &A, const MxP
             if constexpr (decltype(is_int)::value) d[i] = i < nwide ? (double)__float_as_int(raw.v[i]) * ST.w[i] : 0.0;
             else d[i] = i < nwide ? (double)raw.v[i] : 0.0;
         }
-        W16 w0; w0.v[0] = d[0]; w0.v[1] = d[1];
-        *(W16 *)row = w0;
-        if (NW2 > 1) { W16 w1; w1.v[0] = d[2]; w1.v[1] = d[3]; *(W16 *)(row + 4) = w1; }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) if (i < nwide) row[i] = d[i];
     };
 
     // ---- P0b. transfers whose addresses do not depend on the plan metadata ----
@@ -200,12 +202,12 @@ __device__ __forceinline__ void tile_body_mx(const TileArgs<float> &A, const MxP
             load_caller_rows(nt, [&](int jr, uint32_t go) { return row_at(src, (uint32_t)jr, ldc, go); });
         } else {
             load_linear(ftile, nt * NF, A.in + e0 * (int64_t)Fp);
-            load_linear(wt, nt << lgw, P.in_w + e0 * (int64_t)Wp);
+            load_linear((const float *)wd, (nt * nwide + 1) >> 1, (const float *)(P.in_w + e0 * (int64_t)nwide));      // (16-byte chunks: may read one double past the tile's rows -- the next tile's, or the array's slack)
         }
     } else {
-        const int npre = A.last_stage ? 0 : (int)min(surv_cnt, (uint32_t)MX_PRE_ROWS);
+        const int npre = A.last_stage ? 0 : (int)min(surv_cnt, (uint32_t)pre_rows);
         load_linear(spre_f, npre * NF, (const float *)A.wsn + (int64_t)surv_base * Fp);
-        load_linear(spre_w, npre << lgw, (const float *)P.wsn_w + (int64_t)surv_base * Wp);
+        load_linear((const float *)spre_w, (npre * nwide + 1) >> 1, (const float *)(P.wsn_w + (int64_t)surv_base * nwide));
     }
 #pragma unroll
     for (int s = 0; s < SLOTS; ++s) {
@@ -271,6 +273,21 @@ __device__ __forceinline__ void tile_body_mx(const TileArgs<float> &A, const MxP
     sync_lds();                                                            // sync #3 (inverse: every row has landed)
     MX_STAMP(4);
     if constexpr (INV) {
+        // ---- P3b (first part): the prefetched survivor rows (images, from the stage above) move into their slots; the butterfly
+        // records are then written over the bytes they waited in, hence the barrier
+        if (!A.last_stage) {
+            const uint32_t n_pre = min(surv_cnt, (uint32_t)pre_rows);
+            if (c4 < NF) for (uint32_t it = wid; (it << lr) < n_pre; it += nwv) {
+                const uint32_t qc = min((it << lr) + g, n_pre - 1);
+                const V16 x = *(const V16 *)&spre_f[__mul24((int)qc, Fp) + fl * 4];
+                *(V16 *)&ftile[__mul24((int)ssurv[qc], Fp) + fl * 4] = x;
+            }
+            for (uint32_t c = (uint32_t)tid; c < n_pre * (uint32_t)nwide; c += (uint32_t)nthreads) {
+                const uint32_t qc = c / (uint32_t)nwide, i = c - qc * (uint32_t)nwide;
+                wd[__mul24((int)ssurv[qc], nwide) + i] = spre_w[c];
+            }
+        }
+        sync_lds();
         load_steps(fl);
         // roots finalised by a last TILE stage come straight from Q as well: dequantize them in place (no butterfly will)
         if (A.last_stage && c4 < NF) for (int it = wid; (it << lr) < nt; it += nwv) {
@@ -325,28 +342,17 @@ __device__ __forceinline__ void tile_body_mx(const TileArgs<float> &A, const MxP
             rec_pj[pos] = (uint32_t)p | ((uint32_t)j << 16);
         }
     }
-    // ---- P3b. inverse: the survivors' low-pass rows (images, from the stage above) into their slots ----
+    // ---- P3b (second part) ----
     if (INV && !A.last_stage) {
-        const uint32_t n_pre = min(surv_cnt, (uint32_t)MX_PRE_ROWS);
-        // float part: a lane group per row; wide part: NW2 lanes per row
-        if (c4 < NF) for (uint32_t it = wid; (it << lr) < n_pre; it += nwv) {
-            const uint32_t qc = min((it << lr) + g, n_pre - 1);
-            const V16 x = *(const V16 *)&spre_f[__mul24((int)qc, Fp) + fl * 4];
-            *(V16 *)&ftile[__mul24((int)ssurv[qc], Fp) + fl * 4] = x;
-        }
-        for (uint32_t c = (uint32_t)tid; c < (n_pre << lgw); c += (uint32_t)nthreads) {
-            const uint32_t qc = c >> lgw, part = c & (uint32_t)(NW2 - 1);
-            *(V16 *)&wt[__mul24((int)ssurv[qc], Wp) + part * 4] = *(const V16 *)&spre_w[c * 4];
-        }
-        if (c4 < NF) for (uint32_t it = wid; MX_PRE_ROWS + (it << lr) < surv_cnt; it += nwv) {
-            const uint32_t qc = min(MX_PRE_ROWS + (it << lr) + g, surv_cnt - 1);
+        // (second part: the survivors past the prefetched ones, straight from the workspace)
+        if (c4 < NF) for (uint32_t it = wid; pre_rows + (it << lr) < surv_cnt; it += nwv) {
+            const uint32_t qc = min(pre_rows + (it << lr) + g, surv_cnt - 1);
             const V16 x = ld_chunk<float>(row_at((const float *)A.wsn + (int64_t)surv_base * Fp, qc, (uint32_t)Fp, (uint32_t)(fl * 4)));
             *(V16 *)&ftile[__mul24((int)ssurv[qc], Fp) + fl * 4] = x;
         }
-        for (uint32_t c = ((uint32_t)MX_PRE_ROWS << lgw) + (uint32_t)tid; c < (surv_cnt << lgw); c += (uint32_t)nthreads) {
-            const uint32_t qc = c >> lgw, part = c & (uint32_t)(NW2 - 1);
-            const V16 x = ld_chunk<float>((const float *)P.wsn_w + (int64_t)surv_base * Wp + c * 4);
-            *(V16 *)&wt[__mul24((int)ssurv[qc], Wp) + part * 4] = x;
+        for (uint32_t c = (uint32_t)(pre_rows * nwide) + (uint32_t)tid; c < surv_cnt * (uint32_t)nwide; c += (uint32_t)nthreads) {
+            const uint32_t qc = c / (uint32_t)nwide, i = c - qc * (uint32_t)nwide;
+            wd[__mul24((int)ssurv[qc], nwide) + i] = P.wsn_w[(int64_t)surv_base * nwide + c];
         }
     }
     if constexpr (!INV) {
@@ -368,7 +374,7 @@ __device__ __forceinline__ void tile_body_mx(const TileArgs<float> &A, const MxP
     // ---- P4. butterflies, one round per height present ----
     // The float32 channels run exactly as in the float32 kernels: a lane group per butterfly (head and idle lanes shadow the
     // group's last float lane: same reads, same writes, no exec-mask juggling). The wide channels of a level are a SEPARATE, dense
-    // pass over their own LDS array -- NW2 lanes per butterfly, 32 or 64 butterflies per wave instruction -- on other waves.
+    // pass over their own LDS array -- a lane per (butterfly, channel), 16 to 64 butterflies per wave instruction -- on other waves.
     // Levels that fit one wave instruction (most: the chain of small levels needs no workgroup barrier, a wave's LDS operations
     // execute in order) are walked by wave 0 (float) and wave 1 (wide) side by side. (First version: one row array with the wide
     // places in front, the wide lanes taking a float64 branch inside every float butterfly instruction: both branches issued for
@@ -376,10 +382,9 @@ __device__ __forceinline__ void tile_body_mx(const TileArgs<float> &A, const MxP
     // as in the float32 kernel, rocprofv3 SQ_LDS_BANK_CONFLICT 39 M against 11 M cycles per launch.)
     {
         const uint32_t stride = (uint32_t)(nwv << lr);
-        const uint32_t gw = (uint32_t)lane >> lgw, cw4 = (uint32_t)(lane & (NW2 - 1)) * 4u;
+        const uint32_t gw = (uint32_t)lane >> lgw, cw = (uint32_t)min(lane & ((1 << lgw) - 1), nwide - 1);   // (three channels: the group's 4th lane shadows the 3rd)
         const uint32_t bw = 64u >> lgw;                        // wide butterflies per wave instruction
         const uint32_t cf = (uint32_t)fl * 4u;
-        const int wsh = 2 + lgw;                               // slot -> wide-tile offset (floats)
         bool chained = false;
         const int loff_v = (int)loff[lane], hist_v = (int)hist[lane];
         uint64_t mask = __ballot(hist_v > 0);
@@ -432,25 +437,22 @@ __device__ __forceinline__ void tile_body_mx(const TileArgs<float> &A, const MxP
                 const uint32_t m = base + min(m0 + gw, cnt - 1);
                 const uint32_t pj = rec_pj[m];
                 const W16 ab = rec_ab[m];
-                const uint32_t ip = ((pj & 0xffffu) << wsh) + cw4, ij = ((pj >> 16) << wsh) + cw4;
-                const W16 d0 = *(const W16 *)&wt[ip], d1 = *(const W16 *)&wt[ij];
+                const uint32_t ip = __umul24(pj & 0xffffu, (uint32_t)nwide) + cw, ij = __umul24(pj >> 16, (uint32_t)nwide) + cw;
+                const double d0 = wd[ip], d1 = wd[ij];
                 const double ca = ab.v[0], cb = ab.v[1];
-                W16 lo, hi;
-#pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    if (!INV) {                               // RAHT.py:331-332
-                        lo.v[i] = ca * d0.v[i] + cb * d1.v[i];
-                        hi.v[i] = ca * d1.v[i] - cb * d0.v[i];
-                    } else {                                  // iRAHT.py:108-109
-                        lo.v[i] = ca * d0.v[i] - cb * d1.v[i];
-                        hi.v[i] = cb * d0.v[i] + ca * d1.v[i];
-                    }
+                double lo, hi;
+                if (!INV) {                                   // RAHT.py:331-332
+                    lo = ca * d0 + cb * d1;
+                    hi = ca * d1 - cb * d0;
+                } else {                                      // iRAHT.py:108-109
+                    lo = ca * d0 - cb * d1;
+                    hi = cb * d0 + ca * d1;
                 }
-                *(W16 *)&wt[ip] = lo; *(W16 *)&wt[ij] = hi;
+                wd[ip] = lo; wd[ij] = hi;
             };
             if (cnt <= (1u << lr)) {
                 if (wid == 0) pass_f(std::integral_constant<int, 1>());
-                else if (wid == 1) apply_w(0u);
+                else if (wid == 1) { for (uint32_t m0 = 0; m0 < cnt; m0 += bw) apply_w(m0); }     // (narrow rows: a float instruction may hold more butterflies than a wide one)
                 chained = true;
             } else {
                 if (chained) { __syncthreads(); chained = false; }
@@ -479,52 +481,55 @@ __device__ __forceinline__ void tile_body_mx(const TileArgs<float> &A, const MxP
             // narrower store instruction becomes a partial-line write of its own: the fused forward took 0.92 ms instead of
             // 0.31 ms that way (rows are 236 bytes: every line is shared by two rows)
             float *base = A.out + e0 * A.ld_out;
-            // (two row instructions per trip, every LDS read of both in front of the first branch: a trip is one LDS round trip,
-            // and a read inside the head lane's branch would be another one)
+            // Two row instructions per trip. The head lanes alone read their rows' wide results (clamped indices: no branch per
+            // channel, all reads of a trip in flight together); what follows is branch-free -- selects, then ONE store instruction
+            // per row group, pinned behind an empty asm so that the compiler cannot sink it into a head / non-head diamond again
+            // (it did: the rows' first 16 bytes left as a second, narrow store instruction, i.e. a partial-line write per row, and
+            // every wide channel was its own LDS round trip)
             if (rowlane) for (int it = wid; (it << lr) < nt; it += 2 * nwv) {
-                int j[2]; V16 x[2]; W16 w0[2] = {}, w1[2] = {};
+                int j[2]; V16 x[2]; double w[2][4] = {};
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
                     j[u] = min(((it + u * nwv) << lr) + g, nt - 1);
                     x[u] = *(const V16 *)&ftile[__mul24(j[u], Fp) + sp * 4];
                 }
-                if (head) {                                   // (only the head lanes: a read by all 64 lanes moves 1 KiB through the LDS)
+                if (head) {
 #pragma unroll
                     for (int u = 0; u < 2; ++u) {
-                        w0[u] = *(const W16 *)&wt[__mul24(j[u], Wp)];
-                        w1[u] = *(const W16 *)&wt[__mul24(j[u], Wp) + (NW2 - 1) * 4];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) w[u][i] = wd[__mul24(j[u], nwide) + min(i, nwide - 1)];
                     }
                 }
-                asm volatile("" : "+v"(w0[0].v[0]), "+v"(w1[0].v[0]), "+v"(w0[1].v[0]), "+v"(w1[1].v[0]));
+                asm volatile("" : "+v"(w[0][0]), "+v"(w[0][1]), "+v"(w[0][2]), "+v"(w[0][3]), "+v"(w[1][0]), "+v"(w[1][1]), "+v"(w[1][2]), "+v"(w[1][3]));
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
-                    if (head) {
-                        const float d[4] = {(float)w0[u].v[0], (float)w0[u].v[1], NW2 > 1 ? (float)w1[u].v[0] : 0.0f, NW2 > 1 ? (float)w1[u].v[1] : 0.0f};
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) x[u].v[i] = i < nwide ? d[i] : x[u].v[i];
-                    }
-                    if (u == 0 || ((it + nwv) << lr) < nt)
+                    for (int i = 0; i < 4; ++i) { const float f = (float)w[u][i]; x[u].v[i] = (head && i < nwide) ? f : x[u].v[i]; }
+                    asm volatile("" : "+v"(x[u].v[0]), "+v"(x[u].v[1]), "+v"(x[u].v[2]), "+v"(x[u].v[3]));
+                    if (u == 0 || ((it + nwv) << lr) < nt)                  // (wave-uniform)
                         st_chunk<float, true>(row_at(base, (uint32_t)j[u], (uint32_t)A.ld_out, (uint32_t)goff), x[u]);
                 }
             }
         } else {
             // stage k -> ws_k: both parts are contiguous runs of chunks
-            float *bf = A.out + e0 * (int64_t)Fp, *bw_ = P.out_w + e0 * (int64_t)Wp;
+            float *bf = A.out + e0 * (int64_t)Fp;
+            double *bw_ = P.out_w + e0 * (int64_t)nwide;
             for (int c = tid; c < nt * NF; c += nthreads) st_chunk<float>(bf + c * 4, *(const V16 *)&ftile[c * 4]);
-            for (int c = tid; c < (nt << lgw); c += nthreads) st_chunk<float>(bw_ + c * 4, *(const V16 *)&wt[c * 4]);
+            for (int c = tid; c < nt * nwide; c += nthreads) bw_[c] = wd[c];
         }
     } else {
         // survivors, compacted, to the next stage's workspace (row images, two dense arrays)
         if (!A.last_stage) {
-            float *bf = A.wsn + (int64_t)surv_base * Fp, *bw_ = P.wsn_w + (int64_t)surv_base * Wp;
+            float *bf = A.wsn + (int64_t)surv_base * Fp;
+            double *bw_ = P.wsn_w + (int64_t)surv_base * nwide;
             if (c4 < NF) for (uint32_t it = wid; (it << lr) < surv_cnt; it += nwv) {
                 const uint32_t q = min((it << lr) + g, surv_cnt - 1);
                 const V16 x = *(const V16 *)&ftile[__mul24((int)ssurv[q], Fp) + fl * 4];
                 st_chunk<float>(row_at(bf, q, (uint32_t)Fp, (uint32_t)(fl * 4)), x);
             }
-            for (uint32_t c = (uint32_t)tid; c < (surv_cnt << lgw); c += (uint32_t)nthreads) {
-                const uint32_t q = c >> lgw, part = c & (uint32_t)(NW2 - 1);
-                st_chunk<float>(bw_ + c * 4, *(const V16 *)&wt[__mul24((int)ssurv[q], Wp) + part * 4]);
+            for (uint32_t c = (uint32_t)tid; c < surv_cnt * (uint32_t)nwide; c += (uint32_t)nthreads) {
+                const uint32_t q = c / (uint32_t)nwide, i = c - q * (uint32_t)nwide;
+                bw_[c] = wd[__mul24((int)ssurv[q], nwide) + i];
             }
         }
         // rows finalised here, quantized to Q[inv_order[row]] (encode_3dgs.py:204,210,215).
@@ -535,15 +540,14 @@ __device__ __forceinline__ void tile_body_mx(const TileArgs<float> &A, const MxP
         for (int s = 0; s < SLOTS; ++s) {
             const int j = tid0 + s * nthreads;
             if (j < nt && ((uint32_t)sdst[j] >> 31)) {
-                float *row = &wt[__mul24(j, Wp)];
-                double d[4];
-                { const W16 w0 = *(const W16 *)row; d[0] = w0.v[0]; d[1] = w0.v[1]; }
-                d[2] = 0.0; d[3] = 0.0;
-                if (NW2 > 1) { const W16 w1 = *(const W16 *)(row + 4); d[2] = w1.v[0]; d[3] = w1.v[1]; }
-                I16 qi;
+                double *row = &wd[__mul24(j, nwide)];
+                double d[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-                for (int i = 0; i < 4; ++i) qi.v[i] = i < nwide ? quantize_one_f64(d[i], ST.w[i]) : 0;
-                *(I16 *)row = qi;
+                for (int i = 0; i < 4; ++i) if (i < nwide) d[i] = row[i];
+                asm volatile("" ::: "memory");                // (the integers go over the doubles they were made of: every read is above)
+                int32_t *qrow = (int32_t *)row;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) if (i < nwide) qrow[i] = quantize_one_f64(d[i], ST.w[i]);
             }
         }
         sync_lds();
@@ -561,23 +565,28 @@ __device__ __forceinline__ void tile_body_mx(const TileArgs<float> &A, const MxP
                     x[u] = *(const V16 *)&ftile[__mul24(jc[u], Fp) + sp * 4];
                     dv[u] = (uint32_t)sdst[jc[u]];
                 }
-                if (head) {                                   // (only the head lanes: a read by all 64 lanes moves 1 KiB through the LDS)
+                if (head) {                                   // (only the head lanes; clamped indices: no branch per channel)
 #pragma unroll
-                    for (int u = 0; u < 2; ++u) qi[u] = *(const I16 *)&wt[__mul24(jc[u], Wp)];
+                    for (int u = 0; u < 2; ++u) {
+                        const int32_t *qrow = (const int32_t *)&wd[__mul24(jc[u], nwide)];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) qi[u].v[i] = qrow[min(i, nwide - 1)];
+                    }
                 }
-                asm volatile("" : "+v"(x[0].v[0]), "+v"(qi[0].v[0]), "+v"(x[1].v[0]), "+v"(qi[1].v[0]));
+                asm volatile("" : "+v"(x[0].v[0]), "+v"(x[1].v[0]), "+v"(qi[0].v[0]), "+v"(qi[0].v[1]), "+v"(qi[0].v[2]), "+v"(qi[0].v[3]),
+                             "+v"(qi[1].v[0]), "+v"(qi[1].v[1]), "+v"(qi[1].v[2]), "+v"(qi[1].v[3]));
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
-                    if ((dv[u] >> 31) && (u == 0 || ((it + nwv) << lr) < nt)) {
-                        I16 qv;
+                    // branch-free up to ONE store instruction per row group (see the inverse's write-back)
+                    I16 qv;
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) qv.v[i] = quantize_one(x[u].v[i], my_step[i], my_rcp[i], decltype(fast_div)::value);
-                        if (head) {
-#pragma unroll
-                            for (int i = 0; i < 4; ++i) qv.v[i] = i < nwide ? qi[u].v[i] : qv.v[i];
-                        }
-                        st_chunk<int32_t, true>(row_far(A.Q, dv[u] & 0x7fffffffu, (uint32_t)A.ldq, (uint32_t)goff), qv);
+                    for (int i = 0; i < 4; ++i) {
+                        const int32_t q = quantize_one(x[u].v[i], my_step[i], my_rcp[i], decltype(fast_div)::value);
+                        qv.v[i] = (head && i < nwide) ? qi[u].v[i] : q;
                     }
+                    asm volatile("" : "+v"(qv.v[0]), "+v"(qv.v[1]), "+v"(qv.v[2]), "+v"(qv.v[3]));
+                    if ((dv[u] >> 31) && (u == 0 || ((it + nwv) << lr) < nt))
+                        st_chunk<int32_t, true>(row_far(A.Q, dv[u] & 0x7fffffffu, (uint32_t)A.ldq, (uint32_t)goff), qv);
                 }
             }
         };
@@ -598,14 +607,14 @@ __global__ __launch_bounds__(MX_THREADS, 6) void tile_kernel_mx(const TileArgs<f
 // ------------------------------------------------------------------------------------------------
 struct TopArgsMX {
     const float *in_rows;  int64_t ld_in;    // fwd, single-stage schedule: the caller's C rows (entry = row)
-    const float *in_img, *in_img_w;          // fwd, later stage: workspace row images, entry order (float places; wide places)
+    const float *in_img; const double *in_img_w;   // fwd, later stage: workspace row images, entry order (float places; n_wide doubles)
     float *out_rows;       int64_t ld_out;   // inv, single-stage schedule: the caller's C rows
-    float *out_img, *out_img_w;              // inv, later stage: workspace row images
+    float *out_img; double *out_img_w;       // inv, later stage: workspace row images
     int32_t *Q;            int64_t ldq;
     const uint32_t *e_pos;                   // entry -> position in Q
     const uint32_t *pj;                      // butterflies sorted by level: partner entry | own entry << 16
     const float *ab32;  const double *ab64;  // a, b per butterfly
-    int n, n_merges, D, nwide, Fp;           // Fp: floats per row of the float part of an image (the wide part: 4 NW2)
+    int n, n_merges, D, nwide, Fp;           // Fp: floats per row of the float part of an image
     const uint32_t *lev;
     int nlev, nbig;
     uint32_t small_start;
@@ -621,10 +630,10 @@ __device__ __forceinline__ void top_body_mx(const TopArgsMX &A, const StepTableM
     V16 *tile = (V16 *)smem;
     __shared__ uint32_t s_lev[2 * 64];
     const int tid = threadIdx.x;
-    const int nwide = A.nwide, NW2 = (nwide + 1) >> 1;
+    const int nwide = A.nwide;
     const int goff = WIDE ? 2 * chunk : min(chunk * 4, A.D - 4);            // first channel of this chunk in the caller's rows
     // (float chunk 0 holds the wide channels too, as float32 ballast: it never writes them to Q / C -- the wide workgroups do)
-    const int istride = WIDE ? NW2 * 4 : A.Fp, ioff = chunk * 4;              // its place in a row image (floats)
+    const int ioff = chunk * 4;                                              // a float chunk's place in a row image (floats)
     const int n = A.n, nm = A.n_merges;
     if (tid < 2 * A.nlev) s_lev[tid] = A.lev[tid];
     const T *ab = WIDE ? (const T *)A.ab64 : (const T *)A.ab32;
@@ -662,7 +671,12 @@ __device__ __forceinline__ void top_body_mx(const TopArgsMX &A, const StepTableM
         V16 v;
         if constexpr (!INV) {
             if (A.in_img) {
-                v = *(const V16 *)((WIDE ? A.in_img_w : A.in_img) + (int64_t)e * istride + ioff);
+                if constexpr (WIDE) {
+#pragma unroll
+                    for (int i = 0; i < VN; ++i) v.v[i] = live[i] ? A.in_img_w[(int64_t)e * nwide + goff + i] : 0.0;
+                } else {
+                    v = *(const V16 *)(A.in_img + (int64_t)e * A.Fp + ioff);
+                }
             } else if constexpr (WIDE) {
 #pragma unroll
                 for (int i = 0; i < VN; ++i) v.v[i] = live[i] ? (double)A.in_rows[(int64_t)e * A.ld_in + goff + i] : 0.0;
@@ -736,7 +750,12 @@ __device__ __forceinline__ void top_body_mx(const TopArgsMX &A, const StepTableM
         const V16 v = tile[e];
         if constexpr (INV) {
             if (A.out_img) {
-                *(V16 *)((WIDE ? A.out_img_w : A.out_img) + (int64_t)e * istride + ioff) = v;
+                if constexpr (WIDE) {
+#pragma unroll
+                    for (int i = 0; i < VN; ++i) if (live[i]) A.out_img_w[(int64_t)e * nwide + goff + i] = v.v[i];
+                } else {
+                    *(V16 *)(A.out_img + (int64_t)e * A.Fp + ioff) = v;
+                }
             } else if constexpr (WIDE) {
 #pragma unroll
                 for (int i = 0; i < VN; ++i) if (live[i]) A.out_rows[(int64_t)e * A.ld_out + goff + i] = (float)v.v[i];
@@ -812,7 +831,7 @@ static bool mx_geometry(const raht_plan *p, int D, int nwide, MxGeom &g)
     pick_tail_geometry(p, 4, D, 512, &r1, &dc1, &g.Rf);
     const size_t budget = (size_t)42 * 1280;              // three workgroups per CU
     auto fit = [&](int hi, bool ident, size_t cap) {
-        for (int R = hi; R >= 64; --R) if (tile_lds_bytes_mx(R, g.NCp, ident) <= cap) return R;
+        for (int R = hi; R >= 64; --R) if (tile_lds_bytes_mx(R, NF, nwide, ident) <= cap) return R;
         return 0;
     };
     g.R0 = p->tile_rows_override > 0 ? fit(std::min(p->tile_rows_override, TILE_MAX_SLOTS * MX_THREADS), true, (size_t)128 * 1280)
@@ -856,12 +875,10 @@ static int launch_stage_mx(const raht_plan *p, const Schedule &sc, int k, const 
     const Stage &st = sc.stages[(size_t)k];
     const int K = (int)sc.stages.size();
     // a stage's workspace: the float places of every entry, then the wide places of every entry
-    const int Wp = ((g.nwide + 1) / 2) * 4;
     float *ws_k = (k >= 1) ? (float *)st.ws : nullptr;
     float *ws_n = (k + 1 < K) ? (float *)sc.stages[(size_t)k + 1].ws : nullptr;
-    float *ws_k_w = ws_k ? ws_k + (size_t)st.n_entries * g.Dp : nullptr;
-    float *ws_n_w = ws_n ? ws_n + (size_t)sc.stages[(size_t)k + 1].n_entries * g.Dp : nullptr;
-    (void)Wp;
+    double *ws_k_w = ws_k ? (double *)(ws_k + (size_t)st.n_entries * g.Dp) : nullptr;
+    double *ws_n_w = ws_n ? (double *)(ws_n + (size_t)sc.stages[(size_t)k + 1].n_entries * g.Dp) : nullptr;
     if (k >= 1 && !ws_k) { set_error("mixed stage %d: missing stage workspace", k); return RAHT_ERR_INVALID; }
     if (st.is_top) {
         TopArgsMX A;
@@ -915,7 +932,7 @@ static int launch_stage_mx(const raht_plan *p, const Schedule &sc, int k, const 
     P.in_w = (!INV && k >= 1) ? ws_k_w : nullptr;
     P.out_w = (INV && k >= 1) ? ws_k_w : nullptr;
     P.wsn_w = ws_n_w;
-    const size_t lds = tile_lds_bytes_mx(st.tile_rows, g.NCp, st.rows == nullptr);
+    const size_t lds = tile_lds_bytes_mx(st.tile_rows, g.Dp / 4, g.nwide, st.rows == nullptr);
     const bool one = st.tile_rows <= MX_THREADS;
     const unsigned nt = (unsigned)st.n_tiles;
     if (k == 0 && p->ev_before) RAHT_HIP_CHECK(hipEventRecord(p->ev_before, s));
@@ -949,7 +966,7 @@ static int mx_setup(raht_plan *p, int D, int n_wide, int64_t max_ld, hipStream_t
     Schedule *sc = nullptr;
     RAHT_RET(get_schedule(p, g.R0, g.R1, g.Rf, s, &sc));
     if (!sc->valid) return RAHT_OK;
-    RAHT_RET(ensure_workspace(sc, (size_t)g.NCp * 16));
+    RAHT_RET(ensure_workspace(sc, (size_t)g.Dp * 4 + (size_t)g.nwide * 8 + 8));      // float chunks + n_wide doubles (+ slack: the wide part is fetched in 16-byte chunks)
     *sc_out = sc;
     return RAHT_OK;
 }
