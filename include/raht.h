@@ -485,6 +485,19 @@ int raht_rlgr_seg_decode(const uint8_t *in, int64_t in_bytes, const uint32_t *se
                          int D, int seg_len, int flag_signed, int32_t *Q, int64_t chan_stride, uint32_t *bad_dev,
                          raht_stream_t stream);
 
+/* The same coder on ANY of the two layouts of the quantized coefficients: channel-major (sym_stride = 1, chan_stride >= N: the
+ * two functions above) or ROW-MAJOR (chan_stride = 1, sym_stride = ld >= D: symbol n of channel c at Q[n * ld + c], i.e. Q exactly
+ * as raht_fwd_quant leaves it and raht_dequant_inv takes it -- no raht_transpose_i32 in front of the encoder or behind the
+ * decoder: the lanes of a wave are then neighbouring channels at the same position of their segments, so every step of the wave
+ * reads / writes one contiguous piece of a row). Same segments, same container, byte for byte. The container is limited to 4 GiB
+ * (32-bit segment offsets): inputs whose worst case could exceed it are refused (RAHT_ERR_INVALID). */
+int raht_rlgr_seg_encode_strided(const int32_t *Q, int64_t N, int D, int64_t sym_stride, int64_t chan_stride, int seg_len,
+                                 int flag_signed, uint32_t *seg_bytes, uint32_t *seg_off, uint8_t *out, int64_t cap,
+                                 int64_t *total_bytes, raht_stream_t stream);
+int raht_rlgr_seg_decode_strided(const uint8_t *in, int64_t in_bytes, const uint32_t *seg_off, const uint32_t *seg_bytes, int64_t N,
+                                 int D, int seg_len, int flag_signed, int32_t *Q, int64_t sym_stride, int64_t chan_stride,
+                                 uint32_t *bad_dev, raht_stream_t stream);
+
 /* out[c] = sum over rows of (A[i, c] - B[i, c])^2, DEVICE double[D]: what the drivers' five PSNR columns are made of
  * (python/encode_3dgs.py:298-310: torch.mean((C - C_rec) ** 2) over all / quats / scales / opacity / colour columns -- each a
  * sum of these D numbers divided by the element count). A, B: N x D DEVICE matrices of dtype RAHT_F32 or RAHT_F64 (differences

@@ -97,7 +97,8 @@ __device__ __forceinline__ int64_t u2s(uint64_t v) { const int64_t d = (int64_t)
 // blocks of 64 (to take the loads and stores off each other's wait counter) changed nothing for the encoder and made the
 // decoder slower (round 3): memory is not what a lane waits for.
 template <bool WRITE, bool VEC>
-__device__ __forceinline__ uint32_t encode_segment(const int32_t *__restrict__ seq, int n, int flag_signed, uint32_t *out32, uint32_t cap = 0xffffffffu)
+__device__ __forceinline__ uint32_t encode_segment(const int32_t *__restrict__ seq, int n, int flag_signed, uint32_t *out32, uint32_t cap = 0xffffffffu,
+                                                   int64_t sstr = 1)     // sstr: distance between consecutive symbols (VEC: 1)
 {
     DevBitWriter<WRITE> w;
     w.out32 = out32;
@@ -117,7 +118,7 @@ __device__ __forceinline__ uint32_t encode_segment(const int32_t *__restrict__ s
             v = q == 0 ? cur4.x : q == 1 ? cur4.y : q == 2 ? cur4.z : cur4.w;
         } else {
             v = nxt;
-            if (i + 1 < n) nxt = seq[i + 1];                         // one symbol ahead: the load is off the dependent chain
+            if (i + 1 < n) nxt = seq[(int64_t)(i + 1) * sstr];       // one symbol ahead: the load is off the dependent chain
         }
         u = flag_signed ? (v < 0 ? ((uint32_t)(-(int64_t)v) << 1) - 1u : (uint32_t)v << 1) : (uint32_t)v;     // _s2u, membuf.cpp:4-13
         k = k_P / L;
@@ -212,7 +213,7 @@ struct DevBitReader {
 
 // VEC: the segment starts on a 16-byte boundary: symbols leave four at a time
 template <bool VEC>
-__device__ __forceinline__ void decode_segment(const uint32_t *in32, uint32_t nbytes, int n, int flag_signed, int32_t *__restrict__ seq)
+__device__ __forceinline__ void decode_segment(const uint32_t *in32, uint32_t nbytes, int n, int flag_signed, int32_t *__restrict__ seq, int64_t sstr = 1)
 {
     DevBitReader r;
     r.in32 = in32; r.size = nbytes;
@@ -229,7 +230,8 @@ __device__ __forceinline__ void decode_segment(const uint32_t *in32, uint32_t nb
             ++i;
             if ((i & 3) == 0) *(int4 *)(seq + i - 4) = buf;
         } else {
-            seq[i++] = v;
+            seq[(int64_t)i * sstr] = v;
+            ++i;
         }
     };
     while (i < n) {                                                  // membuf.cpp:270-331
@@ -272,45 +274,59 @@ __device__ __forceinline__ void decode_segment(const uint32_t *in32, uint32_t nb
 
 // segment g = c * nseg + s  <->  symbols [s * S, min(N, (s + 1) * S)) of channel c
 template <bool WRITE>
-__global__ __launch_bounds__(64) void seg_encode_kernel(const int32_t *__restrict__ Q, int64_t N, int D, int64_t chan_stride, int S, int nseg,
+__global__ __launch_bounds__(64) void seg_encode_kernel(const int32_t *__restrict__ Q, int64_t N, int D, int64_t sym_stride, int64_t chan_stride, int S, int nseg,
                                                         int flag_signed, uint32_t *__restrict__ seg_bytes, const uint32_t *__restrict__ seg_off,
                                                         uint8_t *__restrict__ out, uint64_t cap, uint32_t *__restrict__ overflow)
 {
-    const int64_t g = (int64_t)blockIdx.x * 64 + threadIdx.x;
-    if (g >= (int64_t)D * nseg) return;
-    const int c = (int)(g / nseg), s = (int)(g - (int64_t)c * nseg);
+    // thread t -> segment g = c * nseg + s. Channel-major input (sym_stride == 1): t = g, a lane walks its own contiguous run.
+    // Row-major input (the quantized coefficients as the transform kernels leave them: symbol n of channel c at Q[n * ld + c]):
+    // t = s * D + c -- the lanes of a wave are NEIGHBOURING CHANNELS at the same position of their segments, so every step of
+    // the wave reads (writes) one contiguous piece of a row: no transpose in front of (behind) the coder.
+    const int64_t t = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    if (t >= (int64_t)D * nseg) return;
+    int c, s;
+    if (sym_stride == 1) { c = (int)(t / nseg); s = (int)(t - (int64_t)c * nseg); }
+    else { s = (int)(t / D); c = (int)(t - (int64_t)s * D); }
+    const int64_t g = (int64_t)c * nseg + s;
     const int64_t i0 = (int64_t)s * S;
     const int n = (int)min((int64_t)S, N - i0);
-    const int32_t *seq = Q + (int64_t)c * chan_stride + i0;
+    const int32_t *seq = Q + (int64_t)c * chan_stride + i0 * sym_stride;
     // 16-byte loads: segment starts aligned and a whole group of four readable behind the last symbol (wave-uniform choice)
-    const bool vec = ((((uintptr_t)Q) & 15) == 0) && ((chan_stride & 3) == 0) && ((S & 3) == 0) && ((N & 3) == 0 || chan_stride >= ((N + 3) & ~(int64_t)3));
+    const bool vec = sym_stride == 1 && ((((uintptr_t)Q) & 15) == 0) && ((chan_stride & 3) == 0) && ((S & 3) == 0) && ((N & 3) == 0 || chan_stride >= ((N + 3) & ~(int64_t)3));
     if (!WRITE) {
-        seg_bytes[g] = vec ? encode_segment<false, true>(seq, n, flag_signed, nullptr) : encode_segment<false, false>(seq, n, flag_signed, nullptr);
+        seg_bytes[g] = vec ? encode_segment<false, true>(seq, n, flag_signed, nullptr) : encode_segment<false, false>(seq, n, flag_signed, nullptr, 0xffffffffu, sym_stride);
     } else {
         const uint64_t off = seg_off[g];                              // 4-byte aligned
         const uint32_t need = (seg_bytes[g] + 3u) & ~3u;
         if (off + need > cap) { atomicOr(overflow, 1u); return; }
         if (vec) (void)encode_segment<true, true>(seq, n, flag_signed, (uint32_t *)(out + off));
-        else (void)encode_segment<true, false>(seq, n, flag_signed, (uint32_t *)(out + off));
+        else (void)encode_segment<true, false>(seq, n, flag_signed, (uint32_t *)(out + off), 0xffffffffu, sym_stride);
     }
 }
 
 // ONE encoding pass: every segment into a fixed slot of `slot` bytes (what the raw integers would take, + 16) of a scratch
 // buffer, its exact length recorded; seg_compact_kernel then moves the streams to their places in the container. A segment that
 // does not fit its slot (incompressible data) raises *overflow and the caller falls back to the two exact passes.
-__global__ __launch_bounds__(64) void seg_encode_slots_kernel(const int32_t *__restrict__ Q, int64_t N, int D, int64_t chan_stride, int S, int nseg,
+__global__ __launch_bounds__(64) void seg_encode_slots_kernel(const int32_t *__restrict__ Q, int64_t N, int D, int64_t sym_stride, int64_t chan_stride, int S, int nseg,
                                                               int flag_signed, uint32_t *__restrict__ seg_bytes, uint8_t *__restrict__ slots, uint32_t slot,
                                                               uint32_t *__restrict__ overflow)
 {
-    const int64_t g = (int64_t)blockIdx.x * 64 + threadIdx.x;
-    if (g >= (int64_t)D * nseg) return;
-    const int c = (int)(g / nseg), s = (int)(g - (int64_t)c * nseg);
+    // thread t -> segment g = c * nseg + s. Channel-major input (sym_stride == 1): t = g, a lane walks its own contiguous run.
+    // Row-major input (the quantized coefficients as the transform kernels leave them: symbol n of channel c at Q[n * ld + c]):
+    // t = s * D + c -- the lanes of a wave are NEIGHBOURING CHANNELS at the same position of their segments, so every step of
+    // the wave reads (writes) one contiguous piece of a row: no transpose in front of (behind) the coder.
+    const int64_t t = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    if (t >= (int64_t)D * nseg) return;
+    int c, s;
+    if (sym_stride == 1) { c = (int)(t / nseg); s = (int)(t - (int64_t)c * nseg); }
+    else { s = (int)(t / D); c = (int)(t - (int64_t)s * D); }
+    const int64_t g = (int64_t)c * nseg + s;
     const int64_t i0 = (int64_t)s * S;
     const int n = (int)min((int64_t)S, N - i0);
-    const int32_t *seq = Q + (int64_t)c * chan_stride + i0;
-    const bool vec = ((((uintptr_t)Q) & 15) == 0) && ((chan_stride & 3) == 0) && ((S & 3) == 0);
+    const int32_t *seq = Q + (int64_t)c * chan_stride + i0 * sym_stride;
+    const bool vec = sym_stride == 1 && ((((uintptr_t)Q) & 15) == 0) && ((chan_stride & 3) == 0) && ((S & 3) == 0);
     uint32_t *o = (uint32_t *)(slots + (size_t)g * slot);
-    const uint32_t nb = vec ? encode_segment<true, true>(seq, n, flag_signed, o, slot) : encode_segment<true, false>(seq, n, flag_signed, o, slot);
+    const uint32_t nb = vec ? encode_segment<true, true>(seq, n, flag_signed, o, slot) : encode_segment<true, false>(seq, n, flag_signed, o, slot, sym_stride);
     seg_bytes[g] = nb;
     if (((nb + 3u) & ~3u) > slot) atomicOr(overflow, 1u);
 }
@@ -340,11 +356,18 @@ __global__ void seg_pad_kernel(const uint32_t *__restrict__ seg_bytes, int64_t n
 
 __global__ __launch_bounds__(64) void seg_decode_kernel(const uint8_t *__restrict__ in, uint64_t in_bytes, const uint32_t *__restrict__ seg_off,
                                                         const uint32_t *__restrict__ seg_bytes, int64_t N, int D, int S, int nseg, int flag_signed,
-                                                        int32_t *__restrict__ Q, int64_t chan_stride, uint32_t *__restrict__ bad)
+                                                        int32_t *__restrict__ Q, int64_t sym_stride, int64_t chan_stride, uint32_t *__restrict__ bad)
 {
-    const int64_t g = (int64_t)blockIdx.x * 64 + threadIdx.x;
-    if (g >= (int64_t)D * nseg) return;
-    const int c = (int)(g / nseg), s = (int)(g - (int64_t)c * nseg);
+    // thread t -> segment g = c * nseg + s. Channel-major input (sym_stride == 1): t = g, a lane walks its own contiguous run.
+    // Row-major input (the quantized coefficients as the transform kernels leave them: symbol n of channel c at Q[n * ld + c]):
+    // t = s * D + c -- the lanes of a wave are NEIGHBOURING CHANNELS at the same position of their segments, so every step of
+    // the wave reads (writes) one contiguous piece of a row: no transpose in front of (behind) the coder.
+    const int64_t t = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    if (t >= (int64_t)D * nseg) return;
+    int c, s;
+    if (sym_stride == 1) { c = (int)(t / nseg); s = (int)(t - (int64_t)c * nseg); }
+    else { s = (int)(t / D); c = (int)(t - (int64_t)s * D); }
+    const int64_t g = (int64_t)c * nseg + s;
     const int64_t i0 = (int64_t)s * S;
     const int n = (int)min((int64_t)S, N - i0);
     // the tables come off the wire: a segment never reaches outside the buffer (its last word is read whole: 4-byte slots)
@@ -353,9 +376,9 @@ __global__ __launch_bounds__(64) void seg_decode_kernel(const uint8_t *__restric
     if ((off & 3) || off > in_bytes || (uint64_t)((nb + 3u) & ~3u) > in_bytes - off) { nb = 0; if (bad) atomicOr(bad, 1u); }
     // (16-byte stores of four buffered symbols measured SLOWER than one 4-byte store per symbol -- 4.2 against 3.0 ms for 3 M x 56
     // at 2048 per segment: the component selects cost more instructions than the stores save; kept behind this switch)
-    const bool vec = false && ((((uintptr_t)Q) & 15) == 0) && ((chan_stride & 3) == 0) && ((S & 3) == 0);
+    const bool vec = false && sym_stride == 1 && ((((uintptr_t)Q) & 15) == 0) && ((chan_stride & 3) == 0) && ((S & 3) == 0);
     if (vec) decode_segment<true>((const uint32_t *)(in + (nb ? off : 0)), nb, n, flag_signed, Q + (int64_t)c * chan_stride + i0);
-    else decode_segment<false>((const uint32_t *)(in + (nb ? off : 0)), nb, n, flag_signed, Q + (int64_t)c * chan_stride + i0);
+    else decode_segment<false>((const uint32_t *)(in + (nb ? off : 0)), nb, n, flag_signed, Q + (int64_t)c * chan_stride + i0 * sym_stride, sym_stride);
 }
 
 }  // namespace rlgr_seg
@@ -374,12 +397,26 @@ extern "C" {
 int raht_rlgr_seg_encode(const int32_t *Q, int64_t N, int D, int64_t chan_stride, int seg_len, int flag_signed, uint32_t *seg_bytes,
                          uint32_t *seg_off, uint8_t *out, int64_t cap, int64_t *total_bytes, raht_stream_t stream)
 {
-    if (!Q || !seg_bytes || !seg_off || !out || !total_bytes || N < 1 || D < 1 || chan_stride < N || seg_len < 64 || cap < 16 || ((uintptr_t)out & 3)) {
-        set_error("raht_rlgr_seg_encode: bad argument");
+    if (chan_stride < N) { set_error("raht_rlgr_seg_encode: bad argument"); return RAHT_ERR_INVALID; }
+    return raht_rlgr_seg_encode_strided(Q, N, D, 1, chan_stride, seg_len, flag_signed, seg_bytes, seg_off, out, cap, total_bytes, stream);
+}
+
+int raht_rlgr_seg_encode_strided(const int32_t *Q, int64_t N, int D, int64_t sym_stride, int64_t chan_stride, int seg_len, int flag_signed,
+                                 uint32_t *seg_bytes, uint32_t *seg_off, uint8_t *out, int64_t cap, int64_t *total_bytes, raht_stream_t stream)
+{
+    if (!Q || !seg_bytes || !seg_off || !out || !total_bytes || N < 1 || D < 1 || sym_stride < 1 || chan_stride < 1 || seg_len < 64 || cap < 16 || ((uintptr_t)out & 3) ||
+        !((sym_stride == 1 && chan_stride >= N) || (chan_stride == 1 && sym_stride >= D))) {
+        set_error("raht_rlgr_seg_encode: bad argument (channel-major: sym_stride 1, chan_stride >= N; row-major: chan_stride 1, sym_stride >= D)");
         return RAHT_ERR_INVALID;
     }
     const int64_t nseg = ceil_div(N, seg_len), G = nseg * D;
     if (nseg >= ((int64_t)1 << 31) || G >= ((int64_t)1 << 31)) { set_error("raht_rlgr_seg_encode: too many segments"); return RAHT_ERR_INVALID; }
+    // segment offsets and the container's total are 32-bit: refuse what could wrap them (worst case: every symbol escapes --
+    // 8 bytes and a bit -- plus the 4-byte padding of every segment)
+    if (raht_rlgr_bound(seg_len) * G + 4 * G >= ((int64_t)1 << 32)) {
+        set_error("raht_rlgr_seg_encode: %lld x %d symbols may need a container of 4 GiB or more (32-bit segment offsets): split the frame", (long long)N, D);
+        return RAHT_ERR_INVALID;
+    }
     hipStream_t s = (hipStream_t)stream;
     return guarded("raht_rlgr_seg_encode", [&]() -> int {
         Scratch tmp(sizeof(uint32_t) * ((size_t)G + 2), s);
@@ -394,7 +431,7 @@ int raht_rlgr_seg_encode(const int32_t *Q, int64_t N, int D, int64_t chan_stride
         if (!two_pass_only && (uint64_t)G * slot < ((uint64_t)1 << 33)) {
             Scratch slots((size_t)G * slot, s);
             if (slots.ok()) {
-                hipLaunchKernelGGL(rlgr_seg::seg_encode_slots_kernel, dim3(gb), dim3(64), 0, s, Q, N, D, chan_stride, seg_len, (int)nseg, flag_signed,
+                hipLaunchKernelGGL(rlgr_seg::seg_encode_slots_kernel, dim3(gb), dim3(64), 0, s, Q, N, D, sym_stride, chan_stride, seg_len, (int)nseg, flag_signed,
                                    seg_bytes, slots.as<uint8_t>(), slot, flags);
                 hipLaunchKernelGGL(rlgr_seg::seg_pad_kernel, dim3((unsigned)ceil_div(G, 256)), dim3(256), 0, s, seg_bytes, G, padded);
                 RAHT_RET(exclusive_scan_u32(padded, seg_off, G, flags + 1, s));
@@ -414,12 +451,12 @@ int raht_rlgr_seg_encode(const int32_t *Q, int64_t N, int D, int64_t chan_stride
                 (void)hipGetLastError();
             }
         }
-        hipLaunchKernelGGL(rlgr_seg::seg_encode_kernel<false>, dim3(gb), dim3(64), 0, s, Q, N, D, chan_stride, seg_len, (int)nseg, flag_signed,
+        hipLaunchKernelGGL(rlgr_seg::seg_encode_kernel<false>, dim3(gb), dim3(64), 0, s, Q, N, D, sym_stride, chan_stride, seg_len, (int)nseg, flag_signed,
                            seg_bytes, (const uint32_t *)nullptr, (uint8_t *)nullptr, (uint64_t)0, flags);
         hipLaunchKernelGGL(rlgr_seg::seg_pad_kernel, dim3((unsigned)ceil_div(G, 256)), dim3(256), 0, s, seg_bytes, G, padded);
         RAHT_RET(exclusive_scan_u32(padded, seg_off, G, flags + 1, s));       // (32-bit offsets: containers below 4 GiB)
         RAHT_HIP_CHECK(hipMemcpyAsync(seg_off + G, flags + 1, 4, hipMemcpyDeviceToDevice, s));
-        hipLaunchKernelGGL(rlgr_seg::seg_encode_kernel<true>, dim3(gb), dim3(64), 0, s, Q, N, D, chan_stride, seg_len, (int)nseg, flag_signed,
+        hipLaunchKernelGGL(rlgr_seg::seg_encode_kernel<true>, dim3(gb), dim3(64), 0, s, Q, N, D, sym_stride, chan_stride, seg_len, (int)nseg, flag_signed,
                            seg_bytes, seg_off, out, (uint64_t)cap, flags);
         RAHT_HIP_CHECK(hipGetLastError());
         uint32_t back[2] = {0, 0};
@@ -437,14 +474,22 @@ int raht_rlgr_seg_encode(const int32_t *Q, int64_t N, int D, int64_t chan_stride
 int raht_rlgr_seg_decode(const uint8_t *in, int64_t in_bytes, const uint32_t *seg_off, const uint32_t *seg_bytes, int64_t N, int D, int seg_len,
                          int flag_signed, int32_t *Q, int64_t chan_stride, uint32_t *bad_dev, raht_stream_t stream)
 {
-    if (!in || in_bytes < 0 || (in_bytes & 3) || !seg_off || !seg_bytes || !Q || N < 1 || D < 1 || chan_stride < N || seg_len < 64 || ((uintptr_t)in & 3)) {
+    if (chan_stride < N) { set_error("raht_rlgr_seg_decode: bad argument"); return RAHT_ERR_INVALID; }
+    return raht_rlgr_seg_decode_strided(in, in_bytes, seg_off, seg_bytes, N, D, seg_len, flag_signed, Q, 1, chan_stride, bad_dev, stream);
+}
+
+int raht_rlgr_seg_decode_strided(const uint8_t *in, int64_t in_bytes, const uint32_t *seg_off, const uint32_t *seg_bytes, int64_t N, int D, int seg_len,
+                                 int flag_signed, int32_t *Q, int64_t sym_stride, int64_t chan_stride, uint32_t *bad_dev, raht_stream_t stream)
+{
+    if (!in || in_bytes < 0 || (in_bytes & 3) || !seg_off || !seg_bytes || !Q || N < 1 || D < 1 || seg_len < 64 || ((uintptr_t)in & 3) ||
+        !((sym_stride == 1 && chan_stride >= N) || (chan_stride == 1 && sym_stride >= D))) {
         set_error("raht_rlgr_seg_decode: bad argument");
         return RAHT_ERR_INVALID;
     }
     const int64_t nseg = ceil_div(N, seg_len), G = nseg * D;
     if (G >= ((int64_t)1 << 31)) { set_error("raht_rlgr_seg_decode: too many segments"); return RAHT_ERR_INVALID; }
     hipLaunchKernelGGL(rlgr_seg::seg_decode_kernel, dim3((unsigned)ceil_div(G, 64)), dim3(64), 0, (hipStream_t)stream, in, (uint64_t)in_bytes, seg_off, seg_bytes, N, D,
-                       seg_len, (int)nseg, flag_signed, Q, chan_stride, bad_dev);
+                       seg_len, (int)nseg, flag_signed, Q, sym_stride, chan_stride, bad_dev);
     RAHT_HIP_CHECK(hipGetLastError());
     return RAHT_OK;
 }

@@ -212,10 +212,8 @@ def _encode_frame_gpu_entropy(V_int, attributes, J, steps, frame, device, dtype,
         coeff_reordered = plan.forward_quant(C, step_arg)
         _sync()
         r["RAHT_transform_time"], r["Quant_time"], r["Coeff_reorder_enc_time"] = time.time() - t0, 0.0, 0.0
-        t0 = time.time()
-        q_dev = rlgr_mod.transpose_on_device(coeff_reordered)
-        _sync()
-        r["Transpose_time"] = time.time() - t0
+        q_dev = coeff_reordered                               # row-major, as the transform leaves it: the coder's lanes are neighbouring
+        r["Transpose_time"] = 0.0                             # channels, every step of a wave reads one piece of a row (no transpose)
         t0 = time.time()
         coder.encode(q_dev)                                   # (returns the size: synchronises)
         r["Entropy_enc_time"] = time.time() - t0
@@ -225,17 +223,14 @@ def _encode_frame_gpu_entropy(V_int, attributes, J, steps, frame, device, dtype,
         size_bytes = len(hdr) + lens.nbytes + payload.nbytes
         assert size_bytes == coder.size_bytes
         t0 = time.time()
-        q_back = coder.decode()
+        q_back = coder.decode(row_major=True)
         _sync()
         r["Entropy_dec_time"] = time.time() - t0
         t0 = time.time()
         assert torch.equal(q_back, q_dev) and int(coder.bad.item()) == 0, "RLGR roundtrip failed"    # encode_3dgs.py:242-245
         r["Roundtrip_check_time"] = time.time() - t0
         r["H2D_time"] = 0.0
-        t0 = time.time()
-        qd = rlgr_mod.transpose_on_device(q_back)
-        _sync()
-        r["Transpose_time"] += time.time() - t0
+        qd = q_back
         t0 = time.time()
         C_rec = _decode_and_measure(plan, qd, step_arg, C, dtype, r, keep_rec)      # inverse + the PSNR columns' sums, one pass
         _sync()

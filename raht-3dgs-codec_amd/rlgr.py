@@ -180,7 +180,7 @@ class SegmentedCoder:
     (D, N) tensor on the device. Nothing but the compressed bytes ever crosses PCIe."""
     MAGIC = b"RLGS0001"
 
-    def __init__(self, N, D, seg_len=2048, flag_signed=1, device="cuda"):
+    def __init__(self, N, D, seg_len=2048, flag_signed=1, device="cuda", payload_cap=None):
         import torch
         self.N, self.D, self.S, self.flag = int(N), int(D), int(seg_len), int(flag_signed)
         self.nseg = (self.N + self.S - 1) // self.S
@@ -188,7 +188,8 @@ class SegmentedCoder:
         self.device = torch.device(device)
         self.seg_bytes = torch.empty(self.G, dtype=torch.int32, device=self.device)
         self.seg_off = torch.empty(self.G + 1, dtype=torch.int32, device=self.device)
-        self.cap = 4 * self.N * self.D + 64 * self.G           # what a raw dump would take, + slack; grown on demand
+        # encoder: what a raw dump would take, + slack (grown on demand); decoder (from_container): the payload it was handed
+        self.cap = 4 * self.N * self.D + 64 * self.G if payload_cap is None else max(16, int(payload_cap))
         self.out = torch.empty(self.cap, dtype=torch.uint8, device=self.device)
         self.bad = torch.zeros(1, dtype=torch.int32, device=self.device)
         self.total = 0
@@ -197,17 +198,29 @@ class SegmentedCoder:
         import torch
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
-    def encode(self, Qcm):
-        """Qcm: (D, N) int32 CUDA tensor, rows contiguous -> total container payload bytes (synchronises: it returns a size)"""
+    def _strides(self, Q, what):
+        """(sym_stride, chan_stride) of a channel-major (D, N) or a row-major (N, D) int32 CUDA tensor"""
         import torch
-        if not Qcm.is_cuda or Qcm.dtype != torch.int32 or tuple(Qcm.shape) != (self.D, self.N) or Qcm.stride(1) != 1:
-            raise ValueError("SegmentedCoder.encode: expected a (D, N) int32 CUDA tensor with contiguous channels")
+        if not Q.is_cuda or Q.dtype != torch.int32 or Q.dim() != 2 or Q.stride(1) != 1:
+            raise ValueError(f"SegmentedCoder.{what}: expected a 2-D int32 CUDA tensor with unit column stride")
+        if tuple(Q.shape) == (self.D, self.N) and (self.D != self.N or Q.stride(0) >= self.N):
+            return 1, Q.stride(0)
+        if tuple(Q.shape) == (self.N, self.D):
+            return Q.stride(0), 1
+        raise ValueError(f"SegmentedCoder.{what}: expected a (D, N) channel-major or an (N, D) row-major tensor")
+
+    def encode(self, Q):
+        """Q: (D, N) channel-major OR (N, D) row-major int32 CUDA tensor (the latter: the quantized coefficients as forward_quant
+        returns them, no transpose) -> total container payload bytes (synchronises: it returns a size). Same container either way."""
+        import torch
+        sym, chan = self._strides(Q, "encode")
+        Qcm = Q
         tot = C.c_int64()
         for attempt in (0, 1):
             with torch.cuda.device(self.device):
-                rc = _lib.lib().raht_rlgr_seg_encode(C.c_void_p(Qcm.data_ptr()), self.N, self.D, Qcm.stride(0), self.S, self.flag,
-                                                     C.c_void_p(self.seg_bytes.data_ptr()), C.c_void_p(self.seg_off.data_ptr()),
-                                                     C.c_void_p(self.out.data_ptr()), self.cap, C.byref(tot), self._stream())
+                rc = _lib.lib().raht_rlgr_seg_encode_strided(C.c_void_p(Qcm.data_ptr()), self.N, self.D, sym, chan, self.S, self.flag,
+                                                             C.c_void_p(self.seg_bytes.data_ptr()), C.c_void_p(self.seg_off.data_ptr()),
+                                                             C.c_void_p(self.out.data_ptr()), self.cap, C.byref(tot), self._stream())
             if rc == _lib.RAHT_OK or attempt == 1 or tot.value <= self.cap:
                 check(rc)
                 break
@@ -235,7 +248,9 @@ class SegmentedCoder:
         return hdr + lens.tobytes() + payload.tobytes()
 
     @classmethod
-    def from_container(cls, blob, device="cuda"):
+    def from_container(cls, blob, device="cuda", max_symbols=None):
+        """max_symbols: refuse containers whose header announces more than this many symbols (N x D): decode() allocates
+        4 N D bytes for them, and the header comes off the wire."""
         import torch
         m = len(cls.MAGIC)
         if blob[:m] != cls.MAGIC:
@@ -249,7 +264,9 @@ class SegmentedCoder:
         G = ((N + S - 1) // S) * D
         if len(blob) < m + 40 + 4 * G + total:
             raise ValueError("segmented RLGR container: shorter than its header says")
-        sc = cls(N, D, S, flag, device)
+        if max_symbols is not None and N * D > int(max_symbols):
+            raise ValueError(f"segmented RLGR container: {N} x {D} symbols, more than the caller allows ({max_symbols})")
+        sc = cls(N, D, S, flag, device, payload_cap=total)     # (the payload only: a decoder never needs the encoder's raw-size buffer)
         lens = np.frombuffer(blob, np.uint32, sc.G, m + 40).astype(np.int64)
         if total % 4 or total > len(blob) - (m + 40 + 4 * sc.G) or int(((lens + 3) // 4 * 4).sum()) != total:
             raise ValueError("segmented RLGR container: inconsistent length table")
@@ -262,15 +279,18 @@ class SegmentedCoder:
         sc.total = total
         return sc
 
-    def decode(self, out=None):
-        """-> (D, N) int32 CUDA tensor (enqueued on the current stream; no synchronisation)"""
+    def decode(self, out=None, row_major=False):
+        """-> (D, N) int32 CUDA tensor, or (N, D) with ``row_major=True`` (what dequant_inverse takes: no transpose behind the
+        decoder); enqueued on the current stream, no synchronisation"""
         import torch
-        Q = torch.empty((self.D, self.N), dtype=torch.int32, device=self.device) if out is None else out
+        if out is None:
+            out = torch.empty((self.N, self.D) if row_major else (self.D, self.N), dtype=torch.int32, device=self.device)
+        sym, chan = self._strides(out, "decode")
         with torch.cuda.device(self.device):
-            check(_lib.lib().raht_rlgr_seg_decode(C.c_void_p(self.out.data_ptr()), (self.total + 3) // 4 * 4, C.c_void_p(self.seg_off.data_ptr()),
-                                                  C.c_void_p(self.seg_bytes.data_ptr()), self.N, self.D, self.S, self.flag,
-                                                  C.c_void_p(Q.data_ptr()), Q.stride(0), C.c_void_p(self.bad.data_ptr()), self._stream()))
-        return Q
+            check(_lib.lib().raht_rlgr_seg_decode_strided(C.c_void_p(self.out.data_ptr()), (self.total + 3) // 4 * 4, C.c_void_p(self.seg_off.data_ptr()),
+                                                          C.c_void_p(self.seg_bytes.data_ptr()), self.N, self.D, self.S, self.flag,
+                                                          C.c_void_p(out.data_ptr()), sym, chan, C.c_void_p(self.bad.data_ptr()), self._stream()))
+        return out
 
     def segment(self, c, s):
         """the bytes of segment s of channel c (host copy; tests)"""

@@ -122,3 +122,48 @@ def test_cost_of_restarting_the_coder_per_segment():
             print(f"[rlgr_seg] step {step} seg_len {S}: {sc.size_bytes} bytes against {one} as one stream per channel: x{ratio:.4f}")
             assert ratio <= bar, (step, S, ratio)
             assert torch.equal(sc.decode(), Qcm)
+
+
+@pytest.mark.parametrize("seg_len,ld_extra", [(64, 0), (1000, 5), (4096, 0)])
+def test_row_major_input_gives_the_same_container(seg_len, ld_extra):
+    """raht_rlgr_seg_encode_strided / _decode_strided on ROW-MAJOR coefficients (symbol n of channel c at Q[n * ld + c], what the
+    transform kernels write and read): the same segments, offsets and bytes as the channel-major call -- no transpose on either
+    side of the coder -- and the decoder writes rows straight back."""
+    import torch
+    from raht_3dgs_codec_amd import rlgr
+    Qcm = torch.from_numpy(_cases()).cuda()                     # (D, N)
+    D, N = Qcm.shape
+    big = torch.full((N, D + ld_extra), 12345, dtype=torch.int32, device="cuda")
+    big[:, :D] = Qcm.t()
+    Qrm = big[:, :D]                                            # (N, D), row stride D + ld_extra
+    a, b = rlgr.SegmentedCoder(N, D, seg_len), rlgr.SegmentedCoder(N, D, seg_len)
+    ta, tb = a.encode(Qcm), b.encode(Qrm)
+    assert ta == tb and torch.equal(a.seg_bytes, b.seg_bytes) and torch.equal(a.seg_off, b.seg_off)
+    assert torch.equal(a.out[:ta], b.out[:tb])
+    assert a.container() == b.container()
+    out = torch.full((N, D + ld_extra), -9, dtype=torch.int32, device="cuda")
+    b.decode(out=out[:, :D])
+    assert torch.equal(out[:, :D], Qrm) and bool((out[:, D:] == -9).all()) and int(b.bad.item()) == 0
+    assert torch.equal(b.decode(row_major=True), Qrm.contiguous())
+    assert torch.equal(a.decode(), Qcm)                         # either decoder layout from either encoder's container
+
+
+def test_container_header_limits():
+    """a decoder allocates from the payload it was handed, not from the header's raw size, and may cap the symbol count"""
+    import torch
+    from raht_3dgs_codec_amd import rlgr
+    Q = torch.zeros((4, 5000), dtype=torch.int32, device="cuda")
+    sc = rlgr.SegmentedCoder(5000, 4, 512)
+    sc.encode(Q)
+    blob = sc.container()
+    d = rlgr.SegmentedCoder.from_container(blob)
+    assert d.cap <= max(16, sc.total) + 16 and torch.equal(d.decode(), Q)
+    with pytest.raises(ValueError):
+        rlgr.SegmentedCoder.from_container(blob, max_symbols=1000)
+    # the 32-bit container: inputs whose worst case could reach 4 GiB are refused before anything runs
+    from raht_3dgs_codec_amd import _lib
+    import ctypes as C
+    tot = C.c_int64()
+    rc = _lib.lib().raht_rlgr_seg_encode_strided(C.c_void_p(Q.data_ptr()), 600_000_000, 1, 1, 600_000_000, 2048, 1, C.c_void_p(sc.seg_bytes.data_ptr()),
+                                                 C.c_void_p(sc.seg_off.data_ptr()), C.c_void_p(sc.out.data_ptr()), sc.cap, C.byref(tot), None)
+    assert rc == -1 and b"4 GiB" in _lib.lib().raht_last_error()
