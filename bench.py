@@ -409,6 +409,62 @@ class SoloScene:
         return lambda: (self.fwd_quant(), self.dequant_inv())
 
 
+def two_stream_loop(R, L, _lib, kd, Cd, nbits, step, reps=200):
+    """The drivers' loop over quantization steps (python/encode_3dgs.py:199-275) with the two directions on two streams -- forward +
+    quantize of step s + 1 next to dequantize + inverse of step s, one workspace set per direction
+    (raht_plan_set_concurrent_directions) -- against the same float32 fused calls back to back on one stream."""
+    p = R.RahtPlan.from_keys(kd, nbits)
+    N, D = int(Cd.shape[0]), int(Cd.shape[1])
+    Q = [torch.empty((N, D), dtype=torch.int32, device=Cd.device) for _ in range(2)]
+    Cr = torch.empty_like(Cd)
+    st = (C.c_float * 1)(step)
+    vp = C.c_void_p
+    sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+
+    def fwd(q, s):
+        _lib.check(L.raht_fwd_quant(p._h, vp(Cd.data_ptr()), D, D, st, 1, vp(q.data_ptr()), D, vp(s.cuda_stream)))
+
+    def inv(q, s):
+        _lib.check(L.raht_dequant_inv(p._h, vp(q.data_ptr()), D, D, st, 1, vp(Cr.data_ptr()), D, vp(s.cuda_stream)))
+
+    def timed_loop(body, n):
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(sa)
+        body(n)
+        sa.wait_stream(sb)
+        e1.record(sa); e1.synchronize()
+        return e0.elapsed_time(e1) / n
+
+    def serial(n):
+        for _ in range(n):
+            fwd(Q[0], sa); inv(Q[0], sa)
+
+    def overlapped(n):
+        ev_f = [torch.cuda.Event() for _ in range(2)]
+        ev_i = [torch.cuda.Event() for _ in range(2)]
+        fwd(Q[0], sa); ev_f[0].record(sa)
+        for i in range(1, n + 1):
+            if i >= 2:
+                sa.wait_event(ev_i[i % 2])                 # the inverse that read this Q buffer two steps ago
+            if i < n:
+                fwd(Q[i % 2], sa); ev_f[i % 2].record(sa)
+            sb.wait_event(ev_f[(i - 1) % 2])
+            inv(Q[(i - 1) % 2], sb); ev_i[(i - 1) % 2].record(sb)
+    serial(40)
+    t1 = timed_loop(serial, reps)
+    ref = Cr.clone()
+    p.set_concurrent_directions(True)
+    overlapped(40)
+    t2 = timed_loop(overlapped, reps)
+    torch.cuda.synchronize()
+    assert torch.equal(Cr, ref), "two-stream loop reconstructs differently"
+    alg = 2 * (8.0 * N * D + 8.0 * N)
+    return {"rows": N, "channels": D, "one_stream_ms_per_step": round(t1, 4), "two_streams_ms_per_step": round(t2, 4),
+            "one_stream_frac_of_peak": round(alg / (t1 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "two_streams_frac_of_peak": round(alg / (t2 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+            "two_streams_value": round(N / (t2 * 1e-3) / 1e6, 1), "unit": "M-Gaussians/s", "bit_identical": True}
+
+
 def device_scene(n_draws, J, D, seed, dev):
     """cfg5: sorted unique 3J-bit keys and N(0,1) attributes generated ON THE DEVICE from `seed` (host generation of
     50 M rows takes minutes). Every rank that calls this with the same seed holds the same scene."""
@@ -895,6 +951,15 @@ def main():
             # 56 attribute channels; 59 with the xyz columns of PCvox)
             out["reference_shape"] = {"what": "python/encode_3dgs.py:20-33: J = 10, ~1 M voxels per frame, 56 attribute channels (59 with xyz)",
                                       "d56": small_leg("ref56", 1_000_000, 10, 56, 1, ""), "d59": small_leg("ref59", 1_000_000, 10, 59, 1, "")}
+            # the drivers' step loop with the two directions on two streams (forward of step s + 1 next to the inverse of step s)
+            tsl = {"what": "python/encode_3dgs.py:199-275: forward + quantize of step s + 1 does not depend on dequantize + inverse of step s; one workspace "
+                           "set per direction (raht_plan_set_concurrent_directions), the two directions on two streams: one direction's latency-bound tail "
+                           "stages run under the other's first stage. float32 fused kernels; same reconstructions bit for bit.",
+                   "cfg3": two_stream_loop(R, L, _lib, kd, sc.Cd, 3 * J, a.quant_step)}
+            for nm, (n_, J_, D_, sd_) in (("reference_shape_d56", (1_000_000, 10, 56, 1)), ("cfg2", synth.CONFIGS["cfg2"])):
+                V_, k_, C_ = synth.scene(n_, J_, D_, sd_)
+                tsl[nm] = two_stream_loop(R, L, _lib, torch.from_numpy(k_.view(np.int64)).to(dev), torch.from_numpy(C_).to(dev), 3 * J_, a.quant_step)
+            out["frame_loop_two_streams"] = tsl
             # a BATCH of such frames (BASELINE configs[3] is a batch of scenes; so is a dynamic sequence): one call per frame
             # against raht_fwd_quant_batch + raht_dequant_inv_batch (stage k of all frames in one launch)
             from raht_3dgs_codec_amd import ops as _ops

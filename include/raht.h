@@ -272,6 +272,15 @@ int raht_dequant_inv_batch(int n, raht_plan *const *plans, const int32_t *const 
  * A plan owns its workspaces: do not run transforms of one plan concurrently on several streams. */
 int raht_plan_prepare(raht_plan *plan, int elem_size, int D, raht_stream_t stream);
 
+/* A plan owns ONE set of per-stage workspaces, so its transforms must be ordered on one stream (above). With this switched on it
+ * keeps one set PER DIRECTION: one forward-direction call (raht_fwd*, raht_fwd_quant*) and one inverse-direction call (raht_inv*,
+ * raht_dequant_inv*) of the same plan may then be in flight at the same time on two streams -- the shape of the drivers' loop
+ * over quantization steps (python/encode_3dgs.py:199-275): the forward of step s + 1 does not depend on the inverse of step s,
+ * and one direction's latency-bound tail stages then run under the other's HBM-bound first stage. Costs a second copy of the
+ * workspaces (~5 % of a coefficient matrix); they are re-allocated by the next transform or raht_plan_prepare. Two calls of the
+ * SAME direction still have to be ordered by the caller. */
+int raht_plan_set_concurrent_directions(raht_plan *plan, int on);
+
 /* Profiling aid: HIP events (hipEvent_t, created by the caller with timing enabled) recorded on the
  * launch stream immediately before and after the STAGE-0 kernel of every following transform of this
  * plan, so that the dominant kernel can be timed inside a real step (hipEventElapsedTime after the

@@ -24,7 +24,7 @@ EXPORTS = [
     "raht_plan_copy_array", "raht_plan_stage_stats", "raht_fwd", "raht_fwd_f64", "raht_inv", "raht_inv_f64", "raht_debug_run_stage", "raht_plan_set_stage0_events", "raht_fwd_quant", "raht_dequant_inv", "raht_plan_prepare",
     "raht_quant_reorder", "raht_dequant_unreorder", "raht_voxelize", "raht_voxelize_all", "raht_voxelize_plan", "raht_morton", "raht_sort_keys",
     "raht_voxel_keys", "raht_sort_fallbacks", "raht_voxelize_residuals", "raht_plan_set_row_map", "raht_rows_gather", "raht_rows_scatter",
-    "raht_plan_set_max_stages", "raht_quant_reorder_f64", "raht_dequant_unreorder_f64", "raht_fwd_quant_f64", "raht_dequant_inv_f64",
+    "raht_plan_set_max_stages", "raht_plan_set_concurrent_directions", "raht_quant_reorder_f64", "raht_dequant_unreorder_f64", "raht_fwd_quant_f64", "raht_dequant_inv_f64",
     "raht_fwd_quant_mixed", "raht_dequant_inv_mixed", "raht_dequant_inv_sqdiff", "raht_plan_mixed_stats",
     "raht_fwd_batch", "raht_inv_batch", "raht_fwd_quant_batch", "raht_dequant_inv_batch",
     "raht_rlgr_bound", "raht_rlgr_encode", "raht_rlgr_decode", "raht_rlgr_encode_channels", "raht_rlgr_decode_channels", "raht_transpose_i32", "raht_i32_equal", "raht_sqdiff_columns", "raht_merge_clusters", "raht_rlgr_seg_encode", "raht_rlgr_seg_decode", "raht_rlgr_seg_encode_strided", "raht_rlgr_seg_decode_strided",
@@ -106,6 +106,7 @@ def lib():
     L.raht_fwd_quant_batch.argtypes = [i32, pp, pp, pi64, i32, C.POINTER(C.c_float), i32, pp, pi64, vp]
     L.raht_dequant_inv_batch.argtypes = [i32, pp, pp, pi64, i32, C.POINTER(C.c_float), i32, pp, pi64, vp]
     L.raht_plan_set_max_stages.argtypes = [vp, i32]
+    L.raht_plan_set_concurrent_directions.argtypes = [vp, i32]
     L.raht_plan_set_row_map.argtypes = [vp, vp, i64, vp]
     for f in (L.raht_rows_gather, L.raht_rows_scatter):
         f.argtypes = [vp, i64, vp, i64, i32, i32, vp, i64, vp]

@@ -526,19 +526,23 @@ static void free_schedule(Schedule &sc)
     sc.stages.clear();
 }
 
-int ensure_workspace(Schedule *sc, size_t row_bytes)
+int ensure_workspace(Schedule *sc, size_t row_bytes, bool split)
 {
-    if (row_bytes <= sc->ws_row_bytes) return RAHT_OK;
+    if (row_bytes <= sc->ws_row_bytes && split == sc->ws_split) return RAHT_OK;
+    row_bytes = std::max(row_bytes, sc->ws_row_bytes);
     for (size_t k = 1; k < sc->stages.size(); ++k) {
         Stage &st = sc->stages[k];
         if (st.ws) { (void)hipDeviceSynchronize(); dev_free(st.ws); st.ws = nullptr; }
-        if (dev_malloc(&st.ws, row_bytes * (size_t)st.n_entries) != hipSuccess) {
-            set_error("workspace allocation failed (%zu bytes)", row_bytes * (size_t)st.n_entries);
+        const size_t one = (row_bytes * (size_t)st.n_entries + 255) & ~(size_t)255;
+        if (dev_malloc(&st.ws, split ? 2 * one : one) != hipSuccess) {
+            set_error("workspace allocation failed (%zu bytes)", split ? 2 * one : one);
             sc->ws_row_bytes = 0;
             return RAHT_ERR_NOMEM;
         }
+        st.ws_inv_off = split ? one : 0;
     }
     sc->ws_row_bytes = row_bytes;
+    sc->ws_split = split;
     return RAHT_OK;
 }
 
@@ -1717,6 +1721,14 @@ int raht_plan_set_max_stages(raht_plan *p, int max_stages)
     for (auto &sc : p->schedules) free_schedule(sc);       // schedules were built under the old limit
     p->schedules.clear();
     p->max_stages = max_stages;
+    return RAHT_OK;
+}
+
+int raht_plan_set_concurrent_directions(raht_plan *p, int on)
+{
+    if (!p) { set_error("raht_plan_set_concurrent_directions: NULL plan"); return RAHT_ERR_INVALID; }
+    RAHT_RET(check_plan_device(p, "raht_plan_set_concurrent_directions"));
+    p->split_ws = on != 0;                                  // (the workspaces are re-made by the next transform / raht_plan_prepare)
     return RAHT_OK;
 }
 

@@ -180,6 +180,8 @@ struct Stage {
     uint32_t *surv_off = nullptr;  // device uint32[n_tiles + 1]: index (in the NEXT stage's entry
                                    // list) of the first survivor of every tile; nullptr on the last stage
     void *ws = nullptr;            // device workspace holding this stage's entries (stages >= 1)
+    size_t ws_inv_off = 0;         // byte offset of the INVERSE direction's own copy of the workspace inside `ws` (0: both directions
+                                   // share one -- the default; raht_plan_set_concurrent_directions gives each its own)
     int tile_rows = 0;             // rows per tile of THIS stage
     // entry-ordered copies of the plan metadata (stages >= 1): one contiguous, single-latency load
     // per tile instead of rows[] -> wl/wr/lvl/inv_order[row] chains. nullptr on stage 0 (entry = row).
@@ -221,6 +223,7 @@ struct Schedule {
     bool valid = false;        // false: tile stages cannot finish the tree -> use the level engine
     std::vector<Stage> stages;
     size_t ws_row_bytes = 0;   // bytes per workspace row currently allocated (D * elem_size)
+    bool ws_split = false;     // the workspaces currently allocated hold one copy per direction
 };
 
 }  // namespace raht
@@ -256,6 +259,7 @@ struct raht_plan {
     const uint32_t *pend_dev = nullptr; uint32_t *pend_host = nullptr; int pend_n = 0;
     hipEvent_t ev_before = nullptr, ev_after = nullptr;   // profiling: recorded around the stage-0 launch
     int max_stages = 24;         // a tile schedule that needs more stages than this is abandoned (level engine)
+    bool split_ws = false;       // one workspace set per direction: a forward and an inverse call may run at the same time
     std::deque<raht::Schedule> schedules;    // cache keyed by tile geometry; a deque: references handed out by
                                              // get_schedule stay valid when another geometry is added
     std::vector<uint8_t> lvl_host;           // lazily downloaded for export_level
@@ -287,7 +291,9 @@ void pick_tail_geometry(const raht_plan *plan, int elem_size, int D, int stage0_
                         int *final_rows);
 // Make sure the per-stage workspaces of `sc` hold rows of at least row_bytes bytes (allocates on
 // first use / growth only).
-int ensure_workspace(Schedule *sc, size_t row_bytes);
+int ensure_workspace(Schedule *sc, size_t row_bytes, bool split = false);
+// stage workspace as a direction sees it
+static inline void *stage_ws(const Stage &st, bool inverse) { return st.ws ? (void *)((char *)st.ws + (inverse ? st.ws_inv_off : 0)) : nullptr; }
 // Rows per LDS tile for an element size / channel count (0 = does not fit).
 int pick_tile_rows(const raht_plan *plan, int elem_size, int chunk_channels);
 int pick_chunk_channels(int elem_size, int D);

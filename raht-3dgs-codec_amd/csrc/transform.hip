@@ -1277,7 +1277,7 @@ template <typename T, bool INV, bool QM>
 static int prepare_top_stage(const raht_plan *p, const Schedule &sc, int k, const XformIO<T> &io, int D, TopArgs<T> &A, size_t &lds)
 {
     const Stage &st = sc.stages[(size_t)k];
-    T *ws_k = (k >= 1) ? (T *)st.ws : nullptr;
+    T *ws_k = (k >= 1) ? (T *)stage_ws(st, INV) : nullptr;
     A.in = nullptr; A.ld_in = 0; A.out = nullptr; A.ld_out = 0;
     if (!INV) { A.in = (k == 0) ? io.src : ws_k; A.ld_in = (k == 0) ? io.ld_src : D; A.fin = io.dst; A.ld_fin = io.ld_dst; }
     else { A.fin = const_cast<T *>(io.src); A.ld_fin = io.ld_src; A.out = (k == 0) ? io.dst : ws_k; A.ld_out = (k == 0) ? io.ld_dst : D; }
@@ -1375,8 +1375,8 @@ static int prepare_tile_stage(const raht_plan *p, const Schedule &sc, int k, con
     A.top_level = p->top_level; A.root_buf = (T *)p->root_buf;
     A.dbg = dbg; A.nwide = 0; A.ref = nullptr; A.ld_ref = 0; A.sq_part = nullptr;
     A.ld_ws = D;
-    A.wsn = (k + 1 < K) ? (T *)sc.stages[(size_t)k + 1].ws : nullptr;
-    T *ws_k = (k >= 1) ? (T *)st.ws : nullptr;
+    A.wsn = (k + 1 < K) ? (T *)stage_ws(sc.stages[(size_t)k + 1], INV) : nullptr;
+    T *ws_k = (k >= 1) ? (T *)stage_ws(st, INV) : nullptr;
     if (!INV) {
         A.in = (k == 0) ? io.src : ws_k; A.ld_in = (k == 0) ? io.ld_src : D;
         A.fin = io.dst; A.ld_fin = io.ld_dst;
@@ -1617,7 +1617,7 @@ static int tile_setup(raht_plan *p, int D, int64_t max_ld, hipStream_t s, Schedu
     if (p->row_map) Rf = RAHT_TOP_MAX_ROWS;           // ONE top stage (the only kernel that addresses rows through the map)
     RAHT_RET(get_schedule(p, R, R1, Rf, s, &sc));
     if (!sc->valid) return RAHT_OK;                   // pathological key pattern, see plan.hip
-    RAHT_RET(ensure_workspace(sc, (size_t)D * sizeof(T)));
+    RAHT_RET(ensure_workspace(sc, (size_t)D * sizeof(T), p->split_ws));
     *sc_out = sc;
     *Dc_out = Dc;
     return RAHT_OK;

@@ -875,8 +875,8 @@ static int launch_stage_mx(const raht_plan *p, const Schedule &sc, int k, const 
     const Stage &st = sc.stages[(size_t)k];
     const int K = (int)sc.stages.size();
     // a stage's workspace: the float places of every entry, then the wide places of every entry
-    float *ws_k = (k >= 1) ? (float *)st.ws : nullptr;
-    float *ws_n = (k + 1 < K) ? (float *)sc.stages[(size_t)k + 1].ws : nullptr;
+    float *ws_k = (k >= 1) ? (float *)stage_ws(st, INV) : nullptr;
+    float *ws_n = (k + 1 < K) ? (float *)stage_ws(sc.stages[(size_t)k + 1], INV) : nullptr;
     double *ws_k_w = ws_k ? (double *)(ws_k + (size_t)st.n_entries * g.Dp) : nullptr;
     double *ws_n_w = ws_n ? (double *)(ws_n + (size_t)sc.stages[(size_t)k + 1].n_entries * g.Dp) : nullptr;
     if (k >= 1 && !ws_k) { set_error("mixed stage %d: missing stage workspace", k); return RAHT_ERR_INVALID; }
@@ -966,7 +966,7 @@ static int mx_setup(raht_plan *p, int D, int n_wide, int64_t max_ld, hipStream_t
     Schedule *sc = nullptr;
     RAHT_RET(get_schedule(p, g.R0, g.R1, g.Rf, s, &sc));
     if (!sc->valid) return RAHT_OK;
-    RAHT_RET(ensure_workspace(sc, (size_t)g.Dp * 4 + (size_t)g.nwide * 8 + 8));      // float chunks + n_wide doubles (+ slack: the wide part is fetched in 16-byte chunks)
+    RAHT_RET(ensure_workspace(sc, (size_t)g.Dp * 4 + (size_t)g.nwide * 8 + 8, p->split_ws));      // float chunks + n_wide doubles (+ slack: the wide part is fetched in 16-byte chunks)
     *sc_out = sc;
     return RAHT_OK;
 }

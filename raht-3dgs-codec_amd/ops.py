@@ -286,6 +286,12 @@ class RahtPlan:
             check(_lib.lib().raht_plan_set_row_map(self._h, C.c_void_p(m.data_ptr()), int(n_matrix_rows), _stream()))
         self.map_rows = int(n_matrix_rows)
 
+    def set_concurrent_directions(self, on=True):
+        """One workspace set per direction: a forward-direction and an inverse-direction call of this plan may then run at the same
+        time on two streams (the drivers' loop over quantization steps: forward of step s + 1 next to the inverse of step s)."""
+        with torch.cuda.device(self.device):
+            check(_lib.lib().raht_plan_set_concurrent_directions(self._h, 1 if on else 0))
+
     def set_max_stages(self, max_stages):
         """Bound on the launches per direction of the tile schedule; above it the level engine runs."""
         with torch.cuda.device(self.device):

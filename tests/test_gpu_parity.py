@@ -1099,3 +1099,40 @@ def test_dequant_inverse_sqdiff_strided_reference_and_big_scene(rt):
     assert torch.allclose(ssd, f32d, rtol=1e-9)
     # orthonormal transform: the distortion equals the quantization error of the coefficients (Parseval), ~ N step^2 / 12 per column
     assert 0.5 < float(ssd.mean()) / (N * 0.02 ** 2 / 12) < 1.5
+
+
+# ---- one workspace set per direction: forward of step s + 1 next to the inverse of step s (encode_3dgs.py:199-275) ----------
+@pytest.mark.gpu
+@pytest.mark.parametrize("mixed", [False, True])
+def test_forward_and_inverse_of_one_plan_on_two_streams(rt, mixed):
+    """raht_plan_set_concurrent_directions: a forward-direction and an inverse-direction call of the same plan in flight at the
+    same time on two streams, many steps in a row -- every reconstruction bit-identical to the one-stream loop."""
+    import torch
+    from raht_3dgs_codec_amd import synth
+    V, keys, Ch = synth.scene(400000, 10, 59, seed=8)
+    p = rt.RahtPlan.from_keys(_dev(keys.view(np.int64)), 30)
+    Cs = [_dev(Ch) * (1.0 + 0.1 * i) for i in range(6)]
+    steps = [0.01 * (i + 1) for i in range(6)]
+    fq = (lambda c, s: p.forward_quant_mixed(c, s, 3)) if mixed else p.forward_quant
+    di = (lambda q, s: p.dequant_inverse_mixed(q, s, 3)) if mixed else p.dequant_inverse
+    want = [di(fq(c, s), s) for c, s in zip(Cs, steps)]
+    torch.cuda.synchronize()
+    p.set_concurrent_directions(True)
+    sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+    got, qs, evs = [], [], []
+    for rep in range(3):
+        got.clear(); qs.clear(); evs.clear()
+        for i in range(len(Cs) + 1):
+            if i < len(Cs):
+                with torch.cuda.stream(sa):
+                    qs.append(fq(Cs[i], steps[i]))
+                    e = torch.cuda.Event(); e.record(sa); evs.append(e)
+            if i >= 1:
+                with torch.cuda.stream(sb):
+                    sb.wait_event(evs[i - 1])
+                    got.append(di(qs[i - 1], steps[i - 1]))
+        torch.cuda.synchronize()
+        for a, b in zip(got, want):
+            assert torch.equal(a, b), rep
+    p.set_concurrent_directions(False)
+    assert torch.equal(di(fq(Cs[0], steps[0]), steps[0]), want[0])
