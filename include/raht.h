@@ -206,6 +206,14 @@ int raht_fwd_quant(const raht_plan *plan, const float *C, int64_t ldc, int D, co
 int raht_dequant_inv(const raht_plan *plan, const int32_t *Q, int64_t ldq, int D, const float *steps,
                      int n_steps, float *C, int64_t ldc, raht_stream_t stream);
 
+/* ONE forward pass, k quantizations: the drivers quantize one coefficient matrix at nine steps (python/encode_3dgs.py:28 colorStep,
+ * :199-217), i.e. the forward transform of a frame is the same for every step. Q[i] = floor(T / steps[i] + 0.5), reordered, for
+ * i < k -- each bit-identical to raht_fwd_quant(plan, C, ..., &steps[i], 1, Q[i], ...) -- from one pass over C: the write-back of
+ * every finalised row quantizes it k times. steps: HOST float[k] (one step for all channels each); Q: HOST array of k DEVICE
+ * matrices (N x D int32, row stride ldq, distinct). Level engine / row-mapped / truncated plans: k single calls inside. */
+int raht_fwd_quant_multi(const raht_plan *plan, const float *C, int64_t ldc, int D, const float *steps, int k,
+                         int32_t *const *Q, int64_t ldq, raht_stream_t stream);
+
 /* raht_dequant_inv fused with the drivers' distortion measurement (python/encode_3dgs.py:274 C_rec = iRAHT(...), then :298-310
  * torch.mean((C - C_rec) ** 2) over all / quats / scales / opacity / colour columns): the stage-0 kernel of the fused inverse
  * compares every row it reconstructs with the ORIGINAL attributes C_ref on its way out.

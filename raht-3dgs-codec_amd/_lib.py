@@ -25,7 +25,7 @@ EXPORTS = [
     "raht_quant_reorder", "raht_dequant_unreorder", "raht_voxelize", "raht_voxelize_all", "raht_voxelize_plan", "raht_morton", "raht_sort_keys",
     "raht_voxel_keys", "raht_sort_fallbacks", "raht_voxelize_residuals", "raht_plan_set_row_map", "raht_rows_gather", "raht_rows_scatter",
     "raht_plan_set_max_stages", "raht_plan_set_concurrent_directions", "raht_quant_reorder_f64", "raht_dequant_unreorder_f64", "raht_fwd_quant_f64", "raht_dequant_inv_f64",
-    "raht_fwd_quant_mixed", "raht_dequant_inv_mixed", "raht_dequant_inv_sqdiff", "raht_plan_mixed_stats",
+    "raht_fwd_quant_mixed", "raht_dequant_inv_mixed", "raht_dequant_inv_sqdiff", "raht_fwd_quant_multi", "raht_plan_mixed_stats",
     "raht_fwd_batch", "raht_inv_batch", "raht_fwd_quant_batch", "raht_dequant_inv_batch",
     "raht_rlgr_bound", "raht_rlgr_encode", "raht_rlgr_decode", "raht_rlgr_encode_channels", "raht_rlgr_decode_channels", "raht_transpose_i32", "raht_i32_equal", "raht_sqdiff_columns", "raht_merge_clusters", "raht_rlgr_seg_encode", "raht_rlgr_seg_decode", "raht_rlgr_seg_encode_strided", "raht_rlgr_seg_decode_strided",
     "raht_xchg_bytes", "raht_xchg_alloc", "raht_xchg_open", "raht_xchg_close", "raht_xchg_free", "raht_xchg_gather", "raht_xchg_buffer", "raht_xchg_status",
@@ -99,6 +99,7 @@ def lib():
     L.raht_fwd_quant_mixed.argtypes = [vp, vp, i64, i32, C.POINTER(dbl), i32, i32, vp, i64, vp]
     L.raht_dequant_inv_mixed.argtypes = [vp, vp, i64, i32, C.POINTER(dbl), i32, i32, vp, i64, vp]
     L.raht_dequant_inv_sqdiff.argtypes = [vp, vp, i64, i32, C.POINTER(C.c_float), i32, vp, i64, vp, i64, vp, vp]
+    L.raht_fwd_quant_multi.argtypes = [vp, vp, i64, i32, C.POINTER(C.c_float), i32, C.POINTER(vp), i64, vp]
     L.raht_plan_mixed_stats.argtypes = [vp, i32, i32, C.POINTER(i32), C.POINTER(i32), C.POINTER(i64), i32]
     pp, pi64 = C.POINTER(vp), C.POINTER(i64)
     L.raht_fwd_batch.argtypes = [i32, pp, pp, pi64, i32, pp, pi64, vp]

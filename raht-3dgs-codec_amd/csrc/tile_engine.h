@@ -103,6 +103,16 @@ __device__ __forceinline__ void load_tile_meta(const TileArgs<T> &A, int64_t t, 
     }
 }
 
+// raht_fwd_quant_multi: one forward pass, several quantizations (the drivers quantize ONE coefficient matrix at nine steps,
+// python/encode_3dgs.py:28,199-217): k scalar steps, k output matrices
+constexpr int MULTI_Q_MAX = 12;
+struct MultiQ {
+    int k;
+    int fast_div;                       // every step within [2^-100, 2^100] (raht_device.h: quantize_one)
+    float step[MULTI_Q_MAX];
+    int32_t *Q[MULTI_Q_MAX];
+};
+
 // Row addressing. The kernel is bound by vector-instruction issue, and a 64 x 64-bit row * stride product
 // per 16-byte chunk (3 quarter-rate multiplies + 5 more instructions) was a tenth of it.
 //  row_at:  rows of the tile being processed: a wave-uniform base (scalar registers) plus a 32-bit byte

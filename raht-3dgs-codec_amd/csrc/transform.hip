@@ -170,9 +170,9 @@ __device__ __forceinline__ void st_chunk_wt(T *p, const RegChunk<T> &x)
 //
 // tile_body is the kernel; tile_kernel runs it for ONE scene (workgroup b takes tiles b, b + gridDim.x, ...), tile_kernel_batch
 // for several scenes in one launch (workgroup b takes ONE tile of the scene whose tile range holds b).
-template <typename T, bool INV, bool IDENT, bool QM, int SLOTS, bool WT = false, bool SQ = false>
+template <typename T, bool INV, bool IDENT, bool QM, int SLOTS, bool WT = false, bool SQ = false, bool MULTI = false>
 __device__ __forceinline__ void tile_body(const TileArgs<T> &A, const typename std::conditional<QM, typename StepsFor<T>::type, NoSteps>::type &ST,
-                                          const int64_t first_tile, const int64_t tile_stride, const int chunk_y)
+                                          const int64_t first_tile, const int64_t tile_stride, const int chunk_y, const MultiQ *MQ = nullptr)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     typedef RegChunk<T> V16;
@@ -748,6 +748,15 @@ __device__ __forceinline__ void tile_body(const TileArgs<T> &A, const typename s
 #pragma unroll
                             for (int i = 0; i < VN; ++i) qv[i] = quantize_one_f64((double)x.v[i], (double)my_step[i]);
                             st_ints<VN>(row_far(A.Q, dv & 0x7fffffffu, (uint32_t)A.ldq, (uint32_t)goff), qv);
+                        } else if constexpr (MULTI) {
+                            // raht_fwd_quant_multi: the row is quantized once per step table, each into its own matrix
+                            for (int kk = 0; kk < MQ->k; ++kk) {
+                                const float sp = MQ->step[kk], rc = refined_rcp(sp);
+                                RegChunk<int32_t> qv;
+#pragma unroll
+                                for (int i = 0; i < VN; ++i) qv.v[i] = quantize_one((float)x.v[i], sp, rc, decltype(fast_div)::value);
+                                st_chunk<int32_t, true>(row_far(MQ->Q[kk], dv & 0x7fffffffu, (uint32_t)A.ldq, (uint32_t)goff), qv);
+                            }
                         } else {
                             RegChunk<int32_t> qv;
 #pragma unroll
@@ -766,6 +775,8 @@ __device__ __forceinline__ void tile_body(const TileArgs<T> &A, const typename s
         if constexpr (QM64) {
             load_steps(lane);
             store_final(std::false_type());
+        } else if constexpr (MULTI) {
+            if (MQ->fast_div) store_final(std::true_type()); else store_final(std::false_type());
         } else if constexpr (QM) {
             load_steps(lane);
             if (ST.fast_div) store_final(std::true_type()); else store_final(std::false_type());
@@ -784,6 +795,13 @@ __global__ __launch_bounds__(512, (sizeof(T) == 4 ? 6 : 4)) void tile_kernel(con
                                                    const typename std::conditional<QM, typename StepsFor<T>::type, NoSteps>::type ST)
 {
     tile_body<T, INV, IDENT, QM, SLOTS>(A, ST, (int64_t)blockIdx.x, (int64_t)gridDim.x, (int)blockIdx.y);
+}
+
+// raht_fwd_quant_multi: the fused forward kernels writing one quantization per step table (tile_body / top_body, MULTI)
+template <bool IDENT, int SLOTS>
+__global__ __launch_bounds__(512, 6) void tile_kernel_multi(const TileArgs<float> A, const StepTable ST, const MultiQ M)
+{
+    tile_body<float, false, IDENT, true, SLOTS, false, false, true>(A, ST, (int64_t)blockIdx.x, (int64_t)gridDim.x, (int)blockIdx.y, &M);
 }
 
 // stage 0 of raht_dequant_inv_sqdiff (tile_body, SQ): the fused inverse that compares its output with a reference matrix on the way out
@@ -940,9 +958,9 @@ struct TopArgs {
     uint32_t small_start;              // first butterfly of the chained part
 };
 
-template <typename T, bool INV, bool QM>
+template <typename T, bool INV, bool QM, bool MULTI = false>
 __device__ __forceinline__ void top_body(const TopArgs<T> &A, const typename std::conditional<QM, typename StepsFor<T>::type, NoSteps>::type &ST,
-                                         const int chunk)
+                                         const int chunk, const MultiQ *MQ = nullptr)
 {
     constexpr bool QM64 = QM && sizeof(T) == 8;              // float64 rows, 2 quantized integers per 16-byte chunk
     extern __shared__ __align__(16) unsigned char smem[];
@@ -1110,6 +1128,14 @@ __device__ __forceinline__ void top_body(const TopArgs<T> &A, const typename std
 #pragma unroll
                     for (int i = 0; i < VN; ++i) qv[i] = quantize_one_f64((double)v.v[i], (double)my_step[i]);
                     st_ints<VN>(A.Q + (int64_t)m_dst[k] * A.ldq + goff, qv);
+                } else if constexpr (MULTI) {
+                    for (int kk = 0; kk < MQ->k; ++kk) {
+                        const float sp = MQ->step[kk], rc = refined_rcp(sp);
+                        RegChunk<int32_t> qv;
+#pragma unroll
+                        for (int i = 0; i < VN; ++i) qv.v[i] = quantize_one((float)v.v[i], sp, rc, MQ->fast_div);
+                        st_chunk<int32_t>(MQ->Q[kk] + (int64_t)m_dst[k] * A.ldq + goff, qv);
+                    }
                 } else {
                     RegChunk<int32_t> qv;
 #pragma unroll
@@ -1128,6 +1154,11 @@ __global__ __launch_bounds__(TOP_THREADS) void top_kernel(const TopArgs<T> A,
                                                           const typename std::conditional<QM, typename StepsFor<T>::type, NoSteps>::type ST)
 {
     top_body<T, INV, QM>(A, ST, (int)blockIdx.x);
+}
+
+__global__ __launch_bounds__(TOP_THREADS) void top_kernel_multi(const TopArgs<float> A, const StepTable ST, const MultiQ M)
+{
+    top_body<float, false, true, true>(A, ST, (int)blockIdx.x, &M);
 }
 
 // the top stages of several scenes in one launch (raht_*_batch): blockIdx.y = scene
@@ -1731,6 +1762,73 @@ static int dequant_inv_impl(const raht_plan *cp, const int32_t *Q, int64_t ldq, 
     return RAHT_OK;
 }
 
+/* One forward pass, k quantizations (python/encode_3dgs.py:28,199-217: the drivers quantize ONE coefficient matrix at nine steps):
+ * Q[i] = floor(T / steps[i] + 0.5), reordered, for i < k, each bit-identical to raht_fwd_quant(..., &steps[i], 1, Q[i], ...). */
+static int fwd_quant_multi_impl(const raht_plan *cp, const float *C, int64_t ldc, int D, const float *steps, int k, int32_t *const *Q,
+                                int64_t ldq, raht_stream_t stream)
+{
+    raht_plan *p = const_cast<raht_plan *>(cp);
+    hipStream_t s = (hipStream_t)stream;
+    if (!p || !C || !Q || !steps || k < 1 || D < 1 || ldc < D || ldq < D) { set_error("raht_fwd_quant_multi: bad argument"); return RAHT_ERR_INVALID; }
+    for (int i = 0; i < k; ++i) {
+        if (!Q[i] || !(steps[i] > 0.0f)) { set_error("raht_fwd_quant_multi: Q[%d] / steps[%d]", i, i); return RAHT_ERR_INVALID; }
+        for (int j = 0; j < i; ++j) if (Q[j] == Q[i]) { set_error("raht_fwd_quant_multi: Q[%d] and Q[%d] are the same matrix", j, i); return RAHT_ERR_INVALID; }
+    }
+    RAHT_RET(check_plan_device(p, "raht_fwd_quant_multi"));
+    Schedule *sc = nullptr;
+    int Dc = 0;
+    if (!p->row_map) RAHT_RET(tile_setup<float>(p, D, std::max(ldc, ldq), s, &sc, &Dc));
+    if (!sc || p->row_map || p->root_buf || p->top_level < 64) {
+        // level engine, row-mapped / truncated plans: one call per step
+        for (int i = 0; i < k; ++i) RAHT_RET(fwd_quant_impl<float>(p, C, ldc, D, &steps[i], 1, Q[i], ldq, stream));
+        return RAHT_OK;
+    }
+    for (int k0 = 0; k0 < k; k0 += MULTI_Q_MAX) {
+        MultiQ M;
+        M.k = std::min(MULTI_Q_MAX, k - k0);
+        M.fast_div = 1;
+        for (int i = 0; i < MULTI_Q_MAX; ++i) {
+            M.step[i] = steps[k0 + std::min(i, M.k - 1)];
+            M.Q[i] = Q[k0 + std::min(i, M.k - 1)];
+            if (!(M.step[i] >= 0x1p-100f && M.step[i] <= 0x1p100f)) M.fast_div = 0;
+        }
+        XformIO<float> io;
+        io.src = C; io.ld_src = ldc; io.Q = M.Q[0]; io.ldq = ldq; io.steps = &steps[k0]; io.n_steps = 1;
+        StepTable st;
+        fill_step_table(st, io.steps, 1);
+        const int K = (int)sc->stages.size();
+        for (int kk = 0; kk < K; ++kk) {
+            const Stage &stg = sc->stages[(size_t)kk];
+            if (stg.is_top) {
+                TopArgs<float> A;
+                size_t lds = 0;
+                RAHT_RET((prepare_top_stage<float, false, true>(p, *sc, kk, io, D, A, lds)));
+                static PerDeviceOnce attr;
+                if (attr.first(current_device())) RAHT_HIP_CHECK(hipFuncSetAttribute((const void *)top_kernel_multi, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
+                hipLaunchKernelGGL(top_kernel_multi, dim3((unsigned)((D + 3) / 4)), dim3(TOP_THREADS), lds, s, A, st, M);
+            } else {
+                TileArgs<float> A;
+                TileGeom G;
+                RAHT_RET((prepare_tile_stage<float, false, true>(p, *sc, kk, io, D, Dc, 0, A, G)));
+                const dim3 grid(G.grid_x, G.nchunks);
+                static PerDeviceOnce a11, a12, a01, a02;
+                if (kk == 0 && p->ev_before) RAHT_HIP_CHECK(hipEventRecord(p->ev_before, s));
+                if (G.ident && G.one) { if (a11.first(current_device())) RAHT_HIP_CHECK(hipFuncSetAttribute((const void *)tile_kernel_multi<true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                                        hipLaunchKernelGGL((tile_kernel_multi<true, 1>), grid, dim3(G.threads), G.lds, s, A, st, M); }
+                else if (G.ident) { if (a12.first(current_device())) RAHT_HIP_CHECK(hipFuncSetAttribute((const void *)tile_kernel_multi<true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                                    hipLaunchKernelGGL((tile_kernel_multi<true, 2>), grid, dim3(G.threads), G.lds, s, A, st, M); }
+                else if (G.one) { if (a01.first(current_device())) RAHT_HIP_CHECK(hipFuncSetAttribute((const void *)tile_kernel_multi<false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                                  hipLaunchKernelGGL((tile_kernel_multi<false, 1>), grid, dim3(G.threads), G.lds, s, A, st, M); }
+                else { if (a02.first(current_device())) RAHT_HIP_CHECK(hipFuncSetAttribute((const void *)tile_kernel_multi<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                       hipLaunchKernelGGL((tile_kernel_multi<false, 2>), grid, dim3(G.threads), G.lds, s, A, st, M); }
+                if (kk == 0 && p->ev_before) RAHT_HIP_CHECK(hipEventRecord(p->ev_after, s));
+            }
+            RAHT_HIP_CHECK(hipGetLastError());
+        }
+    }
+    return RAHT_OK;
+}
+
 /* raht_dequant_inv fused with the drivers' distortion measurement (python/encode_3dgs.py:274,298-310: C_rec = iRAHT(...), then
  * torch.mean((C - C_rec) ** 2) over all / quats / scales / opacity / colour columns): the stage-0 kernel of the fused inverse
  * compares every row it reconstructs with the original on its way out and leaves per-column sums of squared differences; C_rec
@@ -1926,6 +2024,12 @@ int raht_dequant_inv(const raht_plan *plan, const int32_t *Q, int64_t ldq, int D
                      float *C, int64_t ldc, raht_stream_t stream)
 {
     return guarded("raht_dequant_inv", [&]() { return dequant_inv_impl<float>(plan, Q, ldq, D, steps, n_steps, C, ldc, stream); });
+}
+
+int raht_fwd_quant_multi(const raht_plan *plan, const float *C, int64_t ldc, int D, const float *steps, int k, int32_t *const *Q,
+                         int64_t ldq, raht_stream_t stream)
+{
+    return guarded("raht_fwd_quant_multi", [&]() { return fwd_quant_multi_impl(plan, C, ldc, D, steps, k, Q, ldq, stream); });
 }
 
 int raht_dequant_inv_sqdiff(const raht_plan *plan, const int32_t *Q, int64_t ldq, int D, const float *steps, int n_steps,

@@ -360,6 +360,22 @@ class RahtPlan:
                 self._set_roots_buffer(None, D, torch.float32)
         return out
 
+    def forward_quant_multi(self, Cmat, steps):
+        """ONE forward pass, one quantization per (scalar) step: -> [Q_0, ..., Q_{k-1}], each bit-identical to
+        ``forward_quant(C, steps[i])`` (the drivers quantize one coefficient matrix at nine steps, python/encode_3dgs.py:28,199-217)."""
+        _need_cuda(Cmat, "C")
+        X = Cmat.to(torch.float32)
+        if X.stride(1) != 1 or X.stride(0) < X.shape[1]:
+            X = X.contiguous()
+        D = X.shape[1]
+        k = len(steps)
+        st = (C.c_float * k)(*[float(s) for s in steps])
+        Qs = [torch.empty((self.N, D), dtype=torch.int32, device=X.device) for _ in range(k)]
+        ptrs = (C.c_void_p * k)(*[q.data_ptr() for q in Qs])
+        with torch.cuda.device(X.device):
+            check(_lib.lib().raht_fwd_quant_multi(self._h, C.c_void_p(X.data_ptr()), X.stride(0), D, st, k, ptrs, D, _stream()))
+        return Qs
+
     def dequant_inverse_sqdiff(self, Q, steps, C_ref, want_rec=True):
         """Un-reorder + dequantize + inverse RAHT (float32, fused) that also compares its output with the original attributes on the
         way out: -> (C_rec or None, float64[D] per-column sums of (C_rec - C_ref)^2). What the drivers' five PSNR columns are made of

@@ -1136,3 +1136,32 @@ def test_forward_and_inverse_of_one_plan_on_two_streams(rt, mixed):
             assert torch.equal(a, b), rep
     p.set_concurrent_directions(False)
     assert torch.equal(di(fq(Cs[0], steps[0]), steps[0]), want[0])
+
+
+# ---- raht_fwd_quant_multi: one forward pass, one quantization per step (encode_3dgs.py:28,199-217) -------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("tile_rows,tail_rows,final_rows", [(0, 0, 0), (64, 64, 64), (128, 64, 0)])
+@pytest.mark.parametrize("name", ["n1000_j10_d14", "n1500_j12_d56", "n2000_j10_d59", "n257_j3_d11", "n3000_j18_d3", "n8_cube_j1", "t_n1"])
+def test_forward_quant_multi_equals_single_step_calls(rt, name, tile_rows, tail_rows, final_rows):
+    import torch
+    g = load_golden(name)
+    p = _plan(rt, g, "tile", tile_rows, tail_rows, 0, final_rows)
+    C = _dev(g["C"])
+    for steps in ([0.37], [1.0, 4.0, 8.0], [0.01 * s for s in (1, 4, 8, 12, 16, 20, 24, 32, 64)], [0.05 * (i + 1) for i in range(14)], [1e-38, 3e38, 1.0]):
+        Qs = p.forward_quant_multi(C, steps)
+        assert len(Qs) == len(steps)
+        for q, s in zip(Qs, steps):
+            assert torch.equal(q, p.forward_quant(C, s)), (name, s)
+
+
+@pytest.mark.gpu
+def test_forward_quant_multi_level_engine_and_errors(rt):
+    import torch
+    from raht_3dgs_codec_amd._lib import RahtError
+    g = load_golden("n1000_j10_d14")
+    p = _plan(rt, g, "level")
+    C = _dev(g["C"])
+    Qs = p.forward_quant_multi(C, [0.5, 2.0])
+    assert torch.equal(Qs[0], p.forward_quant(C, 0.5)) and torch.equal(Qs[1], p.forward_quant(C, 2.0))
+    with pytest.raises(RahtError):
+        p.forward_quant_multi(C, [0.5, 0.0])
