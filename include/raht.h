@@ -412,6 +412,19 @@ int raht_merge_clusters(const int32_t *cluster_indices, const int32_t *cluster_o
                         float *merged_quats, float *merged_scales, float *merged_opacities,
                         float *merged_colors, raht_stream_t stream);
 
+/* VOXELIZE + MERGE in one call and one pass over the rows (the reference runs its voxelizer and then its CUDA merge
+ * kernel back to back: python/test_voxelize_3dgs.py:203-257, cuda/merge_cluster.cu:2-111 -- the sort permutation and the voxel
+ * starts are the merge's cluster indices / offsets, :225-233).
+ *   G    : N whole Gaussians, row-major [x y z | quat(4) | scale(3) | opacity | colour(color_dim)], row stride ldg >= 11 + color_dim
+ *   Gvox : <= N rows of 11 + color_dim: the voxel's INTEGER coordinates as floats (like PCvox), then the merged attributes --
+ *          the frame the RAHT path takes (59 columns at color_dim = 48); merged_means (<= N x 3, may be NULL): the merged positions
+ * Per column exactly raht_merge_clusters' arithmetic on the members in sorted order (weight = opacity, or 1): bit-identical to
+ * raht_voxelize (sort_idx, voxel_indices) followed by raht_merge_clusters on the five split arrays. Other arguments as raht_voxelize. */
+int raht_voxelize_merge(const float *G, int64_t ldg, int64_t N, int color_dim, int weight_by_opacity, const float *vmin_in,
+                        double width_in, int J, uint64_t *keys_sorted, int64_t *sort_idx, int64_t *voxel_indices, float *Gvox,
+                        float *merged_means, int64_t *n_vox, float vmin_out[3], double *width_out, double *voxel_size_out,
+                        raht_stream_t stream);
+
 /* A few rows at explicit positions: Q[pos[i], :] = floor(X[i, :] / step + 0.5) and X[i, :] =
  * Q[pos[i], :] * step (pos: DEVICE int64[n], NULL = identity). Used for the <= 512 top coefficients of
  * a Morton-prefix sharded scene, which the shard-local fused kernels leave to the caller (no

@@ -448,11 +448,122 @@ int raht_voxelize_residuals(const float *PC, int64_t ldpc, int64_t N, int d, con
     return RAHT_OK;
 }
 
+// VOXELIZE + MERGE in one pass over the gathered rows ("fused into the voxelize dedup"). The reference runs the
+// voxelizer and then its CUDA merge kernel back to back (python/test_voxelize_3dgs.py:203-257; cuda/merge_cluster.cu:2-111): the
+// sort permutation and the voxel starts ARE the cluster indices / offsets (:225-233). Here the kernel that walks every voxel's
+// member rows merges them on the way: rows are whole Gaussians [xyz(3) | quat(4) | scale(3) | opacity(1) | colour(cd)], weight =
+// opacity, and per column exactly the arithmetic of merge.hip / merge_cluster.cu -- members in sorted (= index) order, acc =
+// fma(x, w, acc), means / scales acc / (tw == 0 ? 1 : tw), quaternion acc / |acc| (identity if 0), opacity min(sum, 1), colours
+// tw > 0 ? acc / tw : 0 -- so the result is bit-identical to raht_voxelize followed by raht_merge_clusters. Output rows: the
+// voxel's integer coordinates (from its key, as PCvox carries them, voxelize_pc.py:152,155) and the merged attributes; the
+// merged means optionally on their own. One read of every member row instead of two gathers (mean pass + merge pass over five
+// separate arrays).
+__global__ __launch_bounds__(256) void voxel_merge_chunk_kernel(const float *__restrict__ PC, int64_t ldin, int64_t N, int ld, int lg,
+                                                                const uint64_t *__restrict__ keys_sorted, const uint32_t *__restrict__ sort_idx,
+                                                                const uint32_t *__restrict__ vstart, const uint32_t *__restrict__ nvox_dev,
+                                                                float *__restrict__ Gvox, float *__restrict__ merged_means, int weight_by_opacity)
+{
+    if (nvox_dev[-1] != 0u) return;                           // (a sort that gave up left stale indices: see voxel_full_chunk_kernel)
+    const int64_t nvox = *nvox_dev;
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    const int G = 1 << lg, rpi = 64 >> lg;
+    const int U = min(4, 32 / rpi);
+    const int vpi = U * rpi;
+    const int g = lane >> lg, c4 = lane & (G - 1);
+    const int NC = (ld + 3) >> 2;
+    for (int64_t v0 = wave * vpi; v0 < nvox; v0 += nwaves * vpi) {
+        const int64_t vi = v0 + lane;
+        const uint32_t vs = (lane <= vpi && vi < nvox) ? vstart[vi] : (uint32_t)N;
+        uint32_t first = 0, klo = 0, khi = 0;
+        if (lane < vpi && vi < nvox) {
+            first = sort_idx[vs];
+            const uint64_t k = keys_sorted[vs];
+            klo = (uint32_t)k; khi = (uint32_t)(k >> 32);
+        }
+        uint32_t s0[4], e0[4], i0[4], kl[4], kh[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int sel = min(u, U - 1) * rpi + g;
+            s0[u] = (uint32_t)__shfl((int)vs, sel, 64);
+            e0[u] = (uint32_t)__shfl((int)vs, sel + 1, 64);
+            i0[u] = (uint32_t)__shfl((int)first, sel, 64);
+            kl[u] = (uint32_t)__shfl((int)klo, sel, 64);
+            kh[u] = (uint32_t)__shfl((int)khi, sel, 64);
+        }
+        for (int cb = 0; cb < NC; cb += G) {                   // (every lane walks every block of chunks: the shuffles below need them all)
+            const int cc = cb + c4;
+            const bool act = cc < NC;
+            const int goff = min(min(cc, NC - 1) * 4, ld - 4);
+            RegChunk<float> x0[4];
+            float w0[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                x0[u] = ld_chunk<float, true>(PC + (int64_t)i0[u] * ldin + goff);
+                w0[u] = weight_by_opacity ? PC[(int64_t)i0[u] * ldin + 10] : 1.0f;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int64_t v = v0 + u * rpi + g;
+                const bool live = u < U && v < nvox;
+                float tw = w0[u];
+                RegChunk<float> acc;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc.v[q] = (goff + q == 10) ? x0[u].v[q] : __fmaf_rn(x0[u].v[q], w0[u], 0.0f);     // merge_cluster.cu:38-63
+                if (live) for (uint32_t i = s0[u] + 1; i < e0[u]; ++i) {      // further members, sorted (= index) order
+                    const int64_t r = (int64_t)sort_idx[i] * ldin;
+                    const RegChunk<float> b = ld_chunk<float, true>(PC + r + goff);
+                    const float w = weight_by_opacity ? PC[r + 10] : 1.0f;
+                    tw += w;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) acc.v[q] = (goff + q == 10) ? acc.v[q] + b.v[q] : __fmaf_rn(b.v[q], w, acc.v[q]);
+                }
+                // quaternion norm (merge_cluster.cu:76-78): columns 3 .. 6 sit in chunks 0 and 1 of this row group's first block
+                float n2 = 0.0f;
+                if (cb == 0) {
+                    const int l0 = (g << lg), l1 = (g << lg) + 1;
+                    const float qx = __shfl(acc.v[3], l0, 64), qy = __shfl(acc.v[0], l1, 64), qz = __shfl(acc.v[1], l1, 64), qw = __shfl(acc.v[2], l1, 64);
+                    n2 = qx * qx;
+                    n2 = __fmaf_rn(qy, qy, n2);
+                    n2 = __fmaf_rn(qz, qz, n2);
+                    n2 = __fmaf_rn(qw, qw, n2);
+                }
+                if (!live || !act) continue;
+                RegChunk<float> r;
+                float mm[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int c = goff + q;
+                    float y;
+                    if (c < 3 || (c >= 7 && c < 10)) y = __fdiv_rn(acc.v[q], tw == 0.0f ? 1.0f : tw);              // :66-73, :91-93
+                    else if (c < 7) { const float nrm = __fsqrt_rn(n2); y = (nrm > 0.0f) ? __fdiv_rn(acc.v[q], nrm) : (c == 6 ? 1.0f : 0.0f); }   // :76-89
+                    else if (c == 10) y = fminf(acc.v[q], 1.0f);                                                   // :96
+                    else y = (tw > 0.0f) ? __fdiv_rn(acc.v[q], tw) : 0.0f;                                         // :98-110
+                    mm[q] = y;
+                    r.v[q] = y;
+                }
+                if (goff < 3) {
+                    const uint64_t key = ((uint64_t)kh[u] << 32) | kl[u];
+                    const float cx = (float)vx_compact3(key >> 2), cy = (float)vx_compact3(key >> 1), cz = (float)vx_compact3(key);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int c = goff + q;
+                        if (c < 3) { if (merged_means) merged_means[v * 3 + c] = mm[q]; r.v[q] = (c == 0) ? cx : (c == 1 ? cy : cz); }
+                    }
+                }
+                st_chunk<float, true>(Gvox + v * ld + goff, r);
+            }
+        }
+    }
+}
+
 static int voxelize_impl(const float *PC, int64_t ldpc, int64_t N, int d, const float *vmin_in, double width_in,
                          int J, uint64_t *keys_sorted, int64_t *sort_idx, int64_t *voxel_indices, float *PCvox,
                          int64_t *Vvox, int64_t *n_vox, float vmin_out[3], double *width_out,
                          double *voxel_size_out, raht_stream_t stream, uint64_t *voxel_keys,
-                         float *PCsorted = nullptr, float *DeltaPC = nullptr, hipEvent_t keys_ready = nullptr)
+                         float *PCsorted = nullptr, float *DeltaPC = nullptr, hipEvent_t keys_ready = nullptr,
+                         float *merge_means = nullptr, int merge = 0 /* 1: weight = opacity, 2: weight = 1 */)
 {
     if (!PC || N < 1 || d < 0 || ldpc < 3 + d || J < 1 || J > 21 || !n_vox) { set_error("raht_voxelize: bad argument"); return RAHT_ERR_INVALID; }
     if (N >= ((int64_t)1 << 31)) { set_error("raht_voxelize: N too large"); return RAHT_ERR_INVALID; }
@@ -518,7 +629,11 @@ static int voxelize_impl(const float *PC, int64_t ldpc, int64_t N, int d, const 
             }
             if (PCvox || Vvox || want_res) {
                 const unsigned gv = (unsigned)std::min<int64_t>(ceil_div(N, 64), 8192);        // (N >= the voxel count)
-                if (fused) {
+                if (merge) {
+                    int lg = 1;
+                    while ((1 << lg) < (3 + d + 3) / 4 && lg < 4) ++lg;           // at most 16 lanes per row: rows wider than 64 columns take several blocks of chunks
+                    hipLaunchKernelGGL(voxel_merge_chunk_kernel, dim3(gv), dim3(256), 0, s, PC, ldpc, N, 3 + d, lg, ks, idx, vstart, nv_dev, PCvox, merge_means, merge == 1 ? 1 : 0);
+                } else if (fused) {
                     int lg = 1;
                     while ((1 << lg) < (3 + d + 3) / 4 && lg < 6) ++lg;
                     hipLaunchKernelGGL(voxel_full_chunk_kernel, dim3(gv), dim3(256), 0, s, PC, ldpc, N, 3 + d, lg, ks, idx, vstart, nv_dev, PCvox, Vvox,
@@ -557,6 +672,15 @@ int raht_voxelize(const float *PC, int64_t ldpc, int64_t N, int d, const float *
 {
     return voxelize_impl(PC, ldpc, N, d, vmin_in, width_in, J, keys_sorted, sort_idx, voxel_indices, PCvox, Vvox, n_vox, vmin_out,
                          width_out, voxel_size_out, stream, nullptr);
+}
+
+int raht_voxelize_merge(const float *G, int64_t ldg, int64_t N, int color_dim, int weight_by_opacity, const float *vmin_in, double width_in, int J,
+                        uint64_t *keys_sorted, int64_t *sort_idx, int64_t *voxel_indices, float *Gvox, float *merged_means, int64_t *n_vox,
+                        float vmin_out[3], double *width_out, double *voxel_size_out, raht_stream_t stream)
+{
+    if (color_dim < 0 || !Gvox) { set_error("raht_voxelize_merge: bad argument"); return RAHT_ERR_INVALID; }
+    return voxelize_impl(G, ldg, N, 8 + color_dim, vmin_in, width_in, J, keys_sorted, sort_idx, voxel_indices, Gvox, nullptr, n_vox, vmin_out, width_out,
+                         voxel_size_out, stream, nullptr, nullptr, nullptr, nullptr, merged_means, weight_by_opacity ? 1 : 2);
 }
 
 int raht_voxelize_all(const float *PC, int64_t ldpc, int64_t N, int d, const float *vmin_in, double width_in,

@@ -776,6 +776,42 @@ def voxelize_pc_batched(PC, vmin=None, width=None, J=10, device="cuda", residual
 
 
 @torch.no_grad()
+def voxelize_merge(G, vmin=None, width=None, J=10, device="cuda", weight_by_opacity=True, want_means=True):
+    """N whole Gaussians [xyz | quat(4) | scale(3) | opacity | colour(cd)] -> the voxelized frame in ONE call and one pass over the
+    rows (raht_voxelize_merge): voxelizer + the reference's per-voxel opacity-weighted merge (python/test_voxelize_3dgs.py:203-257,
+    cuda/merge_cluster.cu:2-111), bit-identical to ``voxelize_pc_batched`` followed by ``merge_gaussian_clusters_with_indices``.
+    Returns (Gvox (Nvox, 11 + cd): integer voxel coordinates as floats + merged attributes, info: Nvox, voxel_size, vmin, width,
+    N, sort_idx, keys_sorted, voxel_indices, merged_means)."""
+    G = G.to(device)
+    _need_cuda(G, "G")
+    G = G.to(torch.float32).contiguous()
+    N, ld = G.shape
+    if ld < 11:
+        raise ValueError("voxelize_merge: rows are [xyz | quat(4) | scale(3) | opacity | colours]: at least 11 columns")
+    dev = G.device
+    keys = torch.empty(N, dtype=torch.int64, device=dev)
+    idx = torch.empty(N, dtype=torch.int64, device=dev)
+    vidx = torch.empty(N, dtype=torch.int64, device=dev)
+    gv = torch.empty((N, ld), dtype=torch.float32, device=dev)
+    mm = torch.empty((N, 3), dtype=torch.float32, device=dev) if want_means else None
+    nvox = C.c_int64()
+    vmin_out = (C.c_float * 3)()
+    w_out, vs_out = C.c_double(), C.c_double()
+    vm = None
+    if vmin is not None:
+        vm = (C.c_float * 3)(*[float(x) for x in (vmin.detach().cpu().tolist() if isinstance(vmin, torch.Tensor) else vmin)])
+    with torch.cuda.device(dev):
+        check(_lib.lib().raht_voxelize_merge(C.c_void_p(G.data_ptr()), ld, N, ld - 11, 1 if weight_by_opacity else 0, vm,
+                                             -1.0 if width is None else float(width), int(J), C.c_void_p(keys.data_ptr()), C.c_void_p(idx.data_ptr()),
+                                             C.c_void_p(vidx.data_ptr()), C.c_void_p(gv.data_ptr()), C.c_void_p(mm.data_ptr()) if mm is not None else None,
+                                             C.byref(nvox), vmin_out, C.byref(w_out), C.byref(vs_out), _stream()))
+    nv = nvox.value
+    info = {"Nvox": nv, "voxel_size": vs_out.value, "vmin": _vmin_tensor(tuple(vmin_out), dev), "width": w_out.value, "N": N,
+            "sort_idx": idx, "keys_sorted": keys, "voxel_indices": vidx[:nv], "merged_means": None if mm is None else mm[:nv]}
+    return gv[:nv], info
+
+
+@torch.no_grad()
 def voxelize_plan(PC, vmin=None, width=None, J=10, device="cuda"):
     """Unsorted cloud -> (PCvox, plan, info): the voxelizer's own sorted voxel keys go STRAIGHT into the RAHT plan
     (reference: voxelize_pc_batched, python/voxelize_pc.py:62-172, then -- one script later, through a PLY file --

@@ -480,18 +480,33 @@ def format_row_ply(r):
             f"{r['Entropy_dec_time']:.6f},{r['Dequant_time']:.6f},{r['iRAHT_time']:.6f},{r['psnr']:.6f}")
 
 
-def compress_to_nvox(means, quats, scales, opacities, colors, J=10, device="cuda:0", output_ply=None):
+def compress_to_nvox(means, quats, scales, opacities, colors, J=10, device="cuda:0", output_ply=None, fused=True):
     """N Gaussians -> Nvox voxelized Gaussians: counterpart of the reference's compress_to_nvox
     (python/test_voxelize_3dgs.py:160-288): voxelize the means (:203), use the sort permutation and
     the voxel starts as cluster indices / offsets (:225-233), merge all attributes per voxel with
     opacity weights (:247-257), and optionally save the voxelized frame with integer voxel
     coordinates and the voxel_size / vmin header comments (:281-288) -- the input format of
-    ``encode_3dgs``. Returns (V_int int64 (Nvox,3), attributes float32 (Nvox, 8 + color_dim), info)."""
+    ``encode_3dgs``. Returns (V_int int64 (Nvox,3), attributes float32 (Nvox, 8 + color_dim), info).
+
+    fused=True: ONE call, one pass over the rows (``ops.voxelize_merge`` / raht_voxelize_merge: the kernel that walks every voxel's
+    members merges them on the way); fused=False: the reference's two steps (voxelizer, then the merge kernel). Same bits."""
     from .merge import merge_gaussian_clusters_with_indices
-    from .ops import voxelize_pc_batched
+    from .ops import voxelize_merge, voxelize_pc_batched
     from .ply_io import save_ply
     means = means.to(device).float().contiguous()
     N = means.shape[0]
+    if fused:
+        G = torch.cat([means, quats.to(device).float(), scales.to(device).float(), opacities.to(device).float().reshape(-1, 1),
+                       colors.to(device).float().reshape(N, -1)], dim=1).contiguous()
+        Gvox, info = voxelize_merge(G, J=J, device=device, weight_by_opacity=True)
+        V_int = Gvox[:, :3].long()                                                 # :267
+        attributes = Gvox[:, 3:]                                                   # layout of data_util.py:366
+        mq, ms, mo, mc = Gvox[:, 3:7], Gvox[:, 7:10], Gvox[:, 10], Gvox[:, 11:]
+        if output_ply is not None:
+            save_ply(output_ply, Gvox[:, :3], mq, ms, mo, mc, voxel_size=info["voxel_size"], vmin=info["vmin"])
+        cluster_offsets = torch.cat([info["voxel_indices"], torch.tensor([N], dtype=torch.int64, device=means.device)]).int()
+        info = dict(info, cluster_indices=info["sort_idx"].int(), cluster_offsets=cluster_offsets)
+        return V_int, attributes, info
     PCvox, _, voxel_indices, _, info = voxelize_pc_batched(means, J=J, device=device, residuals=False, sorted_points=False)
     cluster_indices = info["sort_idx"].int()                                       # :225-226
     cluster_offsets = torch.cat([voxel_indices, torch.tensor([N], dtype=torch.int64, device=means.device)]).int()   # :230-233
