@@ -119,7 +119,10 @@ def test_forward_inverse_f64(rt, name, eng):
     p = _plan(rt, g, *eng)
     C = _dev(g["C"].astype(np.float64))
     T, w = p.forward(C)
-    np.testing.assert_allclose(T.cpu().numpy(), g["T"], rtol=1e-12, atol=1e-12)
+    # (frames with xyz columns, mx_*: inputs up to 4095, coefficients up to 1e5 -- the absolute part of the bar scales with the
+    # column's magnitude there, as in tests/test_gpu_fullsize.py; a high-pass coefficient is a difference of such numbers)
+    atol = 1e-12 * np.maximum(1.0, np.abs(g["T"]).max(axis=0)) if name.startswith("mx_") else 1e-12
+    assert np.all(np.abs(T.cpu().numpy() - g["T"]) <= atol + 1e-12 * np.abs(g["T"])), name
     assert np.array_equal(w.cpu().numpy().reshape(-1), g["w"])
     Crec = p.inverse(T)
     np.testing.assert_allclose(Crec.cpu().numpy(), g["C"].astype(np.float64), rtol=1e-12,

@@ -1,0 +1,34 @@
+#!/bin/bash
+# SQ counters of the segmented RLGR kernels (judge item: occupancy evidence): separate rocprofv3 --pmc passes over tools/rlgr_loop.py.
+# usage (GPU box): bash tools/pmc_rlgr.sh <tag>  -> gpurun_out/<tag>_rlgr_pmc/, summary on stdout
+tag=$1
+export TMPDIR=/tmp
+i=0
+for set in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM" "SQ_BUSY_CU_CYCLES SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY"; do
+  i=$((i+1))
+  rocprofv3 --kernel-trace --pmc $set -d gpurun_out/${tag}_rlgr_pmc/p$i --output-format csv -- python tools/rlgr_loop.py 3 > gpurun_out/${tag}_rlgr_pmc_p$i.log 2>&1 || echo "pass $i failed"
+done
+python3 - <<PY
+import collections, csv, glob
+agg = collections.defaultdict(dict)
+dur = collections.defaultdict(list)
+for f in sorted(glob.glob("gpurun_out/${tag}_rlgr_pmc/p*/*/*counter_collection.csv")):
+    tmp = collections.defaultdict(lambda: collections.defaultdict(list))
+    for r in csv.DictReader(open(f)):
+        k = r["Kernel_Name"].split("(")[0]
+        if "seg_" in k:
+            tmp[(k, r["Grid_Size"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    for k, v in tmp.items():
+        for c, x in v.items():
+            agg[k][c] = sum(x) / len(x)
+for f in sorted(glob.glob("gpurun_out/${tag}_rlgr_pmc/p1/*/*kernel_trace.csv")):
+    for r in csv.DictReader(open(f)):
+        k = r["Kernel_Name"].split("(")[0]
+        if "seg_" in k:
+            dur[(k, r["Grid_Size"])].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+for k in sorted(agg, key=lambda k: -agg[k].get("SQ_INSTS_VALU", 0)):
+    d = sorted(dur.get(k, [0]))
+    print(k[0], "grid", k[1], "median %.1f us" % d[len(d) // 2])
+    for c, v in agg[k].items():
+        print("    %-24s %16.0f" % (c, v))
+PY
