@@ -456,11 +456,15 @@ def two_stream_loop(R, L, _lib, kd, Cd, nbits, step, reps=200):
     ref = Cr.clone()
     p.set_concurrent_directions(True)
     overlapped(40)
-    t2 = timed_loop(overlapped, reps)
+    # (how the two streams' launches interleave is up to the hardware queues: small scenes show two modes -- the tails of one
+    # direction under the other's stage 0, or both stage-0 kernels at once and both tails at once: five trials, the median is quoted)
+    trials = sorted(timed_loop(overlapped, reps) for _ in range(5))
+    t2 = trials[2]
     torch.cuda.synchronize()
     assert torch.equal(Cr, ref), "two-stream loop reconstructs differently"
     alg = 2 * (8.0 * N * D + 8.0 * N)
     return {"rows": N, "channels": D, "one_stream_ms_per_step": round(t1, 4), "two_streams_ms_per_step": round(t2, 4),
+            "two_streams_trials_ms": [round(t, 4) for t in trials],
             "one_stream_frac_of_peak": round(alg / (t1 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "two_streams_frac_of_peak": round(alg / (t2 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
             "two_streams_value": round(N / (t2 * 1e-3) / 1e6, 1), "unit": "M-Gaussians/s", "bit_identical": True}
 

@@ -13,6 +13,6 @@ timeout -k 10 300 python3 tools/e2e_frame.py --entropy gpu --keep-rec 0 --out gp
 timeout -k 10 300 bash tools/trace_mx.sh ${tag} > gpurun_out/${tag}_mixed_kernel_durations.txt 2>&1
 timeout -k 10 400 bash tools/pmc_rlgr.sh ${tag} > gpurun_out/${tag}_rlgr_sq_counters.txt 2>&1
 timeout -k 10 300 bash tools/pmc_mx.sh ${tag}mx > gpurun_out/${tag}_mixed_sq_counters.txt 2>&1
-# N > 1 rehearsal on the one GPU (6 ranks: the process guard's limit), so that the multi_gpu fields of such a line can be reviewed
-timeout -k 10 500 python3 bench.py --gpus 6 --backend gloo --workload cfg5 --rows 6000000 --steps 20 --warmup 5 --settle-steps 0 --skip-legs --skip-prelude > gpurun_out/${tag}_rehearsal_6rank_cfg5_gloo_one_gpu.json 2>> gpurun_out/${tag}_bench.err
+# N > 1 rehearsal on the one GPU (4 ranks: the process guard allows 6 processes on the card, and the launcher and the parent count), so that the multi_gpu fields of such a line can be reviewed
+timeout -k 10 500 python3 bench.py --gpus 4 --backend gloo --workload cfg5 --rows 6000000 --steps 20 --warmup 5 --settle-steps 0 --skip-legs --skip-prelude > gpurun_out/${tag}_rehearsal_4rank_cfg5_gloo_one_gpu.json 2>> gpurun_out/${tag}_bench.err
 for f in mixed_vs_f32 two_streams dequant_inv_sqdiff fwd_quant_multi voxelize_merge; do echo "$f: $(cat gpurun_out/${tag}_$f.json | cut -c1-400)"; done

@@ -65,11 +65,12 @@ def run(n, J, D, seed, reps=200):
     ref = Cr.clone()
     p.set_concurrent_directions(True)
     overlapped(20)
-    t_two = timed(overlapped, reps)
+    trials = sorted(timed(overlapped, reps) for _ in range(5))       # (two modes on small scenes: see bench.py two_stream_loop)
+    t_two = trials[2]
     torch.cuda.synchronize()
     assert torch.equal(Cr, ref), "two-stream loop reconstructs differently"
     alg = 2 * (8.0 * N * D + 8.0 * N)
-    return {"rows": N, "channels": D, "J": J, "one_stream_ms_per_step": round(t_serial, 4), "two_streams_ms_per_step": round(t_two, 4),
+    return {"rows": N, "channels": D, "J": J, "one_stream_ms_per_step": round(t_serial, 4), "two_streams_ms_per_step": round(t_two, 4), "two_streams_trials_ms": [round(t, 4) for t in trials],
             "one_stream_frac_of_peak": round(alg / (t_serial * 1e-3) / 8e12, 4), "two_streams_frac_of_peak": round(alg / (t_two * 1e-3) / 8e12, 4),
             "bit_identical": True}
 
