@@ -528,6 +528,28 @@ int raht_rlgr_seg_decode_strided(const uint8_t *in, int64_t in_bytes, const uint
                                  int D, int seg_len, int flag_signed, int32_t *Q, int64_t sym_stride, int64_t chan_stride,
                                  uint32_t *bad_dev, raht_stream_t stream);
 
+/* k frames of ONE shape in one set of launches -- the quantization steps of a frame (python/encode_3dgs.py:199-275 codes them one
+ * after the other; nothing connects them). One frame of 3 M x 56 symbols is 1.25 waves per SIMD of independent streams, and the
+ * coder's time is that of one wave walking its segments; k frames behind blockIdx.y fill the chip's wave slots. Arrays of k
+ * HOST pointers / sizes; every frame keeps its own tables and container and gets EXACTLY the bytes the one-frame entry points
+ * above leave for it (same layouts, same limits per frame, 1 <= k <= RAHT_RLGR_BATCH_MAX). The encoder synchronises and
+ * fills total_bytes[k] (RAHT_ERR_NOMEM: some cap[j] < total_bytes[j]); the decoder does not synchronise and sets bit j of
+ * *bad_dev when a table entry of frame j reached outside in[j]. */
+#define RAHT_RLGR_BATCH_MAX 12
+int raht_rlgr_seg_encode_batch(int k, const int32_t *const *Q, int64_t N, int D, int64_t sym_stride, int64_t chan_stride, int seg_len,
+                               int flag_signed, uint32_t *const *seg_bytes, uint32_t *const *seg_off, uint8_t *const *out,
+                               const int64_t *cap, int64_t *total_bytes, raht_stream_t stream);
+int raht_rlgr_seg_decode_batch(int k, const uint8_t *const *in, const int64_t *in_bytes, const uint32_t *const *seg_off,
+                               const uint32_t *const *seg_bytes, int64_t N, int D, int seg_len, int flag_signed, int32_t *const *Q,
+                               int64_t sym_stride, int64_t chan_stride, uint32_t *bad_dev, raht_stream_t stream);
+
+/* How the decoders' symbols leave the lanes: -1 = chosen by the number of lanes in flight (default: one 4-byte store per symbol
+ * below 200 000 lanes, where the L2 still gathers a lane's line; above, a 16-word LDS column per lane written out as aligned
+ * 64-byte pieces -- with the steps of a frame decoded together the one-word stores cost 5.9 x the symbols' bytes in HBM writes),
+ * 0 = words, 1 = 16-byte register groups, 2 = LDS columns. Same output in every mode (tests walk all of them); a tuning and
+ * testing knob, process-wide. Returns the previous setting. */
+int raht_debug_rlgr_decode_out(int mode);
+
 /* out[c] = sum over rows of (A[i, c] - B[i, c])^2, DEVICE double[D]: what the drivers' five PSNR columns are made of
  * (python/encode_3dgs.py:298-310: torch.mean((C - C_rec) ** 2) over all / quats / scales / opacity / colour columns -- each a
  * sum of these D numbers divided by the element count). A, B: N x D DEVICE matrices of dtype RAHT_F32 or RAHT_F64 (differences

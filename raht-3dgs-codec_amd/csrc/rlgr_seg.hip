@@ -211,10 +211,24 @@ struct DevBitReader {
     }
 };
 
-// VEC: the segment starts on a 16-byte boundary: symbols leave four at a time
-template <bool VEC>
-__device__ __forceinline__ void decode_segment(const uint32_t *in32, uint32_t nbytes, int n, int flag_signed, int32_t *__restrict__ seq, int64_t sstr = 1)
+// How the decoded symbols leave (OUT_*). A lane decodes its own segment, so a wave's store of one symbol per lane touches 64
+// different lines, four bytes each. While few lanes are in flight (one frame: 82 k) the L2 gathers a lane's consecutive symbols
+// into whole lines before they go to HBM; with the steps of a frame decoded together (738 k lanes, 8 waves per SIMD) the
+// half-written lines no longer fit and leave early: 35.4 GB of HBM writes for 6.05 GB of symbols (rocprofv3 WRITE_SIZE,
+// profiles/r04b_rlgr_batch_sq_counters.txt), and that traffic -- not the instruction stream -- was the decoder's time.
+// OUT_LDS: a lane parks its symbols in a 16-word column of LDS ([16][64] words: the bank is the lane, no conflicts) and
+// writes them as one aligned 64-byte piece (4 x 16 bytes, back to back) whenever the column is full. Needs unit symbol stride
+// and 16-byte aligned segment starts.
+// OUT_VEC (kept behind a switch, round 3): four symbols buffered in registers, 16-byte stores -- slower than OUT_WORD on one
+// frame (the component selects cost more than the stores save).
+enum { OUT_WORD = 0, OUT_VEC = 1, OUT_LDS = 2 };
+constexpr int DEC_LDS_WORDS = 16 * 64;
+
+template <int OUT>
+__device__ __forceinline__ void decode_segment(const uint32_t *in32, uint32_t nbytes, int n, int flag_signed, int32_t *__restrict__ seq, int64_t sstr = 1,
+                                               int32_t *lds = nullptr)
 {
+    constexpr bool VEC = OUT == OUT_VEC;
     DevBitReader r;
     r.in32 = in32; r.size = nbytes;
     // 32-bit state, as in the encoder: inside a segment of n < 2^31 symbols of int32 data the symbol values (< 2^32), the run
@@ -223,8 +237,19 @@ __device__ __forceinline__ void decode_segment(const uint32_t *in32, uint32_t nb
     uint32_t k_P = 0, k_RP = 2 * L;
     int i = 0;
     int4 buf = make_int4(0, 0, 0, 0);
+    int32_t *col = lds + (threadIdx.x & 63);                          // OUT_LDS: this lane's column
     auto emit = [&](int32_t v) {
-        if (VEC) {
+        if (OUT == OUT_LDS) {
+            col[(i & 15) * 64] = v;
+            ++i;
+            if ((i & 15) == 0) {                                     // the column is full: one aligned 64-byte piece
+                int4 x[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) x[q] = make_int4(col[(4 * q) * 64], col[(4 * q + 1) * 64], col[(4 * q + 2) * 64], col[(4 * q + 3) * 64]);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) *(int4 *)(seq + i - 16 + 4 * q) = x[q];
+            }
+        } else if (VEC) {
             const int q = i & 3;
             if (q == 0) buf.x = v; else if (q == 1) buf.y = v; else if (q == 2) buf.z = v; else buf.w = v;
             ++i;
@@ -264,12 +289,29 @@ __device__ __forceinline__ void decode_segment(const uint32_t *in32, uint32_t nb
             else k_P += U0;
         }
     }
+    if (OUT == OUT_LDS && (i & 15)) {                                // the last, partial column
+        const int b = i & ~15;
+        for (int q = 0; q < (i & 15); ++q) seq[b + q] = col[q * 64];
+    }
     if (VEC && (i & 3)) {                                            // the last, partial group (n not a multiple of four)
         const int b = i & ~3;
         seq[b] = buf.x;
         if ((i & 3) > 1) seq[b + 1] = buf.y;
         if ((i & 3) > 2) seq[b + 2] = buf.z;
     }
+}
+
+// which way the decoded symbols leave (see OUT_*): RAHT_RLGR_DECODE_OUT=word|vec|lds overrides (A/B knob)
+// Default: by the number of lanes in flight. One 3 M x 56 frame (82 k lanes, 1.25 waves per SIMD) is bound by ONE wave's
+// instruction stream and the L2 still gathers its lines: OUT_WORD 2.86 ms, OUT_LDS 3.36 ms, OUT_VEC 3.97 ms. Nine such frames by
+// one launch (738 k lanes): OUT_WORD 1.76 ms per frame (HBM writes 5.9 x the symbols), OUT_LDS 0.99 ms, OUT_VEC 1.81 ms.
+static int g_decode_out = -1;                                       // raht_debug_rlgr_decode_out
+static int decode_out_mode(int64_t lanes)
+{
+    static const char *e = getenv("RAHT_RLGR_DECODE_OUT");
+    if (g_decode_out >= 0) return g_decode_out;
+    if (e) return e[0] == 'l' ? OUT_LDS : e[0] == 'v' ? OUT_VEC : OUT_WORD;
+    return lanes >= 200000 ? OUT_LDS : OUT_WORD;
 }
 
 // segment g = c * nseg + s  <->  symbols [s * S, min(N, (s + 1) * S)) of channel c
@@ -356,8 +398,9 @@ __global__ void seg_pad_kernel(const uint32_t *__restrict__ seg_bytes, int64_t n
 
 __global__ __launch_bounds__(64) void seg_decode_kernel(const uint8_t *__restrict__ in, uint64_t in_bytes, const uint32_t *__restrict__ seg_off,
                                                         const uint32_t *__restrict__ seg_bytes, int64_t N, int D, int S, int nseg, int flag_signed,
-                                                        int32_t *__restrict__ Q, int64_t sym_stride, int64_t chan_stride, uint32_t *__restrict__ bad)
+                                                        int32_t *__restrict__ Q, int64_t sym_stride, int64_t chan_stride, uint32_t *__restrict__ bad, int out_mode)
 {
+    __shared__ int32_t s_col[DEC_LDS_WORDS];
     // thread t -> segment g = c * nseg + s. Channel-major input (sym_stride == 1): t = g, a lane walks its own contiguous run.
     // Row-major input (the quantized coefficients as the transform kernels leave them: symbol n of channel c at Q[n * ld + c]):
     // t = s * D + c -- the lanes of a wave are NEIGHBOURING CHANNELS at the same position of their segments, so every step of
@@ -376,9 +419,95 @@ __global__ __launch_bounds__(64) void seg_decode_kernel(const uint8_t *__restric
     if ((off & 3) || off > in_bytes || (uint64_t)((nb + 3u) & ~3u) > in_bytes - off) { nb = 0; if (bad) atomicOr(bad, 1u); }
     // (16-byte stores of four buffered symbols measured SLOWER than one 4-byte store per symbol -- 4.2 against 3.0 ms for 3 M x 56
     // at 2048 per segment: the component selects cost more instructions than the stores save; kept behind this switch)
-    const bool vec = false && sym_stride == 1 && ((((uintptr_t)Q) & 15) == 0) && ((chan_stride & 3) == 0) && ((S & 3) == 0);
-    if (vec) decode_segment<true>((const uint32_t *)(in + (nb ? off : 0)), nb, n, flag_signed, Q + (int64_t)c * chan_stride + i0);
-    else decode_segment<false>((const uint32_t *)(in + (nb ? off : 0)), nb, n, flag_signed, Q + (int64_t)c * chan_stride + i0 * sym_stride, sym_stride);
+    const bool aligned = sym_stride == 1 && ((((uintptr_t)Q) & 15) == 0) && ((chan_stride & 3) == 0) && ((S & 3) == 0);
+    if (aligned && out_mode == OUT_LDS) decode_segment<OUT_LDS>((const uint32_t *)(in + (nb ? off : 0)), nb, n, flag_signed, Q + (int64_t)c * chan_stride + i0, 1, s_col);
+    else if (aligned && out_mode == OUT_VEC) decode_segment<OUT_VEC>((const uint32_t *)(in + (nb ? off : 0)), nb, n, flag_signed, Q + (int64_t)c * chan_stride + i0);
+    else decode_segment<OUT_WORD>((const uint32_t *)(in + (nb ? off : 0)), nb, n, flag_signed, Q + (int64_t)c * chan_stride + i0 * sym_stride, sym_stride);
+}
+
+// ---- several frames of ONE shape in one set of launches ------------------------------------------------------------
+// What bounds the coders is the number of independent lanes: one frame (3 M x 56 at 2048 symbols per segment) is 1.25 waves
+// per SIMD, and a wave that is alone on its SIMD waits out the latency of every one of its ~480 k dependent instructions.
+// The quantization steps of a frame (python/encode_3dgs.py:199-275: nine of them) are nine such frames of the same shape with
+// nothing between them: coded by ONE launch (blockIdx.y = frame) they fill every wave slot of the chip. Each frame keeps
+// its own tables and container: the bytes are those of the one-frame entry points.
+constexpr int SEG_BATCH_MAX = RAHT_RLGR_BATCH_MAX;
+struct SegEncJobs {
+    const int32_t *Q[SEG_BATCH_MAX]; uint32_t *seg_bytes[SEG_BATCH_MAX]; uint32_t *seg_off[SEG_BATCH_MAX]; uint8_t *out[SEG_BATCH_MAX];
+    uint64_t cap[SEG_BATCH_MAX];
+};
+struct SegDecJobs {
+    const uint8_t *in[SEG_BATCH_MAX]; uint64_t in_bytes[SEG_BATCH_MAX]; const uint32_t *seg_off[SEG_BATCH_MAX]; const uint32_t *seg_bytes[SEG_BATCH_MAX];
+    int32_t *Q[SEG_BATCH_MAX];
+};
+
+// flags: two words per frame (overflow bits, container bytes)
+__global__ __launch_bounds__(64) void seg_encode_slots_batch_kernel(const SegEncJobs J, int64_t N, int D, int64_t sym_stride, int64_t chan_stride, int S, int nseg,
+                                                                    int flag_signed, uint8_t *__restrict__ slots, uint32_t slot, uint32_t *__restrict__ flags)
+{
+    const int j = blockIdx.y;
+    const int64_t t = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    const int64_t G = (int64_t)D * nseg;
+    if (t >= G) return;
+    int c, s;
+    if (sym_stride == 1) { c = (int)(t / nseg); s = (int)(t - (int64_t)c * nseg); }
+    else { s = (int)(t / D); c = (int)(t - (int64_t)s * D); }
+    const int64_t g = (int64_t)c * nseg + s;
+    const int64_t i0 = (int64_t)s * S;
+    const int n = (int)min((int64_t)S, N - i0);
+    const int32_t *Q = J.Q[j];
+    const int32_t *seq = Q + (int64_t)c * chan_stride + i0 * sym_stride;
+    const bool vec = sym_stride == 1 && ((((uintptr_t)Q) & 15) == 0) && ((chan_stride & 3) == 0) && ((S & 3) == 0);
+    uint32_t *o = (uint32_t *)(slots + ((size_t)j * (size_t)G + (size_t)g) * slot);
+    const uint32_t nb = vec ? encode_segment<true, true>(seq, n, flag_signed, o, slot) : encode_segment<true, false>(seq, n, flag_signed, o, slot, sym_stride);
+    J.seg_bytes[j][g] = nb;
+    if (((nb + 3u) & ~3u) > slot) atomicOr(flags + 2 * j, 1u);
+}
+
+__global__ void seg_pad_batch_kernel(const SegEncJobs J, int64_t G, uint32_t *__restrict__ padded)
+{
+    const int j = blockIdx.y;
+    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g < G) padded[(size_t)j * (size_t)G + g] = (J.seg_bytes[j][g] + 3u) & ~3u;
+}
+
+// (also closes every frame's offset table: seg_off[G] = its container's bytes, left in flags[2 j + 1] by the scan)
+__global__ __launch_bounds__(256) void seg_compact_batch_kernel(const SegEncJobs J, const uint8_t *__restrict__ slots, uint32_t slot, int64_t G,
+                                                                uint32_t *__restrict__ flags)
+{
+    const int j = blockIdx.y;
+    const int64_t g = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    if (blockIdx.x == 0 && threadIdx.x == 0) J.seg_off[j][G] = flags[2 * j + 1];
+    if (g >= G) return;
+    const uint32_t nw = (J.seg_bytes[j][g] + 3u) >> 2;
+    const uint64_t off = J.seg_off[j][g];
+    if (off + 4ull * nw > J.cap[j]) { if (lane == 0) atomicOr(flags + 2 * j, 2u); return; }
+    const uint32_t *src = (const uint32_t *)(slots + ((size_t)j * (size_t)G + (size_t)g) * slot);
+    uint32_t *dst = (uint32_t *)(J.out[j] + off);
+    for (uint32_t i = lane; i < nw; i += 64) dst[i] = src[i];
+}
+
+__global__ __launch_bounds__(64) void seg_decode_batch_kernel(const SegDecJobs J, int64_t N, int D, int S, int nseg, int flag_signed, int64_t sym_stride,
+                                                              int64_t chan_stride, uint32_t *__restrict__ bad, int out_mode)
+{
+    __shared__ int32_t s_col[DEC_LDS_WORDS];
+    const int j = blockIdx.y;
+    const int64_t t = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    if (t >= (int64_t)D * nseg) return;
+    int c, s;
+    if (sym_stride == 1) { c = (int)(t / nseg); s = (int)(t - (int64_t)c * nseg); }
+    else { s = (int)(t / D); c = (int)(t - (int64_t)s * D); }
+    const int64_t g = (int64_t)c * nseg + s;
+    const int64_t i0 = (int64_t)s * S;
+    const int n = (int)min((int64_t)S, N - i0);
+    const uint64_t off = J.seg_off[j][g], in_bytes = J.in_bytes[j];
+    uint32_t nb = J.seg_bytes[j][g];
+    if ((off & 3) || off > in_bytes || (uint64_t)((nb + 3u) & ~3u) > in_bytes - off) { nb = 0; if (bad) atomicOr(bad, 1u << j); }
+    int32_t *Q = J.Q[j];
+    const bool aligned = sym_stride == 1 && ((((uintptr_t)Q) & 15) == 0) && ((chan_stride & 3) == 0) && ((S & 3) == 0);
+    if (aligned && out_mode == OUT_LDS) decode_segment<OUT_LDS>((const uint32_t *)(J.in[j] + (nb ? off : 0)), nb, n, flag_signed, Q + (int64_t)c * chan_stride + i0, 1, s_col);
+    else decode_segment<OUT_WORD>((const uint32_t *)(J.in[j] + (nb ? off : 0)), nb, n, flag_signed, Q + (int64_t)c * chan_stride + i0 * sym_stride, sym_stride);
 }
 
 }  // namespace rlgr_seg
@@ -489,7 +618,115 @@ int raht_rlgr_seg_decode_strided(const uint8_t *in, int64_t in_bytes, const uint
     const int64_t nseg = ceil_div(N, seg_len), G = nseg * D;
     if (G >= ((int64_t)1 << 31)) { set_error("raht_rlgr_seg_decode: too many segments"); return RAHT_ERR_INVALID; }
     hipLaunchKernelGGL(rlgr_seg::seg_decode_kernel, dim3((unsigned)ceil_div(G, 64)), dim3(64), 0, (hipStream_t)stream, in, (uint64_t)in_bytes, seg_off, seg_bytes, N, D,
-                       seg_len, (int)nseg, flag_signed, Q, sym_stride, chan_stride, bad_dev);
+                       seg_len, (int)nseg, flag_signed, Q, sym_stride, chan_stride, bad_dev, rlgr_seg::decode_out_mode(G));
+    RAHT_HIP_CHECK(hipGetLastError());
+    return RAHT_OK;
+}
+
+int raht_debug_rlgr_decode_out(int mode)
+{
+    const int prev = rlgr_seg::g_decode_out;
+    rlgr_seg::g_decode_out = (mode >= 0 && mode <= 2) ? mode : -1;
+    return prev;
+}
+
+/* k frames of one shape (N, D, strides, seg_len) in one set of launches: the quantization steps of a frame coded together.
+ * Every frame j has its own input Q[j], tables seg_bytes[j] / seg_off[j], container out[j] of cap[j] bytes and total_bytes[j]:
+ * exactly what raht_rlgr_seg_encode_strided leaves for that frame alone (same bytes). Synchronises. RAHT_ERR_NOMEM when a
+ * container is too small (total_bytes[] holds what every frame needs). */
+int raht_rlgr_seg_encode_batch(int k, const int32_t *const *Q, int64_t N, int D, int64_t sym_stride, int64_t chan_stride, int seg_len, int flag_signed,
+                               uint32_t *const *seg_bytes, uint32_t *const *seg_off, uint8_t *const *out, const int64_t *cap, int64_t *total_bytes,
+                               raht_stream_t stream)
+{
+    if (k < 1 || k > RAHT_RLGR_BATCH_MAX || !Q || !seg_bytes || !seg_off || !out || !cap || !total_bytes) {
+        set_error("raht_rlgr_seg_encode_batch: bad argument (1 <= k <= %d)", RAHT_RLGR_BATCH_MAX);
+        return RAHT_ERR_INVALID;
+    }
+    if (N < 1 || D < 1 || sym_stride < 1 || chan_stride < 1 || seg_len < 64 ||
+        !((sym_stride == 1 && chan_stride >= N) || (chan_stride == 1 && sym_stride >= D))) {
+        set_error("raht_rlgr_seg_encode_batch: bad argument (channel-major: sym_stride 1, chan_stride >= N; row-major: chan_stride 1, sym_stride >= D)");
+        return RAHT_ERR_INVALID;
+    }
+    for (int j = 0; j < k; ++j)
+        if (!Q[j] || !seg_bytes[j] || !seg_off[j] || !out[j] || cap[j] < 16 || ((uintptr_t)out[j] & 3)) { set_error("raht_rlgr_seg_encode_batch: bad argument (frame %d)", j); return RAHT_ERR_INVALID; }
+    const int64_t nseg = ceil_div(N, seg_len), G = nseg * D;
+    if (nseg >= ((int64_t)1 << 31) || G >= ((int64_t)1 << 31)) { set_error("raht_rlgr_seg_encode_batch: too many segments"); return RAHT_ERR_INVALID; }
+    if (raht_rlgr_bound(seg_len) * G + 4 * G >= ((int64_t)1 << 32)) {
+        set_error("raht_rlgr_seg_encode_batch: %lld x %d symbols may need a container of 4 GiB or more (32-bit segment offsets): split the frame", (long long)N, D);
+        return RAHT_ERR_INVALID;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    auto one_by_one = [&]() -> int {
+        int rc_all = RAHT_OK;
+        for (int j = 0; j < k; ++j) {
+            const int rc = raht_rlgr_seg_encode_strided(Q[j], N, D, sym_stride, chan_stride, seg_len, flag_signed, seg_bytes[j], seg_off[j], out[j], cap[j], &total_bytes[j], stream);
+            if (rc != RAHT_OK && rc_all == RAHT_OK) rc_all = rc;
+            if (rc != RAHT_OK && rc != RAHT_ERR_NOMEM) return rc;
+        }
+        return rc_all;
+    };
+    static const bool no_batch = getenv("RAHT_RLGR_NO_BATCH") != nullptr;          // A/B knob
+    if (k == 1 || no_batch) return one_by_one();
+    const uint32_t slot = 4u * (uint32_t)seg_len + 16u;
+    int rc = guarded("raht_rlgr_seg_encode_batch", [&]() -> int {
+        Scratch tmp(sizeof(uint32_t) * ((size_t)k * (size_t)G + 2 * (size_t)k), s);
+        Scratch slots((size_t)k * (size_t)G * slot, s);
+        if (!tmp.ok() || !slots.ok()) { (void)hipGetLastError(); return RAHT_ERR_UNSUPPORTED; }      // no room for k sets of slots: frame by frame
+        uint32_t *padded = tmp.as<uint32_t>(), *flags = padded + (size_t)k * (size_t)G;
+        RAHT_HIP_CHECK(hipMemsetAsync(flags, 0, 8 * (size_t)k, s));
+        rlgr_seg::SegEncJobs J;
+        for (int j = 0; j < RAHT_RLGR_BATCH_MAX; ++j) {
+            const int q = j < k ? j : 0;
+            J.Q[j] = Q[q]; J.seg_bytes[j] = seg_bytes[q]; J.seg_off[j] = seg_off[q]; J.out[j] = out[q]; J.cap[j] = (uint64_t)cap[q];
+        }
+        hipLaunchKernelGGL(rlgr_seg::seg_encode_slots_batch_kernel, dim3((unsigned)ceil_div(G, 64), (unsigned)k), dim3(64), 0, s, J, N, D, sym_stride, chan_stride, seg_len,
+                           (int)nseg, flag_signed, slots.as<uint8_t>(), slot, flags);
+        hipLaunchKernelGGL(rlgr_seg::seg_pad_batch_kernel, dim3((unsigned)ceil_div(G, 256), (unsigned)k), dim3(256), 0, s, J, G, padded);
+        for (int j = 0; j < k; ++j) RAHT_RET(exclusive_scan_u32(padded + (size_t)j * (size_t)G, seg_off[j], G, flags + 2 * j + 1, s));
+        hipLaunchKernelGGL(rlgr_seg::seg_compact_batch_kernel, dim3((unsigned)ceil_div(G * 64, 256), (unsigned)k), dim3(256), 0, s, J, slots.as<uint8_t>(), slot, G, flags);
+        RAHT_HIP_CHECK(hipGetLastError());
+        uint32_t back[2 * RAHT_RLGR_BATCH_MAX] = {0};
+        RAHT_RET(read_back_u32(back, flags, 2 * k, nullptr, nullptr, 0, s));        // (synchronises: the scratch may go back to the pool)
+        int rc2 = RAHT_OK;
+        for (int j = 0; j < k; ++j) {
+            if (back[2 * j] & 1u) return RAHT_ERR_UNSUPPORTED;                        // a segment outgrew its slot (incompressible data): the exact passes
+            total_bytes[j] = (int64_t)back[2 * j + 1];
+            if ((back[2 * j] & 2u) || (int64_t)back[2 * j + 1] > cap[j]) {
+                set_error("raht_rlgr_seg_encode_batch: frame %d needs %u bytes, cap = %lld", j, back[2 * j + 1], (long long)cap[j]);
+                rc2 = RAHT_ERR_NOMEM;
+            }
+        }
+        return rc2;
+    });
+    if (rc == RAHT_ERR_UNSUPPORTED) return one_by_one();
+    return rc;
+}
+
+/* The inverse for k frames of one shape: in[j] / in_bytes[j] / seg_off[j] / seg_bytes[j] -> Q[j], one launch. Does not
+ * synchronise. *bad_dev (DEVICE uint32, may be NULL): bit j set when a table entry of frame j reached outside in[j]. */
+int raht_rlgr_seg_decode_batch(int k, const uint8_t *const *in, const int64_t *in_bytes, const uint32_t *const *seg_off, const uint32_t *const *seg_bytes,
+                               int64_t N, int D, int seg_len, int flag_signed, int32_t *const *Q, int64_t sym_stride, int64_t chan_stride,
+                               uint32_t *bad_dev, raht_stream_t stream)
+{
+    if (k < 1 || k > RAHT_RLGR_BATCH_MAX || !in || !in_bytes || !seg_off || !seg_bytes || !Q || N < 1 || D < 1 || seg_len < 64 ||
+        !((sym_stride == 1 && chan_stride >= N) || (chan_stride == 1 && sym_stride >= D))) {
+        set_error("raht_rlgr_seg_decode_batch: bad argument (1 <= k <= %d)", RAHT_RLGR_BATCH_MAX);
+        return RAHT_ERR_INVALID;
+    }
+    for (int j = 0; j < k; ++j)
+        if (!in[j] || in_bytes[j] < 0 || (in_bytes[j] & 3) || ((uintptr_t)in[j] & 3) || !seg_off[j] || !seg_bytes[j] || !Q[j]) {
+            set_error("raht_rlgr_seg_decode_batch: bad argument (frame %d)", j);
+            return RAHT_ERR_INVALID;
+        }
+    const int64_t nseg = ceil_div(N, seg_len), G = nseg * D;
+    if (G >= ((int64_t)1 << 31)) { set_error("raht_rlgr_seg_decode_batch: too many segments"); return RAHT_ERR_INVALID; }
+    rlgr_seg::SegDecJobs J;
+    for (int j = 0; j < RAHT_RLGR_BATCH_MAX; ++j) {
+        const int q = j < k ? j : 0;
+        J.in[j] = in[q]; J.in_bytes[j] = (uint64_t)in_bytes[q]; J.seg_off[j] = seg_off[q]; J.seg_bytes[j] = seg_bytes[q]; J.Q[j] = Q[q];
+    }
+    hipLaunchKernelGGL(rlgr_seg::seg_decode_batch_kernel, dim3((unsigned)ceil_div(G, 64), (unsigned)k), dim3(64), 0, (hipStream_t)stream, J, N, D, seg_len, (int)nseg,
+                       flag_signed, sym_stride, chan_stride, bad_dev, rlgr_seg::decode_out_mode((int64_t)k * G));
     RAHT_HIP_CHECK(hipGetLastError());
     return RAHT_OK;
 }

@@ -39,7 +39,7 @@ def _psnr(a, b):
 
 
 def encode_frame(V_int, attributes, J, steps, frame=1, device="cuda:0", dtype=torch.float32, fused=True,
-                 nthreads=0, channel_major=True, overlap=False, entropy="host", seg_len=2048, keep_rec=True):
+                 nthreads=0, channel_major=True, overlap=False, entropy="host", seg_len=2048, keep_rec=True, batch_steps=False):
     """One frame through the whole pipeline. Returns a list of dict rows (one per step) with the CSV
     columns plus ``size_bytes`` and ``C_rec`` (last step) for inspection, and the stages the reference's CSV has no
     column for (``Transpose_time``, ``D2H_time``, ``H2D_time``, ``PSNR_time``, ``Step_wall_time``).
@@ -52,10 +52,17 @@ def encode_frame(V_int, attributes, J, steps, frame=1, device="cuda:0", dtype=to
     inverts and accumulates the PSNR columns' sums of squares (raht_dequant_inv_sqdiff); rows then carry ``C_rec = None``.
     entropy="gpu": the RLGR stage on the device, segmented (rlgr.SegmentedCoder: every ``seg_len`` symbols of a channel an
     independent stream, byte-identical to the reference coder's output for that slice): the integers never leave the GPU, only
-    the container's bytes do (``D2H_time``). Rates then count the container (streams + 4 bytes per segment)."""
+    the container's bytes do (``D2H_time``). Rates then count the container (streams + 4 bytes per segment).
+    batch_steps=True (entropy="gpu", float32, scalar steps): ALL steps of the frame at once -- one forward transform with every
+    step's quantizer (raht_fwd_quant_multi), one set of coder launches for all steps' integers (raht_rlgr_seg_encode_batch: k times
+    the independent streams, which is what the coder's speed depends on), one decoder launch; same rows, same bytes. Stage times of
+    the shared launches are split evenly over the rows, which carry ``Batched_steps``."""
     if entropy == "gpu":
         if not fused:
             raise ValueError("entropy='gpu' goes with the fused path")
+        scalar = all(isinstance(st, (int, float)) for st in steps)
+        if batch_steps and scalar and dtype == torch.float32 and len(steps) > 1:
+            return _encode_frame_gpu_entropy_batched(V_int, attributes, J, steps, frame, device, seg_len, keep_rec)
         return _encode_frame_gpu_entropy(V_int, attributes, J, steps, frame, device, dtype, seg_len, keep_rec)
     if overlap and fused:
         return _encode_frame_overlapped(V_int, attributes, J, steps, frame, device, dtype, nthreads, keep_rec)
@@ -249,6 +256,86 @@ def _encode_frame_gpu_entropy(V_int, attributes, J, steps, frame, device, dtype,
         r["Step_wall_time"] = time.time() - t_step0
         r["C_rec"] = C_rec
         rows.append(r)
+    return rows
+
+
+def _encode_frame_gpu_entropy_batched(V_int, attributes, J, steps, frame, device, seg_len, keep_rec=True):
+    """encode_frame(entropy="gpu", batch_steps=True): the loop of python/encode_3dgs.py:199-275 turned inside out -- every stage
+    runs ONCE for all steps (in chunks of the 12 a call takes): forward RAHT with k quantizers -> k containers from one set of
+    coder launches -> [container bytes to the host] -> k frames decoded by one launch -> round-trip check -> per step the fused
+    dequantize + inverse RAHT + PSNR sums."""
+    N = V_int.shape[0]
+    dev = torch.device(device)
+    dtype = torch.float32
+    C = attributes.to(dtype=dtype).contiguous().to(dev)
+    _sync()
+    V = V_int.to(dtype=torch.float64).to(dev)
+    origin = torch.tensor([0, 0, 0], dtype=V.dtype, device=dev)
+    t0 = time.time()
+    ListC, FlagsC, weightsC, order_RAGFT = RAHT_param_reorder_fast(V, origin, 2 ** J, J)
+    _sync()
+    t_prelude = time.time() - t0
+    plan = plan_of(ListC)
+    D = C.shape[1]
+    rows = []
+    KMAX = rlgr_mod.SegmentedCoder.BATCH_MAX
+    for lo in range(0, len(steps), KMAX):
+        chunk = [float(x) for x in steps[lo: lo + KMAX]]
+        k = len(chunk)
+        t_chunk0 = time.time()
+        t0 = time.time()
+        Qs = plan.forward_quant_multi(C, chunk)                 # one forward pass, k quantizations (row-major (N, D) each)
+        _sync()
+        t_fwd = time.time() - t0
+        coders = [rlgr_mod.SegmentedCoder(N, D, seg_len, 1, dev) for _ in chunk]
+        _sync()
+        t0 = time.time()
+        rlgr_mod.SegmentedCoder.encode_batch(coders, Qs)        # (returns the sizes: synchronises)
+        t_enc = time.time() - t0
+        t0 = time.time()
+        sizes = []
+        for c in coders:                                        # what goes on the wire, frame by frame: page-locked D2H
+            hdr, lens, payload = c.container_parts()
+            sizes.append(len(hdr) + lens.nbytes + payload.nbytes)
+            assert sizes[-1] == c.size_bytes
+        t_d2h = time.time() - t0
+        t0 = time.time()
+        backs = rlgr_mod.SegmentedCoder.decode_batch(coders)    # channel-major (see _encode_frame_gpu_entropy)
+        _sync()
+        t_dec = time.time() - t0
+        t0 = time.time()
+        qds = [rlgr_mod.transpose_on_device(b) for b in backs]
+        _sync()
+        t_tr = time.time() - t0
+        del backs
+        t0 = time.time()
+        for qd, q in zip(qds, Qs):
+            assert torch.equal(qd, q), "RLGR roundtrip failed"                       # encode_3dgs.py:242-245
+        assert int(coders[0].bad.item()) == 0, "RLGR roundtrip failed"
+        t_chk = time.time() - t0
+        del Qs, coders
+        t_shared = time.time() - t_chunk0
+        for j, step in enumerate(chunk):
+            r = dict(Frame=frame, Quantization_Step=steps[lo + j], Batched_steps=k)
+            t_step0 = time.time()
+            r["RAHT_transform_time"], r["Quant_time"], r["Coeff_reorder_enc_time"] = t_fwd / k, 0.0, 0.0
+            r["Transpose_time"], r["Entropy_enc_time"], r["D2H_time"], r["Entropy_dec_time"] = t_tr / k, t_enc / k, t_d2h / k, t_dec / k
+            r["Roundtrip_check_time"], r["H2D_time"] = t_chk / k, 0.0
+            t0 = time.time()
+            C_rec = _decode_and_measure(plan, qds[j], step, C, dtype, r, keep_rec)
+            _sync()
+            r["iRAHT_time"], r["Dequant_time"], r["Coeff_reorder_dec_time"] = time.time() - t0, 0.0, 0.0
+            qds[j] = None
+            r["RAHT_prelude_time"] = t_prelude
+            r["Total_enc_time"] = r["RAHT_transform_time"] + r["Entropy_enc_time"]
+            r["Total_dec_time"] = r["Entropy_dec_time"] + r["iRAHT_time"]
+            r["Pipeline_time"] = t_prelude + r["Total_enc_time"] + r["Total_dec_time"]
+            r["Rate_bpp"] = sizes[j] * 8 / N
+            r["size_bytes"] = sizes[j]
+            r["PSNR_time"] = 0.0
+            r["Step_wall_time"] = t_shared / k + (time.time() - t_step0)
+            r["C_rec"] = C_rec if (keep_rec and lo + j == len(steps) - 1) else None   # (k reconstructions of 0.7 GB each: the last one only)
+            rows.append(r)
     return rows
 
 

@@ -292,6 +292,79 @@ class SegmentedCoder:
                                                           C.c_void_p(out.data_ptr()), sym, chan, C.c_void_p(self.bad.data_ptr()), self._stream()))
         return out
 
+    BATCH_MAX = 12                                            # RAHT_RLGR_BATCH_MAX
+
+    @staticmethod
+    def _same_shape(coders, what):
+        c0 = coders[0]
+        for c in coders[1:]:
+            if (c.N, c.D, c.S, c.flag, c.device) != (c0.N, c0.D, c0.S, c0.flag, c0.device):
+                raise ValueError(f"SegmentedCoder.{what}: the coders of a batch share N, D, seg_len, flag and device")
+        return c0
+
+    @classmethod
+    def encode_batch(cls, coders, Qs):
+        """The quantization steps of a frame coded together (raht_rlgr_seg_encode_batch): ``coders[j].encode(Qs[j])`` for every j,
+        in ONE set of launches -- k times the independent streams of one frame, which is what the coder's speed depends on. Same
+        containers, byte for byte. All Qs in the same layout ((N, D) row-major or (D, N) channel-major) with the same strides.
+        -> list of container payload sizes (synchronises)."""
+        import torch
+        if len(coders) != len(Qs) or not coders:
+            raise ValueError("SegmentedCoder.encode_batch: one input per coder")
+        c0 = cls._same_shape(coders, "encode_batch")
+        st = [c._strides(Q, "encode_batch") for c, Q in zip(coders, Qs)]
+        if any(x != st[0] for x in st):
+            raise ValueError("SegmentedCoder.encode_batch: the inputs of a batch share their layout and strides")
+        sym, chan = st[0]
+        L = _lib.lib()
+        for lo in range(0, len(coders), cls.BATCH_MAX):
+            cs, qs = coders[lo: lo + cls.BATCH_MAX], Qs[lo: lo + cls.BATCH_MAX]
+            k = len(cs)
+            VP, I64 = C.c_void_p * k, C.c_int64 * k
+            tot = I64()
+            for attempt in (0, 1):
+                with torch.cuda.device(c0.device):
+                    rc = L.raht_rlgr_seg_encode_batch(k, VP(*[q.data_ptr() for q in qs]), c0.N, c0.D, sym, chan, c0.S, c0.flag,
+                                                      VP(*[c.seg_bytes.data_ptr() for c in cs]), VP(*[c.seg_off.data_ptr() for c in cs]),
+                                                      VP(*[c.out.data_ptr() for c in cs]), I64(*[c.cap for c in cs]), tot, c0._stream())
+                if rc == _lib.RAHT_OK or attempt == 1 or all(int(tot[j]) <= cs[j].cap for j in range(k)):
+                    check(rc)
+                    break
+                for j, c in enumerate(cs):                    # incompressible data: the exact sizes are known now
+                    if int(tot[j]) > c.cap:
+                        c.cap = int(tot[j]) + 64
+                        c.out = torch.empty(c.cap, dtype=torch.uint8, device=c.device)
+            for j, c in enumerate(cs):
+                c.total = int(tot[j])
+        return [c.total for c in coders]
+
+    @classmethod
+    def decode_batch(cls, coders, outs=None, row_major=False):
+        """``coders[j].decode()`` for every j in ONE launch (raht_rlgr_seg_decode_batch) -> list of (D, N) int32 CUDA tensors ((N, D)
+        with ``row_major=True``); enqueued on the current stream, no synchronisation. ``coders[0].bad`` collects the frames whose
+        tables reached outside their payload (bit j of a chunk of 12)."""
+        import torch
+        if not coders:
+            return []
+        c0 = cls._same_shape(coders, "decode_batch")
+        if outs is None:
+            outs = [torch.empty((c0.N, c0.D) if row_major else (c0.D, c0.N), dtype=torch.int32, device=c0.device) for _ in coders]
+        st = [c._strides(o, "decode_batch") for c, o in zip(coders, outs)]
+        if len(outs) != len(coders) or any(x != st[0] for x in st):
+            raise ValueError("SegmentedCoder.decode_batch: one output per coder, all in the same layout")
+        sym, chan = st[0]
+        L = _lib.lib()
+        for lo in range(0, len(coders), cls.BATCH_MAX):
+            cs, os_ = coders[lo: lo + cls.BATCH_MAX], outs[lo: lo + cls.BATCH_MAX]
+            k = len(cs)
+            VP, I64 = C.c_void_p * k, C.c_int64 * k
+            with torch.cuda.device(c0.device):
+                check(L.raht_rlgr_seg_decode_batch(k, VP(*[c.out.data_ptr() for c in cs]), I64(*[(c.total + 3) // 4 * 4 for c in cs]),
+                                                   VP(*[c.seg_off.data_ptr() for c in cs]), VP(*[c.seg_bytes.data_ptr() for c in cs]),
+                                                   c0.N, c0.D, c0.S, c0.flag, VP(*[o.data_ptr() for o in os_]), sym, chan,
+                                                   C.c_void_p(c0.bad.data_ptr()), c0._stream()))
+        return outs
+
     def segment(self, c, s):
         """the bytes of segment s of channel c (host copy; tests)"""
         g = c * self.nseg + s

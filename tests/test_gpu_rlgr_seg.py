@@ -7,6 +7,16 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(params=[-1, 0, 1, 2], ids=["out_auto", "out_word", "out_vec", "out_lds"], autouse=True)
+def _decoder_output_mode(request):
+    """every test with each of the ways the decoders' symbols leave the lanes (raht_debug_rlgr_decode_out): these frames are far
+    too small for the default to pick the LDS columns by itself"""
+    from raht_3dgs_codec_amd import _lib
+    prev = _lib.lib().raht_debug_rlgr_decode_out(request.param)
+    yield
+    _lib.lib().raht_debug_rlgr_decode_out(prev)
+
+
 def _cases():
     rng = np.random.default_rng(11)
     lap = lambda n, b: np.rint(rng.laplace(0, b, size=n)).astype(np.int64)          # noqa: E731
@@ -167,3 +177,81 @@ def test_container_header_limits():
     rc = _lib.lib().raht_rlgr_seg_encode_strided(C.c_void_p(Q.data_ptr()), 600_000_000, 1, 1, 600_000_000, 2048, 1, C.c_void_p(sc.seg_bytes.data_ptr()),
                                                  C.c_void_p(sc.seg_off.data_ptr()), C.c_void_p(sc.out.data_ptr()), sc.cap, C.byref(tot), None)
     assert rc == -1 and b"4 GiB" in _lib.lib().raht_last_error()
+
+
+def _step_frames(k, N=30000, D=8, seed=5):
+    """k 'quantization steps' of one frame: the same Laplacian coefficients divided by growing steps (sparser and sparser)"""
+    rng = np.random.default_rng(seed)
+    base = rng.laplace(0, 40.0, size=(N, D)) * np.linspace(0.2, 3.0, D)[None, :]
+    return [np.floor(base / (1.0 + 1.7 * j) + 0.5).astype(np.int32) for j in range(k)]
+
+
+@pytest.mark.parametrize("k,seg_len,row_major", [(1, 1000, True), (3, 64, True), (9, 2048, True), (4, 1000, False), (13, 4096, True), (12, 100000, False)])
+def test_batch_of_frames_is_every_frame_alone(k, seg_len, row_major):
+    """raht_rlgr_seg_encode_batch / _decode_batch: the steps of a frame coded by one set of launches -- same tables and containers
+    as one call per frame, byte for byte (k = 13: two chunks of the 12 a call takes)"""
+    import torch
+    from raht_3dgs_codec_amd import rlgr
+    frames = _step_frames(k)
+    N, D = frames[0].shape
+    Qs = [torch.from_numpy(f).cuda() if row_major else torch.from_numpy(np.ascontiguousarray(f.T)).cuda() for f in frames]
+    alone = [rlgr.SegmentedCoder(N, D, seg_len) for _ in range(k)]
+    for c, Q in zip(alone, Qs):
+        c.encode(Q)
+    batch = [rlgr.SegmentedCoder(N, D, seg_len) for _ in range(k)]
+    totals = rlgr.SegmentedCoder.encode_batch(batch, Qs)
+    assert totals == [c.total for c in alone]
+    for a, b in zip(alone, batch):
+        assert torch.equal(a.seg_bytes, b.seg_bytes) and torch.equal(a.seg_off, b.seg_off)
+        assert torch.equal(a.out[: a.total], b.out[: b.total])
+        assert a.container() == b.container()
+    for rm in (False, True):
+        outs = rlgr.SegmentedCoder.decode_batch(batch, row_major=rm)
+        for o, f in zip(outs, frames):
+            assert torch.equal(o, torch.from_numpy(f if rm else np.ascontiguousarray(f.T)).cuda())
+    assert int(batch[0].bad.item()) == 0
+    # decoders built from the wire format, decoded together
+    wire = [rlgr.SegmentedCoder.from_container(b.container()) for b in batch]
+    for o, f in zip(rlgr.SegmentedCoder.decode_batch(wire, row_major=True), frames):
+        assert torch.equal(o, torch.from_numpy(f).cuda())
+
+
+def test_batch_with_an_incompressible_frame_and_bad_arguments():
+    """one frame of a batch outgrows its slots (raw 32-bit noise): the call falls back to the exact passes frame by frame and the
+    buffers grow; corrupt tables of ONE frame set ITS bit; argument checks"""
+    import ctypes as C
+    import torch
+    from raht_3dgs_codec_amd import _lib, rlgr
+    frames = _step_frames(3, N=20000, D=6)
+    rng = np.random.default_rng(2)
+    frames[1] = rng.integers(-2 ** 31, 2 ** 31 - 1, size=frames[1].shape).astype(np.int32)
+    N, D = frames[0].shape
+    Qs = [torch.from_numpy(f).cuda() for f in frames]
+    batch = [rlgr.SegmentedCoder(N, D, 512) for _ in frames]
+    rlgr.SegmentedCoder.encode_batch(batch, Qs)
+    assert batch[1].total > 4 * N * D                                   # the escapes cost more than a raw dump
+    for c, Q in zip(batch, Qs):
+        alone = rlgr.SegmentedCoder(N, D, 512)
+        alone.encode(Q)
+        assert alone.container() == c.container()
+    outs = rlgr.SegmentedCoder.decode_batch(batch, row_major=True)
+    assert all(torch.equal(o, Q) for o, Q in zip(outs, Qs)) and int(batch[0].bad.item()) == 0
+    batch[2].seg_off[5] = 2 ** 31 - 4                                   # a table entry of frame 2 points far outside its payload
+    rlgr.SegmentedCoder.decode_batch(batch, row_major=True)
+    torch.cuda.synchronize()
+    assert int(batch[0].bad.item()) == 1 << 2
+    with pytest.raises(ValueError):
+        rlgr.SegmentedCoder.encode_batch(batch, Qs[:2])
+    with pytest.raises(ValueError):
+        rlgr.SegmentedCoder.encode_batch(batch[:2] + [rlgr.SegmentedCoder(N, D, 1024)], Qs)
+    with pytest.raises(ValueError):
+        rlgr.SegmentedCoder.encode_batch(batch, [Qs[0], Qs[1], Qs[2].t().contiguous()])
+    L = _lib.lib()
+    VP, I64 = C.c_void_p * 1, C.c_int64 * 1
+    tot = I64()
+    c0 = batch[0]
+    args = lambda k, seg: (k, VP(Qs[0].data_ptr()), N, D, D, 1, seg, 1, VP(c0.seg_bytes.data_ptr()), VP(c0.seg_off.data_ptr()), VP(c0.out.data_ptr()),   # noqa: E731
+                           I64(c0.cap), tot, None)
+    assert L.raht_rlgr_seg_encode_batch(*args(0, 512)) == -1                # RAHT_ERR_INVALID
+    assert L.raht_rlgr_seg_encode_batch(*args(13, 512)) == -1                # RAHT_ERR_INVALID
+    assert L.raht_rlgr_seg_encode_batch(*args(1, 8)) == -1                # RAHT_ERR_INVALID

@@ -28,18 +28,19 @@ ap.add_argument("--threads", type=int, default=0)
 ap.add_argument("--entropy", default="host", choices=["host", "gpu"])
 ap.add_argument("--seg-len", type=int, default=2048)
 ap.add_argument("--keep-rec", type=int, default=1, help="0: the decode side never writes C_rec (raht_dequant_inv_sqdiff)")
+ap.add_argument("--batch-steps", type=int, default=0, help="1 (with --entropy gpu): all steps through every stage at once")
 ap.add_argument("--steps", default="0.01,0.04,0.08,0.12,0.16,0.20,0.24,0.32,0.64")
 a = ap.parse_args()
 os.makedirs(a.out, exist_ok=True)
 V, keys, C = synth.scene(a.rows, a.J, a.D, seed=2)
 steps = [float(x) for x in a.steps.split(",")]
 Vt, Ct = torch.from_numpy(V), torch.from_numpy(C)
-kw = dict(nthreads=a.threads, overlap=bool(a.overlap), entropy=a.entropy, seg_len=a.seg_len, keep_rec=bool(a.keep_rec))
-pipeline.encode_frame(Vt, Ct, a.J, steps[:1], frame=0, **kw)         # warm-up (encode_3dgs.py:88-118)
+kw = dict(nthreads=a.threads, overlap=bool(a.overlap), entropy=a.entropy, seg_len=a.seg_len, keep_rec=bool(a.keep_rec), batch_steps=bool(a.batch_steps))
+pipeline.encode_frame(Vt, Ct, a.J, steps[:2] if a.batch_steps else steps[:1], frame=0, **kw)         # warm-up (encode_3dgs.py:88-118)
 t0 = time.time()
 rows = pipeline.encode_frame(Vt, Ct, a.J, steps, frame=1, **kw)
 wall = time.time() - t0
-tag = "gpu_entropy" if a.entropy == "gpu" else ("overlap" if a.overlap else "sequential")
+tag = ("gpu_entropy_batched" if a.batch_steps else "gpu_entropy") if a.entropy == "gpu" else ("overlap" if a.overlap else "sequential")
 with open(os.path.join(a.out, f"runtime_3dgs_{tag}.csv"), "w") as f:
     f.write(pipeline.CSV_HEADER + "\n" + "\n".join(pipeline.format_row(r) for r in rows) + "\n")
 extra = []

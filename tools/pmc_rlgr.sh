@@ -1,12 +1,15 @@
 #!/bin/bash
 # SQ counters of the segmented RLGR kernels (judge item: occupancy evidence): separate rocprofv3 --pmc passes over tools/rlgr_loop.py.
-# usage (GPU box): bash tools/pmc_rlgr.sh <tag>  -> gpurun_out/<tag>_rlgr_pmc/, summary on stdout
+# usage (GPU box): bash tools/pmc_rlgr.sh <tag> [script and its arguments, default "tools/rlgr_loop.py 3"]  -> gpurun_out/<tag>_rlgr_pmc/, summary on stdout
+#   bash tools/pmc_rlgr.sh r04b_batch tools/time_rlgr_batch.py 2     (the nine steps of a frame by one set of launches)
 tag=$1
+shift
+cmd=${*:-tools/rlgr_loop.py 3}
 export TMPDIR=/tmp
 i=0
-for set in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM" "SQ_BUSY_CU_CYCLES SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY"; do
+for set in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM" "SQ_BUSY_CU_CYCLES SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY" "SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INST_CYCLES_VMEM_WR SQ_INST_CYCLES_VMEM_RD" "WRITE_SIZE" "FETCH_SIZE"; do
   i=$((i+1))
-  rocprofv3 --kernel-trace --pmc $set -d gpurun_out/${tag}_rlgr_pmc/p$i --output-format csv -- python tools/rlgr_loop.py 3 > gpurun_out/${tag}_rlgr_pmc_p$i.log 2>&1 || echo "pass $i failed"
+  rocprofv3 --kernel-trace --pmc $set -d gpurun_out/${tag}_rlgr_pmc/p$i --output-format csv -- python3 $cmd > gpurun_out/${tag}_rlgr_pmc_p$i.log 2>&1 || echo "pass $i failed"
 done
 python3 - <<PY
 import collections, csv, glob
@@ -30,5 +33,5 @@ for k in sorted(agg, key=lambda k: -agg[k].get("SQ_INSTS_VALU", 0)):
     d = sorted(dur.get(k, [0]))
     print(k[0], "grid", k[1], "median %.1f us" % d[len(d) // 2])
     for c, v in agg[k].items():
-        print("    %-24s %16.0f" % (c, v))
+        print("    %-24s %16.0f" % (c, v) + ("   (KiB; FETCH_SIZE counts half of wide coalesced reads on gfx950)" if c in ("WRITE_SIZE", "FETCH_SIZE") else ""))
 PY
