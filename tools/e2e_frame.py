@@ -36,7 +36,7 @@ V, keys, C = synth.scene(a.rows, a.J, a.D, seed=2)
 steps = [float(x) for x in a.steps.split(",")]
 Vt, Ct = torch.from_numpy(V), torch.from_numpy(C)
 kw = dict(nthreads=a.threads, overlap=bool(a.overlap), entropy=a.entropy, seg_len=a.seg_len, keep_rec=bool(a.keep_rec), batch_steps=bool(a.batch_steps))
-pipeline.encode_frame(Vt, Ct, a.J, steps[:2] if a.batch_steps else steps[:1], frame=0, **kw)         # warm-up (encode_3dgs.py:88-118)
+pipeline.encode_frame(Vt, Ct, a.J, steps if a.batch_steps else steps[:1], frame=0, **kw)         # warm-up (encode_3dgs.py:88-118)
 t0 = time.time()
 rows = pipeline.encode_frame(Vt, Ct, a.J, steps, frame=1, **kw)
 wall = time.time() - t0
