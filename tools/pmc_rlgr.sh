@@ -28,7 +28,8 @@ for f in sorted(glob.glob("gpurun_out/${tag}_rlgr_pmc/p1/*/*kernel_trace.csv")):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"].split("(")[0]
         if "seg_" in k:
-            dur[(k, r.get("Grid_Size") or r.get("Grid_Size_X"))].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+            g = r.get("Grid_Size") or str(int(r["Grid_Size_X"]) * int(r.get("Grid_Size_Y") or 1) * int(r.get("Grid_Size_Z") or 1))
+            dur[(k, g)].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
 for k in sorted(agg, key=lambda k: -agg[k].get("SQ_INSTS_VALU", 0)):
     d = sorted(dur.get(k, [0]))
     print(k[0], "grid", k[1], "median %.1f us" % d[len(d) // 2])
