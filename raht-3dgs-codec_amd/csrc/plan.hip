@@ -577,6 +577,9 @@ constexpr int HT_MAX_ROWS = 1024, HT_MAX_STAGES = 8;
 struct HeightStage {
     const uint32_t *rows; const int32_t *wl, *wr; const uint8_t *lvl; uint8_t *ht;
     int64_t n; int R; uint32_t first_tile;
+    // launched BEFORE the host knows the stage sizes (build_schedule_fast): the entry count and whether the stage is a tile
+    // stage at all come from the schedule builder's device state; first_tile then counts the tiles of the stages' CAPACITIES
+    const uint32_t *n_dev, *kind_dev; uint32_t kind_tile;
 };
 struct HeightArgs { HeightStage st[HT_MAX_STAGES]; int n_stages; uint32_t n_tiles; int64_t N; int top_level; };
 
@@ -591,13 +594,15 @@ __global__ __launch_bounds__(64) void tile_heights_kernel(const HeightArgs H)
     const int R = S.R;
     const int lane = threadIdx.x;
     const int64_t e0 = (int64_t)(blockIdx.x - S.first_tile) * R;
-    if (e0 >= S.n) return;
+    if (S.kind_dev && *S.kind_dev != S.kind_tile) return;
+    const int64_t Sn = S.n_dev ? (int64_t)*S.n_dev : S.n;
+    if (e0 >= Sn) return;
     const uint32_t *__restrict__ rows = S.rows;
-    const int nt = (int)min((int64_t)R, S.n - e0);
+    const int nt = (int)min((int64_t)R, Sn - e0);
     uint8_t *s_cur = ht_smem;                                   // [R]
     uint32_t *s_row = (uint32_t *)(ht_smem + ((R + 15) & ~15)); // [R], later stages only
     const int64_t start_row = rows ? (int64_t)rows[e0] : e0;
-    const int64_t end_row = (e0 + R < S.n) ? (rows ? (int64_t)rows[e0 + R] : e0 + R) : H.N;
+    const int64_t end_row = (e0 + R < Sn) ? (rows ? (int64_t)rows[e0 + R] : e0 + R) : H.N;
     int lv[SPL], part[SPL];
     int32_t wlv[SPL], wrv[SPL];
     int64_t r[SPL];
@@ -702,6 +707,7 @@ static int launch_stage_heights(raht_plan *plan, Schedule &sc, hipStream_t s)
         HeightStage &h = H.st[H.n_stages++];
         h.rows = st.rows; h.wl = st.rows ? st.e_wl : plan->wl; h.wr = st.rows ? st.e_wr : plan->wr; h.lvl = st.rows ? st.e_lvl : plan->lvl;
         h.ht = st.e_ht; h.n = st.n_entries; h.R = st.tile_rows; h.first_tile = H.n_tiles;
+        h.n_dev = nullptr; h.kind_dev = nullptr; h.kind_tile = 0;
         H.n_tiles += (uint32_t)st.n_tiles;
         maxR = std::max(maxR, st.tile_rows);
         any_rows = any_rows || st.rows != nullptr;
@@ -1225,9 +1231,10 @@ __global__ __launch_bounds__(ST_THREADS) void sched_tail_kernel(SchedState *S, i
 static int get_schedule_exact(raht_plan *plan, int R0, int R1, int Rf, hipStream_t s, Schedule **out);
 
 // -> RAHT_OK and *built = true when the schedule was built; *built = false: use the exact builder
-static int build_schedule_fast(raht_plan *plan, int R0, int R1, int Rf, hipStream_t s, Schedule &sc, bool *built)
+static int build_schedule_fast(raht_plan *plan, int R0, int R1, int Rf, hipStream_t s, Schedule &sc, bool *built, bool *heights_done)
 {
     *built = false;
+    *heights_done = false;
     const int64_t N = plan->N;
     // Sizes are unknown on the host. Stages expected to be large (a stage keeps ~1/20 of its entries at 184 rows per
     // tile, ~1/6 at 64: assume 1/16 resp. 1/4) get the two multi-workgroup launches; from the first stage expected to
@@ -1244,7 +1251,7 @@ static int build_schedule_fast(raht_plan *plan, int R0, int R1, int Rf, hipStrea
         double expect = (double)N;
         while (KS < KB - 1 && KS < plan->max_stages && (KS == 0 || expect > (double)TAIL_MAX * 0.5)) { ++KS; expect /= (R0 >= 128 ? 16.0 : 4.0); }
     }
-    struct Bufs { uint32_t *rows = nullptr; int32_t *wl = nullptr, *wr = nullptr; uint8_t *lvl = nullptr; uint32_t *pos = nullptr; uint32_t *surv = nullptr; };
+    struct Bufs { uint32_t *rows = nullptr; int32_t *wl = nullptr, *wr = nullptr; uint8_t *lvl = nullptr; uint32_t *pos = nullptr; uint32_t *surv = nullptr; uint8_t *ht = nullptr; };
     std::vector<Bufs> B((size_t)KB + 2);
     uint32_t *t_pj = nullptr, *t_root = nullptr, *t_lev = nullptr;
     float *t_ab32 = nullptr;
@@ -1258,13 +1265,20 @@ static int build_schedule_fast(raht_plan *plan, int R0, int R1, int Rf, hipStrea
         const size_t c = (size_t)cap[k + 1];
         take(&nx.rows, 4 * c); take(&nx.wl, 4 * c); take(&nx.wr, 4 * c); take(&nx.lvl, c); take(&nx.pos, 4 * c);
     }
+    // The butterfly heights of every tile stage are enqueued right behind the chain, BEFORE the read-back below: their launch
+    // takes sizes and stage kinds from the device state and a grid that covers the stages' capacities, so the host's wait for the
+    // read-back (~15-20 us of wake-up and launch latency, during which the GPU used to idle) overlaps the kernel.
+    // (RAHT_HEIGHT_STAGES_PER_LAUNCH, the testing aid of launch_stage_heights, keeps the launch behind the read-back.)
+    const bool early_heights = N > Rf && KB <= HT_MAX_STAGES && std::max(R0, R1) <= HT_MAX_ROWS && !getenv("RAHT_HEIGHT_STAGES_PER_LAUNCH");
+    if (early_heights)
+        for (int k = 0; k < KB; ++k) take(&B[(size_t)k].ht, (size_t)cap[k]);
     const size_t tm = (size_t)std::max(Rf, 1);
     take(&t_pj, 4 * tm); take(&t_ab32, 8 * tm); take(&t_ab64, 16 * tm); take(&t_root, 4 * tm); take(&t_lev, 4 * 128);
     // scratch: state | per-block counts | flags
     const size_t nblk0 = (size_t)ceil_div(N, SB_BLOCK);
     Scratch scr(sizeof(SchedState) + sizeof(uint32_t) * nblk0 + (size_t)N + 16, s);
     auto release = [&]() {
-        for (auto &b : B) { dev_free(b.rows); dev_free(b.wl); dev_free(b.wr); dev_free(b.lvl); dev_free(b.pos); dev_free(b.surv); }
+        for (auto &b : B) { dev_free(b.rows); dev_free(b.wl); dev_free(b.wr); dev_free(b.lvl); dev_free(b.pos); dev_free(b.surv); dev_free(b.ht); }
         dev_free(t_pj); dev_free(t_ab32); dev_free(t_ab64); dev_free(t_root); dev_free(t_lev);
     };
     if (!ok || !scr.ok()) { (void)hipDeviceSynchronize(); release(); return RAHT_ERR_NOMEM; }
@@ -1292,11 +1306,27 @@ static int build_schedule_fast(raht_plan *plan, int R0, int R1, int Rf, hipStrea
     }
     hipLaunchKernelGGL(sched_tail_kernel, dim3(1), dim3(ST_THREADS), 0, s, dS, KS, KB, SB, R1, (uint32_t)Rf, (uint32_t)plan->n_roots, N,
                        plan->top_level, TAIL_MAX, plan->wl, plan->wr, plan->lvl, plan->inv_order, plan->wsum, TO, KS == 0 ? N : (int64_t)-1);
+    auto heights_behind = [&]() {
+        HeightArgs H;
+        H.n_stages = 0; H.n_tiles = 0; H.N = N; H.top_level = plan->top_level;
+        for (int k = 0; k < KB; ++k) {
+            const Bufs &b = B[(size_t)k];
+            HeightStage &h = H.st[H.n_stages++];
+            h.rows = b.rows; h.wl = k ? b.wl : plan->wl; h.wr = k ? b.wr : plan->wr; h.lvl = k ? b.lvl : plan->lvl;
+            h.ht = b.ht; h.n = 0; h.R = (k == 0) ? R0 : R1; h.first_tile = H.n_tiles;
+            h.n_dev = &dS->n[k]; h.kind_dev = &dS->kind[k]; h.kind_tile = SK_TILE;
+            H.n_tiles += (uint32_t)ceil_div(cap[k], h.R);
+        }
+        for (int q = H.n_stages; q < HT_MAX_STAGES; ++q) H.st[q] = H.st[0];
+        launch_heights_kernel(H, std::max(R0, R1), true, s);
+    };
     hipError_t e = hipGetLastError();
     SchedState hs;
     int rc = RAHT_ERR_HIP;
     if (e == hipSuccess) {
-        rc = read_back_u32((uint32_t *)&hs, (const uint32_t *)dS, SCHED_STATE_WORDS, plan->pend_host, plan->pend_dev, plan->pend_n, s);
+        rc = read_back_u32((uint32_t *)&hs, (const uint32_t *)dS, SCHED_STATE_WORDS, plan->pend_host, plan->pend_dev, plan->pend_n, s,
+                           early_heights ? std::function<void()>(heights_behind) : std::function<void()>());
+        if (rc == RAHT_OK && hipGetLastError() != hipSuccess) rc = RAHT_ERR_HIP;
         if (rc == RAHT_OK) plan->pend_n = 0;              // delivered
     }
     if (rc != RAHT_OK || !hs.finished || hs.trouble || (int)hs.last_stage >= plan->max_stages) {
@@ -1324,11 +1354,13 @@ static int build_schedule_fast(raht_plan *plan, int R0, int R1, int Rf, hipStrea
             st.n_tiles = ceil_div(st.n_entries, st.tile_rows);
             st.surv_off = b.surv;
             b.surv = nullptr;
+            if (early_heights) { st.e_ht = b.ht; b.ht = nullptr; }
         }
         sc.stages.push_back(st);
     }
     release();                                            // buffers of stages that were not needed
     *built = true;
+    *heights_done = early_heights;
     return RAHT_OK;
 }
 
@@ -1340,10 +1372,10 @@ int get_schedule(raht_plan *plan, int R0, int R1, int Rf, hipStream_t s, Schedul
     if (!exact_only && R0 >= 64 && R1 >= 64 && Rf >= 1 && Rf <= RAHT_TOP_MAX_ROWS) {
         Schedule sc;
         sc.tile_rows = R0; sc.tail_rows = R1; sc.final_rows = Rf; sc.valid = true;
-        bool built = false;
-        RAHT_RET(build_schedule_fast(plan, R0, R1, Rf, s, sc, &built));
+        bool built = false, heights_done = false;
+        RAHT_RET(build_schedule_fast(plan, R0, R1, Rf, s, sc, &built, &heights_done));
         if (built) {
-            const int rch = launch_stage_heights(plan, sc, s);
+            const int rch = heights_done ? RAHT_OK : launch_stage_heights(plan, sc, s);
             if (rch != RAHT_OK) { free_schedule(sc); return rch; }
             plan->schedules.push_back(sc);
             *out = &plan->schedules.back();

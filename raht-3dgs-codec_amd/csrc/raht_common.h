@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <deque>
 #include <exception>
+#include <functional>
 #include <new>
 #include <vector>
 
@@ -155,9 +156,10 @@ int bucket_sort_u8(const uint8_t *bucket, uint32_t *perm_out, int64_t n, int bit
 // Host read-back of a few 32-bit words produced on `s` (na + nb <= 192; b may be NULL): a one-wave kernel
 // stores them into a mapped pinned mailbox and the host polls it -- 9 us instead of the 22 us of a
 // pageable hipMemcpyAsync + hipStreamSynchronize (tools/native/probe_readback.hip). Returns once the
-// words (and therefore all earlier work on `s`) are complete.
+// words (and therefore all earlier work on `s`) are complete. `behind` (may be empty) is called once the read-back has been
+// enqueued and before the host starts waiting: work it enqueues on `s` runs while the host waits and is NOT waited for.
 int read_back_u32(uint32_t *dst_a, const uint32_t *dev_a, int na, uint32_t *dst_b, const uint32_t *dev_b, int nb,
-                  hipStream_t s);
+                  hipStream_t s, const std::function<void()> &behind = std::function<void()>());
 
 // out[k] = in[j] (or j when in == NULL) for the k-th j with flag[j] != 0. *count_host gets the
 // number of kept items (synchronises the stream).

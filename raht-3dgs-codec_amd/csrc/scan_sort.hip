@@ -1081,8 +1081,9 @@ struct Mailbox {
 static Mailbox &mailbox() { static Mailbox m; return m; }
 
 int read_back_u32(uint32_t *dst_a, const uint32_t *dev_a, int na, uint32_t *dst_b, const uint32_t *dev_b, int nb,
-                  hipStream_t s)
+                  hipStream_t s, const std::function<void()> &behind)
 {
+    bool behind_called = false;
     if (na < 0 || nb < 0 || na + nb > MAILBOX_WORDS) { set_error("read_back_u32: too many words"); return RAHT_ERR_INVALID; }
     Mailbox &m = mailbox();
     std::lock_guard<std::mutex> g(m.mu);
@@ -1101,6 +1102,7 @@ int read_back_u32(uint32_t *dst_a, const uint32_t *dev_a, int na, uint32_t *dst_
         const uint32_t seq = ++m.seq ? m.seq : ++m.seq;            // never 0
         hipLaunchKernelGGL(mailbox_publish_kernel, dim3(1), dim3(64), 0, s, dev_a, na, dev_b, nb, m.box, seq);
         if (hipGetLastError() == hipSuccess) {
+            if (behind) { behind(); behind_called = true; }
             volatile uint32_t *flag = m.box;
             for (uint32_t it = 1;; ++it) {
                 if (*flag == seq) { done = true; break; }
@@ -1119,6 +1121,7 @@ int read_back_u32(uint32_t *dst_a, const uint32_t *dev_a, int na, uint32_t *dst_
         }
     }
     if (!done) {                                                     // no mailbox / stream error: the plain way
+        if (behind && !behind_called) behind();
         hipError_t e = hipSuccess;
         if (na) e = hipMemcpyAsync(dst_a, dev_a, sizeof(uint32_t) * (size_t)na, hipMemcpyDeviceToHost, s);
         if (e == hipSuccess && nb) e = hipMemcpyAsync(dst_b, dev_b, sizeof(uint32_t) * (size_t)nb, hipMemcpyDeviceToHost, s);
