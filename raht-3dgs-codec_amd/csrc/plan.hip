@@ -103,6 +103,22 @@ __global__ void morton_i64_kernel(const int64_t *__restrict__ V, int64_t N, uint
 static constexpr int EXT_THREADS = 1024;
 static constexpr int EXT_WAVES = EXT_THREADS / 64;
 
+// Profiling build only (-DRAHT_PHASE_CLOCKS, tools/phase_clocks_plan.py): thread 0 of a plan-build workgroup stamps the shader
+// clock at its phase boundaries. [0] level_extent blocks, [1] tile_heights tiles, [2] sched_tail (one workgroup).
+#ifdef RAHT_PHASE_CLOCKS
+constexpr int PL_CLK_BLOCKS = 4096, PL_CLK_SLOTS = 12;
+__device__ unsigned long long g_phase_clk_plan[3][PL_CLK_BLOCKS][PL_CLK_SLOTS];
+#define PL_STAMP(which, blk, k) do { if (threadIdx.x == 0 && (blk) < PL_CLK_BLOCKS) g_phase_clk_plan[which][blk][k] = __builtin_readcyclecounter(); } while (0)
+#define PL_NOTE_LEVELS(blk, n) do { if (threadIdx.x == 0 && (blk) < PL_CLK_BLOCKS) g_phase_clk_plan[1][blk][PL_CLK_SLOTS - 1] = (unsigned long long)(n); } while (0)
+#define PL_SLOT_DECL int pl_slot = 0
+#define PL_STAMP_NEXT() do { if (pl_slot < 8) { PL_STAMP(2, 0, pl_slot); ++pl_slot; } } while (0)
+#else
+#define PL_STAMP(which, blk, k) do { } while (0)
+#define PL_NOTE_LEVELS(blk, n) do { } while (0)
+#define PL_SLOT_DECL do { } while (0)
+#define PL_STAMP_NEXT() do { } while (0)
+#endif
+
 // The same pass also counts, per block of EXT_THREADS rows, the rows of every order_RAGFT bucket (ORDER_BUCKETS
 // bins) and of every binary level (64 bins) -> bucket_hist[bin * gridDim.x + block]: the input of the stable
 // counting sort that produces order_RAGFT (no separate histogram pass over the rows) and, scanned, the start of
@@ -114,7 +130,7 @@ static constexpr int ORDER_BUCKETS = 32;             // bucket(0) = 0, bucket(i)
 // of dependent loads is what a search costs. Every probe address is a valid row.
 // q = row within the block | direction << 31 (0 = right: where does the node STARTING at the row end;
 // 1 = left: where does the node ENDING at the row before it start).
-static constexpr int EXT_QCAP = 96;                  // queue slots per block handed to extent_search_kernel
+static constexpr int EXT_QCAP = 96;                  // queue slots per block handed to extent_finish_kernel
 __device__ __forceinline__ void extent_search(const uint64_t *__restrict__ keys, int64_t N, int64_t b0, uint32_t q, int ql,
                                               int32_t *__restrict__ wl, int32_t *__restrict__ wr)
 {
@@ -167,12 +183,13 @@ __global__ void __launch_bounds__(EXT_THREADS) level_extent_kernel(const uint64_
                                                                     uint32_t *__restrict__ bucket_hist, uint32_t *__restrict__ gq,
                                                                     uint32_t *__restrict__ gq_count)
 {
-    __shared__ uint64_t s_ge[64][EXT_WAVES];         // [level][wave]: rows of the wave with a level >= `level`
+    __shared__ uint64_t s_ge[EXT_WAVES][64];         // [wave][level]: rows of the wave with a level >= `level`
     __shared__ uint32_t queue[2 * EXT_THREADS];      // row within the block | direction << 31
     __shared__ uint8_t s_lvl[EXT_THREADS];
     __shared__ uint32_t n_queued;
     __shared__ uint32_t s_lh[64];
     __shared__ uint32_t s_present[2];
+    PL_STAMP(0, blockIdx.x, 0);
     if (threadIdx.x == 0) { n_queued = 0; s_present[0] = 0; s_present[1] = 0; }
     if (threadIdx.x < 64) s_lh[threadIdx.x] = 0;
     __syncthreads();
@@ -206,23 +223,41 @@ __global__ void __launch_bounds__(EXT_THREADS) level_extent_kernel(const uint64_
         for (int d = 32; d >= 1; d >>= 1) { plo |= (uint32_t)__shfl_xor((int)plo, d, 64); phi |= (uint32_t)__shfl_xor((int)phi, d, 64); }
         if (lane == 0) { if (plo) atomicOr(&s_present[0], plo); if (phi) atomicOr(&s_present[1], phi); }
     }
+    PL_STAMP(0, blockIdx.x, 1);                       // keys loaded, levels known, lvl / bucket stores issued
     __syncthreads();
+    PL_STAMP(0, blockIdx.x, 2);
     // one word per (level present, wave), and the level histogram (one LDS atomic per wave and level present)
     uint64_t present = (uint64_t)s_present[0] | ((uint64_t)s_present[1] << 32);
     if (nbits < 64) present &= ((uint64_t)1 << max(nbits, 1)) - 1;    // levels are < nbits (out-of-range keys are reported, not indexed)
     present &= ~((uint64_t)1 << 63);
-    while (present) {
-        const int t = __ffsll((unsigned long long)present) - 1;
-        present &= present - 1;
-        const uint64_t ge = __ballot(l >= t);
-        const uint32_t eq = (uint32_t)__popcll(__ballot(l == t));
-        if (lane == 0) {
-            s_ge[t][wv] = ge;
-            if (eq) atomicAdd(&s_lh[t], eq);
+    // (the words of a wave collect in LANE t of three registers -- v_writelane, no branch and no LDS traffic inside the loop -- and
+    // leave with one store and one atomic per wave: the loop was 28 % of this kernel, a third of it the lane-0 branches)
+    {
+        // (`present` came from LDS, i.e. in vector registers: made scalar, the loop's control runs on the scalar unit)
+        present = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)present) |
+                  ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(present >> 32)) << 32);
+        const uint64_t present_all = present;
+        uint32_t w_lo = 0, w_hi = 0, w_eq = 0;
+        while (present) {
+            const int t = __ffsll((unsigned long long)present) - 1;
+            present &= present - 1;
+            const uint64_t ge = __ballot(l >= t);
+            const uint32_t ge_lo = (uint32_t)ge, ge_hi = (uint32_t)(ge >> 32), eq = (uint32_t)__popcll(__ballot(l == t));
+            // (no writelane builtin in this hipcc; the lane select goes through M0: two SGPR operands exceed the constant bus)
+            // (M0 is saved and restored: the compiler does not track it as a clobber)
+            uint32_t m0_keep;
+            asm volatile("s_mov_b32 %3, m0\n\ts_mov_b32 m0, %7\n\tv_writelane_b32 %0, %4, m0\n\tv_writelane_b32 %1, %5, m0\n\tv_writelane_b32 %2, %6, m0\n\ts_mov_b32 m0, %3"
+                         : "+v"(w_lo), "+v"(w_hi), "+v"(w_eq), "=&s"(m0_keep) : "s"(ge_lo), "s"(ge_hi), "s"(eq), "s"(t));
+        }
+        if ((present_all >> lane) & 1) {
+            s_ge[wv][lane] = (uint64_t)w_lo | ((uint64_t)w_hi << 32);
+            if (w_eq) atomicAdd(&s_lh[lane], w_eq);
         }
     }
     if (i == 0) s_lh[63] = 1;                        // row 0 (lvl 255): alone in level bin 63
+    PL_STAMP(0, blockIdx.x, 3);                       // words of every present level published
     __syncthreads();
+    PL_STAMP(0, blockIdx.x, 4);
     const uint64_t below = ((uint64_t)1 << lane) - 1, above = ~(below | ((uint64_t)1 << lane));
     bool q_r = false, q_l = false;
     if (searching) {
@@ -230,10 +265,10 @@ __global__ void __launch_bounds__(EXT_THREADS) level_extent_kernel(const uint64_
         // right neighbour: own wave, then the following waves of the block
         int found = -1;
         {
-            const uint64_t m = s_ge[lc][wv] & above;
+            const uint64_t m = s_ge[wv][lc] & above;
             if (m) found = wv * 64 + __ffsll((unsigned long long)m) - 1;
             for (int w2 = wv + 1; found < 0 && w2 < EXT_WAVES; ++w2) {
-                const uint64_t m2 = s_ge[lc][w2];
+                const uint64_t m2 = s_ge[w2][lc];
                 if (m2) found = w2 * 64 + __ffsll((unsigned long long)m2) - 1;
             }
         }
@@ -243,10 +278,10 @@ __global__ void __launch_bounds__(EXT_THREADS) level_extent_kernel(const uint64_
         // left neighbour: own wave, then the preceding waves
         found = -1;
         {
-            const uint64_t m = s_ge[lc][wv] & below;
+            const uint64_t m = s_ge[wv][lc] & below;
             if (m) found = wv * 64 + 63 - __clzll((long long)m);
             for (int w2 = wv - 1; found < 0 && w2 >= 0; --w2) {
-                const uint64_t m2 = s_ge[lc][w2];
+                const uint64_t m2 = s_ge[w2][lc];
                 if (m2) found = w2 * 64 + 63 - __clzll((long long)m2);
             }
         }
@@ -255,6 +290,7 @@ __global__ void __launch_bounds__(EXT_THREADS) level_extent_kernel(const uint64_
     } else if (valid) {
         wl[0] = 0; wr[0] = 0;
     }
+    PL_STAMP(0, blockIdx.x, 5);                       // neighbours found, wl / wr stores issued
     const uint64_t m_r = __ballot(q_r), m_l = __ballot(q_l);
     if (m_r | m_l) {
         uint32_t base = 0;
@@ -274,8 +310,10 @@ __global__ void __launch_bounds__(EXT_THREADS) level_extent_kernel(const uint64_
         else if (b <= 21) { const int l0 = 3 * (21 - b); c = s_lh[l0] + s_lh[l0 + 1] + s_lh[l0 + 2]; }
         bucket_hist[(size_t)b * gridDim.x + blockIdx.x] = c;
     }
+    PL_STAMP(0, blockIdx.x, 6);                       // queue + histograms written
     __syncthreads();
-    // The queued searches go to extent_search_kernel: a block that ran them itself kept its 16 wave slots
+    PL_STAMP(0, blockIdx.x, 7);
+    // The queued searches go to extent_finish_kernel: a block that ran them itself kept its 16 wave slots
     // until its slowest search (a chain of ~5 dependent loads) had finished, and the next block of the CU could
     // not start -- that tail, not the work, was two thirds of this kernel's 75 us. Each block owns EXT_QCAP slots
     // of a global queue; the (pathological) rest it still searches itself.
@@ -286,13 +324,14 @@ __global__ void __launch_bounds__(EXT_THREADS) level_extent_kernel(const uint64_
         const uint32_t q = queue[t];
         extent_search(keys, N, b0, q, s_lvl[q & 0x7fffffffu], wl, wr);
     }
+    PL_STAMP(0, blockIdx.x, 8);
 }
 
-__global__ void __launch_bounds__(256) extent_search_kernel(const uint64_t *__restrict__ keys, int64_t N, const uint8_t *__restrict__ lvl,
-                                                            const uint32_t *__restrict__ gq, const uint32_t *__restrict__ gq_count,
-                                                            uint32_t nblk, int32_t *__restrict__ wl, int32_t *__restrict__ wr)
+__device__ __forceinline__ void extent_search_block(uint32_t block, const uint64_t *__restrict__ keys, int64_t N, const uint8_t *__restrict__ lvl,
+                                                    const uint32_t *__restrict__ gq, const uint32_t *__restrict__ gq_count,
+                                                    uint32_t nblk, int32_t *__restrict__ wl, int32_t *__restrict__ wr)
 {
-    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t g = block * blockDim.x + threadIdx.x;
     const uint32_t b = g / EXT_QCAP, slot = g - b * EXT_QCAP;
     if (b >= nblk || slot >= gq_count[b]) return;
     const uint32_t q = gq[(size_t)b * EXT_QCAP + slot];
@@ -309,10 +348,10 @@ __global__ void __launch_bounds__(256) extent_search_kernel(const uint64_t *__re
 // bin (exclusive, in place) and the bin's total; the scatter adds up the totals of the bins before its own by itself (96 values).
 // (The generic two-launch scan over the whole array cost 17 us of a 200 us build, and a third of a launch gap.)
 constexpr int BSCAN_THREADS = 256;
-__global__ void __launch_bounds__(BSCAN_THREADS) bucket_scan_kernel(uint32_t *__restrict__ hist, uint32_t nblk, uint32_t *__restrict__ bin_total)
+__device__ __forceinline__ void bucket_scan_block(uint32_t bin, uint32_t *__restrict__ hist, uint32_t nblk, uint32_t *__restrict__ bin_total)
 {
     __shared__ uint32_t ws[BSCAN_THREADS / 64];
-    uint32_t *row = hist + (size_t)blockIdx.x * nblk;
+    uint32_t *row = hist + (size_t)bin * nblk;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     uint32_t carry = 0;
     for (uint32_t b0 = 0; b0 < nblk; b0 += BSCAN_THREADS * 8) {
@@ -334,7 +373,19 @@ __global__ void __launch_bounds__(BSCAN_THREADS) bucket_scan_kernel(uint32_t *__
         for (int k = 0; k < 8; ++k) { if (i0 + k < nblk) row[i0 + k] = ex; ex += v[k]; }
         carry += all;
     }
-    if (threadIdx.x == 0) bin_total[blockIdx.x] = carry;
+    if (threadIdx.x == 0) bin_total[bin] = carry;
+}
+
+// Second launch of a plan build, two jobs that both wait for level_extent_kernel and for nothing else: the first ORDER_BUCKETS + 64
+// workgroups scan one histogram bin each, the others run the queued extent searches (one launch instead of two: a back-to-back
+// launch costs ~4.6 us even when the chip could run both at once)
+__global__ void __launch_bounds__(BSCAN_THREADS) extent_finish_kernel(const uint64_t *__restrict__ keys, int64_t N, const uint8_t *__restrict__ lvl,
+                                                                      const uint32_t *__restrict__ gq, const uint32_t *__restrict__ gq_count,
+                                                                      uint32_t nblk, int32_t *__restrict__ wl, int32_t *__restrict__ wr,
+                                                                      uint32_t *__restrict__ hist, uint32_t *__restrict__ bin_total)
+{
+    if (blockIdx.x < ORDER_BUCKETS + 64) bucket_scan_block(blockIdx.x, hist, nblk, bin_total);
+    else extent_search_block(blockIdx.x - (ORDER_BUCKETS + 64), keys, N, lvl, gq, gq_count, nblk, wl, wr);
 }
 
 __global__ void __launch_bounds__(EXT_THREADS) order_scatter_kernel(const uint8_t *__restrict__ order_bucket, int64_t N,
@@ -590,6 +641,7 @@ __global__ __launch_bounds__(64) void tile_heights_kernel(const HeightArgs H)
     int k = 0;
 #pragma unroll
     for (int q = 1; q < HT_MAX_STAGES; ++q) k += (q < H.n_stages && blockIdx.x >= H.st[q].first_tile) ? 1 : 0;
+    PL_STAMP(1, blockIdx.x, 0);
     const HeightStage &S = H.st[k];
     const int R = S.R;
     const int lane = threadIdx.x;
@@ -622,6 +674,7 @@ __global__ __launch_bounds__(64) void tile_heights_kernel(const HeightArgs H)
 #pragma unroll
     for (int s = 0; s < SPL; ++s) { const int j = lane + s * 64; if (j < nt) s_cur[j] = 0; }
     __syncthreads();
+    PL_STAMP(1, blockIdx.x, 1);                       // metadata loaded
     uint64_t mask = 0;
 #pragma unroll
     for (int s = 0; s < SPL; ++s) {
@@ -649,6 +702,8 @@ __global__ __launch_bounds__(64) void tile_heights_kernel(const HeightArgs H)
     int ht[SPL];
 #pragma unroll
     for (int s = 0; s < SPL; ++s) ht[s] = 0;
+    PL_STAMP(1, blockIdx.x, 2);                       // partners resolved, level mask reduced
+    PL_NOTE_LEVELS(blockIdx.x, __popcll(mask));
     while (mask) {
         const int l = __ffsll((unsigned long long)mask) - 1;
         mask &= mask - 1;
@@ -663,8 +718,10 @@ __global__ __launch_bounds__(64) void tile_heights_kernel(const HeightArgs H)
             if (lv[s] == l) { ht[s] = h[s]; s_cur[part[s]] = (uint8_t)h[s]; }
         __syncthreads();                                    // one wave: orders the LDS traffic of consecutive levels
     }
+    PL_STAMP(1, blockIdx.x, 3);                       // levels walked
 #pragma unroll
     for (int s = 0; s < SPL; ++s) { const int j = lane + s * 64; if (j < nt) S.ht[e0 + j] = (uint8_t)ht[s]; }
+    PL_STAMP(1, blockIdx.x, 4);
 }
 
 static void launch_heights_kernel(const HeightArgs &H, int maxR, bool any_rows, hipStream_t s)
@@ -1044,6 +1101,7 @@ __device__ __forceinline__ void sched_top_body(SchedState *__restrict__ S, int k
     if (tid == 0) root_base = 0;
     for (int e = tid; e < n; e += ST_THREADS) s_rows[e] = rows ? rows[e] : (uint32_t)e;
     __syncthreads();
+    PL_STAMP(2, 0, 8);                                              // top: entry rows in LDS
     // pass 1: level histogram of the butterflies; root ranks in entry order
     for (int e0 = 0; e0 < n; e0 += ST_THREADS) {
         const int e = e0 + tid;
@@ -1065,6 +1123,7 @@ __device__ __forceinline__ void sched_top_body(SchedState *__restrict__ S, int k
         if (tid == 0) { uint32_t t = 0; for (int w = 0; w < ST_THREADS / 64; ++w) t += wtot[w]; root_base += t; }
         __syncthreads();
     }
+    PL_STAMP(2, 0, 9);                                              // top: pass 1 done
     // level offsets + the level program: wave 0, lane l = binary level l
     if (wid == 0) {
         const uint32_t h = (lane < 63) ? hist[lane] : 0u;
@@ -1101,6 +1160,7 @@ __device__ __forceinline__ void sched_top_body(SchedState *__restrict__ S, int k
         }
     }
     __syncthreads();
+    PL_STAMP(2, 0, 10);                                             // top: level program written
     // pass 2: resolve and place every butterfly (any order inside a level: they are independent)
     for (int e = tid; e < n; e += ST_THREADS) {
         const uint32_t r = s_rows[e];
@@ -1122,6 +1182,7 @@ __device__ __forceinline__ void sched_top_body(SchedState *__restrict__ S, int k
         t_ab64[2 * pos] = a; t_ab64[2 * pos + 1] = b;
         t_ab32[2 * pos] = (float)a; t_ab32[2 * pos + 1] = (float)b;
     }
+    PL_STAMP(2, 0, 11);                                             // top: pass 2 issued
 }
 
 // The END of the chain in ONE launch of one workgroup: from stage k0 on, every tile stage of at most `tail_max`
@@ -1144,6 +1205,8 @@ __global__ __launch_bounds__(ST_THREADS) void sched_tail_kernel(SchedState *S, i
     __shared__ uint32_t wcnt[8 * (ST_THREADS / 64)], woff[8 * (ST_THREADS / 64) + 1];
     __shared__ uint32_t s_state[2];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    PL_SLOT_DECL;
+    PL_STAMP_NEXT();                                                        // [0] start
     if (n_first >= 0) { sched_state_init(S, (uint32_t)n_first, SK_TOP); __threadfence(); __syncthreads(); }   // (a tree that fits the top stage)
     // stages 1 .. k_multi - 1 had the multi-workgroup launches if they were tile stages; one of them may have turned out
     // to be the top stage already (a tree that shrank faster than expected)
@@ -1152,6 +1215,7 @@ __global__ __launch_bounds__(ST_THREADS) void sched_tail_kernel(SchedState *S, i
         __syncthreads();
         const uint32_t kind = s_state[0], n = s_state[1];
         __syncthreads();
+        PL_STAMP_NEXT();                                                    // state of stage k read
         if (kind == SK_TOP) {
             sched_top_body(S, k, (int)n, B.rows[k], p_wl, p_wr, p_lvl, wsum, top_level, O);
             return;
@@ -1547,13 +1611,12 @@ static int finish_plan(raht_plan *p, const int64_t *leaf_weights, hipStream_t s,
     // everything below is enqueued speculatively; the error word is checked at the single sync
     hipLaunchKernelGGL(level_extent_kernel, dim3(nblk), dim3(EXT_THREADS), 0, s, p->keys, N,
                        p->nbits, p->lvl, bucket, p->wl, p->wr, derr, bhist, gq, gq_count);
-    hipLaunchKernelGGL(extent_search_kernel, dim3((unsigned)ceil_div((int64_t)nblk * EXT_QCAP, 256)), dim3(256), 0, s, p->keys, N, p->lvl,
-                       gq, gq_count, nblk, p->wl, p->wr);
+    hipLaunchKernelGGL(extent_finish_kernel, dim3((unsigned)(ORDER_BUCKETS + 64 + ceil_div((int64_t)nblk * EXT_QCAP, BSCAN_THREADS))), dim3(BSCAN_THREADS), 0, s,
+                       p->keys, N, p->lvl, gq, gq_count, nblk, p->wl, p->wr, bhist, bin_total);
     // order_RAGFT and its inverse: stable counting sort by bucket (histogram from the pass above). (Measured and dropped,
     // round 3: this pair on a second stream next to the extent searches and the first schedule pass, and the stage-0 butterfly
     // heights on a third next to the whole schedule build -- 0.245 / 0.235 ms against 0.226 ms on one stream: a cross-queue
     // dependency costs ~13 us, and kernels this small slow each other down when they share the chip.)
-    hipLaunchKernelGGL(bucket_scan_kernel, dim3(ORDER_BUCKETS + 64), dim3(BSCAN_THREADS), 0, s, bhist, nblk, bin_total);
     hipLaunchKernelGGL(order_scatter_kernel, dim3(nblk), dim3(EXT_THREADS), 0, s, bucket, N, bhist, bin_total, p->order, p->inv_order, lhist);
     if (getenv("RAHT_DEBUG_IDENTITY_ORDER")) {    // timing experiments only: order_RAGFT := identity
         hipLaunchKernelGGL(order_to_identity_kernel, dim3(gb), dim3(256), 0, s, p->order, N);
@@ -1614,6 +1677,18 @@ static int finish_plan(raht_plan *p, const int64_t *leaf_weights, hipStream_t s,
 using namespace raht;
 
 extern "C" {
+
+#ifdef RAHT_PHASE_CLOCKS
+/* profiling build only: dst[3][n_blocks][12] <- the plan-build kernels' phase stamps (tools/phase_clocks_plan.py) */
+int raht_debug_read_phase_clocks_plan(unsigned long long *dst, int which, int n_blocks)
+{
+    if (which < 0 || which > 2) return RAHT_ERR_INVALID;
+    RAHT_HIP_CHECK(hipDeviceSynchronize());
+    RAHT_HIP_CHECK(hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_phase_clk_plan), sizeof(unsigned long long) * PL_CLK_SLOTS * (size_t)std::min(n_blocks, PL_CLK_BLOCKS),
+                                       sizeof(unsigned long long) * PL_CLK_SLOTS * PL_CLK_BLOCKS * (size_t)which));
+    return PL_CLK_SLOTS;
+}
+#endif
 
 const char *raht_last_error(void) { return g_err; }
 int raht_version(void) { return RAHT_VERSION; }
