@@ -1203,18 +1203,22 @@ __global__ __launch_bounds__(ST_THREADS) void sched_tail_kernel(SchedState *S, i
                                                                 const int64_t *__restrict__ wsum, SchedTopOut O, int64_t n_first)
 {
     __shared__ uint32_t wcnt[8 * (ST_THREADS / 64)], woff[8 * (ST_THREADS / 64) + 1];
-    __shared__ uint32_t s_state[2];
+    __shared__ uint32_t s_kind[SCHED_SPEC_MAX + 2], s_n[SCHED_SPEC_MAX + 2];   // the chain's state: ONE read at the start, then kept here
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     PL_SLOT_DECL;
     PL_STAMP_NEXT();                                                        // [0] start
-    if (n_first >= 0) { sched_state_init(S, (uint32_t)n_first, SK_TOP); __threadfence(); __syncthreads(); }   // (a tree that fits the top stage)
+    if (n_first >= 0) { sched_state_init(S, (uint32_t)n_first, SK_TOP); __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __syncthreads(); }   // (a tree that fits the top stage)
     // stages 1 .. k_multi - 1 had the multi-workgroup launches if they were tile stages; one of them may have turned out
     // to be the top stage already (a tree that shrank faster than expected)
+    // (what this workgroup itself decides about stage k + 1 goes to the state in memory AND into these copies: a global read
+    // per stage was a ~2 us round trip on a chip that runs nothing else)
+    if (tid < SCHED_SPEC_MAX + 2) {
+        s_kind[tid] = (n_first >= 0) ? (tid == 0 ? (uint32_t)SK_TOP : (uint32_t)SK_NONE) : __atomic_load_n(&S->kind[tid], __ATOMIC_RELAXED);
+        s_n[tid] = (n_first >= 0) ? (tid == 0 ? (uint32_t)n_first : 0u) : __atomic_load_n(&S->n[tid], __ATOMIC_RELAXED);
+    }
+    __syncthreads();
     for (int k = (k_multi == 0) ? 0 : 1; k <= k_last; ++k) {
-        if (tid == 0) { s_state[0] = __atomic_load_n(&S->kind[k], __ATOMIC_RELAXED); s_state[1] = __atomic_load_n(&S->n[k], __ATOMIC_RELAXED); }
-        __syncthreads();
-        const uint32_t kind = s_state[0], n = s_state[1];
-        __syncthreads();
+        const uint32_t kind = s_kind[k], n = s_n[k];
         PL_STAMP_NEXT();                                                    // state of stage k read
         if (kind == SK_TOP) {
             sched_top_body(S, k, (int)n, B.rows[k], p_wl, p_wr, p_lvl, wsum, top_level, O);
@@ -1235,18 +1239,28 @@ __global__ __launch_bounds__(ST_THREADS) void sched_tail_kernel(SchedState *S, i
         // other, so a 7 013-entry stage is ONE round of dependent L2 round trips instead of seven
         constexpr int TI = 8, NWV = ST_THREADS / 64;
         for (uint32_t base = 0; base < n; base += ST_THREADS * TI) {
-            uint32_t r[TI];
+            // every load of a pass is issued before the first one is used (two loops): with the survivor test in the loading
+            // loop the compiler waited per iteration -- eight dependent round trips of ~2 us for one 7 013-entry stage
+            uint32_t r[TI], e_start[TI], e_end[TI];
+            int32_t e_wl[TI], e_wr[TI];
+            uint8_t e_lv[TI];
             uint64_t bal[TI];
+#pragma unroll
+            for (int q = 0; q < TI; ++q) {
+                const uint32_t j = min(base + (uint32_t)(q * ST_THREADS + tid), n - 1);
+                const uint32_t j0 = j / (uint32_t)R * (uint32_t)R, j1 = j0 + (uint32_t)R;
+                r[q] = rows[j]; e_lv[q] = lvl[j]; e_wl[q] = wl[j]; e_wr[q] = wr[j];
+                e_start[q] = rows[j0];
+                e_end[q] = rows[min(j1, n - 1)];
+            }
 #pragma unroll
             for (int q = 0; q < TI; ++q) {
                 const uint32_t j = base + (uint32_t)(q * ST_THREADS + tid);
                 bool surv = false;
-                r[q] = 0;
                 if (j < n) {
-                    const uint32_t j0 = j / (uint32_t)R * (uint32_t)R, j1 = j0 + (uint32_t)R;
-                    const int64_t start = (int64_t)rows[j0], end = (j1 < n) ? (int64_t)rows[j1] : N;
-                    r[q] = rows[j];
-                    const bool merged = (r[q] > 0) && ((int)lvl[j] < top_level) && ((int64_t)r[q] - wl[j] >= start) && ((int64_t)r[q] + wr[j] <= end);
+                    const uint32_t j1 = j / (uint32_t)R * (uint32_t)R + (uint32_t)R;
+                    const int64_t start = (int64_t)e_start[q], end = (j1 < n) ? (int64_t)e_end[q] : N;
+                    const bool merged = (r[q] > 0) && ((int)e_lv[q] < top_level) && ((int64_t)r[q] - e_wl[q] >= start) && ((int64_t)r[q] + e_wr[q] <= end);
                     surv = !merged;
                 }
                 bal[q] = __ballot(surv);
@@ -1262,6 +1276,15 @@ __global__ __launch_bounds__(ST_THREADS) void sched_tail_kernel(SchedState *S, i
                 woff[2 * lane + 1] = inc - c1;
                 if (lane == 63) woff[TI * NWV] = inc;
             }
+            // the survivors' plan rows: gathered (all in flight) while wave 0 scans, stored once the offsets are known
+            int32_t g_wl[TI], g_wr[TI];
+            uint32_t g_inv[TI];
+            uint8_t g_lv[TI];
+#pragma unroll
+            for (int q = 0; q < TI; ++q) {
+                g_wl[q] = 0; g_wr[q] = 0; g_inv[q] = 0; g_lv[q] = 0;
+                if ((bal[q] >> lane) & 1) { const uint32_t rr = r[q]; g_wl[q] = p_wl[rr]; g_wr[q] = p_wr[rr]; g_lv[q] = p_lvl[rr]; g_inv[q] = p_inv[rr]; }
+            }
             __syncthreads();
 #pragma unroll
             for (int q = 0; q < TI; ++q) {
@@ -1270,8 +1293,7 @@ __global__ __launch_bounds__(ST_THREADS) void sched_tail_kernel(SchedState *S, i
                     const uint32_t pos = running + woff[q * NWV + wid] + (uint32_t)__popcll(bal[q] & (((uint64_t)1 << lane) - 1));
                     if (j % (uint32_t)R == 0) surv_off[j / (uint32_t)R] = pos;     // first survivor of the tile
                     if (((bal[q] >> lane) & 1) && pos < cap_next) {
-                        const uint32_t rr = r[q];
-                        n_rows[pos] = rr; n_wl[pos] = p_wl[rr]; n_wr[pos] = p_wr[rr]; n_lvl[pos] = p_lvl[rr]; n_pos[pos] = p_inv[rr];
+                        n_rows[pos] = r[q]; n_wl[pos] = g_wl[q]; n_wr[pos] = g_wr[q]; n_lvl[pos] = g_lv[q]; n_pos[pos] = g_inv[q];
                     }
                 }
             }
@@ -1282,12 +1304,16 @@ __global__ __launch_bounds__(ST_THREADS) void sched_tail_kernel(SchedState *S, i
             const uint32_t total = running;
             surv_off[(n + (uint32_t)R - 1) / (uint32_t)R] = total;
             S->n[k + 1] = total;
+            s_n[k + 1] = total;
             if (total > cap_next) S->trouble = 1;                                                      // (and the chain stops)
             else if (total == n_roots) { S->finished = 1; S->last_stage = (uint32_t)k; S->last_is_top = 0; }   // only the roots are left
             else if (total >= n) S->trouble = 2;                                                       // no progress
-            else S->kind[k + 1] = (total <= Rf) ? SK_TOP : SK_TILE;
+            else { const uint32_t nk = (total <= Rf) ? SK_TOP : SK_TILE; S->kind[k + 1] = nk; s_kind[k + 1] = nk; }
         }
-        __threadfence();                                                     // the next stage reads what this one wrote
+        // The next stage of THIS workgroup reads what this one wrote: workgroup scope (its waves share the CU's vector cache;
+        // the stores are complete before the barrier). An agent-scope __threadfence() here wrote the XCD's whole L2 back -- tens
+        // of MB of the earlier kernels' dirty lines -- once per wave: 18 of this kernel's 24 us (profiles/r04b_plan_phase_clocks.txt).
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __syncthreads();
     }
 }
