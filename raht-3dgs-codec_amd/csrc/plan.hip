@@ -1055,20 +1055,34 @@ __global__ __launch_bounds__(SB_THREADS) void sched_emit_kernel(SchedState *__re
     uint32_t tile = (uint32_t)base / (uint32_t)R;
     uint32_t next_start = tile * (uint32_t)R;               // first tile boundary at or after `base`
     if (next_start < (uint32_t)base) { ++tile; next_start += (uint32_t)R; }
+    // three loops -- the survivors' rows, their plan entries, the stores -- so that every load of a phase is in flight before the
+    // first one is used (one loop made each survivor two dependent round trips of its own: see sched_tail_kernel)
+    uint32_t g_r[SB_ITEMS], g_pos[SB_ITEMS], g_inv[SB_ITEMS];
+    int32_t g_wl[SB_ITEMS], g_wr[SB_ITEMS];
+    uint8_t g_lv[SB_ITEMS];
+    bool keep[SB_ITEMS];
 #pragma unroll
     for (int q = 0; q < SB_ITEMS; ++q) {
         const int64_t j = base + q;
+        keep[q] = false; g_pos[q] = 0; g_r[q] = (uint32_t)j;
         if (j < n) {
             if ((uint32_t)j == next_start) { surv_off[tile] = pos; ++tile; next_start += (uint32_t)R; }   // first survivor of the tile
             if (f[q]) {
-                if (pos < cap_next) {
-                    const uint32_t r = rows ? rows[j] : (uint32_t)j;
-                    n_rows[pos] = r; n_wl[pos] = p_wl[r]; n_wr[pos] = p_wr[r]; n_lvl[pos] = p_lvl[r]; n_pos[pos] = p_inv[r];
-                }
+                keep[q] = pos < cap_next;
+                g_pos[q] = pos;
+                if (keep[q] && rows) g_r[q] = rows[j];
                 ++pos;
             }
         }
     }
+#pragma unroll
+    for (int q = 0; q < SB_ITEMS; ++q) {
+        g_wl[q] = 0; g_wr[q] = 0; g_lv[q] = 0; g_inv[q] = 0;
+        if (keep[q]) { const uint32_t r = g_r[q]; g_wl[q] = p_wl[r]; g_wr[q] = p_wr[r]; g_lv[q] = p_lvl[r]; g_inv[q] = p_inv[r]; }
+    }
+#pragma unroll
+    for (int q = 0; q < SB_ITEMS; ++q)
+        if (keep[q]) { const uint32_t o = g_pos[q]; n_rows[o] = g_r[q]; n_wl[o] = g_wl[q]; n_wr[o] = g_wr[q]; n_lvl[o] = g_lv[q]; n_pos[o] = g_inv[q]; }
     if ((int64_t)blockIdx.x == nblk - 1 && threadIdx.x == 0) {
         const uint32_t total = block_base + block_tot;
         surv_off[(n + R - 1) / R] = total;
