@@ -549,6 +549,9 @@ int raht_rlgr_seg_decode_batch(int k, const uint8_t *const *in, const int64_t *i
  * 0 = words, 1 = 16-byte register groups, 2 = LDS columns. Same output in every mode (tests walk all of them); a tuning and
  * testing knob, process-wide. Returns the previous setting. */
 int raht_debug_rlgr_decode_out(int mode);
+/* The same for the words of the batched ENCODER's streams on their way into its slots: -1 = by the lanes in flight, 0 = one
+ * 4-byte store per word, 2 = LDS columns, 64-byte pieces (9 steps of a 3 M x 56 frame: 0.79 -> 0.71 ms per step). */
+int raht_debug_rlgr_encode_out(int mode);
 
 /* out[c] = sum over rows of (A[i, c] - B[i, c])^2, DEVICE double[D]: what the drivers' five PSNR columns are made of
  * (python/encode_3dgs.py:298-310: torch.mean((C - C_rec) ** 2) over all / quats / scales / opacity / colour columns -- each a

@@ -24,21 +24,42 @@ constexpr uint32_t L = 4, U0 = 3, D0 = 1, U1 = 2, D1 = 1;
 
 // MSB-first bit writer, same byte stream as membuf::write / flush (and as BitWriter of rlgr.hip): < 32 bits pending after
 // every put, whole 32-bit words leave big-endian. WRITE = false only counts. `out` is 4-byte aligned.
-template <bool WRITE>
+// LDSOUT (out32 16-byte aligned): the words of a lane collect in a 16-word LDS column ([16][64] words per wave, as in the
+// decoder below) and leave as one 64-byte piece -- with the steps of a frame coded together the one-word stores of 738 k lanes
+// cost 8 x the streams' bytes in HBM writes (3.7 GB for 0.47 GB, rocprofv3 WRITE_SIZE).
+template <bool WRITE, bool LDSOUT = false>
 struct DevBitWriter {
     uint32_t *out32;
     uint32_t size = 0;       // bytes (keeps counting past cap: the exact length is known either way)
     uint32_t cap = 0xffffffffu;   // bytes that may be written at out32 (a multiple of 4); past it nothing is stored
     uint64_t acc = 0;
     int nbits = 0;
+    uint32_t *col = nullptr; // LDSOUT: this lane's column
 
+    __device__ __forceinline__ void store_word(uint32_t w)          // the word at byte offset `size`
+    {
+        if (!WRITE || size + 4 > cap) return;
+        if (LDSOUT) {
+            const uint32_t wi = size >> 2, q = wi & 15u;
+            col[q * 64] = w;
+            if (q == 15u) {
+                uint4 x[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) x[t] = make_uint4(col[(4 * t) * 64], col[(4 * t + 1) * 64], col[(4 * t + 2) * 64], col[(4 * t + 3) * 64]);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) *(uint4 *)(out32 + wi - 15 + 4 * t) = x[t];
+            }
+        } else {
+            out32[size >> 2] = w;
+        }
+    }
     __device__ __forceinline__ void put(uint64_t v, int bits)      // bits <= 32, v < 2^bits
     {
         acc = (acc << bits) | v;
         nbits += bits;
         if (nbits >= 32) {
             nbits -= 32;
-            if (WRITE && size + 4 <= cap) out32[size >> 2] = __builtin_bswap32((uint32_t)(acc >> nbits));
+            store_word(__builtin_bswap32((uint32_t)(acc >> nbits)));
             size += 4;
         }
     }
@@ -63,11 +84,17 @@ struct DevBitWriter {
     __device__ __forceinline__ void close()                         // membuf.cpp:47-58
     {
         if (nbits & 7) put(0, 8 - (nbits & 7));
+        uint32_t words = size >> 2;                                 // whole words so far
         if (nbits > 0) {                                            // 1..3 whole bytes left: the last, partial word (zero filled)
             const uint32_t word = (uint32_t)(acc << (32 - nbits));
-            if (WRITE && size + 4 <= cap) out32[size >> 2] = __builtin_bswap32(word);
+            store_word(__builtin_bswap32(word));
+            if (size + 4 <= cap) ++words;
             size += (uint32_t)(nbits >> 3);
             nbits = 0;
+        }
+        if (WRITE && LDSOUT) {                                      // the last, partial column (a full one left when its 16th word came)
+            const uint32_t stored = min(words, cap >> 2);
+            for (uint32_t wi = stored & ~15u; wi < stored; ++wi) out32[wi] = col[(wi & 15u) * 64];
         }
     }
 };
@@ -96,13 +123,15 @@ __device__ __forceinline__ int64_t u2s(uint64_t v) { const int64_t d = (int64_t)
 // that of ONE wave walking its segments: proportional to seg_len above ~1500. Staging the symbols / the output through LDS in
 // blocks of 64 (to take the loads and stores off each other's wait counter) changed nothing for the encoder and made the
 // decoder slower (round 3): memory is not what a lane waits for.
-template <bool WRITE, bool VEC>
+template <bool WRITE, bool VEC, bool LDSOUT = false>
 __device__ __forceinline__ uint32_t encode_segment(const int32_t *__restrict__ seq, int n, int flag_signed, uint32_t *out32, uint32_t cap = 0xffffffffu,
-                                                   int64_t sstr = 1)     // sstr: distance between consecutive symbols (VEC: 1)
+                                                   int64_t sstr = 1,     // sstr: distance between consecutive symbols (VEC: 1)
+                                                   uint32_t *lds = nullptr)
 {
-    DevBitWriter<WRITE> w;
+    DevBitWriter<WRITE, LDSOUT> w;
     w.out32 = out32;
     w.cap = cap;
+    w.col = lds + (threadIdx.x & 63);
     // 32-bit state: u = s2u(int32) < 2^32; inside a segment of n < 2^31 symbols the run counter m and the run exponent
     // k (<= log2 n + 1) stay far below 32 bits; k_RP is capped at 32 L. (The host coder carries them in 64 bits because one
     // stream may hold 2^32 symbols and more; 64-bit integer arithmetic is several instructions per operation here.)
@@ -306,6 +335,7 @@ __device__ __forceinline__ void decode_segment(const uint32_t *in32, uint32_t nb
 // instruction stream and the L2 still gathers its lines: OUT_WORD 2.86 ms, OUT_LDS 3.36 ms, OUT_VEC 3.97 ms. Nine such frames by
 // one launch (738 k lanes): OUT_WORD 1.76 ms per frame (HBM writes 5.9 x the symbols), OUT_LDS 0.99 ms, OUT_VEC 1.81 ms.
 static int g_decode_out = -1;                                       // raht_debug_rlgr_decode_out
+static int g_encode_out = -1;                                       // raht_debug_rlgr_encode_out (the batched encoder: words or LDS columns)
 static int decode_out_mode(int64_t lanes)
 {
     static const char *e = getenv("RAHT_RLGR_DECODE_OUT");
@@ -443,8 +473,10 @@ struct SegDecJobs {
 
 // flags: two words per frame (overflow bits, container bytes)
 __global__ __launch_bounds__(64) void seg_encode_slots_batch_kernel(const SegEncJobs J, int64_t N, int D, int64_t sym_stride, int64_t chan_stride, int S, int nseg,
-                                                                    int flag_signed, uint8_t *__restrict__ slots, uint32_t slot, uint32_t *__restrict__ flags)
+                                                                    int flag_signed, uint8_t *__restrict__ slots, uint32_t slot, uint32_t *__restrict__ flags,
+                                                                    int lds_out)
 {
+    __shared__ uint32_t s_col[16 * 64];
     const int j = blockIdx.y;
     const int64_t t = (int64_t)blockIdx.x * 64 + threadIdx.x;
     const int64_t G = (int64_t)D * nseg;
@@ -459,7 +491,9 @@ __global__ __launch_bounds__(64) void seg_encode_slots_batch_kernel(const SegEnc
     const int32_t *seq = Q + (int64_t)c * chan_stride + i0 * sym_stride;
     const bool vec = sym_stride == 1 && ((((uintptr_t)Q) & 15) == 0) && ((chan_stride & 3) == 0) && ((S & 3) == 0);
     uint32_t *o = (uint32_t *)(slots + ((size_t)j * (size_t)G + (size_t)g) * slot);
-    const uint32_t nb = vec ? encode_segment<true, true>(seq, n, flag_signed, o, slot) : encode_segment<true, false>(seq, n, flag_signed, o, slot, sym_stride);
+    uint32_t nb;
+    if (lds_out) nb = vec ? encode_segment<true, true, true>(seq, n, flag_signed, o, slot, 1, s_col) : encode_segment<true, false, true>(seq, n, flag_signed, o, slot, sym_stride, s_col);
+    else nb = vec ? encode_segment<true, true>(seq, n, flag_signed, o, slot) : encode_segment<true, false>(seq, n, flag_signed, o, slot, sym_stride);
     J.seg_bytes[j][g] = nb;
     if (((nb + 3u) & ~3u) > slot) atomicOr(flags + 2 * j, 1u);
 }
@@ -630,6 +664,13 @@ int raht_debug_rlgr_decode_out(int mode)
     return prev;
 }
 
+int raht_debug_rlgr_encode_out(int mode)
+{
+    const int prev = rlgr_seg::g_encode_out;
+    rlgr_seg::g_encode_out = (mode == 0 || mode == 2) ? mode : -1;
+    return prev;
+}
+
 /* k frames of one shape (N, D, strides, seg_len) in one set of launches: the quantization steps of a frame coded together.
  * Every frame j has its own input Q[j], tables seg_bytes[j] / seg_off[j], container out[j] of cap[j] bytes and total_bytes[j]:
  * exactly what raht_rlgr_seg_encode_strided leaves for that frame alone (same bytes). Synchronises. RAHT_ERR_NOMEM when a
@@ -667,7 +708,11 @@ int raht_rlgr_seg_encode_batch(int k, const int32_t *const *Q, int64_t N, int D,
     };
     static const bool no_batch = getenv("RAHT_RLGR_NO_BATCH") != nullptr;          // A/B knob
     if (k == 1 || no_batch) return one_by_one();
-    const uint32_t slot = 4u * (uint32_t)seg_len + 16u;
+    // slots of whole 64-byte pieces (16-byte aligned starts are what the LDS-column output needs; 64: whole pieces)
+    const uint32_t slot = (4u * (uint32_t)seg_len + 16u + 63u) & ~63u;
+    static const char *enc_out = getenv("RAHT_RLGR_ENCODE_OUT");                  // A/B knob: word | lds
+    const int lds_out = rlgr_seg::g_encode_out >= 0 ? (rlgr_seg::g_encode_out == rlgr_seg::OUT_LDS)
+                                                    : enc_out ? (enc_out[0] == 'l') : ((int64_t)k * G >= 200000);
     int rc = guarded("raht_rlgr_seg_encode_batch", [&]() -> int {
         Scratch tmp(sizeof(uint32_t) * ((size_t)k * (size_t)G + 2 * (size_t)k), s);
         Scratch slots((size_t)k * (size_t)G * slot, s);
@@ -680,7 +725,7 @@ int raht_rlgr_seg_encode_batch(int k, const int32_t *const *Q, int64_t N, int D,
             J.Q[j] = Q[q]; J.seg_bytes[j] = seg_bytes[q]; J.seg_off[j] = seg_off[q]; J.out[j] = out[q]; J.cap[j] = (uint64_t)cap[q];
         }
         hipLaunchKernelGGL(rlgr_seg::seg_encode_slots_batch_kernel, dim3((unsigned)ceil_div(G, 64), (unsigned)k), dim3(64), 0, s, J, N, D, sym_stride, chan_stride, seg_len,
-                           (int)nseg, flag_signed, slots.as<uint8_t>(), slot, flags);
+                           (int)nseg, flag_signed, slots.as<uint8_t>(), slot, flags, lds_out);
         hipLaunchKernelGGL(rlgr_seg::seg_pad_batch_kernel, dim3((unsigned)ceil_div(G, 256), (unsigned)k), dim3(256), 0, s, J, G, padded);
         for (int j = 0; j < k; ++j) RAHT_RET(exclusive_scan_u32(padded + (size_t)j * (size_t)G, seg_off[j], G, flags + 2 * j + 1, s));
         hipLaunchKernelGGL(rlgr_seg::seg_compact_batch_kernel, dim3((unsigned)ceil_div(G * 64, 256), (unsigned)k), dim3(256), 0, s, J, slots.as<uint8_t>(), slot, G, flags);

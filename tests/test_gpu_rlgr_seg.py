@@ -13,8 +13,10 @@ def _decoder_output_mode(request):
     too small for the default to pick the LDS columns by itself"""
     from raht_3dgs_codec_amd import _lib
     prev = _lib.lib().raht_debug_rlgr_decode_out(request.param)
+    prev_e = _lib.lib().raht_debug_rlgr_encode_out(request.param)          # (the batched encoder: words / LDS columns)
     yield
     _lib.lib().raht_debug_rlgr_decode_out(prev)
+    _lib.lib().raht_debug_rlgr_encode_out(prev_e)
 
 
 def _cases():
