@@ -185,13 +185,46 @@ __device__ __forceinline__ uint32_t encode_segment(const int32_t *__restrict__ s
 }
 
 // MSB-first bit reader over a 4-byte aligned segment of `size` bytes; bits past the end read as zeros
-struct DevBitReader {
+// LDSIN: the stream's words come through an 8-word LDS column per lane ([8][64] words per wave), fetched as one aligned 32-byte
+// piece (2 x 16 bytes) when the lane crosses into it -- a lane's 4-byte reads, far apart in time, found their line evicted
+// between two of them once the steps of a frame decode together (FETCH_SIZE 12 x the streams' bytes). Pieces are aligned
+// in memory, not to the segment: the first one may begin before the segment (inside the container: `lo`), the last one may
+// reach past it (`hi`: words at or beyond it read as zero and are never consumed: fill() stops at `size`).
+template <bool LDSIN>
+struct DevBitReaderT {
     const uint32_t *in32;
     uint32_t size, pos = 0;      // bytes; pos is a multiple of 4 (whole words are consumed, the last one zero-extended)
     uint64_t acc = 0;
     int nbits = 0;
+    uint32_t *col = nullptr;     // LDSIN: this lane's column
+    uint32_t w0 = 0;             // LDSIN: word index of the segment's start inside its first 32-byte piece
+    int64_t hi_words = 0;        // LDSIN: words from the segment's start to the end of the container
 
-    __device__ __forceinline__ uint32_t word(uint32_t w) { return in32[w]; }
+    __device__ __forceinline__ uint32_t word(uint32_t w)
+    {
+        if (!LDSIN) return in32[w];
+        const uint32_t gw = w + w0, q = gw & 7u;
+        if (q == 0 || w == 0) {                                      // into a new piece (or the very first word): fetch it
+            const int64_t first = (int64_t)w - (int64_t)q;           // word index (from the segment's start) of the piece's first word; >= -7
+            const uint4 *src = (const uint4 *)(in32 + first);
+            uint4 a = make_uint4(0, 0, 0, 0), b = a;
+            if (first + 8 <= hi_words) { a = src[0]; b = src[1]; }
+            else {                                                   // the container ends inside this piece: word by word
+                const uint32_t *sw = in32 + first;
+                if (first + 0 < hi_words) a.x = sw[0];
+                if (first + 1 < hi_words) a.y = sw[1];
+                if (first + 2 < hi_words) a.z = sw[2];
+                if (first + 3 < hi_words) a.w = sw[3];
+                if (first + 4 < hi_words) b.x = sw[4];
+                if (first + 5 < hi_words) b.y = sw[5];
+                if (first + 6 < hi_words) b.z = sw[6];
+                if (first + 7 < hi_words) b.w = sw[7];
+            }
+            col[0 * 64] = a.x; col[1 * 64] = a.y; col[2 * 64] = a.z; col[3 * 64] = a.w;
+            col[4 * 64] = b.x; col[5 * 64] = b.y; col[6 * 64] = b.z; col[7 * 64] = b.w;
+        }
+        return col[q * 64];
+    }
     __device__ __forceinline__ void fill()                           // afterwards nbits > 32 unless the stream ended
     {
         if (nbits <= 32 && pos < size) {
@@ -253,13 +286,14 @@ struct DevBitReader {
 enum { OUT_WORD = 0, OUT_VEC = 1, OUT_LDS = 2 };
 constexpr int DEC_LDS_WORDS = 16 * 64;
 
-template <int OUT>
+template <int OUT, bool LDSIN = false>
 __device__ __forceinline__ void decode_segment(const uint32_t *in32, uint32_t nbytes, int n, int flag_signed, int32_t *__restrict__ seq, int64_t sstr = 1,
-                                               int32_t *lds = nullptr)
+                                               int32_t *lds = nullptr, int32_t *lds_in = nullptr, int64_t hi_words = 0)
 {
     constexpr bool VEC = OUT == OUT_VEC;
-    DevBitReader r;
+    DevBitReaderT<LDSIN> r;
     r.in32 = in32; r.size = nbytes;
+    if (LDSIN) { r.col = (uint32_t *)lds_in + (threadIdx.x & 63); r.w0 = (uint32_t)(((uintptr_t)in32 & 31) >> 2); r.hi_words = hi_words; }
     // 32-bit state, as in the encoder: inside a segment of n < 2^31 symbols of int32 data the symbol values (< 2^32), the run
     // length m and the exponents stay within 32 bits; a corrupt stream may overflow them -- it then decodes to different garbage
     // than a 64-bit decoder would, inside the same bounds (every store is at i < n, every read below `size`).
@@ -342,6 +376,13 @@ static int decode_out_mode(int64_t lanes)
     if (g_decode_out >= 0) return g_decode_out;
     if (e) return e[0] == 'l' ? OUT_LDS : e[0] == 'v' ? OUT_VEC : OUT_WORD;
     return lanes >= 200000 ? OUT_LDS : OUT_WORD;
+}
+
+// (with OUT_LDS) the streams' words through LDS as well: RAHT_RLGR_DECODE_IN=word switches it off (A/B knob)
+static int decode_lds_in()
+{
+    static const char *e = getenv("RAHT_RLGR_DECODE_IN");
+    return e ? (e[0] == 'l') : 1;
 }
 
 // segment g = c * nseg + s  <->  symbols [s * S, min(N, (s + 1) * S)) of channel c
@@ -523,9 +564,10 @@ __global__ __launch_bounds__(256) void seg_compact_batch_kernel(const SegEncJobs
 }
 
 __global__ __launch_bounds__(64) void seg_decode_batch_kernel(const SegDecJobs J, int64_t N, int D, int S, int nseg, int flag_signed, int64_t sym_stride,
-                                                              int64_t chan_stride, uint32_t *__restrict__ bad, int out_mode)
+                                                              int64_t chan_stride, uint32_t *__restrict__ bad, int out_mode, int lds_in)
 {
     __shared__ int32_t s_col[DEC_LDS_WORDS];
+    __shared__ int32_t s_in[8 * 64];
     const int j = blockIdx.y;
     const int64_t t = (int64_t)blockIdx.x * 64 + threadIdx.x;
     if (t >= (int64_t)D * nseg) return;
@@ -540,7 +582,10 @@ __global__ __launch_bounds__(64) void seg_decode_batch_kernel(const SegDecJobs J
     if ((off & 3) || off > in_bytes || (uint64_t)((nb + 3u) & ~3u) > in_bytes - off) { nb = 0; if (bad) atomicOr(bad, 1u << j); }
     int32_t *Q = J.Q[j];
     const bool aligned = sym_stride == 1 && ((((uintptr_t)Q) & 15) == 0) && ((chan_stride & 3) == 0) && ((S & 3) == 0);
-    if (aligned && out_mode == OUT_LDS) decode_segment<OUT_LDS>((const uint32_t *)(J.in[j] + (nb ? off : 0)), nb, n, flag_signed, Q + (int64_t)c * chan_stride + i0, 1, s_col);
+    const uint64_t o = nb ? off : 0;
+    if (aligned && out_mode == OUT_LDS && (((uintptr_t)J.in[j]) & 31) == 0 && lds_in)
+        decode_segment<OUT_LDS, true>((const uint32_t *)(J.in[j] + o), nb, n, flag_signed, Q + (int64_t)c * chan_stride + i0, 1, s_col, s_in, (int64_t)((in_bytes - o) >> 2));
+    else if (aligned && out_mode == OUT_LDS) decode_segment<OUT_LDS>((const uint32_t *)(J.in[j] + o), nb, n, flag_signed, Q + (int64_t)c * chan_stride + i0, 1, s_col);
     else decode_segment<OUT_WORD>((const uint32_t *)(J.in[j] + (nb ? off : 0)), nb, n, flag_signed, Q + (int64_t)c * chan_stride + i0 * sym_stride, sym_stride);
 }
 
@@ -771,7 +816,7 @@ int raht_rlgr_seg_decode_batch(int k, const uint8_t *const *in, const int64_t *i
         J.in[j] = in[q]; J.in_bytes[j] = (uint64_t)in_bytes[q]; J.seg_off[j] = seg_off[q]; J.seg_bytes[j] = seg_bytes[q]; J.Q[j] = Q[q];
     }
     hipLaunchKernelGGL(rlgr_seg::seg_decode_batch_kernel, dim3((unsigned)ceil_div(G, 64), (unsigned)k), dim3(64), 0, (hipStream_t)stream, J, N, D, seg_len, (int)nseg,
-                       flag_signed, sym_stride, chan_stride, bad_dev, rlgr_seg::decode_out_mode((int64_t)k * G));
+                       flag_signed, sym_stride, chan_stride, bad_dev, rlgr_seg::decode_out_mode((int64_t)k * G), rlgr_seg::decode_lds_in());
     RAHT_HIP_CHECK(hipGetLastError());
     return RAHT_OK;
 }
