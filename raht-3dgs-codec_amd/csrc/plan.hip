@@ -704,6 +704,10 @@ __global__ __launch_bounds__(64) void tile_heights_kernel(const HeightArgs H)
     for (int s = 0; s < SPL; ++s) ht[s] = 0;
     PL_STAMP(1, blockIdx.x, 2);                       // partners resolved, level mask reduced
     PL_NOTE_LEVELS(blockIdx.x, __popcll(mask));
+    // (the reduced mask is the same in every lane but lives in vector registers: made scalar, the loop's counter, find-first-set
+    // and branch run on the scalar unit -- see level_extent_kernel)
+    mask = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)mask) |
+           ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(mask >> 32)) << 32);
     while (mask) {
         const int l = __ffsll((unsigned long long)mask) - 1;
         mask &= mask - 1;

@@ -188,7 +188,8 @@ def _step_frames(k, N=30000, D=8, seed=5):
     return [np.floor(base / (1.0 + 1.7 * j) + 0.5).astype(np.int32) for j in range(k)]
 
 
-@pytest.mark.parametrize("k,seg_len,row_major", [(1, 1000, True), (3, 64, True), (9, 2048, True), (4, 1000, False), (13, 4096, True), (12, 100000, False)])
+@pytest.mark.parametrize("k,seg_len,row_major", [(1, 1000, True), (3, 64, True), (9, 2048, True), (4, 1000, False), (13, 4096, True), (12, 100000, False),
+                                                   (3, 1001, False), (2, 333, True)])       # (segment starts off the 16-byte grid: the word paths)
 def test_batch_of_frames_is_every_frame_alone(k, seg_len, row_major):
     """raht_rlgr_seg_encode_batch / _decode_batch: the steps of a frame coded by one set of launches -- same tables and containers
     as one call per frame, byte for byte (k = 13: two chunks of the 12 a call takes)"""
