@@ -10,8 +10,12 @@ timeout -k 10 200 python3 tools/time_sqdiff.py 2>/dev/null | tail -1 > gpurun_ou
 timeout -k 10 200 python3 tools/time_multi.py 2>/dev/null | tail -1 > gpurun_out/${tag}_fwd_quant_multi.json
 timeout -k 10 200 python3 tools/time_voxmerge.py 2>/dev/null | tail -1 > gpurun_out/${tag}_voxelize_merge.json
 timeout -k 10 300 python3 tools/e2e_frame.py --entropy gpu --keep-rec 0 --out gpurun_out/${tag}_e2e > gpurun_out/${tag}_e2e_frame_gpu_entropy.txt 2>&1
+timeout -k 10 300 python3 tools/e2e_frame.py --entropy gpu --keep-rec 0 --batch-steps 1 --out gpurun_out/${tag}_e2e > gpurun_out/${tag}_e2e_frame_gpu_entropy_batched.txt 2>&1
+timeout -k 10 200 python3 tools/time_rlgr_batch.py 3 2048 2>/dev/null | tail -1 > gpurun_out/${tag}_rlgr_batch.json
+timeout -k 10 200 python3 tools/prelude_loop.py > gpurun_out/${tag}_prelude_wall.txt 2>/dev/null
 timeout -k 10 300 bash tools/trace_mx.sh ${tag} > gpurun_out/${tag}_mixed_kernel_durations.txt 2>&1
 timeout -k 10 400 bash tools/pmc_rlgr.sh ${tag} > gpurun_out/${tag}_rlgr_sq_counters.txt 2>&1
+timeout -k 10 400 bash tools/pmc_rlgr.sh ${tag}_batch tools/time_rlgr_batch.py 2 > gpurun_out/${tag}_rlgr_batch_sq_counters.txt 2>&1
 timeout -k 10 300 bash tools/pmc_mx.sh ${tag}mx > gpurun_out/${tag}_mixed_sq_counters.txt 2>&1
 # N > 1 rehearsal on the one GPU (4 ranks: the process guard allows 6 processes on the card, and the launcher and the parent count), so that the multi_gpu fields of such a line can be reviewed
 timeout -k 10 500 python3 bench.py --gpus 4 --backend gloo --workload cfg5 --rows 6000000 --steps 20 --warmup 5 --settle-steps 0 --skip-legs --skip-prelude > gpurun_out/${tag}_rehearsal_4rank_cfg5_gloo_one_gpu.json 2>> gpurun_out/${tag}_bench.err
