@@ -409,7 +409,22 @@ class SoloScene:
         return lambda: (self.fwd_quant(), self.dequant_inv())
 
 
-def two_stream_loop(R, L, _lib, kd, Cd, nbits, step, reps=200):
+def two_stream_loop(R, L, _lib, kd, Cd, nbits, step, reps=200, streams=None):
+    """_two_stream_loop_on with a side stream that does NOT share a hardware queue with the main one. HIP multiplexes streams onto
+    a few hardware queues (4 by default, GPU_MAX_HW_QUEUES); two streams on one queue run their kernels in order whatever the
+    events say -- the loop then takes LONGER than on one stream (0.244 against 0.225 ms on the reference's shape; with any other
+    side stream: 0.191; tools/probe_stream_pairs.py: which pair collides is fixed per process). Three candidates are probed with a
+    few steps each and the best one carries the measurement; the probe's figures go into the line."""
+    if streams is not None:
+        return _two_stream_loop_on(R, L, _lib, kd, Cd, nbits, step, reps, streams)
+    main, sides = torch.cuda.Stream(), [torch.cuda.Stream() for _ in range(3)]
+    probe = [_two_stream_loop_on(R, L, _lib, kd, Cd, nbits, step, 40, (main, sb), trials=1)["two_streams_ms_per_step"] for sb in sides]
+    r = _two_stream_loop_on(R, L, _lib, kd, Cd, nbits, step, reps, (main, sides[int(np.argmin(probe))]))
+    r["side_stream_probe_ms"] = probe
+    return r
+
+
+def _two_stream_loop_on(R, L, _lib, kd, Cd, nbits, step, reps, streams, trials=5):
     """The drivers' loop over quantization steps (python/encode_3dgs.py:199-275) with the two directions on two streams -- forward +
     quantize of step s + 1 next to dequantize + inverse of step s, one workspace set per direction
     (raht_plan_set_concurrent_directions) -- against the same float32 fused calls back to back on one stream."""
@@ -419,7 +434,7 @@ def two_stream_loop(R, L, _lib, kd, Cd, nbits, step, reps=200):
     Cr = torch.empty_like(Cd)
     st = (C.c_float * 1)(step)
     vp = C.c_void_p
-    sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+    sa, sb = streams
 
     def fwd(q, s):
         _lib.check(L.raht_fwd_quant(p._h, vp(Cd.data_ptr()), D, D, st, 1, vp(q.data_ptr()), D, vp(s.cuda_stream)))
@@ -456,10 +471,8 @@ def two_stream_loop(R, L, _lib, kd, Cd, nbits, step, reps=200):
     ref = Cr.clone()
     p.set_concurrent_directions(True)
     overlapped(40)
-    # (how the two streams' launches interleave is up to the hardware queues: small scenes show two modes -- the tails of one
-    # direction under the other's stage 0, or both stage-0 kernels at once and both tails at once: five trials, the median is quoted)
-    trials = sorted(timed_loop(overlapped, reps) for _ in range(5))
-    t2 = trials[2]
+    trials = sorted(timed_loop(overlapped, reps) for _ in range(trials))
+    t2 = trials[len(trials) // 2]
     torch.cuda.synchronize()
     assert torch.equal(Cr, ref), "two-stream loop reconstructs differently"
     alg = 2 * (8.0 * N * D + 8.0 * N)
