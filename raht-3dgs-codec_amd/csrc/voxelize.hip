@@ -713,10 +713,6 @@ int raht_voxelize_plan(const float *PC, int64_t ldpc, int64_t N, int d, const fl
     const int dev = current_device();
     hipStream_t s = (hipStream_t)stream;
     if (!serial && !side[dev]) {
-        // (experiment knob: RAHT_VOXPLAN_SIDE=n creates n streams first -- which hardware queue a stream lands on follows from the
-        // order of creation, and two streams that share one do not overlap)
-        const int skip = getenv("RAHT_VOXPLAN_SIDE") ? atoi(getenv("RAHT_VOXPLAN_SIDE")) : 0;
-        for (int q = 0; q < skip && q < 8; ++q) { hipStream_t dummy; RAHT_HIP_CHECK(hipStreamCreateWithFlags(&dummy, hipStreamNonBlocking)); }
         RAHT_HIP_CHECK(hipStreamCreateWithFlags(&side[dev], hipStreamNonBlocking));
         RAHT_HIP_CHECK(hipEventCreateWithFlags(&ev_keys[dev], hipEventDisableTiming));
         RAHT_HIP_CHECK(hipEventCreateWithFlags(&ev_plan[dev], hipEventDisableTiming));
