@@ -364,6 +364,63 @@ __device__ __forceinline__ void decode_segment(const uint32_t *in32, uint32_t nb
     }
 }
 
+// SYMBOL-SYNCHRONOUS decoding (row-major output). decode_segment above lets every lane run ahead on its own: a lane in a run of
+// zeros emits them in an inner loop while the wave's other lanes wait, and the lanes of a wave are at different symbols at any
+// time -- in a row-major layout their stores then hit 64 different rows. Here every iteration of the wave produces symbol i of
+// EVERY lane: a lane inside a run just counts it down (its zeros cost nothing beside the other lanes' codes), a lane that starts a
+// run reads the run's header and emits its first zero, everybody else decodes one Golomb-Rice code (the run's closing symbol
+// and an ordinary symbol share that code path; they differ by selects). The lanes of a wave are neighbouring channels at the
+// SAME row, so the store of an iteration is one contiguous piece of a row: no LDS staging, no transpose behind the decoder.
+// Same streams, same symbols (membuf.cpp:270-331 with the run's state carried across iterations: z zeros still to come, tail = its
+// closing symbol still to decode -- not decoded when the segment ends first, as in the original's break).
+template <bool LDSIN>
+__device__ __forceinline__ void decode_segment_sync(const uint32_t *in32, uint32_t nbytes, int n, int flag_signed, int32_t *__restrict__ seq, int64_t sstr,
+                                                    int32_t *lds_in = nullptr, int64_t hi_words = 0)
+{
+    DevBitReaderT<LDSIN> r;
+    r.in32 = in32; r.size = nbytes;
+    if (LDSIN) { r.col = (uint32_t *)lds_in + (threadIdx.x & 63); r.w0 = (uint32_t)(((uintptr_t)in32 & 31) >> 2); r.hi_words = hi_words; }
+    uint32_t k_P = 0, k_RP = 2 * L, z = 0;
+    bool tail = false;
+    for (int i = 0; i < n; ++i) {
+        int32_t v = 0;
+        if (z) {
+            --z;
+        } else {
+            bool code = true;
+            if (!tail) {
+                uint32_t k = k_P / L;
+                if (k) {                                             // a run starts: its header
+                    uint32_t m = 0;
+                    while (r.bit()) {
+                        if (k >= 31) { m = (uint32_t)n; break; }     // corrupt stream guard (a run of 2^31 zeros in one segment)
+                        m += 1u << k;
+                        k_P += U1;
+                        k = k_P / L;
+                        if (m > (uint32_t)n) break;                  // corrupt stream guard
+                    }
+                    m += (uint32_t)r.get_wide((int)min(k, 32u));
+                    tail = true;
+                    if (m) { z = m - 1; code = false; }              // this iteration emits the first of its zeros
+                }
+            }
+            if (code) {
+                const uint32_t k_R = k_RP / L;
+                const uint32_t u = (uint32_t)r.golomb_rice((int)k_R);
+                const uint32_t uu = tail ? u + 1u : u;               // (membuf.cpp: the symbol that ends a run is coded minus one)
+                v = flag_signed ? ((uu & 1u) ? -(int32_t)(uu >> 1) - 1 : (int32_t)(uu >> 1)) : (int32_t)uu;
+                const uint32_t p = (k_R < 32) ? (u >> k_R) : 0u;
+                RLGS_ADAPT_KRP32(p);
+                if (tail || u) k_P = k_P ? k_P - 1u : 0u;            // D0 = D1 = 1
+                else k_P += U0;
+                tail = false;
+            }
+        }
+        seq[(int64_t)i * sstr] = v;
+    }
+}
+static_assert(D0 == 1 && D1 == 1, "decode_segment_sync folds the two decrements");
+
 // which way the decoded symbols leave (see OUT_*): RAHT_RLGR_DECODE_OUT=word|vec|lds overrides (A/B knob)
 // Default: by the number of lanes in flight. One 3 M x 56 frame (82 k lanes, 1.25 waves per SIMD) is bound by ONE wave's
 // instruction stream and the L2 still gathers its lines: OUT_WORD 2.86 ms, OUT_LDS 3.36 ms, OUT_VEC 3.97 ms. Nine such frames by
@@ -376,6 +433,16 @@ static int decode_out_mode(int64_t lanes)
     if (g_decode_out >= 0) return g_decode_out;
     if (e) return e[0] == 'l' ? OUT_LDS : e[0] == 'v' ? OUT_VEC : OUT_WORD;
     return lanes >= 200000 ? OUT_LDS : OUT_WORD;
+}
+
+// row-major output: the symbol-synchronous decoder (RAHT_RLGR_DECODE_SYNC=0: the per-lane one with strided stores; A/B knob;
+// raht_debug_rlgr_decode_out(3) / (4) force it on / off for the tests)
+static int g_decode_sync = -1;
+static int decode_sync_rows()
+{
+    static const char *e = getenv("RAHT_RLGR_DECODE_SYNC");
+    if (g_decode_sync >= 0) return g_decode_sync;
+    return e ? atoi(e) != 0 : 1;
 }
 
 // (with OUT_LDS) the streams' words through LDS as well: RAHT_RLGR_DECODE_IN=word switches it off (A/B knob)
@@ -469,7 +536,8 @@ __global__ void seg_pad_kernel(const uint32_t *__restrict__ seg_bytes, int64_t n
 
 __global__ __launch_bounds__(64) void seg_decode_kernel(const uint8_t *__restrict__ in, uint64_t in_bytes, const uint32_t *__restrict__ seg_off,
                                                         const uint32_t *__restrict__ seg_bytes, int64_t N, int D, int S, int nseg, int flag_signed,
-                                                        int32_t *__restrict__ Q, int64_t sym_stride, int64_t chan_stride, uint32_t *__restrict__ bad, int out_mode)
+                                                        int32_t *__restrict__ Q, int64_t sym_stride, int64_t chan_stride, uint32_t *__restrict__ bad, int out_mode,
+                                                        int sync_rows)
 {
     __shared__ int32_t s_col[DEC_LDS_WORDS];
     // thread t -> segment g = c * nseg + s. Channel-major input (sym_stride == 1): t = g, a lane walks its own contiguous run.
@@ -491,7 +559,8 @@ __global__ __launch_bounds__(64) void seg_decode_kernel(const uint8_t *__restric
     // (16-byte stores of four buffered symbols measured SLOWER than one 4-byte store per symbol -- 4.2 against 3.0 ms for 3 M x 56
     // at 2048 per segment: the component selects cost more instructions than the stores save; kept behind this switch)
     const bool aligned = sym_stride == 1 && ((((uintptr_t)Q) & 15) == 0) && ((chan_stride & 3) == 0) && ((S & 3) == 0);
-    if (aligned && out_mode == OUT_LDS) decode_segment<OUT_LDS>((const uint32_t *)(in + (nb ? off : 0)), nb, n, flag_signed, Q + (int64_t)c * chan_stride + i0, 1, s_col);
+    if (sym_stride != 1 && sync_rows) decode_segment_sync<false>((const uint32_t *)(in + (nb ? off : 0)), nb, n, flag_signed, Q + (int64_t)c * chan_stride + i0 * sym_stride, sym_stride);
+    else if (aligned && out_mode == OUT_LDS) decode_segment<OUT_LDS>((const uint32_t *)(in + (nb ? off : 0)), nb, n, flag_signed, Q + (int64_t)c * chan_stride + i0, 1, s_col);
     else if (aligned && out_mode == OUT_VEC) decode_segment<OUT_VEC>((const uint32_t *)(in + (nb ? off : 0)), nb, n, flag_signed, Q + (int64_t)c * chan_stride + i0);
     else decode_segment<OUT_WORD>((const uint32_t *)(in + (nb ? off : 0)), nb, n, flag_signed, Q + (int64_t)c * chan_stride + i0 * sym_stride, sym_stride);
 }
@@ -564,7 +633,7 @@ __global__ __launch_bounds__(256) void seg_compact_batch_kernel(const SegEncJobs
 }
 
 __global__ __launch_bounds__(64) void seg_decode_batch_kernel(const SegDecJobs J, int64_t N, int D, int S, int nseg, int flag_signed, int64_t sym_stride,
-                                                              int64_t chan_stride, uint32_t *__restrict__ bad, int out_mode, int lds_in)
+                                                              int64_t chan_stride, uint32_t *__restrict__ bad, int out_mode, int lds_in, int sync_rows)
 {
     __shared__ int32_t s_col[DEC_LDS_WORDS];
     __shared__ int32_t s_in[8 * 64];
@@ -583,7 +652,11 @@ __global__ __launch_bounds__(64) void seg_decode_batch_kernel(const SegDecJobs J
     int32_t *Q = J.Q[j];
     const bool aligned = sym_stride == 1 && ((((uintptr_t)Q) & 15) == 0) && ((chan_stride & 3) == 0) && ((S & 3) == 0);
     const uint64_t o = nb ? off : 0;
-    if (aligned && out_mode == OUT_LDS && (((uintptr_t)J.in[j]) & 31) == 0 && lds_in)
+    if (sym_stride != 1 && sync_rows) {
+        if ((((uintptr_t)J.in[j]) & 31) == 0 && lds_in)
+            decode_segment_sync<true>((const uint32_t *)(J.in[j] + o), nb, n, flag_signed, Q + (int64_t)c * chan_stride + i0 * sym_stride, sym_stride, s_in, (int64_t)((in_bytes - o) >> 2));
+        else decode_segment_sync<false>((const uint32_t *)(J.in[j] + o), nb, n, flag_signed, Q + (int64_t)c * chan_stride + i0 * sym_stride, sym_stride);
+    } else if (aligned && out_mode == OUT_LDS && (((uintptr_t)J.in[j]) & 31) == 0 && lds_in)
         decode_segment<OUT_LDS, true>((const uint32_t *)(J.in[j] + o), nb, n, flag_signed, Q + (int64_t)c * chan_stride + i0, 1, s_col, s_in, (int64_t)((in_bytes - o) >> 2));
     else if (aligned && out_mode == OUT_LDS) decode_segment<OUT_LDS>((const uint32_t *)(J.in[j] + o), nb, n, flag_signed, Q + (int64_t)c * chan_stride + i0, 1, s_col);
     else decode_segment<OUT_WORD>((const uint32_t *)(J.in[j] + (nb ? off : 0)), nb, n, flag_signed, Q + (int64_t)c * chan_stride + i0 * sym_stride, sym_stride);
@@ -697,7 +770,7 @@ int raht_rlgr_seg_decode_strided(const uint8_t *in, int64_t in_bytes, const uint
     const int64_t nseg = ceil_div(N, seg_len), G = nseg * D;
     if (G >= ((int64_t)1 << 31)) { set_error("raht_rlgr_seg_decode: too many segments"); return RAHT_ERR_INVALID; }
     hipLaunchKernelGGL(rlgr_seg::seg_decode_kernel, dim3((unsigned)ceil_div(G, 64)), dim3(64), 0, (hipStream_t)stream, in, (uint64_t)in_bytes, seg_off, seg_bytes, N, D,
-                       seg_len, (int)nseg, flag_signed, Q, sym_stride, chan_stride, bad_dev, rlgr_seg::decode_out_mode(G));
+                       seg_len, (int)nseg, flag_signed, Q, sym_stride, chan_stride, bad_dev, rlgr_seg::decode_out_mode(G), rlgr_seg::decode_sync_rows());
     RAHT_HIP_CHECK(hipGetLastError());
     return RAHT_OK;
 }
@@ -705,7 +778,9 @@ int raht_rlgr_seg_decode_strided(const uint8_t *in, int64_t in_bytes, const uint
 int raht_debug_rlgr_decode_out(int mode)
 {
     const int prev = rlgr_seg::g_decode_out;
+    if (mode == 3 || mode == 4) { rlgr_seg::g_decode_sync = (mode == 3); return prev; }     // row-major output: symbol-synchronous decoder on / off
     rlgr_seg::g_decode_out = (mode >= 0 && mode <= 2) ? mode : -1;
+    if (mode < 0) rlgr_seg::g_decode_sync = -1;
     return prev;
 }
 
@@ -816,7 +891,7 @@ int raht_rlgr_seg_decode_batch(int k, const uint8_t *const *in, const int64_t *i
         J.in[j] = in[q]; J.in_bytes[j] = (uint64_t)in_bytes[q]; J.seg_off[j] = seg_off[q]; J.seg_bytes[j] = seg_bytes[q]; J.Q[j] = Q[q];
     }
     hipLaunchKernelGGL(rlgr_seg::seg_decode_batch_kernel, dim3((unsigned)ceil_div(G, 64), (unsigned)k), dim3(64), 0, (hipStream_t)stream, J, N, D, seg_len, (int)nseg,
-                       flag_signed, sym_stride, chan_stride, bad_dev, rlgr_seg::decode_out_mode((int64_t)k * G), rlgr_seg::decode_lds_in());
+                       flag_signed, sym_stride, chan_stride, bad_dev, rlgr_seg::decode_out_mode((int64_t)k * G), rlgr_seg::decode_lds_in(), rlgr_seg::decode_sync_rows());
     RAHT_HIP_CHECK(hipGetLastError());
     return RAHT_OK;
 }

@@ -194,9 +194,9 @@ def encode_frame(V_int, attributes, J, steps, frame=1, device="cuda:0", dtype=to
 
 
 def _encode_frame_gpu_entropy(V_int, attributes, J, steps, frame, device, dtype, seg_len, keep_rec=True):
-    """encode_frame with the entropy stage on the device (entropy="gpu"): forward RAHT + quantize + reorder -> channel-major
-    transpose -> segmented RLGR encode (device) -> [container bytes to the host: the codec's output] -> segmented RLGR decode
-    (device) -> round-trip check (device) -> transpose -> dequantize + un-reorder + inverse RAHT -> PSNR."""
+    """encode_frame with the entropy stage on the device (entropy="gpu"): forward RAHT + quantize + reorder -> segmented RLGR
+    encode of the row-major integers (device) -> [container bytes to the host: the codec's output] -> segmented RLGR decode, row-major
+    (device) -> round-trip check (device) -> dequantize + un-reorder + inverse RAHT -> PSNR. No transpose on either side."""
     N = V_int.shape[0]
     dev = torch.device(device)
     C = attributes.to(dtype=dtype).contiguous().to(dev)
@@ -230,14 +230,9 @@ def _encode_frame_gpu_entropy(V_int, attributes, J, steps, frame, device, dtype,
         size_bytes = len(hdr) + lens.nbytes + payload.nbytes
         assert size_bytes == coder.size_bytes
         t0 = time.time()
-        q_back = coder.decode()                               # channel-major: a decoding lane advances at its own pace (zero runs), so its
-        _sync()                                               # stores only stay line-friendly in a layout where its symbols are neighbours
-        r["Entropy_dec_time"] = time.time() - t0              # (row-major decode measured 4.1 ms against 2.9 + 0.3 ms with the transpose)
-        t0 = time.time()
-        t0t = time.time()
-        qd = rlgr_mod.transpose_on_device(q_back)
-        _sync()
-        r["Transpose_time"] += time.time() - t0t
+        qd = coder.decode(row_major=True)                     # row-major, as the inverse takes it: the symbol-synchronous decoder (every
+        _sync()                                               # iteration of a wave is symbol i of all its lanes = one piece of a row):
+        r["Entropy_dec_time"] = time.time() - t0              # 2.1 ms against 2.9 + 0.3 ms for channel-major + transpose
         t0 = time.time()
         assert torch.equal(qd, q_dev) and int(coder.bad.item()) == 0, "RLGR roundtrip failed"    # encode_3dgs.py:242-245
         r["Roundtrip_check_time"] = time.time() - t0
@@ -300,14 +295,10 @@ def _encode_frame_gpu_entropy_batched(V_int, attributes, J, steps, frame, device
             assert sizes[-1] == c.size_bytes
         t_d2h = time.time() - t0
         t0 = time.time()
-        backs = rlgr_mod.SegmentedCoder.decode_batch(coders)    # channel-major (see _encode_frame_gpu_entropy)
+        qds = rlgr_mod.SegmentedCoder.decode_batch(coders, row_major=True)    # (see _encode_frame_gpu_entropy: no transpose behind it)
         _sync()
         t_dec = time.time() - t0
-        t0 = time.time()
-        qds = [rlgr_mod.transpose_on_device(b) for b in backs]
-        _sync()
-        t_tr = time.time() - t0
-        del backs
+        t_tr = 0.0
         t0 = time.time()
         for qd, q in zip(qds, Qs):
             assert torch.equal(qd, q), "RLGR roundtrip failed"                       # encode_3dgs.py:242-245

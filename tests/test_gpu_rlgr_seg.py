@@ -7,10 +7,11 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(params=[-1, 0, 1, 2], ids=["out_auto", "out_word", "out_vec", "out_lds"], autouse=True)
+@pytest.fixture(params=[-1, 0, 1, 2, 4], ids=["out_auto", "out_word", "out_vec", "out_lds", "rows_per_lane"], autouse=True)
 def _decoder_output_mode(request):
     """every test with each of the ways the decoders' symbols leave the lanes (raht_debug_rlgr_decode_out): these frames are far
-    too small for the default to pick the LDS columns by itself"""
+    too small for the default to pick the LDS columns by itself. rows_per_lane: row-major output from the per-lane decoder with
+    strided stores instead of the symbol-synchronous one (the default for that layout)"""
     from raht_3dgs_codec_amd import _lib
     prev = _lib.lib().raht_debug_rlgr_decode_out(request.param)
     prev_e = _lib.lib().raht_debug_rlgr_encode_out(request.param)          # (the batched encoder: words / LDS columns)

@@ -44,7 +44,13 @@ assert [c.container() for c in coders[:2]] == ref
 db = wall(lambda: SC.decode_batch(coders, outs=outs))
 for o, q in zip(outs, Qs):
     assert torch.equal(o.t(), q)
+del outs
+outs_rm = [torch.empty((N, D), dtype=torch.int32, device="cuda") for _ in steps]
+d1_rm = wall(lambda: [c.decode(out=o) for c, o in zip(coders, outs_rm)])
+db_rm = wall(lambda: SC.decode_batch(coders, outs=outs_rm))
+for o, q in zip(outs_rm, Qs):
+    assert torch.equal(o, q)
 print(json.dumps({"symbols_per_step": N * D, "steps": k, "seg_len": S, "lanes_per_step": coders[0].G,
-                  "one_call_per_step": {"encode_ms_per_step": round(e1 / k, 3), "decode_ms_per_step": round(d1 / k, 3)},
-                  "all_steps_one_launch": {"encode_ms_per_step": round(eb / k, 3), "decode_ms_per_step": round(db / k, 3)},
+                  "one_call_per_step": {"encode_ms_per_step": round(e1 / k, 3), "decode_ms_per_step": round(d1 / k, 3), "decode_row_major_ms_per_step": round(d1_rm / k, 3)},
+                  "all_steps_one_launch": {"encode_ms_per_step": round(eb / k, 3), "decode_ms_per_step": round(db / k, 3), "decode_row_major_ms_per_step": round(db_rm / k, 3)},
                   "bytes": [c.size_bytes for c in coders]}))
