@@ -542,6 +542,14 @@ int raht_rlgr_seg_encode_batch(int k, const int32_t *const *Q, int64_t N, int D,
 int raht_rlgr_seg_decode_batch(int k, const uint8_t *const *in, const int64_t *in_bytes, const uint32_t *const *seg_off,
                                const uint32_t *const *seg_bytes, int64_t N, int D, int seg_len, int flag_signed, int32_t *const *Q,
                                int64_t sym_stride, int64_t chan_stride, uint32_t *bad_dev, raht_stream_t stream);
+/* The same, ROW-MAJOR frames only (chan_stride = 1), with the drivers' round-trip assertion (python/encode_3dgs.py:242-245: what was
+ * decoded equals what was encoded) inside the decoder: expect[j] (DEVICE, layout and strides of Q[j]) is compared symbol by symbol
+ * on the way out -- in this layout one more contiguous read per iteration of a wave -- and bit 16 + j of *bad_dev (required) is set
+ * when frame j differs. Replaces a comparison pass over two N x D arrays per frame. */
+int raht_rlgr_seg_decode_batch_check(int k, const uint8_t *const *in, const int64_t *in_bytes, const uint32_t *const *seg_off,
+                                     const uint32_t *const *seg_bytes, int64_t N, int D, int seg_len, int flag_signed,
+                                     int32_t *const *Q, const int32_t *const *expect, int64_t sym_stride, int64_t chan_stride,
+                                     uint32_t *bad_dev, raht_stream_t stream);
 
 /* How the decoders' symbols leave the lanes: -1 = chosen by the number of lanes in flight (default: one 4-byte store per symbol
  * below 200 000 lanes, where the L2 still gathers a lane's line; above, a 16-word LDS column per lane written out as aligned

@@ -27,7 +27,7 @@ EXPORTS = [
     "raht_plan_set_max_stages", "raht_plan_set_concurrent_directions", "raht_quant_reorder_f64", "raht_dequant_unreorder_f64", "raht_fwd_quant_f64", "raht_dequant_inv_f64",
     "raht_fwd_quant_mixed", "raht_dequant_inv_mixed", "raht_dequant_inv_sqdiff", "raht_fwd_quant_multi", "raht_plan_mixed_stats",
     "raht_fwd_batch", "raht_inv_batch", "raht_fwd_quant_batch", "raht_dequant_inv_batch",
-    "raht_rlgr_bound", "raht_rlgr_encode", "raht_rlgr_decode", "raht_rlgr_encode_channels", "raht_rlgr_decode_channels", "raht_transpose_i32", "raht_i32_equal", "raht_sqdiff_columns", "raht_merge_clusters", "raht_voxelize_merge", "raht_rlgr_seg_encode", "raht_rlgr_seg_decode", "raht_rlgr_seg_encode_strided", "raht_rlgr_seg_decode_strided", "raht_rlgr_seg_encode_batch", "raht_rlgr_seg_decode_batch", "raht_debug_rlgr_decode_out", "raht_debug_rlgr_encode_out",
+    "raht_rlgr_bound", "raht_rlgr_encode", "raht_rlgr_decode", "raht_rlgr_encode_channels", "raht_rlgr_decode_channels", "raht_transpose_i32", "raht_i32_equal", "raht_sqdiff_columns", "raht_merge_clusters", "raht_voxelize_merge", "raht_rlgr_seg_encode", "raht_rlgr_seg_decode", "raht_rlgr_seg_encode_strided", "raht_rlgr_seg_decode_strided", "raht_rlgr_seg_encode_batch", "raht_rlgr_seg_decode_batch", "raht_rlgr_seg_decode_batch_check", "raht_debug_rlgr_decode_out", "raht_debug_rlgr_encode_out",
     "raht_xchg_bytes", "raht_xchg_alloc", "raht_xchg_open", "raht_xchg_close", "raht_xchg_free", "raht_xchg_gather", "raht_xchg_buffer", "raht_xchg_status",
 ]
 
@@ -149,6 +149,7 @@ def lib():
     L.raht_debug_rlgr_encode_out.argtypes = [i32]
     L.raht_rlgr_seg_encode_batch.argtypes = [i32, C.POINTER(vp), i64, i32, i64, i64, i32, i32, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(i64), C.POINTER(i64), vp]
     L.raht_rlgr_seg_decode_batch.argtypes = [i32, C.POINTER(vp), C.POINTER(i64), C.POINTER(vp), C.POINTER(vp), i64, i32, i32, i32, C.POINTER(vp), i64, i64, vp, vp]
+    L.raht_rlgr_seg_decode_batch_check.argtypes = [i32, C.POINTER(vp), C.POINTER(i64), C.POINTER(vp), C.POINTER(vp), i64, i32, i32, i32, C.POINTER(vp), C.POINTER(vp), i64, i64, vp, vp]
     L.raht_xchg_bytes.argtypes = [i32, i64, C.POINTER(i64)]
     L.raht_xchg_alloc.argtypes = [i32, i64, C.POINTER(vp), vp]
     L.raht_xchg_open.argtypes = [vp, C.POINTER(vp)]

@@ -373,10 +373,14 @@ __device__ __forceinline__ void decode_segment(const uint32_t *in32, uint32_t nb
 // SAME row, so the store of an iteration is one contiguous piece of a row: no LDS staging, no transpose behind the decoder.
 // Same streams, same symbols (membuf.cpp:270-331 with the run's state carried across iterations: z zeros still to come, tail = its
 // closing symbol still to decode -- not decoded when the segment ends first, as in the original's break).
+// expect (may be NULL): what the symbols should be, same layout as seq -- the drivers' round-trip assertion
+// (python/encode_3dgs.py:242-245) inside the decoder: in this layout the comparison is one more contiguous read per iteration.
+// -> true when a symbol differs.
 template <bool LDSIN>
-__device__ __forceinline__ void decode_segment_sync(const uint32_t *in32, uint32_t nbytes, int n, int flag_signed, int32_t *__restrict__ seq, int64_t sstr,
-                                                    int32_t *lds_in = nullptr, int64_t hi_words = 0)
+__device__ __forceinline__ bool decode_segment_sync(const uint32_t *in32, uint32_t nbytes, int n, int flag_signed, int32_t *__restrict__ seq, int64_t sstr,
+                                                    int32_t *lds_in = nullptr, int64_t hi_words = 0, const int32_t *__restrict__ expect = nullptr)
 {
+    bool differs = false;
     DevBitReaderT<LDSIN> r;
     r.in32 = in32; r.size = nbytes;
     if (LDSIN) { r.col = (uint32_t *)lds_in + (threadIdx.x & 63); r.w0 = (uint32_t)(((uintptr_t)in32 & 31) >> 2); r.hi_words = hi_words; }
@@ -417,7 +421,9 @@ __device__ __forceinline__ void decode_segment_sync(const uint32_t *in32, uint32
             }
         }
         seq[(int64_t)i * sstr] = v;
+        if (expect) differs |= expect[(int64_t)i * sstr] != v;
     }
+    return differs;
 }
 static_assert(D0 == 1 && D1 == 1, "decode_segment_sync folds the two decrements");
 
@@ -579,6 +585,7 @@ struct SegEncJobs {
 struct SegDecJobs {
     const uint8_t *in[SEG_BATCH_MAX]; uint64_t in_bytes[SEG_BATCH_MAX]; const uint32_t *seg_off[SEG_BATCH_MAX]; const uint32_t *seg_bytes[SEG_BATCH_MAX];
     int32_t *Q[SEG_BATCH_MAX];
+    const int32_t *expect[SEG_BATCH_MAX];        // (may be NULL) what Q[j] should become: compared inside the row-major decoder
 };
 
 // flags: two words per frame (overflow bits, container bytes)
@@ -652,10 +659,14 @@ __global__ __launch_bounds__(64) void seg_decode_batch_kernel(const SegDecJobs J
     int32_t *Q = J.Q[j];
     const bool aligned = sym_stride == 1 && ((((uintptr_t)Q) & 15) == 0) && ((chan_stride & 3) == 0) && ((S & 3) == 0);
     const uint64_t o = nb ? off : 0;
-    if (sym_stride != 1 && sync_rows) {
+    if (sym_stride != 1 && (sync_rows || J.expect[j])) {
+        const int64_t at = (int64_t)c * chan_stride + i0 * sym_stride;
+        const int32_t *ex = J.expect[j] ? J.expect[j] + at : nullptr;
+        bool differs;
         if ((((uintptr_t)J.in[j]) & 31) == 0 && lds_in)
-            decode_segment_sync<true>((const uint32_t *)(J.in[j] + o), nb, n, flag_signed, Q + (int64_t)c * chan_stride + i0 * sym_stride, sym_stride, s_in, (int64_t)((in_bytes - o) >> 2));
-        else decode_segment_sync<false>((const uint32_t *)(J.in[j] + o), nb, n, flag_signed, Q + (int64_t)c * chan_stride + i0 * sym_stride, sym_stride);
+            differs = decode_segment_sync<true>((const uint32_t *)(J.in[j] + o), nb, n, flag_signed, Q + at, sym_stride, s_in, (int64_t)((in_bytes - o) >> 2), ex);
+        else differs = decode_segment_sync<false>((const uint32_t *)(J.in[j] + o), nb, n, flag_signed, Q + at, sym_stride, nullptr, 0, ex);
+        if (__ballot(differs) && (threadIdx.x & 63) == 0 && bad) atomicOr(bad, 1u << (16 + j));
     } else if (aligned && out_mode == OUT_LDS && (((uintptr_t)J.in[j]) & 31) == 0 && lds_in)
         decode_segment<OUT_LDS, true>((const uint32_t *)(J.in[j] + o), nb, n, flag_signed, Q + (int64_t)c * chan_stride + i0, 1, s_col, s_in, (int64_t)((in_bytes - o) >> 2));
     else if (aligned && out_mode == OUT_LDS) decode_segment<OUT_LDS>((const uint32_t *)(J.in[j] + o), nb, n, flag_signed, Q + (int64_t)c * chan_stride + i0, 1, s_col);
@@ -869,9 +880,33 @@ int raht_rlgr_seg_encode_batch(int k, const int32_t *const *Q, int64_t N, int D,
 
 /* The inverse for k frames of one shape: in[j] / in_bytes[j] / seg_off[j] / seg_bytes[j] -> Q[j], one launch. Does not
  * synchronise. *bad_dev (DEVICE uint32, may be NULL): bit j set when a table entry of frame j reached outside in[j]. */
+static int seg_decode_batch_impl(int k, const uint8_t *const *in, const int64_t *in_bytes, const uint32_t *const *seg_off, const uint32_t *const *seg_bytes,
+                                 int64_t N, int D, int seg_len, int flag_signed, int32_t *const *Q, const int32_t *const *expect, int64_t sym_stride,
+                                 int64_t chan_stride, uint32_t *bad_dev, raht_stream_t stream);
+
 int raht_rlgr_seg_decode_batch(int k, const uint8_t *const *in, const int64_t *in_bytes, const uint32_t *const *seg_off, const uint32_t *const *seg_bytes,
                                int64_t N, int D, int seg_len, int flag_signed, int32_t *const *Q, int64_t sym_stride, int64_t chan_stride,
                                uint32_t *bad_dev, raht_stream_t stream)
+{
+    return seg_decode_batch_impl(k, in, in_bytes, seg_off, seg_bytes, N, D, seg_len, flag_signed, Q, nullptr, sym_stride, chan_stride, bad_dev, stream);
+}
+
+/* ... and compares every frame with what it should decode to (expect[j]: DEVICE, the layout and strides of Q[j]; ROW-MAJOR only:
+ * chan_stride = 1) on the way: bit 16 + j of *bad_dev (required) is set when a symbol of frame j differs -- the drivers'
+ * round-trip assertion (python/encode_3dgs.py:242-245) without a pass of its own over two N x D arrays. */
+int raht_rlgr_seg_decode_batch_check(int k, const uint8_t *const *in, const int64_t *in_bytes, const uint32_t *const *seg_off, const uint32_t *const *seg_bytes,
+                                     int64_t N, int D, int seg_len, int flag_signed, int32_t *const *Q, const int32_t *const *expect, int64_t sym_stride,
+                                     int64_t chan_stride, uint32_t *bad_dev, raht_stream_t stream)
+{
+    if (!expect || !bad_dev || chan_stride != 1) { set_error("raht_rlgr_seg_decode_batch_check: needs expect[], bad_dev and row-major frames (chan_stride 1)"); return RAHT_ERR_INVALID; }
+    for (int j = 0; j < k && j < RAHT_RLGR_BATCH_MAX; ++j)
+        if (!expect[j]) { set_error("raht_rlgr_seg_decode_batch_check: expect[%d] is NULL", j); return RAHT_ERR_INVALID; }
+    return seg_decode_batch_impl(k, in, in_bytes, seg_off, seg_bytes, N, D, seg_len, flag_signed, Q, expect, sym_stride, chan_stride, bad_dev, stream);
+}
+
+static int seg_decode_batch_impl(int k, const uint8_t *const *in, const int64_t *in_bytes, const uint32_t *const *seg_off, const uint32_t *const *seg_bytes,
+                                 int64_t N, int D, int seg_len, int flag_signed, int32_t *const *Q, const int32_t *const *expect, int64_t sym_stride,
+                                 int64_t chan_stride, uint32_t *bad_dev, raht_stream_t stream)
 {
     if (k < 1 || k > RAHT_RLGR_BATCH_MAX || !in || !in_bytes || !seg_off || !seg_bytes || !Q || N < 1 || D < 1 || seg_len < 64 ||
         !((sym_stride == 1 && chan_stride >= N) || (chan_stride == 1 && sym_stride >= D))) {
@@ -889,6 +924,7 @@ int raht_rlgr_seg_decode_batch(int k, const uint8_t *const *in, const int64_t *i
     for (int j = 0; j < RAHT_RLGR_BATCH_MAX; ++j) {
         const int q = j < k ? j : 0;
         J.in[j] = in[q]; J.in_bytes[j] = (uint64_t)in_bytes[q]; J.seg_off[j] = seg_off[q]; J.seg_bytes[j] = seg_bytes[q]; J.Q[j] = Q[q];
+        J.expect[j] = expect ? expect[q] : nullptr;
     }
     hipLaunchKernelGGL(rlgr_seg::seg_decode_batch_kernel, dim3((unsigned)ceil_div(G, 64), (unsigned)k), dim3(64), 0, (hipStream_t)stream, J, N, D, seg_len, (int)nseg,
                        flag_signed, sym_stride, chan_stride, bad_dev, rlgr_seg::decode_out_mode((int64_t)k * G), rlgr_seg::decode_lds_in(), rlgr_seg::decode_sync_rows());

@@ -295,14 +295,14 @@ def _encode_frame_gpu_entropy_batched(V_int, attributes, J, steps, frame, device
             assert sizes[-1] == c.size_bytes
         t_d2h = time.time() - t0
         t0 = time.time()
-        qds = rlgr_mod.SegmentedCoder.decode_batch(coders, row_major=True)    # (see _encode_frame_gpu_entropy: no transpose behind it)
+        # row-major (see _encode_frame_gpu_entropy: no transpose behind it), and the round-trip assertion of encode_3dgs.py:242-245
+        # inside the decoder: every decoded symbol is compared with what was encoded on its way out (raht_rlgr_seg_decode_batch_check)
+        qds = rlgr_mod.SegmentedCoder.decode_batch(coders, row_major=True, expect=Qs)
         _sync()
         t_dec = time.time() - t0
         t_tr = 0.0
         t0 = time.time()
-        for qd, q in zip(qds, Qs):
-            assert torch.equal(qd, q), "RLGR roundtrip failed"                       # encode_3dgs.py:242-245
-        assert int(coders[0].bad.item()) == 0, "RLGR roundtrip failed"
+        assert not rlgr_mod.SegmentedCoder.roundtrip_failed(coders), "RLGR roundtrip failed"
         t_chk = time.time() - t0
         del Qs, coders
         t_shared = time.time() - t_chunk0

@@ -339,10 +339,13 @@ class SegmentedCoder:
         return [c.total for c in coders]
 
     @classmethod
-    def decode_batch(cls, coders, outs=None, row_major=False):
+    def decode_batch(cls, coders, outs=None, row_major=False, expect=None):
         """``coders[j].decode()`` for every j in ONE launch (raht_rlgr_seg_decode_batch) -> list of (D, N) int32 CUDA tensors ((N, D)
         with ``row_major=True``); enqueued on the current stream, no synchronisation. ``coders[0].bad`` collects the frames whose
-        tables reached outside their payload (bit j of a chunk of 12)."""
+        tables reached outside their payload (bit j of a chunk of 12).
+        ``expect`` (row-major only): one (N, D) tensor per coder, what the frame should decode to -- compared inside the decoder
+        (raht_rlgr_seg_decode_batch_check: the drivers' round-trip assertion without a pass of its own); bit 16 + j of
+        ``coders[0].bad`` reports frame j of a chunk; ``roundtrip_failed(coders)`` reads it."""
         import torch
         if not coders:
             return []
@@ -353,17 +356,37 @@ class SegmentedCoder:
         if len(outs) != len(coders) or any(x != st[0] for x in st):
             raise ValueError("SegmentedCoder.decode_batch: one output per coder, all in the same layout")
         sym, chan = st[0]
+        if expect is not None:
+            if not row_major and chan != 1:
+                raise ValueError("SegmentedCoder.decode_batch: expect= goes with row-major frames")
+            if len(expect) != len(coders) or any(c._strides(e, "decode_batch") != (sym, chan) for c, e in zip(coders, expect)):
+                raise ValueError("SegmentedCoder.decode_batch: one expected frame per coder, in the layout and strides of the outputs")
         L = _lib.lib()
         for lo in range(0, len(coders), cls.BATCH_MAX):
             cs, os_ = coders[lo: lo + cls.BATCH_MAX], outs[lo: lo + cls.BATCH_MAX]
             k = len(cs)
             VP, I64 = C.c_void_p * k, C.c_int64 * k
+            args = (k, VP(*[c.out.data_ptr() for c in cs]), I64(*[(c.total + 3) // 4 * 4 for c in cs]),
+                    VP(*[c.seg_off.data_ptr() for c in cs]), VP(*[c.seg_bytes.data_ptr() for c in cs]),
+                    c0.N, c0.D, c0.S, c0.flag, VP(*[o.data_ptr() for o in os_]))
+            bad = cs[0].bad                                       # (every chunk reports into its own first coder)
             with torch.cuda.device(c0.device):
-                check(L.raht_rlgr_seg_decode_batch(k, VP(*[c.out.data_ptr() for c in cs]), I64(*[(c.total + 3) // 4 * 4 for c in cs]),
-                                                   VP(*[c.seg_off.data_ptr() for c in cs]), VP(*[c.seg_bytes.data_ptr() for c in cs]),
-                                                   c0.N, c0.D, c0.S, c0.flag, VP(*[o.data_ptr() for o in os_]), sym, chan,
-                                                   C.c_void_p(c0.bad.data_ptr()), c0._stream()))
+                if expect is None:
+                    check(L.raht_rlgr_seg_decode_batch(*args, sym, chan, C.c_void_p(bad.data_ptr()), c0._stream()))
+                else:
+                    ex = expect[lo: lo + cls.BATCH_MAX]
+                    check(L.raht_rlgr_seg_decode_batch_check(*args, VP(*[e.data_ptr() for e in ex]), sym, chan, C.c_void_p(bad.data_ptr()), c0._stream()))
         return outs
+
+    @classmethod
+    def roundtrip_failed(cls, coders):
+        """after ``decode_batch(..., expect=...)``: -> list of the indices of the frames that did not decode to what was expected, or
+        whose tables reached outside their payload (synchronises)"""
+        out = []
+        for lo in range(0, len(coders), cls.BATCH_MAX):
+            w = int(coders[lo].bad.item()) & 0xffffffff
+            out += [lo + j for j in range(min(cls.BATCH_MAX, len(coders) - lo)) if (w >> j) & 1 or (w >> (16 + j)) & 1]
+        return out
 
     def segment(self, c, s):
         """the bytes of segment s of channel c (host copy; tests)"""

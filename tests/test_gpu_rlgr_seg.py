@@ -259,3 +259,29 @@ def test_batch_with_an_incompressible_frame_and_bad_arguments():
     assert L.raht_rlgr_seg_encode_batch(*args(0, 512)) == -1                # RAHT_ERR_INVALID
     assert L.raht_rlgr_seg_encode_batch(*args(13, 512)) == -1                # RAHT_ERR_INVALID
     assert L.raht_rlgr_seg_encode_batch(*args(1, 8)) == -1                # RAHT_ERR_INVALID
+
+
+def test_round_trip_assertion_inside_the_batch_decoder():
+    """decode_batch(expect=...): raht_rlgr_seg_decode_batch_check compares every decoded symbol with what it should be on its way out
+    (python/encode_3dgs.py:242-245 without a pass of its own); one flipped symbol in one frame is found, in that frame only"""
+    import torch
+    from raht_3dgs_codec_amd import rlgr
+    frames = _step_frames(13, N=9000, D=7)
+    N, D = frames[0].shape
+    Qs = [torch.from_numpy(f).cuda() for f in frames]
+    coders = [rlgr.SegmentedCoder(N, D, 512) for _ in frames]
+    rlgr.SegmentedCoder.encode_batch(coders, Qs)
+    outs = rlgr.SegmentedCoder.decode_batch(coders, row_major=True, expect=Qs)
+    assert rlgr.SegmentedCoder.roundtrip_failed(coders) == []
+    assert all(torch.equal(o, q) for o, q in zip(outs, Qs))
+    wrong = [q.clone() for q in Qs]
+    wrong[4][8191, 3] += 1                                              # (the last symbol of a segment)
+    wrong[12][0, 0] -= 2                                                # (second chunk of the 12 a call takes)
+    fresh = [rlgr.SegmentedCoder.from_container(c.container()) for c in coders]
+    outs = rlgr.SegmentedCoder.decode_batch(fresh, row_major=True, expect=wrong)
+    assert rlgr.SegmentedCoder.roundtrip_failed(fresh) == [4, 12]
+    assert all(torch.equal(o, q) for o, q in zip(outs, Qs))            # (what was decoded is what was encoded, whatever was expected)
+    with pytest.raises(ValueError):
+        rlgr.SegmentedCoder.decode_batch(coders, row_major=False, expect=Qs)
+    with pytest.raises(ValueError):
+        rlgr.SegmentedCoder.decode_batch(coders, row_major=True, expect=Qs[:3])
