@@ -152,26 +152,29 @@ __device__ __forceinline__ uint32_t encode_segment(const int32_t *__restrict__ s
         u = flag_signed ? (v < 0 ? ((uint32_t)(-(int64_t)v) << 1) - 1u : (uint32_t)v << 1) : (uint32_t)v;     // _s2u, membuf.cpp:4-13
         k = k_P / L;
         const uint32_t k_R = k_RP / L;
+        // ONE Golomb-Rice site for both modes (the symbol that ends a run and a no-run symbol differ by what precedes the code and by
+        // the k_P step): a wave whose lanes disagree about the mode walks the code path once, not twice
+        bool code = true;
+        const bool nz = u != 0;
         if (k) {                                                    // run mode
-            if (u) {
-                --u;
-                w.put(0, 1);
-                w.put_wide(m, (int)k);
-                w.golomb_rice(u, (int)k_R);
-                const uint32_t p = (k_R < 32) ? (u >> k_R) : 0u;      // (k_R reaches 32 after an escape: a 32-bit shift by 32 is not 0)
-                RLGS_ADAPT_KRP32(p);
-                k_P = (k_P < D1) ? 0 : k_P - D1;
-                m = 0;
-            } else if (++m == ((k < 32) ? (1u << k) : 0u)) {         // (k >= 32 needs 2^32 zeros in one segment: never)
-                w.put(1, 1);
-                k_P += U1;
-                m = 0;
+            if (nz) {
+                --u;                                                // (in place, as membuf.cpp does: the open-run test behind the loop sees it)
+                if (k < 32) w.put((uint64_t)(m & ((1u << k) - 1u)), (int)k + 1);      // a 0 bit, then the run length in k bits
+                else { w.put(0, 1); w.put_wide(m, (int)k); }
+            } else {
+                code = false;
+                if (++m == ((k < 32) ? (1u << k) : 0u)) {           // (k >= 32 needs 2^32 zeros in one segment: never)
+                    w.put(1, 1);
+                    k_P += U1;
+                    m = 0;
+                }
             }
-        } else {                                                    // no-run mode
+        }
+        if (code) {
             w.golomb_rice(u, (int)k_R);
-            const uint32_t p = (k_R < 32) ? (u >> k_R) : 0u;      // (k_R reaches 32 after an escape: a 32-bit shift by 32 is not 0)
+            const uint32_t p = (k_R < 32) ? (u >> k_R) : 0u;        // (k_R reaches 32 after an escape: a 32-bit shift by 32 is not 0)
             RLGS_ADAPT_KRP32(p);
-            if (u) k_P = (k_P < D0) ? 0 : k_P - D0;
+            if (k || nz) k_P = k_P ? k_P - 1u : 0u;                  // D0 = D1 = 1 (run mode: always; no-run mode: after a nonzero symbol)
             else k_P += U0;
             m = 0;
         }
@@ -337,20 +340,16 @@ __device__ __forceinline__ void decode_segment(const uint32_t *in32, uint32_t nb
             m += (uint32_t)r.get_wide((int)min(k, 32u));
             while (m-- && i < n) emit(0);
             if (i >= n) break;
-            const uint32_t u = (uint32_t)r.golomb_rice((int)k_R);
-            const uint32_t u1 = u + 1u;
-            emit(flag_signed ? ((u1 & 1u) ? -(int32_t)(u1 >> 1) - 1 : (int32_t)(u1 >> 1)) : (int32_t)u1);
-            const uint32_t p = (k_R < 32) ? (u >> k_R) : 0u;
-            RLGS_ADAPT_KRP32(p);
-            k_P = (k_P < D1) ? 0 : k_P - D1;
-        } else {
-            const uint32_t u = (uint32_t)r.golomb_rice((int)k_R);
-            emit(flag_signed ? ((u & 1u) ? -(int32_t)(u >> 1) - 1 : (int32_t)(u >> 1)) : (int32_t)u);
-            const uint32_t p = (k_R < 32) ? (u >> k_R) : 0u;
-            RLGS_ADAPT_KRP32(p);
-            if (u) k_P = (k_P < D0) ? 0 : k_P - D0;
-            else k_P += U0;
         }
+        // ONE Golomb-Rice site for both modes (a run's closing symbol is coded minus one and always steps k_P down)
+        const bool closing = k != 0;
+        const uint32_t u = (uint32_t)r.golomb_rice((int)k_R);
+        const uint32_t uu = closing ? u + 1u : u;
+        emit(flag_signed ? ((uu & 1u) ? -(int32_t)(uu >> 1) - 1 : (int32_t)(uu >> 1)) : (int32_t)uu);
+        const uint32_t p = (k_R < 32) ? (u >> k_R) : 0u;
+        RLGS_ADAPT_KRP32(p);
+        if (closing || u) k_P = k_P ? k_P - 1u : 0u;                 // D0 = D1 = 1
+        else k_P += U0;
     }
     if (OUT == OUT_LDS && (i & 15)) {                                // the last, partial column
         const int b = i & ~15;
