@@ -193,8 +193,16 @@ __device__ __forceinline__ uint32_t encode_segment(const int32_t *__restrict__ s
 // between two of them once the steps of a frame decode together (FETCH_SIZE 12 x the streams' bytes). Pieces are aligned
 // in memory, not to the segment: the first one may begin before the segment (inside the container: `lo`), the last one may
 // reach past it (`hi`: words at or beyond it read as zero and are never consumed: fill() stops at `size`).
-template <bool LDSIN>
+// MODE 2 (the symbol-synchronous decoder): a RING of 16 words per lane ([16][64] words per wave) that ALL lanes of the wave top up
+// at the same iterations (top_up(), every 32 symbols): the wave then waits for stream words once per 32 iterations instead of
+// whenever some lane crosses into a new piece -- with 64 lanes that was most iterations, and for a frame on its own (1.25 waves
+// per SIMD, nothing else to run meanwhile) each such wait is a memory round trip on the wave's only chain. A lane that drains its
+// ring before the next top-up (more than 16 bits per symbol over 32 symbols) reads its words one by one until then.
+template <int MODE>
 struct DevBitReaderT {
+    static constexpr bool LDSIN = MODE == 1;
+    static constexpr int RING = 16;
+    uint32_t have = 0;           // MODE 2: words [0, have) have been fetched (the ring holds the last RING of them at most)
     const uint32_t *in32;
     uint32_t size, pos = 0;      // bytes; pos is a multiple of 4 (whole words are consumed, the last one zero-extended)
     uint64_t acc = 0;
@@ -203,8 +211,20 @@ struct DevBitReaderT {
     uint32_t w0 = 0;             // LDSIN: word index of the segment's start inside its first 32-byte piece
     int64_t hi_words = 0;        // LDSIN: words from the segment's start to the end of the container
 
+    __device__ __forceinline__ void top_up()                         // MODE 2, called by every lane of the wave at the same time
+    {
+        const uint32_t next = pos >> 2, nwords = (size + 3u) >> 2;  // next word to consume; words of this stream
+        if (have < next) have = next;                               // (the lane read ahead of its ring word by word)
+#pragma unroll
+        for (int t = 0; t < RING; ++t) {
+            const uint32_t w = have + (uint32_t)t;
+            if (w < next + RING && w < nwords) col[(w & (RING - 1)) * 64] = in32[w];
+        }
+        have = min(min(have + (uint32_t)RING, next + (uint32_t)RING), nwords);
+    }
     __device__ __forceinline__ uint32_t word(uint32_t w)
     {
+        if (MODE == 2) return (w < have) ? col[(w & (RING - 1)) * 64] : in32[w];
         if (!LDSIN) return in32[w];
         const uint32_t gw = w + w0, q = gw & 7u;
         if (q == 0 || w == 0) {                                      // into a new piece (or the very first word): fetch it
@@ -375,17 +395,18 @@ __device__ __forceinline__ void decode_segment(const uint32_t *in32, uint32_t nb
 // expect (may be NULL): what the symbols should be, same layout as seq -- the drivers' round-trip assertion
 // (python/encode_3dgs.py:242-245) inside the decoder: in this layout the comparison is one more contiguous read per iteration.
 // -> true when a symbol differs.
-template <bool LDSIN>
+template <int RMODE>
 __device__ __forceinline__ bool decode_segment_sync(const uint32_t *in32, uint32_t nbytes, int n, int flag_signed, int32_t *__restrict__ seq, int64_t sstr,
                                                     int32_t *lds_in = nullptr, int64_t hi_words = 0, const int32_t *__restrict__ expect = nullptr)
 {
     bool differs = false;
-    DevBitReaderT<LDSIN> r;
+    DevBitReaderT<RMODE> r;
     r.in32 = in32; r.size = nbytes;
-    if (LDSIN) { r.col = (uint32_t *)lds_in + (threadIdx.x & 63); r.w0 = (uint32_t)(((uintptr_t)in32 & 31) >> 2); r.hi_words = hi_words; }
+    if (RMODE != 0) { r.col = (uint32_t *)lds_in + (threadIdx.x & 63); r.w0 = (uint32_t)(((uintptr_t)in32 & 31) >> 2); r.hi_words = hi_words; }
     uint32_t k_P = 0, k_RP = 2 * L, z = 0;
     bool tail = false;
     for (int i = 0; i < n; ++i) {
+        if (RMODE == 2 && (i & 31) == 0) r.top_up();
         int32_t v = 0;
         if (z) {
             --z;
@@ -564,7 +585,8 @@ __global__ __launch_bounds__(64) void seg_decode_kernel(const uint8_t *__restric
     // (16-byte stores of four buffered symbols measured SLOWER than one 4-byte store per symbol -- 4.2 against 3.0 ms for 3 M x 56
     // at 2048 per segment: the component selects cost more instructions than the stores save; kept behind this switch)
     const bool aligned = sym_stride == 1 && ((((uintptr_t)Q) & 15) == 0) && ((chan_stride & 3) == 0) && ((S & 3) == 0);
-    if (sym_stride != 1 && sync_rows) decode_segment_sync<false>((const uint32_t *)(in + (nb ? off : 0)), nb, n, flag_signed, Q + (int64_t)c * chan_stride + i0 * sym_stride, sym_stride);
+    if (sym_stride != 1 && sync_rows == 2) decode_segment_sync<2>((const uint32_t *)(in + (nb ? off : 0)), nb, n, flag_signed, Q + (int64_t)c * chan_stride + i0 * sym_stride, sym_stride, s_col);
+    else if (sym_stride != 1 && sync_rows) decode_segment_sync<0>((const uint32_t *)(in + (nb ? off : 0)), nb, n, flag_signed, Q + (int64_t)c * chan_stride + i0 * sym_stride, sym_stride);
     else if (aligned && out_mode == OUT_LDS) decode_segment<OUT_LDS>((const uint32_t *)(in + (nb ? off : 0)), nb, n, flag_signed, Q + (int64_t)c * chan_stride + i0, 1, s_col);
     else if (aligned && out_mode == OUT_VEC) decode_segment<OUT_VEC>((const uint32_t *)(in + (nb ? off : 0)), nb, n, flag_signed, Q + (int64_t)c * chan_stride + i0);
     else decode_segment<OUT_WORD>((const uint32_t *)(in + (nb ? off : 0)), nb, n, flag_signed, Q + (int64_t)c * chan_stride + i0 * sym_stride, sym_stride);
@@ -662,9 +684,8 @@ __global__ __launch_bounds__(64) void seg_decode_batch_kernel(const SegDecJobs J
         const int64_t at = (int64_t)c * chan_stride + i0 * sym_stride;
         const int32_t *ex = J.expect[j] ? J.expect[j] + at : nullptr;
         bool differs;
-        if ((((uintptr_t)J.in[j]) & 31) == 0 && lds_in)
-            differs = decode_segment_sync<true>((const uint32_t *)(J.in[j] + o), nb, n, flag_signed, Q + at, sym_stride, s_in, (int64_t)((in_bytes - o) >> 2), ex);
-        else differs = decode_segment_sync<false>((const uint32_t *)(J.in[j] + o), nb, n, flag_signed, Q + at, sym_stride, nullptr, 0, ex);
+        if (lds_in) differs = decode_segment_sync<2>((const uint32_t *)(J.in[j] + o), nb, n, flag_signed, Q + at, sym_stride, s_col, 0, ex);
+        else differs = decode_segment_sync<0>((const uint32_t *)(J.in[j] + o), nb, n, flag_signed, Q + at, sym_stride, nullptr, 0, ex);
         if (__ballot(differs) && (threadIdx.x & 63) == 0 && bad) atomicOr(bad, 1u << (16 + j));
     } else if (aligned && out_mode == OUT_LDS && (((uintptr_t)J.in[j]) & 31) == 0 && lds_in)
         decode_segment<OUT_LDS, true>((const uint32_t *)(J.in[j] + o), nb, n, flag_signed, Q + (int64_t)c * chan_stride + i0, 1, s_col, s_in, (int64_t)((in_bytes - o) >> 2));
@@ -780,7 +801,7 @@ int raht_rlgr_seg_decode_strided(const uint8_t *in, int64_t in_bytes, const uint
     const int64_t nseg = ceil_div(N, seg_len), G = nseg * D;
     if (G >= ((int64_t)1 << 31)) { set_error("raht_rlgr_seg_decode: too many segments"); return RAHT_ERR_INVALID; }
     hipLaunchKernelGGL(rlgr_seg::seg_decode_kernel, dim3((unsigned)ceil_div(G, 64)), dim3(64), 0, (hipStream_t)stream, in, (uint64_t)in_bytes, seg_off, seg_bytes, N, D,
-                       seg_len, (int)nseg, flag_signed, Q, sym_stride, chan_stride, bad_dev, rlgr_seg::decode_out_mode(G), rlgr_seg::decode_sync_rows());
+                       seg_len, (int)nseg, flag_signed, Q, sym_stride, chan_stride, bad_dev, rlgr_seg::decode_out_mode(G), rlgr_seg::decode_sync_rows() ? (rlgr_seg::decode_lds_in() ? 2 : 1) : 0);
     RAHT_HIP_CHECK(hipGetLastError());
     return RAHT_OK;
 }
