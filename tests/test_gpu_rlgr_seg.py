@@ -285,3 +285,26 @@ def test_round_trip_assertion_inside_the_batch_decoder():
         rlgr.SegmentedCoder.decode_batch(coders, row_major=False, expect=Qs)
     with pytest.raises(ValueError):
         rlgr.SegmentedCoder.decode_batch(coders, row_major=True, expect=Qs[:3])
+
+
+@pytest.mark.parametrize("N,D,seg_len", [(5000, 1, 64), (777, 130, 128), (64, 3, 64), (4097, 59, 4096)])
+def test_odd_shapes_in_both_layouts(N, D, seg_len):
+    """one channel, more channels than a wave has lanes, one segment, a last segment of one symbol: single-frame and batched calls,
+    channel-major and row-major, against each other and against the input"""
+    import torch
+    from raht_3dgs_codec_amd import rlgr
+    rng = np.random.default_rng(N + D)
+    frames = [np.rint(rng.laplace(0, 3.0 + 20.0 * j, size=(N, D))).astype(np.int32) * (rng.random((N, D)) < 0.6) for j in range(3)]
+    Qs = [torch.from_numpy(f).cuda() for f in frames]
+    coders = [rlgr.SegmentedCoder(N, D, seg_len) for _ in frames]
+    rlgr.SegmentedCoder.encode_batch(coders, Qs)
+    for c, Q, f in zip(coders, Qs, frames):
+        alone = rlgr.SegmentedCoder(N, D, seg_len)
+        alone.encode(torch.from_numpy(np.ascontiguousarray(f.T)).cuda())          # channel-major input, one frame
+        assert alone.container() == c.container()
+        assert torch.equal(c.decode(row_major=True), Q) and torch.equal(c.decode(), Q.t())
+    for rm in (True, False):
+        outs = rlgr.SegmentedCoder.decode_batch(coders, row_major=rm)
+        assert all(torch.equal(o, Q if rm else Q.t()) for o, Q in zip(outs, Qs))
+    rlgr.SegmentedCoder.decode_batch(coders, row_major=True, expect=Qs)
+    assert rlgr.SegmentedCoder.roundtrip_failed(coders) == []
