@@ -51,6 +51,11 @@ def main():
         _lib.check(L.raht_dequant_inv_sqdiff(p._h, vp(Q.data_ptr()), D, D, st, 1, vp(Cd.data_ptr()), D, vp(rec.data_ptr()) if keep else None, D, vp(ssd.data_ptr()), s_()))
     out = {"rows": N, "channels": D, "dequant_inv_ms": round(timed(inv_only), 4), "dequant_inv_then_sqdiff_columns_ms": round(timed(two), 4),
            "dequant_inv_sqdiff_keep_rec_ms": round(timed(lambda: fused(True)), 4), "dequant_inv_sqdiff_no_rec_ms": round(timed(lambda: fused(False)), 4)}
+    # algorithmic bytes: Q in + C in (+ C_rec out) + 8 bytes of plan per row; against the 8 TB/s peak
+    for key, nmat in (("dequant_inv_sqdiff_keep_rec", 3), ("dequant_inv_sqdiff_no_rec", 2), ("dequant_inv", 2)):
+        alg = nmat * 4.0 * N * D + 8.0 * N
+        out[key + "_roofline"] = {"bound": "hbm", "alg_bytes": alg, "achieved_GBs": round(alg / (out[key + "_ms"] * 1e-3) / 1e9, 1),
+                                  "frac_of_peak": round(alg / (out[key + "_ms"] * 1e-3) / 1e9 / 8000.0, 4)}
     print(json.dumps(out))
 
 
