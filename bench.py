@@ -966,6 +966,14 @@ def main():
                        "value": round(s2.N / (t2 * 1e-3) / 1e6, 1), "unit": "M-Gaussians/s", "alg_bytes_fwd_inv": alg2,
                        "frac_of_peak": round(alg2 / (t2 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                        "active_rows_per_stage": s2.plan.stage_stats(4, D2)["rows_per_stage"]}
+                if s2.mixed and not a.no_quant:
+                    # frames with xyz columns: the step above carries them in float64; the all-float32 step beside it
+                    f32 = lambda: (s2.fwd_quant_f32(), s2.dequant_inv_f32())                                    # noqa: E731
+                    for _ in range(32):
+                        f32()
+                    t32 = timed(f32, 200)
+                    leg["precision"] = "xyz columns float64 inside the float32 launches (mixed)"
+                    leg["f32_only"] = {"ms_per_step": round(t32, 4), "frac_of_peak": round(alg2 / (t32 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
                 del s2
                 return leg
             n2, J2, D2, seed2 = synth.CONFIGS["cfg2"]
