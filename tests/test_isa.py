@@ -52,3 +52,42 @@ def test_tile_kernels_do_not_spill(tu, at_least):
     for ln in rows:
         m = re.search(r"spill (\d+) scratch (\d+)", ln)
         assert m and int(m.group(1)) == 0 and int(m.group(2)) == 0, ln
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="needs hipcc")
+def test_plan_kernels_save_and_restore_m0_around_their_writelanes(tmp_path):
+    """level_extent_kernel collects its per-level words with `v_writelane_b32 v, s, m0` in inline assembly (no writelane builtin
+    in this hipcc; two SGPR operands exceed the constant bus, so the lane select goes through M0). The compiler does not track M0
+    as a clobber: the asm saves and restores it. Pinned here: every use of M0 in plan.hip is one of those four instructions."""
+    out = tmp_path / "plan.s"
+    r = subprocess.run([HIPCC, "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-I" + os.path.join(ROOT, "include"), "-fno-fast-math",
+                        "-ffp-contract=on", "-S", "--offload-device-only", os.path.join(CSRC, "plan.hip"), "-o", str(out)],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    code = [ln.split(";")[0].strip() for ln in out.read_text().splitlines()]
+    uses = [ln for ln in code if re.search(r"\bm0\b", ln) and not ln.startswith(".")]
+    assert sum(1 for ln in uses if ln.startswith("v_writelane_b32")) >= 3, uses[:10]
+    for ln in uses:
+        assert re.fullmatch(r"s_mov_b32 s\d+, m0|s_mov_b32 m0, s\d+|v_writelane_b32 v\d+, s\d+, m0", ln), f"unexpected use of m0: {ln!r}"
+    saves = sum(1 for ln in uses if re.fullmatch(r"s_mov_b32 s\d+, m0", ln))
+    sets = sum(1 for ln in uses if re.fullmatch(r"s_mov_b32 m0, s\d+", ln))
+    assert saves >= 1 and sets == 2 * saves, (saves, sets)              # (set for the writes, set back)
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="needs hipcc")
+@pytest.mark.parametrize("tu", ["rlgr_seg.hip", "plan.hip"])
+def test_coder_and_plan_kernels_do_not_spill(tu):
+    """the segmented coder's kernels must keep 7-8 waves per SIMD (that is where their batched speed comes from): no scratch, at most
+    72 VGPRs; the plan kernels: no scratch"""
+    r = subprocess.run([HIPCC, "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-I" + os.path.join(ROOT, "include"), "-fno-fast-math",
+                        "-ffp-contract=on", "-Rpass-analysis=kernel-resource-usage", "-c", os.path.join(CSRC, tu), "-o", os.devnull],
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    names = re.findall(r"Function Name: (\S+)", r.stderr)
+    scratch = [int(x) for x in re.findall(r"ScratchSize \[bytes/lane\]: (\d+)", r.stderr)]
+    vgprs = [int(x) for x in re.findall(r" VGPRs: (\d+)", r.stderr)]
+    assert len(names) >= 8 and len(names) == len(scratch) == len(vgprs)
+    for n, sc, v in zip(names, scratch, vgprs):
+        assert sc == 0, (n, sc)
+        if tu == "rlgr_seg.hip" and ("seg_encode" in n or "seg_decode" in n):
+            assert v <= 72, (n, v)
