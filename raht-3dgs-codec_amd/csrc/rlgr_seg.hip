@@ -137,6 +137,7 @@ __device__ __forceinline__ uint32_t encode_segment(const int32_t *__restrict__ s
     // stream may hold 2^32 symbols and more; 64-bit integer arithmetic is several instructions per operation here.)
     uint32_t u = 0, k_P = 0, k_RP = 2 * L, m = 0, k = 0;
     int32_t nxt = (!VEC && n > 0) ? seq[0] : 0;
+    const int32_t *rp = seq;                                         // (walked by pointer: a 64-bit multiply per symbol otherwise)
     int4 cur4 = make_int4(0, 0, 0, 0), nxt4 = make_int4(0, 0, 0, 0);
     if (VEC && n > 0) nxt4 = *(const int4 *)seq;                     // (whole groups of four are readable: see the kernel)
     for (int i = 0; i < n; ++i) {
@@ -147,7 +148,7 @@ __device__ __forceinline__ uint32_t encode_segment(const int32_t *__restrict__ s
             v = q == 0 ? cur4.x : q == 1 ? cur4.y : q == 2 ? cur4.z : cur4.w;
         } else {
             v = nxt;
-            if (i + 1 < n) nxt = seq[(int64_t)(i + 1) * sstr];       // one symbol ahead: the load is off the dependent chain
+            if (i + 1 < n) { rp += sstr; nxt = *rp; }                // one symbol ahead: the load is off the dependent chain
         }
         u = flag_signed ? (v < 0 ? ((uint32_t)(-(int64_t)v) << 1) - 1u : (uint32_t)v << 1) : (uint32_t)v;     // _s2u, membuf.cpp:4-13
         k = k_P / L;
@@ -405,7 +406,9 @@ __device__ __forceinline__ bool decode_segment_sync(const uint32_t *in32, uint32
     if (RMODE != 0) { r.col = (uint32_t *)lds_in + (threadIdx.x & 63); r.w0 = (uint32_t)(((uintptr_t)in32 & 31) >> 2); r.hi_words = hi_words; }
     uint32_t k_P = 0, k_RP = 2 * L, z = 0;
     bool tail = false;
-    for (int i = 0; i < n; ++i) {
+    int32_t *wp = seq;                                               // (walked by pointer: a 64-bit multiply per symbol otherwise)
+    const int32_t *ep = expect;
+    for (int i = 0; i < n; ++i, wp += sstr) {
         if (RMODE == 2 && (i & 31) == 0) r.top_up();
         int32_t v = 0;
         if (z) {
@@ -440,8 +443,8 @@ __device__ __forceinline__ bool decode_segment_sync(const uint32_t *in32, uint32
                 tail = false;
             }
         }
-        seq[(int64_t)i * sstr] = v;
-        if (expect) differs |= expect[(int64_t)i * sstr] != v;
+        *wp = v;
+        if (expect) { differs |= *ep != v; ep += sstr; }
     }
     return differs;
 }
